@@ -1,0 +1,121 @@
+"""ORACLE -- test infrastructure only.  ctypes front of oracle/roi_ops_ref.c (our plain-C
+restatement of /root/reference/wsovod/layers/ROILoopPool/ROILoopPool_cpu.cpp:13-123 and of
+torchvision roi_align) and of oracle/_ref (the reference's own RoIPool, compiled where it
+lies).  All tensors are CPU, fp32, NCHW, contiguous.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import build as _build
+
+_c = None
+_ref = None
+
+
+def _clib():
+    global _c
+    if _c is None:
+        _c = C.CDLL(_build.build_c())
+    return _c
+
+
+def ref_available():
+    return _build.build_ref() is not None
+
+
+def _reflib():
+    global _ref
+    if _ref is None:
+        path = _build.build_ref()
+        if path is None:
+            raise RuntimeError("oracle/_ref is not built and /root/reference is absent")
+        _ref = C.CDLL(path)
+    return _ref
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _prep(feat, rois):
+    feat = feat.detach().to(torch.float32).contiguous()
+    rois = rois.detach().to(torch.float32).contiguous()
+    assert feat.dim() == 4 and rois.dim() == 2 and rois.size(1) == 5
+    return feat, rois
+
+
+def roi_pool_forward(feat, rois, spatial_scale, output_size):
+    """-> (out (R,C,ph,pw) fp32, argmax int32)."""
+    feat, rois = _prep(feat, rois)
+    ph, pw = output_size
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.zeros(R, Cc, ph, pw, dtype=torch.float32)
+    arg = torch.zeros(R, Cc, ph, pw, dtype=torch.int32)
+    if R:
+        _clib().roi_pool_forward(_p(feat), C.c_float(spatial_scale), Cc, H, W, ph, pw, _p(rois), R,
+                                 _p(out), _p(arg))
+    return out, arg
+
+
+def roi_pool_backward(grad, rois, argmax, input_shape):
+    N, Cc, H, W = input_shape
+    grad = grad.detach().to(torch.float32).contiguous()
+    rois = rois.detach().to(torch.float32).contiguous()
+    R, _, ph, pw = grad.shape
+    gi = torch.zeros(N, Cc, H, W, dtype=torch.float32)
+    if R:
+        _clib().roi_pool_backward(_p(grad), _p(argmax.contiguous()), R, Cc, H, W, ph, pw, _p(gi), _p(rois))
+    return gi
+
+
+def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned):
+    feat, rois = _prep(feat, rois)
+    ph, pw = output_size
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.zeros(R, Cc, ph, pw, dtype=torch.float32)
+    if R:
+        _clib().roi_align_forward(_p(feat), C.c_float(spatial_scale), Cc, H, W, ph, pw,
+                                  int(sampling_ratio), int(bool(aligned)), _p(rois), R, _p(out))
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, sampling_ratio, aligned, input_shape):
+    N, Cc, H, W = input_shape
+    grad = grad.detach().to(torch.float32).contiguous()
+    rois = rois.detach().to(torch.float32).contiguous()
+    R, _, ph, pw = grad.shape
+    gi = torch.zeros(N, Cc, H, W, dtype=torch.float32)
+    if R:
+        _clib().roi_align_backward(_p(grad), C.c_float(spatial_scale), Cc, H, W, ph, pw,
+                                   int(sampling_ratio), int(bool(aligned)), _p(rois), R, _p(gi))
+    return gi
+
+
+# ---- the reference's own compiled RoIPool (oracle/_ref) ----
+def ref_roi_pool_forward(feat, rois, spatial_scale, output_size):
+    feat, rois = _prep(feat, rois)
+    ph, pw = output_size
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.zeros(R, Cc, ph, pw, dtype=torch.float32)
+    arg = torch.zeros(R, Cc, ph, pw, dtype=torch.int32)
+    if R:
+        _reflib().ref_roi_pool_forward(_p(feat), N, Cc, H, W, _p(rois), R, C.c_float(spatial_scale),
+                                       ph, pw, _p(out), _p(arg))
+    return out, arg
+
+
+def ref_roi_pool_backward(grad, rois, argmax, spatial_scale, input_shape):
+    N, Cc, H, W = input_shape
+    grad = grad.detach().to(torch.float32).contiguous()
+    rois = rois.detach().to(torch.float32).contiguous()
+    R, _, ph, pw = grad.shape
+    gi = torch.zeros(N, Cc, H, W, dtype=torch.float32)
+    if R:
+        _reflib().ref_roi_pool_backward(_p(grad), _p(rois), _p(argmax.contiguous()), R,
+                                        C.c_float(spatial_scale), ph, pw, N, Cc, H, W, _p(gi))
+    return gi

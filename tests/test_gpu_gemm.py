@@ -1,0 +1,114 @@
+"""GPU parity: MFMA contraction kernel (plain + implicit-GEMM conv) vs a torch fp32/fp64 CPU reference."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_mm(A, B):
+    return (A.double() @ B.double().t()).float()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("tile", [0, 128128, 128064, 64128, 64064])
+@pytest.mark.parametrize("shape", [(512, 4096, 1024), (100, 40, 256), (333, 129, 192), (64, 4, 4096)])
+def test_gemm_nt_plain(gpu, dtype, tile, shape):
+    from wsovod_amd.layers import hip_ops
+
+    M, N, K = shape
+    torch.manual_seed(0)
+    A = torch.randn(M, K).to(dtype)
+    B = torch.randn(N, K).to(dtype)
+    ref = _ref_mm(A, B)
+    out = hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, tile_hint=tile)
+    # fp32 path: exact-fp32 MFMA (fmaf chain) -> 1e-5 relative to sum|a||b|; bf16 inputs are exact
+    # products accumulated in fp32 -> same bound
+    tol = 2e-6 * K ** 0.5 * 4
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=tol * 10)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue(gpu, dtype):
+    from wsovod_amd.layers import hip_ops
+
+    M, N, K = 200, 96, 320
+    torch.manual_seed(1)
+    A = torch.randn(M, K).to(dtype)
+    B = torch.randn(N, K).to(dtype)
+    bias = torch.randn(N)
+    rs = torch.rand(M) + 0.5
+    res = torch.randn(M, N)
+    grp = torch.randint(0, 3, (M,), dtype=torch.int32)
+    ga = torch.randn(3, N)
+    ref = torch.relu(_ref_mm(A, B) * 0.5 * rs[:, None] + bias[None] + res) + ga[grp.long()]
+    out_t = torch.zeros(N, 256, device=gpu)
+    out = hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, alpha=0.5, row_scale=rs.to(gpu),
+                          bias=bias.to(gpu), residual=res.to(gpu), relu=True, row_group=grp.to(gpu),
+                          group_add=ga.to(gpu), out_t=out_t)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(out_t.cpu()[:, :M], ref.t(), rtol=1e-4, atol=1e-3)
+    assert torch.all(out_t.cpu()[:, M:] == 0)
+    # backward-style mask + accumulate
+    mask = torch.randn(M, N)
+    acc0 = torch.randn(M, N)
+    out2 = acc0.clone().to(gpu)
+    hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out=out2, mask_src=mask.to(gpu), mask_scale=2.0, accumulate=True)
+    ref2 = acc0 + torch.where(mask > 0, _ref_mm(A, B) * 2.0, torch.zeros(()))
+    torch.testing.assert_close(out2.cpu(), ref2, rtol=1e-4, atol=1e-3)
+    # bf16 output rounding
+    out3 = hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.bfloat16)
+    torch.testing.assert_close(out3.cpu().float(), _ref_mm(A, B), rtol=1e-2, atol=1e-1)
+
+
+def test_gemm_dropout_statistics(gpu):
+    from wsovod_amd.layers import hip_ops
+
+    M, N, K = 512, 1024, 64
+    A = torch.ones(M, K, device=gpu)
+    B = torch.ones(N, K, device=gpu)
+    out = hip_ops.gemm_nt(A, B, dropout_p=0.5, dropout_seed=1234)
+    kept = (out > 0).float().mean().item()
+    assert abs(kept - 0.5) < 0.01  # 524288 Bernoulli(0.5) draws: sigma = 7e-4
+    assert torch.all((out == 0) | (out == 2.0 * K))
+    out_b = hip_ops.gemm_nt(A, B, dropout_p=0.5, dropout_seed=1234)
+    assert torch.equal(out, out_b)  # counter-based: reproducible
+    out_c = hip_ops.gemm_nt(A, B, dropout_p=0.5, dropout_seed=99)
+    assert not torch.equal(out, out_c)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [
+    dict(Cin=64, Cout=64, H=38, W=50, k=3, stride=1, pad=1, dil=1),
+    dict(Cin=128, Cout=256, H=19, W=25, k=3, stride=1, pad=2, dil=2),
+    dict(Cin=64, Cout=128, H=19, W=25, k=1, stride=1, pad=0, dil=1),
+    dict(Cin=64, Cout=96, H=20, W=26, k=3, stride=2, pad=1, dil=1),
+])
+def test_conv_implicit_gemm(gpu, dtype, cfg):
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(2)
+    n = 2
+    x = torch.randn(n, cfg["Cin"], cfg["H"], cfg["W"]).to(dtype)
+    w = (torch.randn(cfg["Cout"], cfg["Cin"], cfg["k"], cfg["k"]) * 0.05).to(dtype)
+    bias = torch.randn(cfg["Cout"])
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), cfg["stride"], cfg["pad"], cfg["dil"])).float()
+    Ho, Wo = ref.shape[2:]
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    w_k = w.permute(0, 2, 3, 1).reshape(cfg["Cout"], -1).contiguous().to(gpu)
+    geom = dict(n_img=n, H=cfg["H"], W=cfg["W"], Cin=cfg["Cin"], Ho=Ho, Wo=Wo, KH=cfg["k"], KW=cfg["k"],
+                stride=cfg["stride"], pad=cfg["pad"], dil=cfg["dil"])
+    out = hip_ops.gemm_nt(x_nhwc, w_k, conv=geom, bias=bias.to(gpu), relu=True, out_dtype=torch.float32)
+    out = out.view(n, Ho, Wo, cfg["Cout"]).permute(0, 3, 1, 2).cpu()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-3)
+
+
+def test_gemm_argument_errors(gpu):
+    from wsovod_amd.layers import hip_ops
+
+    A = torch.randn(8, 30, device=gpu)
+    B = torch.randn(8, 30, device=gpu)
+    with pytest.raises(RuntimeError, match="multiple"):
+        hip_ops.gemm_nt(A, B)  # K=30 is not a multiple of 4 fp32 elements (16-B chunks)
+    with pytest.raises(RuntimeError):
+        hip_ops.gemm_nt(A.cpu(), B.cpu())

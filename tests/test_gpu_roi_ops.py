@@ -1,0 +1,94 @@
+"""GPU parity: HIP RoIPool / ROIAlign through the C-ABI vs the C oracle (bit-exact indices)."""
+import pytest
+import torch
+
+from oracle import roi_ops as O
+from tests.util import random_rois
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [8, 64, 100])
+def test_roi_pool_forward_bit_exact(gpu, channels_last, dtype, C):
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(1)
+    feat = torch.randn(2, C, 75, 100).to(dtype)
+    rois = random_rois(96, 2, 600, 800, seed=3)
+    ref_out, ref_arg = O.roi_pool_forward(feat.float(), rois, 0.125, (7, 7))
+    f = feat.to(gpu)
+    if channels_last:
+        f = f.contiguous(memory_format=torch.channels_last)
+    out, arg = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(arg.cpu(), ref_arg)  # int32 argmax: bit-exact
+    assert torch.equal(out.cpu(), ref_out)  # values are copies: bit-exact
+
+
+def test_roi_pool_scale_and_no_argmax(gpu):
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(2)
+    feat = torch.randn(1, 128, 75, 100)
+    rois = random_rois(64, 1, 600, 800, seed=5)
+    sc = torch.rand(64) + 1.0
+    ref_out, _ = O.roi_pool_forward(feat, rois, 0.125, (7, 7))
+    ref_out = ref_out * sc.view(-1, 1, 1, 1)
+    f = feat.to(gpu).contiguous(memory_format=torch.channels_last)
+    out, arg = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), roi_scale=sc.to(gpu), need_argmax=False)
+    assert arg is None
+    assert torch.equal(out.cpu(), ref_out)
+    out_bf, _ = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), roi_scale=sc.to(gpu),
+                                         out_dtype=torch.bfloat16, need_argmax=False)
+    assert torch.equal(out_bf.cpu(), ref_out.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_roi_pool_backward(gpu, channels_last):
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(3)
+    feat = torch.randn(2, 16, 40, 50)
+    rois = random_rois(40, 2, 320, 400, seed=7)
+    _, arg = O.roi_pool_forward(feat, rois, 0.125, (7, 7))
+    g = torch.randn(40, 16, 7, 7)
+    ref = O.roi_pool_backward(g, rois, arg, feat.shape)
+    gi = hip_ops.roi_pool_backward(g.to(gpu), rois.to(gpu), arg.to(gpu), feat.shape, channels_last=channels_last)
+    # atomic scatter-add: order-dependent fp32 sums -> tolerance, not bit-exact
+    torch.testing.assert_close(gi.cpu().contiguous(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("aligned", [True, False])
+@pytest.mark.parametrize("sampling_ratio", [0, 2])
+def test_roi_align_forward_backward(gpu, channels_last, aligned, sampling_ratio):
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(4)
+    feat = torch.randn(2, 24, 40, 50)
+    rois = random_rois(48, 2, 320, 400, seed=9)
+    ref = O.roi_align_forward(feat, rois, 0.125, (7, 7), sampling_ratio, aligned)
+    f = feat.to(gpu)
+    if channels_last:
+        f = f.contiguous(memory_format=torch.channels_last)
+    out = hip_ops.roi_align_forward(f, rois.to(gpu), 0.125, (7, 7), sampling_ratio, aligned)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)  # fp32 bilinear; FMA contraction differs
+    g = torch.randn_like(ref)
+    ref_gi = O.roi_align_backward(g, rois, 0.125, sampling_ratio, aligned, feat.shape)
+    gi = hip_ops.roi_align_backward(g.to(gpu), rois.to(gpu), 0.125, sampling_ratio, aligned, feat.shape,
+                                    channels_last=channels_last)
+    torch.testing.assert_close(gi.cpu().contiguous(), ref_gi, rtol=1e-4, atol=1e-4)
+
+
+def test_roi_pool_empty_and_errors(gpu):
+    from wsovod_amd.layers import hip_ops
+
+    feat = torch.randn(1, 8, 10, 10, device=gpu)
+    out, arg = hip_ops.roi_pool_forward(feat, torch.zeros(0, 5, device=gpu), 0.125, (7, 7))
+    assert out.shape == (0, 8, 7, 7) and arg.shape == (0, 8, 7, 7)
+    with pytest.raises(RuntimeError):
+        hip_ops.roi_pool_forward(feat, torch.zeros(3, 4, device=gpu), 0.125, (7, 7))
+    with pytest.raises(RuntimeError):
+        hip_ops.roi_pool_forward(feat.cpu(), torch.zeros(3, 5), 0.125, (7, 7))

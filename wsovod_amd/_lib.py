@@ -1,0 +1,120 @@
+"""ctypes binding of the C-ABI library `libwsovod_hip.so` (see include/wsovod_hip.h).
+
+This is the reference-side binding a maintainer would add in place of the pybind module
+`wsovod._C` (/root/reference/wsovod/layers/vision.cpp:9-13).  The product path has no CPU
+fallback: if the library is missing or a call fails, a RuntimeError is raised (the
+reference's convention: AT_ERROR -> RuntimeError).
+"""
+import ctypes as C
+import os
+
+import torch  # must be imported first: the library resolves libamdhip64.so.7 to torch's copy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libwsovod_hip.so")
+
+F32, BF16 = 0, 1
+NCHW, NHWC = 0, 1
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in
+                ("n_img", "H", "W", "Cin", "Ho", "Wo", "KH", "KW", "stride", "pad", "dil")]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("dtype_in", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_longlong),
+        ("B", C.c_void_p), ("ldb", C.c_longlong),
+        ("C", C.c_void_p), ("ldc", C.c_longlong), ("dtype_c", C.c_int),
+        ("Ct", C.c_void_p), ("ldct", C.c_longlong), ("dtype_ct", C.c_int),
+        ("alpha", C.c_float),
+        ("row_scale", C.c_void_p), ("bias", C.c_void_p),
+        ("residual", C.c_void_p), ("ldr", C.c_longlong), ("dtype_r", C.c_int),
+        ("relu", C.c_int),
+        ("dropout_p", C.c_float), ("dropout_seed", C.c_ulonglong),
+        ("row_group", C.c_void_p), ("group_add", C.c_void_p), ("ld_ga", C.c_longlong),
+        ("mask_src", C.c_void_p), ("ldm", C.c_longlong), ("dtype_m", C.c_int),
+        ("mask_scale", C.c_float),
+        ("accumulate", C.c_int),
+        ("conv", C.c_int), ("geom", ConvGeom),
+        ("tile_hint", C.c_int), ("prof_tag", C.c_int),
+    ]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_longlong), ("ms", C.c_double),
+                ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; fail loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"wsovod_amd: HIP extension {LIB_PATH} is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc); "
+                "there is no CPU fallback on the product path."
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _lib.wsovod_last_error.restype = C.c_char_p
+        _lib.wsovod_profile_collect.argtypes = [C.POINTER(ProfEntry), C.c_int]
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().wsovod_last_error().decode(errors="replace")
+        raise RuntimeError(f"wsovod_hip {what} failed (status {rc}): {msg}")
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"wsovod_hip: unsupported dtype {t} (float32 / bfloat16 only)")
+
+
+def ptr(t):
+    """Device pointer of a tensor as c_void_p (None -> NULL)."""
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    """The current torch HIP stream as a raw hipStream_t."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "wsovod_hip: tensors must live on an MI355X device (got a CPU tensor); "
+                "the HIP path has no CPU fallback"
+            )
+
+
+def profile_enable(on=True):
+    return lib().wsovod_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().wsovod_profile_reset()
+
+
+def profile_collect():
+    buf = (ProfEntry * 256)()
+    n = lib().wsovod_profile_collect(buf, 256)
+    return [
+        dict(name=buf[i].name.decode(), launches=buf[i].launches, ms=buf[i].ms,
+             flops=buf[i].flops, bytes=buf[i].bytes)
+        for i in range(n)
+    ]

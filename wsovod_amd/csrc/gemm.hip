@@ -1,0 +1,434 @@
+// MFMA contraction kernel of the hot path: C[M][N] = epilogue(sum_k A[m][k] * B[n][k]).
+//
+// One kernel structure serves every dense contraction on the path:
+//   * nn.Linear forward  (A = activations, B = weight [out][in])         box_head.py:60-75
+//   * nn.Linear dX       (A = dY,          B = weight^T shadow)
+//   * nn.Linear dW       (A = dY^T,        B = X^T; reduction over proposals)
+//   * conv + folded FrozenBN + ReLU (+ residual) as an implicit GEMM over NHWC input
+//     (A rows are gathered per 3x3 tap; never materialised)         resnet_wsl.py:94-110
+//   * region x text-embedding cosine-similarity GEMM with the 1/||x|| * T row scale
+//     folded into the epilogue                          open_vocabulary_classifier.py:91-102
+//
+// CDNA4 mapping: 256 threads = 4 wavefronts (2x2), each wavefront owns a
+// (BM/2)x(BN/2) block of 16x16 MFMA tiles.  A K-step is 128 BYTES of K per row for both
+// dtypes (64 bf16 -> 2x v_mfma_f32_16x16x32_bf16, 32 fp32 -> 8x v_mfma_f32_16x16x4_f32),
+// so one LDS image [rows][128 B] and one loader serve bf16 and exact-fp32 alike.
+// LDS rows are XOR-swizzled in 16-B chunks (chunk ^= (row>>1)&7): ds_read_b128 fragment
+// reads of 16 consecutive rows and the 8-lane ds_write_b128 groups are conflict-free
+// (MI355X_MICROARCH.md, LDS table).  Global->LDS is register staged, software-pipelined
+// one K-step ahead with LDS double buffering (one barrier per K-step).
+// Workgroup ids are remapped so that the 8 XCDs each get a contiguous run of tiles that
+// share the B (weight) slab in their private L2.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  const char* A;
+  const char* B;
+  long long lda, ldb;  // elements
+  int M, N, K;
+  void* C;
+  long long ldc;
+  int dtype_c;
+  void* Ct;
+  long long ldct;
+  int dtype_ct;
+  float alpha;
+  const float* row_scale;
+  const float* bias;
+  const void* residual;
+  long long ldr;
+  int dtype_r;
+  int relu;
+  float dropout_p;
+  unsigned long long seed;
+  const int* row_group;
+  const float* group_add;
+  long long ld_ga;
+  const void* mask_src;
+  long long ldm;
+  int dtype_m;
+  float mask_scale;
+  int accumulate;
+  // implicit-GEMM convolution geometry
+  int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
+  int tiles_m, tiles_n;
+};
+
+template <typename T>
+struct Traits;
+template <>
+struct Traits<float> {
+  static constexpr int EPC = 4;   // elements per 16-byte chunk
+  static constexpr int BKE = 32;  // elements per K-step (128 B)
+};
+template <>
+struct Traits<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int BKE = 64;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ float load_as_f32(const void* p, long long idx, int dtype) {
+  return dtype == WSOVOD_BF16 ? (float)((const bf16_t*)p)[idx] : ((const float*)p)[idx];
+}
+__device__ __forceinline__ void store_from_f32(void* p, long long idx, int dtype, float v) {
+  if (dtype == WSOVOD_BF16)
+    ((bf16_t*)p)[idx] = (bf16_t)v;
+  else
+    ((float*)p)[idx] = v;
+}
+
+// splitmix64 finaliser: counter-based, stateless dropout mask on (seed, m, n)
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+template <typename T, int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
+  constexpr int EPC = Traits<T>::EPC;
+  constexpr int BKE = Traits<T>::BKE;
+  constexpr int TM = BM / 32;  // 16x16 tiles per wavefront along M
+  constexpr int TN = BN / 32;
+  constexpr int RA = BM / 32;  // 16-B chunks each thread stages per K-step (A)
+  constexpr int RB = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + 2 * BM * 128;
+
+  // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD; give each XCD a contiguous
+  // run of tile ids (M fastest), i.e. tiles that stream the same weight slab. Bijective.
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = wg % p.tiles_m;
+  const int tile_n = wg / p.tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lrow = tid >> 3, lchunk = tid & 7;
+
+  // ---- per-thread loader state
+  const char* a_ptr[RA];
+  bool a_ok[RA];
+  int hi0[RA], wi0[RA];
+#pragma unroll
+  for (int i = 0; i < RA; ++i) {
+    const int m = m0 + lrow + 32 * i;
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int mm = a_ok[i] ? m : 0;
+      const int img = mm / hw;
+      const int rem = mm - img * hw;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      hi0[i] = ho * p.stride - p.pad;
+      wi0[i] = wo * p.stride - p.pad;
+      a_ptr[i] = p.A + ((long long)img * p.H * p.W * p.Cin + lchunk * EPC) * (long long)sizeof(T);
+    } else {
+      hi0[i] = wi0[i] = 0;
+      a_ptr[i] = p.A + ((long long)(a_ok[i] ? m : 0) * p.lda + lchunk * EPC) * (long long)sizeof(T);
+    }
+  }
+  const char* b_ptr[RB];
+  bool b_ok[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int n = n0 + lrow + 32 * i;
+    b_ok[i] = n < p.N;
+    b_ptr[i] = p.B + ((long long)(b_ok[i] ? n : 0) * p.ldb + lchunk * EPC) * (long long)sizeof(T);
+  }
+
+  const int nk = (p.K + BKE - 1) / BKE;
+  uint4 ra[RA], rb[RB];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_global = [&](int kt) {
+    const int kbase = kt * BKE;
+    const bool k_ok = kbase + lchunk * EPC < p.K;
+    if (CONV) {
+      const int cpt = p.Cin / BKE;  // K-steps per filter tap
+      const int tap = kt / cpt;
+      const int c0 = (kt - tap * cpt) * BKE;
+      const int r = tap / p.KW;
+      const int q = tap - r * p.KW;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int hi = hi0[i] + r * p.dil;
+        const int wi = wi0[i] + q * p.dil;
+        const bool ok = a_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const long long off = ((long long)(hi * p.W + wi) * p.Cin + c0) * (long long)sizeof(T);
+        ra[i] = ok ? *(const uint4*)(a_ptr[i] + off) : zero4;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        ra[i] = (a_ok[i] && k_ok) ? *(const uint4*)(a_ptr[i] + (long long)kbase * sizeof(T)) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      rb[i] = (b_ok[i] && k_ok) ? *(const uint4*)(b_ptr[i] + (long long)kbase * sizeof(T)) : zero4;
+  };
+  auto store_lds = [&](int buf) {
+    char* dA = sA + buf * BM * 128;
+    char* dB = sB + buf * BN * 128;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *(uint4*)(dA + lds_off(lrow + 32 * i, lchunk)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *(uint4*)(dB + lds_off(lrow + 32 * i, lchunk)) = rb[i];
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_global(0);
+  store_lds(0);
+  __syncthreads();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_global(kt + 1);  // in flight under the MFMAs below
+    const char* cA = sA + cur * BM * 128 + (wm * (BM / 2)) * 128;
+    const char* cB = sB + cur * BN * 128 + (wn * (BN / 2)) * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = fq + 4 * ks;
+      uint4 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = i * 16 + frow;  // (wm*(BM/2)) is a multiple of 16: swizzle unchanged
+        af[i] = *(const uint4*)(cA + row * 128 + ((chunk ^ (((row + wm * (BM / 2)) >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + frow;
+        bfr[j] = *(const uint4*)(cB + row * 128 + ((chunk ^ (((row + wn * (BN / 2)) >> 1) & 7)) << 4));
+      }
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                  __builtin_bit_cast(f32x4, af[i])[e], __builtin_bit_cast(f32x4, bfr[j])[e], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue (fp32): D[row=(lane>>4)*4+reg][col=lane&15]
+  const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 16 + frow;
+      const int mb = m0 + wm * (BM / 2) + i * 16 + fq * 4;
+      if (n >= p.N) continue;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mb + r;
+        float x = acc[i][j][r] * p.alpha;
+        if (m < p.M) {
+          if (p.row_scale) x *= p.row_scale[m];
+          x += bias;
+          if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+          if (p.relu) x = fmaxf(x, 0.f);
+          if (p.dropout_p > 0.f) {
+            const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+            x = u >= p.dropout_p ? x * keep_scale : 0.f;
+          }
+          if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
+          if (p.mask_src)
+            x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+          if (p.C) {
+            if (p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
+            store_from_f32(p.C, (long long)m * p.ldc + n, p.dtype_c, x);
+          }
+        }
+        v[r] = x;
+      }
+      if (p.Ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (mb + r < p.M) store_from_f32(p.Ct, (long long)n * p.ldct + mb + r, p.dtype_ct, v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, bool CONV>
+int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
+  static int slot = wsovod::prof_slot(slot_name);
+  static bool attr_set = false;
+  constexpr int lds_bytes = 2 * (BM + BN) * 128;
+  auto kfn = gemm_nt_kernel<T, BM, BN, CONV>;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = ceil_div(a.M, BM);
+  args.tiles_n = ceil_div(a.N, BN);
+  wsovod::ProfScope prof(slot, s, flops, bytes);
+  hipLaunchKernelGGL(kfn, dim3(args.tiles_m * args.tiles_n), dim3(256), lds_bytes, s, args);
+  WS_CHECK_LAUNCH(slot_name);
+  return WSOVOD_OK;
+}
+
+template <typename T, bool CONV>
+int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, double bytes) {
+  constexpr bool bf = sizeof(T) == 2;
+  switch (tile) {
+    case 128128:
+      return launch<T, 128, 128, CONV>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x128" : "conv_igemm_f32_128x128")
+                                                 : (bf ? "gemm_nt_bf16_128x128" : "gemm_nt_f32_128x128"),
+                                       flops, bytes);
+    case 128064:
+      return launch<T, 128, 64, CONV>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x64" : "conv_igemm_f32_128x64")
+                                                : (bf ? "gemm_nt_bf16_128x64" : "gemm_nt_f32_128x64"),
+                                      flops, bytes);
+    case 64128:
+      return launch<T, 64, 128, CONV>(a, s, CONV ? (bf ? "conv_igemm_bf16_64x128" : "conv_igemm_f32_64x128")
+                                                : (bf ? "gemm_nt_bf16_64x128" : "gemm_nt_f32_64x128"),
+                                      flops, bytes);
+    case 64064:
+      return launch<T, 64, 64, CONV>(a, s, CONV ? (bf ? "conv_igemm_bf16_64x64" : "conv_igemm_f32_64x64")
+                                               : (bf ? "gemm_nt_bf16_64x64" : "gemm_nt_f32_64x64"),
+                                     flops, bytes);
+    default:
+      wsovod::set_error("wsovod_gemm_nt: unknown tile_hint %d", tile);
+      return WSOVOD_ERR_INVALID_ARGUMENT;
+  }
+}
+
+// Pick the largest tile that still gives the 256 CUs >= ~2 workgroups each; fall back to
+// the smallest tile (most workgroups) for small problems.
+int auto_tile(int M, int N) {
+  const int cands[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+  for (int c = 0; c < 4; ++c) {
+    const int bm = cands[c][0], bn = cands[c][1];
+    if (N <= 64 && bn == 128) continue;
+    if (M <= 64 && bm == 128) continue;
+    const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn);
+    if (tiles >= 512) return bm * 1000 + bn;
+  }
+  if (N <= 64 && M > 64) {
+    // few columns: keep rows big only if that still fills the chip
+    return (long long)ceil_div(M, 128) >= 256 ? 128064 : 64064;
+  }
+  return 64064;
+}
+
+}  // namespace
+
+extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream) {
+  WS_CHECK_ARG(d != nullptr, "wsovod_gemm_nt: null descriptor");
+  WS_CHECK_ARG(d->dtype_in == WSOVOD_F32 || d->dtype_in == WSOVOD_BF16, "wsovod_gemm_nt: bad dtype_in %d", d->dtype_in);
+  WS_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "wsovod_gemm_nt: negative dimension");
+  if (d->M == 0 || d->N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(d->A && d->B, "wsovod_gemm_nt: null operand");
+  WS_CHECK_ARG(d->C || d->Ct, "wsovod_gemm_nt: no output");
+  const int esz = d->dtype_in == WSOVOD_BF16 ? 2 : 4;
+  const int epc = 16 / esz;
+  WS_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "wsovod_gemm_nt: A/B must be 16-byte aligned");
+  WS_CHECK_ARG(d->ldb % epc == 0, "wsovod_gemm_nt: ldb=%lld must be a multiple of %d elements", d->ldb, epc);
+  WS_CHECK_ARG(d->K % epc == 0, "wsovod_gemm_nt: K=%d must be a multiple of %d elements", d->K, epc);
+  WS_CHECK_ARG(!d->accumulate || (d->C && d->dtype_c == WSOVOD_F32), "wsovod_gemm_nt: accumulate needs an fp32 C");
+  WS_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "wsovod_gemm_nt: dropout_p must be in [0,1)");
+  WS_CHECK_ARG(!d->group_add || d->row_group, "wsovod_gemm_nt: group_add needs row_group");
+
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = (const char*)d->A;
+  a.B = (const char*)d->B;
+  a.lda = d->lda;
+  a.ldb = d->ldb;
+  a.M = d->M;
+  a.N = d->N;
+  a.K = d->K;
+  a.C = d->C;
+  a.ldc = d->ldc;
+  a.dtype_c = d->dtype_c;
+  a.Ct = d->Ct;
+  a.ldct = d->ldct;
+  a.dtype_ct = d->dtype_ct;
+  a.alpha = d->alpha;
+  a.row_scale = d->row_scale;
+  a.bias = d->bias;
+  a.residual = d->residual;
+  a.ldr = d->ldr;
+  a.dtype_r = d->dtype_r;
+  a.relu = d->relu;
+  a.dropout_p = d->dropout_p;
+  a.seed = d->dropout_seed;
+  a.row_group = d->row_group;
+  a.group_add = d->group_add;
+  a.ld_ga = d->ld_ga;
+  a.mask_src = d->mask_src;
+  a.ldm = d->ldm;
+  a.dtype_m = d->dtype_m;
+  a.mask_scale = d->mask_scale;
+  a.accumulate = d->accumulate;
+
+  double bytes;
+  if (d->conv) {
+    const wsovod_conv_geom& g = d->geom;
+    const int bke = d->dtype_in == WSOVOD_BF16 ? 64 : 32;
+    WS_CHECK_ARG(g.Cin > 0 && g.Cin % bke == 0, "wsovod_gemm_nt(conv): Cin=%d must be a multiple of %d", g.Cin, bke);
+    WS_CHECK_ARG(d->K == g.KH * g.KW * g.Cin, "wsovod_gemm_nt(conv): K=%d != KH*KW*Cin", d->K);
+    WS_CHECK_ARG((long long)d->M == (long long)g.n_img * g.Ho * g.Wo, "wsovod_gemm_nt(conv): M=%d != n_img*Ho*Wo", d->M);
+    WS_CHECK_ARG(g.stride >= 1 && g.dil >= 1 && g.pad >= 0, "wsovod_gemm_nt(conv): bad stride/dil/pad");
+    a.H = g.H;
+    a.W = g.W;
+    a.Cin = g.Cin;
+    a.Ho = g.Ho;
+    a.Wo = g.Wo;
+    a.KH = g.KH;
+    a.KW = g.KW;
+    a.stride = g.stride;
+    a.pad = g.pad;
+    a.dil = g.dil;
+    bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K) * esz;
+  } else {
+    WS_CHECK_ARG(d->lda % epc == 0, "wsovod_gemm_nt: lda=%lld must be a multiple of %d elements", d->lda, epc);
+    bytes = ((double)d->M * d->K + (double)d->N * d->K) * esz;
+  }
+  bytes += (double)d->M * d->N * ((d->C ? (d->dtype_c == WSOVOD_BF16 ? 2 : 4) : 0) + (d->Ct ? (d->dtype_ct == WSOVOD_BF16 ? 2 : 4) : 0));
+  const double flops = 2.0 * d->M * d->N * d->K;
+  const int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->dtype_in == WSOVOD_BF16)
+    return d->conv ? dispatch_tile<bf16_t, true>(a, tile, s, flops, bytes) : dispatch_tile<bf16_t, false>(a, tile, s, flops, bytes);
+  return d->conv ? dispatch_tile<float, true>(a, tile, s, flops, bytes) : dispatch_tile<float, false>(a, tile, s, flops, bytes);
+}

@@ -1,0 +1,514 @@
+// RoI max pooling and ROIAlign over precomputed (SAM) proposals.
+//
+// Replaces torchvision.ops.RoIPool / detectron2.layers.ROIAlign as dispatched by
+// wsovod/modeling/poolers.py:169-197,284 and the reference's own native op
+// (wsovod/layers/ROILoopPool/ROILoopPool_cpu.cpp:13-123 is the algorithm restated here).
+//
+// NHWC kernels (the fast path, fed by the HIP backbone): one WAVEFRONT owns one
+// (roi, 64-channel group).  Lane = channel, so every feature read is one coalesced
+// 256-B (fp32) / 128-B (bf16) wave access; the 49 bin results per lane are transposed
+// through a per-wavefront LDS tile ([64][49], stride 49 words = conflict-free) and leave
+// as one contiguous, 16-B-per-lane coalesced run of the reference's (R,C,7,7) output.
+// NCHW kernels (the reference's layout, kept for drop-in use): one thread per output bin.
+//
+// All bin/index arithmetic is fp32 + int32 exactly as the reference writes it
+// (round half away from zero, floor/ceil of fp32 products), so argmax is bit-exact.
+#include <float.h>
+
+#include "common.h"
+
+namespace {
+
+struct RoiBox {
+  int batch, start_w, start_h, roi_w, roi_h;
+  float bin_h, bin_w;
+};
+
+// ROILoopPool_cpu.cpp:27-39
+__device__ __forceinline__ RoiBox decode_roi(const float* roi, float spatial_scale, int ph, int pw) {
+  RoiBox b;
+  b.batch = (int)roi[0];
+  b.start_w = (int)roundf(roi[1] * spatial_scale);
+  b.start_h = (int)roundf(roi[2] * spatial_scale);
+  const int end_w = (int)roundf(roi[3] * spatial_scale);
+  const int end_h = (int)roundf(roi[4] * spatial_scale);
+  b.roi_w = max(end_w - b.start_w + 1, 1);
+  b.roi_h = max(end_h - b.start_h + 1, 1);
+  b.bin_h = (float)b.roi_h / (float)ph;
+  b.bin_w = (float)b.roi_w / (float)pw;
+  return b;
+}
+
+// ROILoopPool_cpu.cpp:41-51
+__device__ __forceinline__ void bin_window(const RoiBox& b, int ph, int pw, int H, int W, int& hs, int& he,
+                                           int& ws, int& we) {
+  hs = (int)floorf((float)ph * b.bin_h);
+  ws = (int)floorf((float)pw * b.bin_w);
+  he = (int)ceilf((float)(ph + 1) * b.bin_h);
+  we = (int)ceilf((float)(pw + 1) * b.bin_w);
+  hs = min(max(hs + b.start_h, 0), H);
+  he = min(max(he + b.start_h, 0), H);
+  ws = min(max(ws + b.start_w, 0), W);
+  we = min(max(we + b.start_w, 0), W);
+}
+
+// ---------------------------------------------------------------------------------
+// RoIPool forward, NHWC: wavefront per (roi, 64 channels)
+// ---------------------------------------------------------------------------------
+template <typename T, bool ARGMAX>
+__global__ __launch_bounds__(256) void roi_pool_fwd_nhwc(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                         const float* __restrict__ roi_scale, int R, int C, int H,
+                                                         int W, int PH, int PW, float spatial_scale, void* out,
+                                                         int out_dtype, int* __restrict__ argmax, int cgroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbins = PH * PW;
+  const int per_wave_words = 64 * nbins * (ARGMAX ? 2 : 1);
+  float* sval = (float*)smem + wave * per_wave_words;
+  int* sarg = (int*)(sval + 64 * nbins);
+  const long long item = (long long)blockIdx.x * 4 + wave;
+  if (item >= (long long)R * cgroups) return;  // whole wavefront exits together
+  const int r = (int)(item / cgroups);
+  const int c0 = (int)(item % cgroups) * 64;
+  const int c = c0 + lane;
+  const bool c_ok = c < C;
+  const RoiBox b = decode_roi(rois + (long long)r * 5, spatial_scale, PH, PW);
+  const float scale = roi_scale ? roi_scale[r] : 1.0f;
+  const T* base = feat + (long long)b.batch * H * W * C + (c_ok ? c : 0);
+  for (int ph = 0; ph < PH; ++ph) {
+    for (int pw = 0; pw < PW; ++pw) {
+      int hs, he, ws, we;
+      bin_window(b, ph, pw, H, W, hs, he, ws, we);
+      const bool empty = (he <= hs) || (we <= ws);
+      float maxval = empty ? 0.f : -FLT_MAX;
+      int maxidx = -1;
+      for (int h = hs; h < he; ++h) {
+        const T* row = base + (long long)h * W * C;
+        for (int w = ws; w < we; ++w) {
+          const float v = to_f32(row[(long long)w * C]);
+          if (v > maxval) {
+            maxval = v;
+            maxidx = h * W + w;
+          }
+        }
+      }
+      const int bin = ph * PW + pw;
+      sval[lane * nbins + bin] = roi_scale ? maxval * scale : maxval;
+      if (ARGMAX) sarg[lane * nbins + bin] = maxidx;
+    }
+  }
+  // wavefront-private LDS tile: no barrier needed beyond the wave's own ordering
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nvalid = min(64, C - c0) * nbins;
+  const long long obase = ((long long)r * C + c0) * nbins;
+  if (out_dtype == WSOVOD_F32) {
+    float* o = (float*)out + obase;
+    if ((nvalid & 3) == 0 && (obase & 3) == 0) {
+      for (int i = lane * 4; i < nvalid; i += 256) *(float4*)(o + i) = *(const float4*)(sval + i);
+    } else {
+      for (int i = lane; i < nvalid; i += 64) o[i] = sval[i];
+    }
+  } else {
+    bf16_t* o = (bf16_t*)out + obase;
+    if ((nvalid & 3) == 0 && (obase & 3) == 0) {
+      for (int i = lane * 4; i < nvalid; i += 256) {
+        const float4 v = *(const float4*)(sval + i);
+        bf16x4 pk = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+        *(bf16x4*)(o + i) = pk;
+      }
+    } else {
+      for (int i = lane; i < nvalid; i += 64) o[i] = (bf16_t)sval[i];
+    }
+  }
+  if (ARGMAX) {
+    int* o = argmax + obase;
+    if ((nvalid & 3) == 0 && (obase & 3) == 0) {
+      for (int i = lane * 4; i < nvalid; i += 256) *(int4*)(o + i) = *(const int4*)(sarg + i);
+    } else {
+      for (int i = lane; i < nvalid; i += 64) o[i] = sarg[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// RoIPool forward, NCHW: thread per output bin (grid-stride)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_fwd_nchw(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                         const float* __restrict__ roi_scale, long long total, int C,
+                                                         int H, int W, int PH, int PW, float spatial_scale, void* out,
+                                                         int out_dtype, int* __restrict__ argmax) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % PW);
+    const int ph = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long long)PW * PH)) % C);
+    const int r = (int)(idx / ((long long)PW * PH * C));
+    const RoiBox b = decode_roi(rois + (long long)r * 5, spatial_scale, PH, PW);
+    int hs, he, ws, we;
+    bin_window(b, ph, pw, H, W, hs, he, ws, we);
+    const bool empty = (he <= hs) || (we <= ws);
+    float maxval = empty ? 0.f : -FLT_MAX;
+    int maxidx = -1;
+    const T* plane = feat + ((long long)b.batch * C + c) * H * W;
+    for (int h = hs; h < he; ++h)
+      for (int w = ws; w < we; ++w) {
+        const float v = to_f32(plane[h * W + w]);
+        if (v > maxval) {
+          maxval = v;
+          maxidx = h * W + w;
+        }
+      }
+    if (roi_scale) maxval *= roi_scale[r];
+    if (out_dtype == WSOVOD_F32)
+      ((float*)out)[idx] = maxval;
+    else
+      ((bf16_t*)out)[idx] = (bf16_t)maxval;
+    if (argmax) argmax[idx] = maxidx;
+  }
+}
+
+// RoIPool backward: scatter-add through argmax (ROILoopPool_cpu.cpp:82-123).
+__global__ __launch_bounds__(256) void roi_pool_bwd(const float* __restrict__ grad_out, const float* __restrict__ rois,
+                                                    const float* __restrict__ roi_scale,
+                                                    const int* __restrict__ argmax, long long total, int C, int H,
+                                                    int W, int PH, int PW, int nhwc, float* grad_in) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int am = argmax[idx];
+    if (am < 0) continue;
+    const int c = (int)((idx / ((long long)PW * PH)) % C);
+    const int r = (int)(idx / ((long long)PW * PH * C));
+    const int n = (int)rois[(long long)r * 5];
+    float g = grad_out[idx];
+    if (roi_scale) g *= roi_scale[r];
+    const long long off = nhwc ? ((long long)n * H * W + am) * C + c : ((long long)n * C + c) * H * W + am;
+    atomicAdd(grad_in + off, g);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// ROIAlign (torchvision roi_align semantics; detectron2 ROIAlign(aligned=...))
+// ---------------------------------------------------------------------------------
+struct AlignBox {
+  int batch;
+  float start_w, start_h, bin_h, bin_w;
+  int grid_h, grid_w;
+  float inv_count;
+};
+__device__ __forceinline__ AlignBox decode_align(const float* roi, float spatial_scale, int PH, int PW,
+                                                 int sampling_ratio, int aligned) {
+  AlignBox a;
+  a.batch = (int)roi[0];
+  const float offset = aligned ? 0.5f : 0.0f;
+  a.start_w = roi[1] * spatial_scale - offset;
+  a.start_h = roi[2] * spatial_scale - offset;
+  const float end_w = roi[3] * spatial_scale - offset;
+  const float end_h = roi[4] * spatial_scale - offset;
+  float rw = end_w - a.start_w, rh = end_h - a.start_h;
+  if (!aligned) {
+    rw = fmaxf(rw, 1.f);
+    rh = fmaxf(rh, 1.f);
+  }
+  a.bin_h = rh / (float)PH;
+  a.bin_w = rw / (float)PW;
+  a.grid_h = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rh / (float)PH);
+  a.grid_w = sampling_ratio > 0 ? sampling_ratio : (int)ceilf(rw / (float)PW);
+  a.inv_count = 1.0f / (float)max(a.grid_h * a.grid_w, 1);
+  return a;
+}
+struct Bilinear {
+  int yl, yh, xl, xh;
+  float w1, w2, w3, w4;
+  bool valid;
+};
+__device__ __forceinline__ Bilinear bilinear_setup(float y, float x, int H, int W) {
+  Bilinear s;
+  s.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  s.yl = (int)y;
+  s.xl = (int)x;
+  if (s.yl >= H - 1) {
+    s.yh = s.yl = H - 1;
+    y = (float)s.yl;
+  } else {
+    s.yh = s.yl + 1;
+  }
+  if (s.xl >= W - 1) {
+    s.xh = s.xl = W - 1;
+    x = (float)s.xl;
+  } else {
+    s.xh = s.xl + 1;
+  }
+  const float ly = y - (float)s.yl, lx = x - (float)s.xl;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  s.w1 = hy * hx;
+  s.w2 = hy * lx;
+  s.w3 = ly * hx;
+  s.w4 = ly * lx;
+  return s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                          const float* __restrict__ roi_scale, int R, int C, int H,
+                                                          int W, int PH, int PW, float spatial_scale,
+                                                          int sampling_ratio, int aligned, void* out, int out_dtype,
+                                                          int cgroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nbins = PH * PW;
+  float* sval = (float*)smem + wave * 64 * nbins;
+  const long long item = (long long)blockIdx.x * 4 + wave;
+  if (item >= (long long)R * cgroups) return;
+  const int r = (int)(item / cgroups);
+  const int c0 = (int)(item % cgroups) * 64;
+  const int c = c0 + lane;
+  const bool c_ok = c < C;
+  const AlignBox a = decode_align(rois + (long long)r * 5, spatial_scale, PH, PW, sampling_ratio, aligned);
+  const float scale = roi_scale ? roi_scale[r] : 1.0f;
+  const T* base = feat + (long long)a.batch * H * W * C + (c_ok ? c : 0);
+  for (int ph = 0; ph < PH; ++ph)
+    for (int pw = 0; pw < PW; ++pw) {
+      float acc = 0.f;
+      for (int iy = 0; iy < a.grid_h; ++iy) {
+        const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
+        for (int ix = 0; ix < a.grid_w; ++ix) {
+          const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+          const Bilinear s = bilinear_setup(y, x, H, W);
+          if (!s.valid) continue;
+          const float v1 = to_f32(base[((long long)s.yl * W + s.xl) * C]);
+          const float v2 = to_f32(base[((long long)s.yl * W + s.xh) * C]);
+          const float v3 = to_f32(base[((long long)s.yh * W + s.xl) * C]);
+          const float v4 = to_f32(base[((long long)s.yh * W + s.xh) * C]);
+          acc += s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4;
+        }
+      }
+      acc *= a.inv_count;
+      sval[lane * nbins + ph * PW + pw] = roi_scale ? acc * scale : acc;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int nvalid = min(64, C - c0) * nbins;
+  const long long obase = ((long long)r * C + c0) * nbins;
+  if (out_dtype == WSOVOD_F32) {
+    float* o = (float*)out + obase;
+    for (int i = lane; i < nvalid; i += 64) o[i] = sval[i];
+  } else {
+    bf16_t* o = (bf16_t*)out + obase;
+    for (int i = lane; i < nvalid; i += 64) o[i] = (bf16_t)sval[i];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void roi_align_fwd_nchw(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                          const float* __restrict__ roi_scale, long long total, int C,
+                                                          int H, int W, int PH, int PW, float spatial_scale,
+                                                          int sampling_ratio, int aligned, void* out, int out_dtype) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % PW);
+    const int ph = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long long)PW * PH)) % C);
+    const int r = (int)(idx / ((long long)PW * PH * C));
+    const AlignBox a = decode_align(rois + (long long)r * 5, spatial_scale, PH, PW, sampling_ratio, aligned);
+    const T* plane = feat + ((long long)a.batch * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < a.grid_h; ++iy) {
+      const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
+      for (int ix = 0; ix < a.grid_w; ++ix) {
+        const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+        const Bilinear s = bilinear_setup(y, x, H, W);
+        if (!s.valid) continue;
+        acc += s.w1 * to_f32(plane[s.yl * W + s.xl]) + s.w2 * to_f32(plane[s.yl * W + s.xh]) +
+               s.w3 * to_f32(plane[s.yh * W + s.xl]) + s.w4 * to_f32(plane[s.yh * W + s.xh]);
+      }
+    }
+    acc *= a.inv_count;
+    if (roi_scale) acc *= roi_scale[r];
+    if (out_dtype == WSOVOD_F32)
+      ((float*)out)[idx] = acc;
+    else
+      ((bf16_t*)out)[idx] = (bf16_t)acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void roi_align_bwd(const float* __restrict__ grad_out,
+                                                     const float* __restrict__ rois,
+                                                     const float* __restrict__ roi_scale, long long total, int C,
+                                                     int H, int W, int PH, int PW, float spatial_scale,
+                                                     int sampling_ratio, int aligned, int nhwc, float* grad_in) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % PW);
+    const int ph = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long long)PW * PH)) % C);
+    const int r = (int)(idx / ((long long)PW * PH * C));
+    const AlignBox a = decode_align(rois + (long long)r * 5, spatial_scale, PH, PW, sampling_ratio, aligned);
+    float g = grad_out[idx] * a.inv_count;
+    if (roi_scale) g *= roi_scale[r];
+    for (int iy = 0; iy < a.grid_h; ++iy) {
+      const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
+      for (int ix = 0; ix < a.grid_w; ++ix) {
+        const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+        const Bilinear s = bilinear_setup(y, x, H, W);
+        if (!s.valid) continue;
+        auto off = [&](int yy, int xx) -> long long {
+          return nhwc ? (((long long)a.batch * H + yy) * W + xx) * C + c
+                      : (((long long)a.batch * C + c) * H + yy) * W + xx;
+        };
+        atomicAdd(grad_in + off(s.yl, s.xl), g * s.w1);
+        atomicAdd(grad_in + off(s.yl, s.xh), g * s.w2);
+        atomicAdd(grad_in + off(s.yh, s.xl), g * s.w3);
+        atomicAdd(grad_in + off(s.yh, s.xh), g * s.w4);
+      }
+    }
+  }
+}
+
+int check_common(const char* fn, const void* feat, int dtype, int layout, const float* rois, int R, int N, int C,
+                 int H, int W, int ph, int pw, const void* out) {
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "%s: bad dtype %d", fn, dtype);
+  WS_CHECK_ARG(layout == WSOVOD_NCHW || layout == WSOVOD_NHWC, "%s: bad layout %d", fn, layout);
+  WS_CHECK_ARG(R >= 0 && N >= 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0, "%s: bad shape", fn);
+  WS_CHECK_ARG((long long)H * W < (1ll << 31), "%s: H*W overflows int32 argmax", fn);
+  if (R > 0) WS_CHECK_ARG(feat && rois && out, "%s: null pointer", fn);
+  return WSOVOD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                            int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,
+                            int out_dtype, int* argmax, wsovod_stream_t stream) {
+  int rc = check_common("wsovod_roi_pool_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
+  if (rc) return rc;
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16, "wsovod_roi_pool_forward: bad out_dtype");
+  if (R == 0) return WSOVOD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = dtype == WSOVOD_BF16 ? 2 : 4, osz = out_dtype == WSOVOD_BF16 ? 2 : 4;
+  const double out_elems = (double)R * C * ph * pw;
+  // algorithmic bytes: every feature element once + outputs (+argmax) + rois
+  const double bytes = (double)N * C * H * W * esz + out_elems * (osz + (argmax ? 4 : 0)) + 20.0 * R;
+  if (layout == WSOVOD_NHWC) {
+    static int slot = wsovod::prof_slot("roi_pool_fwd_nhwc");
+    const int cgroups = ceil_div(C, 64);
+    const long long items = (long long)R * cgroups;
+    const int grid = (int)ceil_div_ll(items, 4);
+    const int lds = 4 * 64 * ph * pw * 4 * (argmax ? 2 : 1);
+    WS_CHECK_ARG(lds <= 160 * 1024, "wsovod_roi_pool_forward: pooled size %dx%d too large for LDS tile", ph, pw);
+    wsovod::ProfScope prof(slot, s, 0.0, bytes);
+#define LAUNCH_POOL(T, AM)                                                                                        \
+  do {                                                                                                            \
+    auto k = roi_pool_fwd_nhwc<T, AM>;                                                                            \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)feat, rois, roi_scale, R, C, H, W, ph, pw,      \
+                       spatial_scale, out, out_dtype, argmax, cgroups);                                           \
+  } while (0)
+    if (dtype == WSOVOD_BF16) {
+      if (argmax) LAUNCH_POOL(bf16_t, true); else LAUNCH_POOL(bf16_t, false);
+    } else {
+      if (argmax) LAUNCH_POOL(float, true); else LAUNCH_POOL(float, false);
+    }
+#undef LAUNCH_POOL
+  } else {
+    static int slot = wsovod::prof_slot("roi_pool_fwd_nchw");
+    const long long total = (long long)R * C * ph * pw;
+    const int grid = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
+    wsovod::ProfScope prof(slot, s, 0.0, bytes);
+    if (dtype == WSOVOD_BF16)
+      hipLaunchKernelGGL(roi_pool_fwd_nchw<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois, roi_scale,
+                         total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax);
+    else
+      hipLaunchKernelGGL(roi_pool_fwd_nchw<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, roi_scale,
+                         total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax);
+  }
+  WS_CHECK_LAUNCH("wsovod_roi_pool_forward");
+  return WSOVOD_OK;
+}
+
+int wsovod_roi_pool_backward(const float* grad_out, const float* rois, const float* roi_scale, const int* argmax, int R,
+                             int N, int C, int H, int W, int ph, int pw, int layout, float* grad_in,
+                             wsovod_stream_t stream) {
+  WS_CHECK_ARG(layout == WSOVOD_NCHW || layout == WSOVOD_NHWC, "wsovod_roi_pool_backward: bad layout");
+  WS_CHECK_ARG(R >= 0 && N >= 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0, "wsovod_roi_pool_backward: bad shape");
+  if (R == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(grad_out && rois && argmax && grad_in, "wsovod_roi_pool_backward: null pointer");
+  static int slot = wsovod::prof_slot("roi_pool_bwd");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)R * C * ph * pw;
+  const int grid = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)total * 12.0);
+  hipLaunchKernelGGL(roi_pool_bwd, dim3(grid), dim3(256), 0, s, grad_out, rois, roi_scale, argmax, total, C, H, W, ph,
+                     pw, layout == WSOVOD_NHWC ? 1 : 0, grad_in);
+  WS_CHECK_LAUNCH("wsovod_roi_pool_backward");
+  return WSOVOD_OK;
+}
+
+int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                             int N, int C, int H, int W, int ph, int pw, float spatial_scale, int sampling_ratio,
+                             int aligned, void* out, int out_dtype, wsovod_stream_t stream) {
+  int rc = check_common("wsovod_roi_align_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
+  if (rc) return rc;
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16, "wsovod_roi_align_forward: bad out_dtype");
+  if (R == 0) return WSOVOD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = dtype == WSOVOD_BF16 ? 2 : 4, osz = out_dtype == WSOVOD_BF16 ? 2 : 4;
+  const double bytes = (double)N * C * H * W * esz + (double)R * C * ph * pw * osz + 20.0 * R;
+  if (layout == WSOVOD_NHWC) {
+    static int slot = wsovod::prof_slot("roi_align_fwd_nhwc");
+    const int cgroups = ceil_div(C, 64);
+    const int grid = (int)ceil_div_ll((long long)R * cgroups, 4);
+    const int lds = 4 * 64 * ph * pw * 4;
+    WS_CHECK_ARG(lds <= 160 * 1024, "wsovod_roi_align_forward: pooled size too large for LDS tile");
+    wsovod::ProfScope prof(slot, s, 0.0, bytes);
+    if (dtype == WSOVOD_BF16) {
+      auto k = roi_align_fwd_nhwc<bf16_t>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const bf16_t*)feat, rois, roi_scale, R, C, H, W, ph, pw,
+                         spatial_scale, sampling_ratio, aligned, out, out_dtype, cgroups);
+    } else {
+      auto k = roi_align_fwd_nhwc<float>;
+      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const float*)feat, rois, roi_scale, R, C, H, W, ph, pw,
+                         spatial_scale, sampling_ratio, aligned, out, out_dtype, cgroups);
+    }
+  } else {
+    static int slot = wsovod::prof_slot("roi_align_fwd_nchw");
+    const long long total = (long long)R * C * ph * pw;
+    const int grid = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
+    wsovod::ProfScope prof(slot, s, 0.0, bytes);
+    if (dtype == WSOVOD_BF16)
+      hipLaunchKernelGGL(roi_align_fwd_nchw<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois,
+                         roi_scale, total, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, out, out_dtype);
+    else
+      hipLaunchKernelGGL(roi_align_fwd_nchw<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, roi_scale,
+                         total, C, H, W, ph, pw, spatial_scale, sampling_ratio, aligned, out, out_dtype);
+  }
+  WS_CHECK_LAUNCH("wsovod_roi_align_forward");
+  return WSOVOD_OK;
+}
+
+int wsovod_roi_align_backward(const float* grad_out, const float* rois, const float* roi_scale, int R, int N, int C,
+                              int H, int W, int ph, int pw, float spatial_scale, int sampling_ratio, int aligned,
+                              int layout, float* grad_in, wsovod_stream_t stream) {
+  WS_CHECK_ARG(layout == WSOVOD_NCHW || layout == WSOVOD_NHWC, "wsovod_roi_align_backward: bad layout");
+  WS_CHECK_ARG(R >= 0 && N >= 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0, "wsovod_roi_align_backward: bad shape");
+  if (R == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(grad_out && rois && grad_in, "wsovod_roi_align_backward: null pointer");
+  static int slot = wsovod::prof_slot("roi_align_bwd");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)R * C * ph * pw;
+  const int grid = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)total * 20.0);
+  hipLaunchKernelGGL(roi_align_bwd, dim3(grid), dim3(256), 0, s, grad_out, rois, roi_scale, total, C, H, W, ph, pw,
+                     spatial_scale, sampling_ratio, aligned, layout == WSOVOD_NHWC ? 1 : 0, grad_in);
+  WS_CHECK_LAUNCH("wsovod_roi_align_backward");
+  return WSOVOD_OK;
+}
+
+}  // extern "C"
