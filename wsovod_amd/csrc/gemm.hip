@@ -53,6 +53,7 @@ struct GemmArgs {
   int accumulate;
   // implicit-GEMM convolution geometry
   int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
+  long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
   int tiles_m, tiles_n;
 };
 
@@ -121,43 +122,55 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int lrow = tid >> 3, lchunk = tid & 7;
 
-  // ---- per-thread loader state
-  const char* a_ptr[RA];
-  bool a_ok[RA];
+  // ---- per-thread loader state.  All global reads are raw buffer loads: a lane whose row
+  // or K-chunk is out of range gets voffset = -1, which the hardware range check turns into
+  // zeros -- no select on the loaded data, so the loads stay in flight under the MFMAs.
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const int esz = (int)sizeof(T);
+  __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  int a_off[RA];  // byte offset of this lane's chunk at k = 0 (plain) / of the image (conv); <0 = invalid row
   int hi0[RA], wi0[RA];
+  if (CONV) {
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  } else {
+    const long long rows = min(BM, p.M - m0);
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * esz), 0,
+                                              (int)(rows * p.lda * esz), 0x00020000);
+  }
+  {
+    const long long rows = min(BN, p.N - n0);
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n0 * p.ldb * esz), 0,
+                                              (int)(rows * p.ldb * esz), 0x00020000);
+  }
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     const int m = m0 + lrow + 32 * i;
-    a_ok[i] = m < p.M;
+    const bool ok = m < p.M;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
-      const int mm = a_ok[i] ? m : 0;
+      const int mm = ok ? m : 0;
       const int img = mm / hw;
       const int rem = mm - img * hw;
       const int ho = rem / p.Wo;
       const int wo = rem - ho * p.Wo;
-      hi0[i] = ho * p.stride - p.pad;
+      hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);  // invalid row: every tap falls outside
       wi0[i] = wo * p.stride - p.pad;
-      a_ptr[i] = p.A + ((long long)img * p.H * p.W * p.Cin + lchunk * EPC) * (long long)sizeof(T);
+      a_off[i] = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
     } else {
       hi0[i] = wi0[i] = 0;
-      a_ptr[i] = p.A + ((long long)(a_ok[i] ? m : 0) * p.lda + lchunk * EPC) * (long long)sizeof(T);
+      a_off[i] = ok ? (int)(((long long)(lrow + 32 * i) * p.lda + lchunk * EPC) * esz) : -1;
     }
   }
-  const char* b_ptr[RB];
-  bool b_ok[RB];
+  int b_off[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
     const int n = n0 + lrow + 32 * i;
-    b_ok[i] = n < p.N;
-    b_ptr[i] = p.B + ((long long)(b_ok[i] ? n : 0) * p.ldb + lchunk * EPC) * (long long)sizeof(T);
+    b_off[i] = n < p.N ? (int)(((long long)(lrow + 32 * i) * p.ldb + lchunk * EPC) * esz) : -1;
   }
 
   const int nk = (p.K + BKE - 1) / BKE;
-  uint4 ra[RA], rb[RB];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-  auto load_global = [&](int kt) {
+  auto load_global = [&](int kt, u32x4 (&ra)[RA], u32x4 (&rb)[RB]) {
     const int kbase = kt * BKE;
     const bool k_ok = kbase + lchunk * EPC < p.K;
     if (CONV) {
@@ -170,26 +183,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       for (int i = 0; i < RA; ++i) {
         const int hi = hi0[i] + r * p.dil;
         const int wi = wi0[i] + q * p.dil;
-        const bool ok = a_ok[i] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        const long long off = ((long long)(hi * p.W + wi) * p.Cin + c0) * (long long)sizeof(T);
-        ra[i] = ok ? *(const uint4*)(a_ptr[i] + off) : zero4;
+        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + c0) * esz;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, ok ? off : -1, 0, 0);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
-        ra[i] = (a_ok[i] && k_ok) ? *(const uint4*)(a_ptr[i] + (long long)kbase * sizeof(T)) : zero4;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (k_ok && a_off[i] >= 0) ? a_off[i] + kbase * esz : -1, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i)
-      rb[i] = (b_ok[i] && k_ok) ? *(const uint4*)(b_ptr[i] + (long long)kbase * sizeof(T)) : zero4;
+      rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (k_ok && b_off[i] >= 0) ? b_off[i] + kbase * esz : -1, 0, 0);
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, const u32x4 (&ra)[RA], const u32x4 (&rb)[RB]) {
     char* dA = sA + buf * BM * 128;
     char* dB = sB + buf * BN * 128;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *(uint4*)(dA + lds_off(lrow + 32 * i, lchunk)) = ra[i];
+    for (int i = 0; i < RA; ++i) *(u32x4*)(dA + lds_off(lrow + 32 * i, lchunk)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *(uint4*)(dB + lds_off(lrow + 32 * i, lchunk)) = rb[i];
+    for (int i = 0; i < RB; ++i) *(u32x4*)(dB + lds_off(lrow + 32 * i, lchunk)) = rb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -198,14 +211,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_global(0);
-  store_lds(0);
-  __syncthreads();
-
   const int frow = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_global(kt + 1);  // in flight under the MFMAs below
+  auto compute = [&](int cur) {
     const char* cA = sA + cur * BM * 128 + (wm * (BM / 2)) * 128;
     const char* cB = sB + cur * BN * 128 + (wn * (BN / 2)) * 128;
 #pragma unroll
@@ -214,13 +221,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       uint4 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int row = i * 16 + frow;  // (wm*(BM/2)) is a multiple of 16: swizzle unchanged
-        af[i] = *(const uint4*)(cA + row * 128 + ((chunk ^ (((row + wm * (BM / 2)) >> 1) & 7)) << 4));
+        const int row = i * 16 + frow;  // wm*(BM/2) is a multiple of 16: the swizzle term is unchanged
+        af[i] = *(const uint4*)(cA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = j * 16 + frow;
-        bfr[j] = *(const uint4*)(cB + row * 128 + ((chunk ^ (((row + wn * (BN / 2)) >> 1) & 7)) << 4));
+        bfr[j] = *(const uint4*)(cB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -240,7 +247,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
                   __builtin_bit_cast(f32x4, af[i])[e], __builtin_bit_cast(f32x4, bfr[j])[e], acc[i][j], 0, 0, 0);
       }
     }
-    if (kt + 1 < nk) store_lds(cur ^ 1);
+  };
+
+  // ---- software pipeline: two K-steps of global loads in flight (register sets 0/1),
+  // LDS double buffered, one barrier per K-step.
+  u32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+  load_global(0, ra0, rb0);
+  if (nk > 1) load_global(1, ra1, rb1);
+  store_lds(0, ra0, rb0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even step: LDS[0] holds kt, set1 holds kt+1 (in flight), set0 is free
+    if (kt + 2 < nk) load_global(kt + 2, ra0, rb0);
+    compute(0);
+    if (kt + 1 < nk) store_lds(1, ra1, rb1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    // odd step: LDS[1] holds kt+1, set0 holds kt+2 (in flight), set1 is free
+    if (kt + 3 < nk) load_global(kt + 3, ra1, rb1);
+    compute(1);
+    if (kt + 2 < nk) store_lds(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -363,6 +389,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   const int epc = 16 / esz;
   WS_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "wsovod_gemm_nt: A/B must be 16-byte aligned");
   WS_CHECK_ARG(d->ldb % epc == 0, "wsovod_gemm_nt: ldb=%lld must be a multiple of %d elements", d->ldb, epc);
+  WS_CHECK_ARG(128ll * d->ldb * esz < (1ll << 31), "wsovod_gemm_nt: ldb too large for buffer addressing");
   WS_CHECK_ARG(d->K % epc == 0, "wsovod_gemm_nt: K=%d must be a multiple of %d elements", d->K, epc);
   WS_CHECK_ARG(!d->accumulate || (d->C && d->dtype_c == WSOVOD_F32), "wsovod_gemm_nt: accumulate needs an fp32 C");
   WS_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "wsovod_gemm_nt: dropout_p must be in [0,1)");
@@ -419,9 +446,12 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     a.stride = g.stride;
     a.pad = g.pad;
     a.dil = g.dil;
+    a.a_bytes = (long long)g.n_img * g.H * g.W * g.Cin * esz;
+    WS_CHECK_ARG(a.a_bytes < (1ll << 31), "wsovod_gemm_nt(conv): input of %lld bytes exceeds the 2 GiB buffer-addressing limit", a.a_bytes);
     bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K) * esz;
   } else {
     WS_CHECK_ARG(d->lda % epc == 0, "wsovod_gemm_nt: lda=%lld must be a multiple of %d elements", d->lda, epc);
+    WS_CHECK_ARG(128ll * d->lda * esz < (1ll << 31), "wsovod_gemm_nt: lda too large for buffer addressing");
     bytes = ((double)d->M * d->K + (double)d->N * d->K) * esz;
   }
   bytes += (double)d->M * d->N * ((d->C ? (d->dtype_c == WSOVOD_BF16 ? 2 : 4) : 0) + (d->Ct ? (d->dtype_ct == WSOVOD_BF16 ? 2 : 4) : 0));

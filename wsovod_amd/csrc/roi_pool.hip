@@ -132,13 +132,104 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nhwc(const T* __restrict__ f
 }
 
 // ---------------------------------------------------------------------------------
+// RoIPool forward, NHWC, pooled width PWT (7 on every shipped config): one WORKGROUP per
+// (roi, 64-channel group), one wavefront per pooled row ph.  The PWT bins of the row are
+// scanned together: each inner iteration issues PWT independent coalesced loads (one per
+// bin) before any compare, so a wavefront keeps PWT loads in flight instead of one.  The
+// scan order inside every bin is still (h ascending, w ascending) with a strict '>' --
+// the reference's first-maximum argmax semantics (ROILoopPool_cpu.cpp:63-71).
+// ---------------------------------------------------------------------------------
+template <typename T, bool ARGMAX, int PWT>
+__global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
+                                       const float* __restrict__ roi_scale, int C, int H, int W, int PH,
+                                       float spatial_scale, void* out, int out_dtype, int* __restrict__ argmax,
+                                       int cgroups) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int nbins = PH * PWT;
+  float* sval = (float*)smem;
+  int* sarg = (int*)(sval + 64 * nbins);
+  const int r = blockIdx.x / cgroups;
+  const int c0 = (blockIdx.x - r * cgroups) * 64;
+  const int c = c0 + lane;
+  const RoiBox b = decode_roi(rois + (long long)r * 5, spatial_scale, PH, PWT);
+  const float scale = roi_scale ? roi_scale[r] : 1.0f;
+  const T* base = feat + (long long)b.batch * H * W * C + (c < C ? c : 0);
+  int hs, he, ws[PWT], we[PWT];
+  float maxv[PWT];
+  int maxi[PWT];
+  int bw = 0;
+#pragma unroll
+  for (int pw = 0; pw < PWT; ++pw) {
+    bin_window(b, ph, pw, H, W, hs, he, ws[pw], we[pw]);
+    const bool empty = (he <= hs) || (we[pw] <= ws[pw]);
+    maxv[pw] = empty ? 0.f : -FLT_MAX;
+    maxi[pw] = -1;
+    bw = max(bw, we[pw] - ws[pw]);
+  }
+  for (int h = hs; h < he; ++h) {
+    const T* row = base + (long long)h * W * C;
+    for (int j = 0; j < bw; ++j) {
+      float v[PWT];
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        const int w = min(ws[pw] + j, W - 1);  // clamped: lanes past the bin load a valid cell and ignore it
+        v[pw] = to_f32(row[(long long)w * C]);
+      }
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        const int w = ws[pw] + j;
+        if (w < we[pw] && v[pw] > maxv[pw]) {
+          maxv[pw] = v[pw];
+          maxi[pw] = h * W + w;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int pw = 0; pw < PWT; ++pw) {
+    sval[lane * nbins + ph * PWT + pw] = roi_scale ? maxv[pw] * scale : maxv[pw];
+    if (ARGMAX) sarg[lane * nbins + ph * PWT + pw] = maxi[pw];
+  }
+  __syncthreads();
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int nvalid = min(64, C - c0) * nbins;
+  const long long obase = ((long long)r * C + c0) * nbins;
+  const bool vec = (nvalid & 3) == 0 && (obase & 3) == 0;
+  if (out_dtype == WSOVOD_F32) {
+    float* o = (float*)out + obase;
+    if (vec)
+      for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+  } else {
+    bf16_t* o = (bf16_t*)out + obase;
+    if (vec)
+      for (int i = tid * 4; i < nvalid; i += nthreads * 4) {
+        const float4 q = *(const float4*)(sval + i);
+        bf16x4 pk = {(bf16_t)q.x, (bf16_t)q.y, (bf16_t)q.z, (bf16_t)q.w};
+        *(bf16x4*)(o + i) = pk;
+      }
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = (bf16_t)sval[i];
+  }
+  if (ARGMAX) {
+    int* o = argmax + obase;
+    if (vec)
+      for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(int4*)(o + i) = *(const int4*)(sarg + i);
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = sarg[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // RoIPool forward, NCHW: thread per output bin (grid-stride)
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_fwd_nchw(const T* __restrict__ feat, const float* __restrict__ rois,
                                                          const float* __restrict__ roi_scale, long long total, int C,
                                                          int H, int W, int PH, int PW, float spatial_scale, void* out,
-                                                         int out_dtype, int* __restrict__ argmax) {
+                                                         int out_dtype, int* __restrict__ argmax, int nhwc) {
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int pw = (int)(idx % PW);
@@ -151,10 +242,12 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nchw(const T* __restrict__ f
     const bool empty = (he <= hs) || (we <= ws);
     float maxval = empty ? 0.f : -FLT_MAX;
     int maxidx = -1;
-    const T* plane = feat + ((long long)b.batch * C + c) * H * W;
+    // element (h,w) of channel c: plane[(h*W+w)*estride]
+    const T* plane = nhwc ? feat + (long long)b.batch * H * W * C + c : feat + ((long long)b.batch * C + c) * H * W;
+    const long long estride = nhwc ? C : 1;
     for (int h = hs; h < he; ++h)
       for (int w = ws; w < we; ++w) {
-        const float v = to_f32(plane[h * W + w]);
+        const float v = to_f32(plane[(long long)(h * W + w) * estride]);
         if (v > maxval) {
           maxval = v;
           maxidx = h * W + w;
@@ -400,8 +493,20 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     const long long items = (long long)R * cgroups;
     const int grid = (int)ceil_div_ll(items, 4);
     const int lds = 4 * 64 * ph * pw * 4 * (argmax ? 2 : 1);
-    WS_CHECK_ARG(lds <= 160 * 1024, "wsovod_roi_pool_forward: pooled size %dx%d too large for LDS tile", ph, pw);
     wsovod::ProfScope prof(slot, s, 0.0, bytes);
+    if (lds > 160 * 1024 && !(pw == 7 && ph <= 16)) {
+      // pooled tile does not fit the per-wavefront LDS transpose: thread-per-bin fallback
+      const long long total = (long long)R * C * ph * pw;
+      const int g = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
+      if (dtype == WSOVOD_BF16)
+        hipLaunchKernelGGL(roi_pool_fwd_nchw<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)feat, rois, roi_scale,
+                           total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax, 1);
+      else
+        hipLaunchKernelGGL(roi_pool_fwd_nchw<float>, dim3(g), dim3(256), 0, s, (const float*)feat, rois, roi_scale,
+                           total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax, 1);
+      WS_CHECK_LAUNCH("wsovod_roi_pool_forward");
+      return WSOVOD_OK;
+    }
 #define LAUNCH_POOL(T, AM)                                                                                        \
   do {                                                                                                            \
     auto k = roi_pool_fwd_nhwc<T, AM>;                                                                            \
@@ -409,7 +514,20 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)feat, rois, roi_scale, R, C, H, W, ph, pw,      \
                        spatial_scale, out, out_dtype, argmax, cgroups);                                           \
   } while (0)
-    if (dtype == WSOVOD_BF16) {
+    if (pw == 7 && ph <= 16) {
+      // fast path: workgroup per (roi, channel group), wavefront per pooled row
+      const int lds7 = 64 * ph * pw * 4 * (argmax ? 2 : 1);
+      const int grid7 = R * cgroups;
+#define LAUNCH_ROWS(T, AM)                                                                                   \
+  hipLaunchKernelGGL((roi_pool_fwd_nhwc_rows<T, AM, 7>), dim3(grid7), dim3(64 * ph), lds7, s, (const T*)feat, \
+                     rois, roi_scale, C, H, W, ph, spatial_scale, out, out_dtype, argmax, cgroups)
+      if (dtype == WSOVOD_BF16) {
+        if (argmax) LAUNCH_ROWS(bf16_t, true); else LAUNCH_ROWS(bf16_t, false);
+      } else {
+        if (argmax) LAUNCH_ROWS(float, true); else LAUNCH_ROWS(float, false);
+      }
+#undef LAUNCH_ROWS
+    } else if (dtype == WSOVOD_BF16) {
       if (argmax) LAUNCH_POOL(bf16_t, true); else LAUNCH_POOL(bf16_t, false);
     } else {
       if (argmax) LAUNCH_POOL(float, true); else LAUNCH_POOL(float, false);
@@ -422,10 +540,10 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     wsovod::ProfScope prof(slot, s, 0.0, bytes);
     if (dtype == WSOVOD_BF16)
       hipLaunchKernelGGL(roi_pool_fwd_nchw<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois, roi_scale,
-                         total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax);
+                         total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax, 0);
     else
       hipLaunchKernelGGL(roi_pool_fwd_nchw<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, roi_scale,
-                         total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax);
+                         total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax, 0);
   }
   WS_CHECK_LAUNCH("wsovod_roi_pool_forward");
   return WSOVOD_OK;
