@@ -156,6 +156,112 @@ typedef struct {
 
 int wsovod_gemm_nt(const wsovod_gemm_desc* desc_host, wsovod_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Image preprocessing.  Replaces GeneralizedRCNN_WSOVOD.preprocess_image
+ * (wsovod/modeling/meta_arch/rcnn_wsovod.py:321-328): (x - mean) / std on uint8 CHW BGR
+ * images already copied into one (N,3,Hp,Wp) canvas; pixels outside image n's own
+ * (sizes[2n], sizes[2n+1]) = (h, w) are ZERO after normalisation (ImageList.from_tensors).
+ * mean_host/std_host are HOST arrays of 3 floats.
+ * wsovod_stem_im2col fuses that with the im2col of the stem's first conv (3x3, stride 2,
+ * pad 1, Cin = 3; resnet_wsl.py:375-383): out is (N*Ho*Wo, 32), column k = (r*3+q)*3+c for
+ * k < 27, zero above; Ho = (Hp-1)/2+1, Wo = (Wp-1)/2+1.  It is the A operand of wsovod_gemm_nt.
+ * ---------------------------------------------------------------------------------- */
+int wsovod_preprocess_image(const unsigned char* img, const int* sizes, const float* mean_host,
+                            const float* std_host, int N, int Hp, int Wp, float* out_nchw,
+                            wsovod_stream_t stream);
+int wsovod_stem_im2col(const unsigned char* img, const int* sizes, const float* mean_host,
+                       const float* std_host, int N, int Hp, int Wp, void* out, int out_dtype,
+                       wsovod_stream_t stream);
+
+/* 2x2 max pool over NHWC, stride 1 or 2; zero_pad_br=1 first pads one zero row/column at the
+ * bottom/right (nn.ZeroPad2d((0,1,0,1)) + MaxPool2d(2, 1)).  Replaces the pools of
+ * resnet_wsl.py:85-92,408. */
+int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C, int stride,
+                           int zero_pad_br, void* out, wsovod_stream_t stream);
+/* AdaptiveAvgPool2d(1) over NHWC -> (N,C) fp32 (data_aware_features_head.py:62,124). */
+int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out,
+                               wsovod_stream_t stream);
+/* dst[c][r] = (dst_dtype) src[r][c]; leading dimensions in elements. */
+int wsovod_transpose_cast(const void* src, int src_dtype, long long ld_src, int R, int C, void* dst,
+                          int dst_dtype, long long ld_dst, wsovod_stream_t stream);
+int wsovod_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n,
+                wsovod_stream_t stream);
+
+/* Cosine-similarity head (open_vocabulary_classifier.py:91-92): row_scale[m] =
+ * temperature / max(||x_m||_2, eps), consumed as the row_scale of wsovod_gemm_nt.
+ * Backward of zn = row_scale * z (u = dL/dzn), optionally masked by the ReLU that produced z. */
+int wsovod_row_l2norm_scale(const void* x, int dtype, long long ld, int M, int D, float temperature,
+                            float eps, float* row_scale, wsovod_stream_t stream);
+int wsovod_row_l2norm_backward(const void* z, int dtype, long long ldz, const float* u, long long ldu,
+                               int M, int D, float temperature, float eps, int relu_mask, float* dz,
+                               long long lddz, wsovod_stream_t stream);
+
+/* out[g][n] (+)= sum over rows m in [seg_offsets[g], seg_offsets[g+1]) of x[m][n]. */
+int wsovod_segment_colsum(const void* x, int dtype, long long ld, const int* seg_offsets, int G, int M,
+                          int N, float* out, long long ldo, int accumulate, wsovod_stream_t stream);
+/* x *= num[0] / den[0]; either pointer may be NULL (= 1). Device scalars: no host sync. */
+int wsovod_scale_by_device_scalar(float* x, long long n, const float* num, const float* den,
+                                  wsovod_stream_t stream);
+
+/* Fused SGD step (torch.optim.SGD semantics as configured by wsovod/engine/defaults.py:274-318):
+ *   g = grad*grad_scale + weight_decay*p;  buf = momentum*buf + g;  p -= lr*buf;
+ * optionally refreshing a bf16 shadow copy of p in the same pass. */
+int wsovod_sgd_momentum(float* param, const float* grad, float* momentum_buf, long long n, float lr,
+                        float momentum, float weight_decay, float grad_scale, void* bf16_shadow,
+                        wsovod_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Proposal-concept MIL head.  Per-image segments: proposals of image g are rows
+ * [seg_offsets[g], seg_offsets[g+1]).
+ * wsovod_mil_forward replaces ObjectMiningOutputLayers.forward's
+ *   softmax(C, dim=1) * softmax(D, dim=0) per image   (fast_rcnn_open_vocabulary.py:342-354)
+ * on logits (M, 2K) = [C | D]; P, Q (M,K) are saved for the backward.
+ * wsovod_image_bce_* replaces predict_probs_img + binary_cross_entropy (:604-618, :429-437):
+ *   loss = sum BCE(clamp(sum_r scores, 1e-6, 1-1e-6), y) / norm.
+ * ---------------------------------------------------------------------------------- */
+int wsovod_mil_forward(const float* logits, long long ld, const int* seg_offsets, int G, int K,
+                       float* scores, float* P, float* Q, wsovod_stream_t stream);
+int wsovod_mil_backward(const float* dscores, const float* P, const float* Q, const int* seg_offsets,
+                        int G, int K, float* dlogits, long long ld, wsovod_stream_t stream);
+int wsovod_image_bce_forward(const float* scores, const int* seg_offsets, int G, int K,
+                             const float* labels_onehot, float norm, float* img_scores, float* dS_img,
+                             float* loss, wsovod_stream_t stream);
+int wsovod_image_bce_backward(const float* dS_img, const int* seg_offsets, int G, int K,
+                              const float* grad_out, float* dscores, wsovod_stream_t stream);
+
+/* Weighted softmax cross-entropy of the instance-refinement branch
+ * (fast_rcnn_open_vocabulary.py:799-802,813-820). gt_classes int64 in {-1, 0..K}; weighted=0
+ * gives the plain mean over non-ignored rows.  dlogits receives the UN-normalised gradient;
+ * accum2[1] the normaliser (scale with wsovod_scale_by_device_scalar(dlogits, n, gout, accum2+1)). */
+int wsovod_weighted_ce_forward(const float* logits, long long ld, int M, int K1,
+                               const long long* gt_classes, const float* weights, int weighted,
+                               float* dlogits, long long ldd, float* accum2, float* loss,
+                               wsovod_stream_t stream);
+/* Weighted smooth-L1 box loss, class-agnostic deltas (fast_rcnn_open_vocabulary.py:822-892):
+ * dpred receives d loss / d pred_deltas (already divided by max(M,1)). */
+int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, const float* proposal_boxes,
+                                   const float* gt_boxes, const long long* gt_classes,
+                                   const float* weights, int M, int K, const float* bbox_weights_host,
+                                   float beta, int weighted, float* dpred, float* accum2, float* loss,
+                                   wsovod_stream_t stream);
+
+/* Pseudo-ground-truth mining + proposal labelling, no grad.  Replaces
+ * WSOVODROIHeads.get_pgt_top_k (roi_heads.py:1043-1343; top_k=1, sam=None) followed by
+ * label_and_sample_proposals_wsl (roi_heads.py:1722-1825) with Matcher([thr],[0,1]) when every
+ * proposal is kept (R <= BATCH_SIZE_PER_IMAGE, POSITIVE_FRACTION 1.0).
+ *   gt_classes_img : concatenated sorted-unique image-level classes, image g owns
+ *                    [gt_offsets[g], gt_offsets[g+1])  (get_image_level_gt, roi_heads.py:158-174)
+ *   img_scores     : (G,K) clamped image-level scores (pred_class_img_logits)
+ * Outputs per GT slot: pgt_* (pgt_index = proposal index inside its image or -1); per image:
+ * pgt_count; per proposal: label, matched box / score / weight / matched slot. */
+int wsovod_pgt_mine_and_label(const float* scores, long long ld_scores, const float* boxes,
+                              const int* seg_offsets, int G, const long long* gt_classes_img,
+                              const int* gt_offsets, const float* img_scores, int K,
+                              float iou_threshold, float* pgt_boxes, long long* pgt_classes,
+                              float* pgt_scores, float* pgt_weights, int* pgt_index, int* pgt_count,
+                              long long* out_classes, float* out_boxes, float* out_scores,
+                              float* out_weights, int* out_matched, wsovod_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,5 +72,5 @@ __device__ __forceinline__ float wave_reduce_max(float v) {
   return v;
 }
 
-static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

@@ -1,0 +1,478 @@
+// HBM-bound helper kernels of the hot path: image preprocessing + stem im2col, NHWC max pool,
+// global average pool, transpose/cast (weight shadows, X^T for dW), row L2 norm (+backward),
+// segmented column sums (bias / data-aware grads), device-scalar scaling, fused SGD-momentum.
+// All are coalesced 16-B-per-lane streaming kernels; none is reshaped into a GEMM.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxGrid = 256 * 16;  // 256 CUs x 16 workgroups, grid-stride beyond that
+
+inline int grid_for(long long work_items, int per_block) {
+  return (int)std::max<long long>(1, std::min<long long>(ceil_div_ll(work_items, per_block), kMaxGrid));
+}
+
+// ---------------------------------------------------------------------------------
+// (a1) preprocess_image: (x - mean) / std on uint8 CHW BGR, zero outside each image's own
+// size (ImageList.from_tensors pads AFTER normalisation).  rcnn_wsovod.py:321-328
+// ---------------------------------------------------------------------------------
+__global__ void preprocess_nchw_kernel(const uint8_t* __restrict__ img, const int* __restrict__ sizes,
+                                       float m0, float m1, float m2, float s0, float s1, float s2, int N, int Hp,
+                                       int Wp, float* __restrict__ out) {
+  const long long total = (long long)N * 3 * Hp * Wp;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % Wp);
+    const int h = (int)((i / Wp) % Hp);
+    const int c = (int)((i / ((long long)Wp * Hp)) % 3);
+    const int n = (int)(i / ((long long)Wp * Hp * 3));
+    const bool inside = h < sizes[2 * n] && w < sizes[2 * n + 1];
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+    const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    out[i] = inside ? ((float)img[i] - mean) / sd : 0.f;
+  }
+}
+
+// Stem conv1 (3x3, stride 2, pad 1, Cin=3; resnet_wsl.py:375-383) as a GEMM operand: row m =
+// output pixel, 32 columns: k = (r*3+q)*3 + c for k < 27 (matching the [Cout][kh][kw][Cin]
+// weight order), zeros above.  Normalisation is fused; padding is zero AFTER normalisation.
+template <typename T>
+__global__ void stem_im2col_kernel(const uint8_t* __restrict__ img, const int* __restrict__ sizes, float m0,
+                                   float m1, float m2, float s0, float s1, float s2, int N, int Hp, int Wp, int Ho,
+                                   int Wo, T* __restrict__ out) {
+  const long long total = (long long)N * Ho * Wo * 32;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i & 31);
+    const long long m = i >> 5;
+    const int wo = (int)(m % Wo);
+    const int ho = (int)((m / Wo) % Ho);
+    const int n = (int)(m / ((long long)Wo * Ho));
+    float v = 0.f;
+    if (k < 27) {
+      const int c = k % 3, tap = k / 3, r = tap / 3, q = tap % 3;
+      const int h = ho * 2 - 1 + r, w = wo * 2 - 1 + q;
+      if (h >= 0 && w >= 0 && h < sizes[2 * n] && w < sizes[2 * n + 1]) {
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+        const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        v = ((float)img[(((long long)n * 3 + c) * Hp + h) * Wp + w] - mean) / sd;
+      }
+    }
+    out[i] = from_f32<T>(v);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// 2x2 max pool over NHWC (stem pool s2; res2 tail s2; res3 tail ZeroPad2d((0,1,0,1)) + s1).
+// resnet_wsl.py:85-92,408.  8 channels (bf16) / 4 channels (fp32) per lane = 16 B.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void maxpool2x2_nhwc_kernel(const T* __restrict__ in, int N, int H, int W, int C, int Ho, int Wo,
+                                       int stride, int zero_pad, T* __restrict__ out) {
+  constexpr int V = 16 / sizeof(T);
+  const int cv = C / V;
+  const long long total = (long long)N * Ho * Wo * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * V;
+    const int wo = (int)((i / cv) % Wo);
+    const int ho = (int)((i / ((long long)cv * Wo)) % Ho);
+    const int n = (int)(i / ((long long)cv * Wo * Ho));
+    float best[V];
+    bool any = false;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int h = ho * stride + dy, w = wo * stride + dx;
+        float v[V];
+        if (h < H && w < W) {
+          const uint4 raw = *(const uint4*)(in + (((long long)n * H + h) * W + w) * C + c);
+          const T* e = (const T*)&raw;
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[j] = to_f32(e[j]);
+        } else if (zero_pad) {
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[j] = 0.f;
+        } else {
+          continue;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) best[j] = any ? fmaxf(best[j], v[j]) : v[j];
+        any = true;
+      }
+    uint4 o;
+    T* oe = (T*)&o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) oe[j] = from_f32<T>(best[j]);
+    *(uint4*)(out + (((long long)n * Ho + ho) * Wo + wo) * C + c) = o;
+  }
+}
+
+// Global average pool over NHWC -> (N,C) fp32 (DataAwareFeaturesHead.GAP,
+// data_aware_features_head.py:62,124).  Workgroup per (image, 64-channel group): 4 wavefronts
+// stride the pixels, lane = channel (coalesced), LDS combine.
+template <typename T>
+__global__ __launch_bounds__(256) void gap_nhwc_kernel(const T* __restrict__ in, int HW, int C,
+                                                       float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = ceil_div(C, 64);
+  const int n = blockIdx.x / cg, c = (blockIdx.x % cg) * 64 + lane;
+  float acc = 0.f;
+  if (c < C) {
+    const T* p = in + (long long)n * HW * C + c;
+    for (int i = wave; i < HW; i += 4) acc += to_f32(p[(long long)i * C]);
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) out[(long long)n * C + c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)HW;
+}
+
+// ---------------------------------------------------------------------------------
+// transpose + cast: dst[c][r] = src[r][c]  (64x64 LDS tile, padded), and plain cast.
+// ---------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const TS* __restrict__ src, long long lds_, int R, int C,
+                                                             TD* __restrict__ dst, long long ldd) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? to_f32(src[(long long)r * lds_ + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(long long)c * ldd + r] = from_f32<TD>(tile[tx][i]);
+  }
+}
+
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<TD>(to_f32(src[i]));
+}
+
+// ---------------------------------------------------------------------------------
+// Row L2 norm for the cosine-similarity head: row_scale[m] = T / max(||x_m||, eps)
+// (F.normalize eps=1e-12, open_vocabulary_classifier.py:91-92).  Wavefront per row.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void row_l2norm_kernel(const T* __restrict__ x, long long ld, int M, int D,
+                                                         float temp, float eps, float* __restrict__ row_scale) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float s = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float v = to_f32(x[(long long)m * ld + d]);
+    s += v * v;
+  }
+  s = wave_reduce_sum(s);
+  if (lane == 0) row_scale[m] = temp / fmaxf(sqrtf(s), eps);
+}
+
+// backward of zn = T*z/max(||z||,eps) followed by the ReLU that produced z:
+//   dz = s*(u - z*(z.u)/||z||^2)   (||z|| > eps)     | dz = s*u (clamped branch);  dz *= (z > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const T* __restrict__ z, long long ldz,
+                                                             const float* __restrict__ u, long long ldu, int M, int D,
+                                                             float temp, float eps, int relu_mask,
+                                                             float* __restrict__ dz, long long lddz) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  float nn = 0.f, zu = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float zv = to_f32(z[(long long)m * ldz + d]);
+    nn += zv * zv;
+    zu += zv * u[(long long)m * ldu + d];
+  }
+  nn = wave_reduce_sum(nn);
+  zu = wave_reduce_sum(zu);
+  const float nrm = sqrtf(nn);
+  const bool clamped = nrm <= eps;
+  const float s = temp / fmaxf(nrm, eps);
+  const float coef = clamped ? 0.f : zu / nn;
+  for (int d = lane; d < D; d += 64) {
+    const float zv = to_f32(z[(long long)m * ldz + d]);
+    float g = s * (u[(long long)m * ldu + d] - zv * coef);
+    if (relu_mask && !(zv > 0.f)) g = 0.f;
+    dz[(long long)m * lddz + d] = g;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Segmented column sum: out[g][n] = sum_{m in [seg[g], seg[g+1])} x[m][n]   (bias grads with
+// one segment; per-image data-aware-feature grads).  Workgroup per (segment, 64 columns).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, long long ld,
+                                                             const int* __restrict__ seg, int N,
+                                                             float* __restrict__ out, long long ldo, int accumulate) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cg = ceil_div(N, 64);
+  const int g = blockIdx.x / cg, n = (blockIdx.x % cg) * 64 + lane;
+  const int m0 = seg ? seg[g] : 0, m1 = seg ? seg[g + 1] : 0;
+  float acc = 0.f;
+  if (n < N)
+    for (int m = m0 + wave; m < m1; m += 4) acc += to_f32(x[(long long)m * ld + n]);
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    float* o = out + (long long)g * ldo + n;
+    *o = accumulate ? *o + v : v;
+  }
+}
+
+// x *= num[0] / den[0]  (device scalars: upstream loss grad / normaliser; no host sync)
+__global__ void scale_by_device_scalar_kernel(float* __restrict__ x, long long n, const float* __restrict__ num,
+                                              const float* __restrict__ den) {
+  const float f = (num ? num[0] : 1.f) / (den ? den[0] : 1.f);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    x[i] *= f;
+}
+
+// ---------------------------------------------------------------------------------
+// Fused SGD with momentum + weight decay (torch.optim.SGD semantics, dampening 0, as built by
+// wsovod/engine/defaults.py:274-318):  g += wd*p; buf = mu*buf + g; p -= lr*buf.
+// Optionally refreshes the bf16 shadow of p in the same pass.  float4 per lane.
+// ---------------------------------------------------------------------------------
+__global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                    long long n, float lr, float mu, float wd, float gscale,
+                                    bf16_t* __restrict__ shadow) {
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+       i += (long long)gridDim.x * blockDim.x) {
+    float4 pv = ((float4*)p)[i];
+    const float4 gv = ((const float4*)g)[i];
+    float4 bv = ((float4*)buf)[i];
+    bv.x = mu * bv.x + (gv.x * gscale + wd * pv.x);
+    bv.y = mu * bv.y + (gv.y * gscale + wd * pv.y);
+    bv.z = mu * bv.z + (gv.z * gscale + wd * pv.z);
+    bv.w = mu * bv.w + (gv.w * gscale + wd * pv.w);
+    pv.x -= lr * bv.x;
+    pv.y -= lr * bv.y;
+    pv.z -= lr * bv.z;
+    pv.w -= lr * bv.w;
+    ((float4*)buf)[i] = bv;
+    ((float4*)p)[i] = pv;
+    if (shadow) {
+      bf16x4 s = {(bf16_t)pv.x, (bf16_t)pv.y, (bf16_t)pv.z, (bf16_t)pv.w};
+      ((bf16x4*)shadow)[i] = s;
+    }
+  }
+  // tail (n not a multiple of 4)
+  const long long t0 = n4 << 2;
+  for (long long i = t0 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    float b = mu * buf[i] + (g[i] * gscale + wd * p[i]);
+    buf[i] = b;
+    const float pv = p[i] - lr * b;
+    p[i] = pv;
+    if (shadow) shadow[i] = (bf16_t)pv;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int wsovod_preprocess_image(const unsigned char* img, const int* sizes, const float* mean_host,
+                            const float* std_host, int N, int Hp, int Wp, float* out, wsovod_stream_t stream) {
+  WS_CHECK_ARG(N >= 0 && Hp > 0 && Wp > 0, "wsovod_preprocess_image: bad shape");
+  if (N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(img && sizes && mean_host && std_host && out, "wsovod_preprocess_image: null pointer");
+  static int slot = wsovod::prof_slot("preprocess_nchw");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)N * 3 * Hp * Wp;
+  wsovod::ProfScope prof(slot, s, 0.0, total * 5.0);
+  hipLaunchKernelGGL(preprocess_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, img, sizes, mean_host[0],
+                     mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, out);
+  WS_CHECK_LAUNCH("wsovod_preprocess_image");
+  return WSOVOD_OK;
+}
+
+int wsovod_stem_im2col(const unsigned char* img, const int* sizes, const float* mean_host, const float* std_host,
+                       int N, int Hp, int Wp, void* out, int out_dtype, wsovod_stream_t stream) {
+  WS_CHECK_ARG(N >= 0 && Hp > 0 && Wp > 0, "wsovod_stem_im2col: bad shape");
+  if (N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(img && sizes && mean_host && std_host && out, "wsovod_stem_im2col: null pointer");
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16, "wsovod_stem_im2col: bad dtype");
+  static int slot = wsovod::prof_slot("stem_im2col");
+  hipStream_t s = (hipStream_t)stream;
+  const int Ho = (Hp - 1) / 2 + 1, Wo = (Wp - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo * 32;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)N * 3 * Hp * Wp + total * (out_dtype == WSOVOD_BF16 ? 2.0 : 4.0));
+  if (out_dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, sizes,
+                       mean_host[0], mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, Ho,
+                       Wo, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, img, sizes,
+                       mean_host[0], mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, Ho,
+                       Wo, (float*)out);
+  WS_CHECK_LAUNCH("wsovod_stem_im2col");
+  return WSOVOD_OK;
+}
+
+int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C, int stride, int zero_pad_br,
+                           void* out, wsovod_stream_t stream) {
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_maxpool2x2_nhwc: bad dtype");
+  WS_CHECK_ARG(stride == 1 || stride == 2, "wsovod_maxpool2x2_nhwc: stride must be 1 or 2");
+  const int V = dtype == WSOVOD_BF16 ? 8 : 4;
+  WS_CHECK_ARG(C % V == 0, "wsovod_maxpool2x2_nhwc: C=%d must be a multiple of %d", C, V);
+  const int Hin = H + (zero_pad_br ? 1 : 0), Win = W + (zero_pad_br ? 1 : 0);
+  const int Ho = (Hin - 2) / stride + 1, Wo = (Win - 2) / stride + 1;
+  if (N == 0 || Ho <= 0 || Wo <= 0) return WSOVOD_OK;
+  WS_CHECK_ARG(in && out, "wsovod_maxpool2x2_nhwc: null pointer");
+  static int slot = wsovod::prof_slot("maxpool2x2_nhwc");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)N * Ho * Wo * (C / V);
+  const double esz = dtype == WSOVOD_BF16 ? 2.0 : 4.0;
+  wsovod::ProfScope prof(slot, s, 0.0, ((double)N * H * W * C + (double)N * Ho * Wo * C) * esz);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(maxpool2x2_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16_t*)in,
+                       N, H, W, C, Ho, Wo, stride, zero_pad_br, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(maxpool2x2_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, N,
+                       H, W, C, Ho, Wo, stride, zero_pad_br, (float*)out);
+  WS_CHECK_LAUNCH("wsovod_maxpool2x2_nhwc");
+  return WSOVOD_OK;
+}
+
+int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out, wsovod_stream_t stream) {
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_global_avgpool_nhwc: bad dtype");
+  if (N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(in && out && HW > 0 && C > 0, "wsovod_global_avgpool_nhwc: bad argument");
+  static int slot = wsovod::prof_slot("gap_nhwc");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)N * HW * C * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
+  const int grid = N * ceil_div(C, 64);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(gap_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, HW, C, out);
+  else
+    hipLaunchKernelGGL(gap_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, HW, C, out);
+  WS_CHECK_LAUNCH("wsovod_global_avgpool_nhwc");
+  return WSOVOD_OK;
+}
+
+int wsovod_transpose_cast(const void* src, int src_dtype, long long ld_src, int R, int C, void* dst, int dst_dtype,
+                          long long ld_dst, wsovod_stream_t stream) {
+  if (R == 0 || C == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(src && dst, "wsovod_transpose_cast: null pointer");
+  static int slot = wsovod::prof_slot("transpose_cast");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ceil_div(C, 64), ceil_div(R, 64));
+  wsovod::ProfScope prof(slot, s, 0.0, (double)R * C * ((src_dtype == WSOVOD_BF16 ? 2.0 : 4.0) + (dst_dtype == WSOVOD_BF16 ? 2.0 : 4.0)));
+#define TC(TS, TD) hipLaunchKernelGGL((transpose_cast_kernel<TS, TD>), grid, dim3(256), 0, s, (const TS*)src, ld_src, R, C, (TD*)dst, ld_dst)
+  if (src_dtype == WSOVOD_F32 && dst_dtype == WSOVOD_F32) TC(float, float);
+  else if (src_dtype == WSOVOD_F32 && dst_dtype == WSOVOD_BF16) TC(float, bf16_t);
+  else if (src_dtype == WSOVOD_BF16 && dst_dtype == WSOVOD_F32) TC(bf16_t, float);
+  else if (src_dtype == WSOVOD_BF16 && dst_dtype == WSOVOD_BF16) TC(bf16_t, bf16_t);
+  else { wsovod::set_error("wsovod_transpose_cast: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+#undef TC
+  WS_CHECK_LAUNCH("wsovod_transpose_cast");
+  return WSOVOD_OK;
+}
+
+int wsovod_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long long n, wsovod_stream_t stream) {
+  if (n == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(src && dst, "wsovod_cast: null pointer");
+  static int slot = wsovod::prof_slot("cast");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)n * ((src_dtype == WSOVOD_BF16 ? 2.0 : 4.0) + (dst_dtype == WSOVOD_BF16 ? 2.0 : 4.0)));
+  const int grid = grid_for(n, 256);
+  if (src_dtype == WSOVOD_F32 && dst_dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == WSOVOD_BF16 && dst_dtype == WSOVOD_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == WSOVOD_F32 && dst_dtype == WSOVOD_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+  else if (src_dtype == WSOVOD_BF16 && dst_dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+  else { wsovod::set_error("wsovod_cast: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+  WS_CHECK_LAUNCH("wsovod_cast");
+  return WSOVOD_OK;
+}
+
+int wsovod_row_l2norm_scale(const void* x, int dtype, long long ld, int M, int D, float temperature, float eps,
+                            float* row_scale, wsovod_stream_t stream) {
+  if (M == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(x && row_scale && D > 0, "wsovod_row_l2norm_scale: bad argument");
+  static int slot = wsovod::prof_slot("row_l2norm");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * D * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(row_l2norm_kernel<bf16_t>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const bf16_t*)x, ld, M, D, temperature, eps, row_scale);
+  else
+    hipLaunchKernelGGL(row_l2norm_kernel<float>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const float*)x, ld, M, D, temperature, eps, row_scale);
+  WS_CHECK_LAUNCH("wsovod_row_l2norm_scale");
+  return WSOVOD_OK;
+}
+
+int wsovod_row_l2norm_backward(const void* z, int dtype, long long ldz, const float* u, long long ldu, int M, int D,
+                               float temperature, float eps, int relu_mask, float* dz, long long lddz,
+                               wsovod_stream_t stream) {
+  if (M == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(z && u && dz && D > 0, "wsovod_row_l2norm_backward: bad argument");
+  static int slot = wsovod::prof_slot("row_l2norm_bwd");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * D * 12.0);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(row_l2norm_bwd_kernel<bf16_t>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const bf16_t*)z, ldz, u, ldu, M, D, temperature, eps, relu_mask, dz, lddz);
+  else
+    hipLaunchKernelGGL(row_l2norm_bwd_kernel<float>, dim3(ceil_div(M, 4)), dim3(256), 0, s, (const float*)z, ldz, u, ldu, M, D, temperature, eps, relu_mask, dz, lddz);
+  WS_CHECK_LAUNCH("wsovod_row_l2norm_backward");
+  return WSOVOD_OK;
+}
+
+int wsovod_segment_colsum(const void* x, int dtype, long long ld, const int* seg_offsets, int G, int M, int N,
+                          float* out, long long ldo, int accumulate, wsovod_stream_t stream) {
+  if (G == 0 || N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(x && out && seg_offsets, "wsovod_segment_colsum: null pointer");
+  (void)M;
+  static int slot = wsovod::prof_slot("segment_colsum");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
+  const int grid = G * ceil_div(N, 64);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ld, seg_offsets, N, out, ldo, accumulate);
+  else
+    hipLaunchKernelGGL(segment_colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, seg_offsets, N, out, ldo, accumulate);
+  WS_CHECK_LAUNCH("wsovod_segment_colsum");
+  return WSOVOD_OK;
+}
+
+int wsovod_scale_by_device_scalar(float* x, long long n, const float* num, const float* den, wsovod_stream_t stream) {
+  if (n == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(x, "wsovod_scale_by_device_scalar: null pointer");
+  static int slot = wsovod::prof_slot("scale_by_scalar");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)n * 8.0);
+  hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, n, num, den);
+  WS_CHECK_LAUNCH("wsovod_scale_by_device_scalar");
+  return WSOVOD_OK;
+}
+
+int wsovod_sgd_momentum(float* param, const float* grad, float* momentum_buf, long long n, float lr, float momentum,
+                        float weight_decay, float grad_scale, void* bf16_shadow, wsovod_stream_t stream) {
+  if (n == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(param && grad && momentum_buf, "wsovod_sgd_momentum: null pointer");
+  WS_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)momentum_buf) & 15) == 0,
+               "wsovod_sgd_momentum: param/grad/momentum must be 16-byte aligned");
+  WS_CHECK_ARG(!bf16_shadow || ((uintptr_t)bf16_shadow & 7) == 0, "wsovod_sgd_momentum: shadow must be 8-byte aligned");
+  static int slot = wsovod::prof_slot("sgd_momentum");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 3.0 * n, (double)n * (20.0 + (bf16_shadow ? 2.0 : 0.0)));
+  hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, param, grad, momentum_buf,
+                     n, lr, momentum, weight_decay, grad_scale, (bf16_t*)bf16_shadow);
+  WS_CHECK_LAUNCH("wsovod_sgd_momentum");
+  return WSOVOD_OK;
+}
+
+}  // extern "C"
