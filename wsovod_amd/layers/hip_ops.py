@@ -154,3 +154,225 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
     d.tile_hint = int(tile_hint)
     check(lib().wsovod_gemm_nt(C.byref(d), stream()), "gemm_nt")
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# elementwise / reduction kernels
+# ---------------------------------------------------------------------------------------
+def _f3(vals):
+    return (C.c_float * 3)(*[float(v) for v in vals])
+
+
+def preprocess_image(images_u8, sizes, mean, std):
+    """(N,3,Hp,Wp) uint8 canvas + (N,2) int32 sizes -> normalised fp32 NCHW (zero outside each image)."""
+    require_gpu(images_u8, sizes)
+    N, _, Hp, Wp = images_u8.shape
+    out = torch.empty((N, 3, Hp, Wp), dtype=torch.float32, device=images_u8.device)
+    check(lib().wsovod_preprocess_image(ptr(images_u8), ptr(sizes), _f3(mean), _f3(std), N, Hp, Wp, ptr(out),
+                                        stream()), "preprocess_image")
+    return out
+
+
+def stem_im2col(images_u8, sizes, mean, std, dtype):
+    """-> ((N*Ho*Wo, 32) operand of the stem conv1 GEMM, Ho, Wo)."""
+    require_gpu(images_u8, sizes)
+    N, _, Hp, Wp = images_u8.shape
+    Ho, Wo = (Hp - 1) // 2 + 1, (Wp - 1) // 2 + 1
+    out = torch.empty((N * Ho * Wo, 32), dtype=dtype, device=images_u8.device)
+    check(lib().wsovod_stem_im2col(ptr(images_u8), ptr(sizes), _f3(mean), _f3(std), N, Hp, Wp, ptr(out),
+                                   dtype_code(dtype), stream()), "stem_im2col")
+    return out, Ho, Wo
+
+
+def maxpool2x2_nhwc(x, stride, zero_pad_br=False):
+    """x: (N,H,W,C) contiguous -> (N,Ho,Wo,C)."""
+    require_gpu(x)
+    N, H, W, Cc = x.shape
+    Hin, Win = H + int(zero_pad_br), W + int(zero_pad_br)
+    Ho, Wo = (Hin - 2) // stride + 1, (Win - 2) // stride + 1
+    out = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    check(lib().wsovod_maxpool2x2_nhwc(ptr(x), dtype_code(x.dtype), N, H, W, Cc, stride, int(zero_pad_br), ptr(out),
+                                       stream()), "maxpool2x2_nhwc")
+    return out
+
+
+def global_avgpool_nhwc(x):
+    """x: (N,H,W,C) contiguous -> (N,C) fp32."""
+    require_gpu(x)
+    N, H, W, Cc = x.shape
+    out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+    check(lib().wsovod_global_avgpool_nhwc(ptr(x), dtype_code(x.dtype), N, H * W, Cc, ptr(out), stream()), "gap")
+    return out
+
+
+def transpose_cast(src, dst_dtype, ld_dst=None, out=None):
+    """(R,C) -> (C, ld_dst>=R) transposed copy in dst_dtype; padding columns are zero."""
+    require_gpu(src)
+    R, Cc = src.shape
+    if out is None:
+        ld = ld_dst or R
+        out = torch.zeros((Cc, ld), dtype=dst_dtype, device=src.device) if ld != R else torch.empty(
+            (Cc, R), dtype=dst_dtype, device=src.device)
+    check(lib().wsovod_transpose_cast(ptr(src), dtype_code(src.dtype), _ld(src), R, Cc, ptr(out),
+                                      dtype_code(out.dtype), _ld(out), stream()), "transpose_cast")
+    return out
+
+
+def cast(src, dst_dtype, out=None):
+    require_gpu(src)
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=dst_dtype, device=src.device)
+    check(lib().wsovod_cast(ptr(src), dtype_code(src.dtype), ptr(out), dtype_code(out.dtype), src.numel(), stream()),
+          "cast")
+    return out
+
+
+def row_l2norm_scale(x, temperature, eps=1e-12):
+    require_gpu(x)
+    M, D = x.shape
+    out = torch.empty((M,), dtype=torch.float32, device=x.device)
+    check(lib().wsovod_row_l2norm_scale(ptr(x), dtype_code(x.dtype), _ld(x), M, D, C.c_float(temperature),
+                                        C.c_float(eps), ptr(out), stream()), "row_l2norm_scale")
+    return out
+
+
+def row_l2norm_backward(z, u, temperature, eps=1e-12, relu_mask=True):
+    require_gpu(z, u)
+    M, D = z.shape
+    dz = torch.empty((M, D), dtype=torch.float32, device=z.device)
+    check(lib().wsovod_row_l2norm_backward(ptr(z), dtype_code(z.dtype), _ld(z), ptr(u), _ld(u), M, D,
+                                           C.c_float(temperature), C.c_float(eps), int(relu_mask), ptr(dz), _ld(dz),
+                                           stream()), "row_l2norm_backward")
+    return dz
+
+
+def segment_colsum(x, seg_offsets, out=None, accumulate=False):
+    """x (M,N), seg_offsets int32 (G+1) -> (G,N) fp32 column sums per segment."""
+    require_gpu(x, seg_offsets)
+    M, N = x.shape
+    G = seg_offsets.numel() - 1
+    if out is None:
+        out = torch.empty((G, N), dtype=torch.float32, device=x.device)
+    check(lib().wsovod_segment_colsum(ptr(x), dtype_code(x.dtype), _ld(x), ptr(seg_offsets), G, M, N, ptr(out),
+                                      _ld(out), int(accumulate), stream()), "segment_colsum")
+    return out
+
+
+def scale_by_device_scalar(x, num=None, den=None):
+    require_gpu(x, num, den)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    check(lib().wsovod_scale_by_device_scalar(ptr(x), x.numel(), ptr(num), ptr(den), stream()), "scale_by_scalar")
+    return x
+
+
+def sgd_momentum(param, grad, buf, lr, momentum, weight_decay, grad_scale=1.0, bf16_shadow=None):
+    require_gpu(param, grad, buf, bf16_shadow)
+    assert param.is_contiguous() and grad.is_contiguous() and buf.is_contiguous()
+    check(lib().wsovod_sgd_momentum(ptr(param), ptr(grad), ptr(buf), param.numel(), C.c_float(lr),
+                                    C.c_float(momentum), C.c_float(weight_decay), C.c_float(grad_scale),
+                                    ptr(bf16_shadow), stream()), "sgd_momentum")
+
+
+# ---------------------------------------------------------------------------------------
+# MIL head kernels
+# ---------------------------------------------------------------------------------------
+def mil_forward(logits, seg_offsets, K):
+    """logits (M,2K) fp32 [cls|det] -> (scores, P, Q) each (M,K)."""
+    require_gpu(logits, seg_offsets)
+    M = logits.size(0)
+    G = seg_offsets.numel() - 1
+    scores = torch.empty((M, K), dtype=torch.float32, device=logits.device)
+    P = torch.empty_like(scores)
+    Q = torch.empty_like(scores)
+    check(lib().wsovod_mil_forward(ptr(logits), _ld(logits), ptr(seg_offsets), G, K, ptr(scores), ptr(P), ptr(Q),
+                                   stream()), "mil_forward")
+    return scores, P, Q
+
+
+def mil_backward(dscores, P, Q, seg_offsets, K):
+    require_gpu(dscores, P, Q, seg_offsets)
+    M = P.size(0)
+    G = seg_offsets.numel() - 1
+    dlogits = torch.empty((M, 2 * K), dtype=torch.float32, device=P.device)
+    check(lib().wsovod_mil_backward(ptr(dscores.contiguous()), ptr(P), ptr(Q), ptr(seg_offsets), G, K, ptr(dlogits),
+                                    _ld(dlogits), stream()), "mil_backward")
+    return dlogits
+
+
+def image_bce_forward(scores, seg_offsets, labels_onehot, norm):
+    require_gpu(scores, seg_offsets, labels_onehot)
+    G, K = labels_onehot.shape
+    img = torch.empty((G, K), dtype=torch.float32, device=scores.device)
+    dS = torch.empty_like(img)
+    loss = torch.empty((1,), dtype=torch.float32, device=scores.device)
+    check(lib().wsovod_image_bce_forward(ptr(scores), ptr(seg_offsets), G, K, ptr(labels_onehot), C.c_float(norm),
+                                         ptr(img), ptr(dS), ptr(loss), stream()), "image_bce_forward")
+    return loss, img, dS
+
+
+def image_bce_backward(dS_img, seg_offsets, M, grad_out):
+    require_gpu(dS_img, seg_offsets, grad_out)
+    G, K = dS_img.shape
+    d = torch.empty((M, K), dtype=torch.float32, device=dS_img.device)
+    check(lib().wsovod_image_bce_backward(ptr(dS_img), ptr(seg_offsets), G, K, ptr(grad_out), ptr(d), stream()),
+          "image_bce_backward")
+    return d
+
+
+def weighted_ce_forward(logits, gt_classes, weights, weighted=True):
+    """-> (loss (1), dlogits un-normalised (M,K1), accum (2): [sum, count])."""
+    require_gpu(logits, gt_classes, weights)
+    M, K1 = logits.shape
+    dl = torch.empty((M, K1), dtype=torch.float32, device=logits.device)
+    accum = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device)
+    check(lib().wsovod_weighted_ce_forward(ptr(logits), _ld(logits), M, K1, ptr(gt_classes), ptr(weights),
+                                           int(weighted), ptr(dl), _ld(dl), ptr(accum), ptr(loss), stream()),
+          "weighted_ce_forward")
+    return loss, dl, accum
+
+
+def weighted_l1_box_forward(pred, proposal_boxes, gt_boxes, gt_classes, weights, K, bbox_weights, beta, weighted=True):
+    """-> (loss (1), dpred (M,4) already divided by max(M,1))."""
+    require_gpu(pred, proposal_boxes, gt_boxes, gt_classes, weights)
+    M = pred.size(0)
+    dp = torch.empty((M, 4), dtype=torch.float32, device=pred.device)
+    accum = torch.empty((2,), dtype=torch.float32, device=pred.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=pred.device)
+    bw = (C.c_float * 4)(*[float(v) for v in bbox_weights])
+    check(lib().wsovod_weighted_l1_box_forward(ptr(pred), _ld(pred), ptr(proposal_boxes), ptr(gt_boxes),
+                                               ptr(gt_classes), ptr(weights), M, K, bw, C.c_float(beta),
+                                               int(weighted), ptr(dp), ptr(accum), ptr(loss), stream()),
+          "weighted_l1_box_forward")
+    return loss, dp
+
+
+def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, img_scores, K, iou_threshold):
+    """See include/wsovod_hip.h.  Returns a dict of device tensors."""
+    require_gpu(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, img_scores)
+    dev = scores.device
+    M = scores.size(0)
+    G = seg_offsets.numel() - 1
+    T = gt_classes_img.numel()
+    o = dict(
+        pgt_boxes=torch.zeros((T, 4), dtype=torch.float32, device=dev),
+        pgt_classes=torch.zeros((T,), dtype=torch.int64, device=dev),
+        pgt_scores=torch.zeros((T,), dtype=torch.float32, device=dev),
+        pgt_weights=torch.zeros((T,), dtype=torch.float32, device=dev),
+        pgt_index=torch.full((T,), -1, dtype=torch.int32, device=dev),
+        pgt_count=torch.zeros((G,), dtype=torch.int32, device=dev),
+        gt_classes=torch.empty((M,), dtype=torch.int64, device=dev),
+        gt_boxes=torch.empty((M, 4), dtype=torch.float32, device=dev),
+        gt_scores=torch.empty((M,), dtype=torch.float32, device=dev),
+        gt_weights=torch.empty((M,), dtype=torch.float32, device=dev),
+        matched=torch.empty((M,), dtype=torch.int32, device=dev),
+    )
+    boxes = boxes.to(torch.float32).contiguous()
+    check(lib().wsovod_pgt_mine_and_label(
+        ptr(scores), _ld(scores), ptr(boxes), ptr(seg_offsets), G, ptr(gt_classes_img), ptr(gt_offsets),
+        ptr(img_scores), K, C.c_float(iou_threshold), ptr(o["pgt_boxes"]), ptr(o["pgt_classes"]),
+        ptr(o["pgt_scores"]), ptr(o["pgt_weights"]), ptr(o["pgt_index"]), ptr(o["pgt_count"]), ptr(o["gt_classes"]),
+        ptr(o["gt_boxes"]), ptr(o["gt_scores"]), ptr(o["gt_weights"]), ptr(o["matched"]), stream()),
+        "pgt_mine_and_label")
+    return o
