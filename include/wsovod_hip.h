@@ -262,6 +262,31 @@ int wsovod_pgt_mine_and_label(const float* scores, long long ld_scores, const fl
                               long long* out_classes, float* out_boxes, float* out_scores,
                               float* out_weights, int* out_matched, wsovod_stream_t stream);
 
+/* Backward prologue of Linear+ReLU(+Dropout) (box_head.py:60-66): dA = dy * [y > 0] * scale
+ * written as [M][N] and/or transposed [N][ldt] (either output may be NULL; y NULL = no mask). */
+int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype,
+                          int M, int N, float scale, void* dA, long long ldda, void* dAt, long long ldt,
+                          int out_dtype, wsovod_stream_t stream);
+/* out[m][:] = x[m][:] + add[row_group[m]][:]  (box_features += data_aware_features,
+ * roi_heads.py:762-763, without materialising the per-proposal repeat). */
+int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* row_group, const float* add,
+                          long long ld_add, int M, int N, void* out, long long ldo, wsovod_stream_t stream);
+/* out[r][:] = x[r][:] * row_scale[r]  (F.normalize of the class text embeddings,
+ * open_vocabulary_classifier.py:59-60,87-89). */
+int wsovod_scale_rows(const float* x, long long ldx, const float* row_scale, int R, int C, void* out,
+                      long long ldo, int out_dtype, wsovod_stream_t stream);
+
+/* DataAwareFeaturesHead on the GAP vector (data_aware_features_head.py:103-129):
+ * h1 = relu(W1 gap + b1) (N,Hd); h2 = tanh(W2 h1 + b2) (N,P); daf = h2 @ E (N,F).  All fp32.
+ * The backward takes d loss / d daf (N,F) and OVERWRITES the five parameter gradients. */
+int wsovod_data_aware_forward(const float* gap, int N, int C, const float* W1, const float* b1, int Hd,
+                              const float* W2, const float* b2, int P, const float* E, int F, float* h1,
+                              float* h2, float* daf, wsovod_stream_t stream);
+int wsovod_data_aware_backward(const float* ddaf, int N, const float* gap, int C, const float* W2,
+                               const float* E, int F, const float* h1, int Hd, const float* h2, int P,
+                               float* dW1, float* db1, float* dW2, float* db2, float* dE,
+                               wsovod_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

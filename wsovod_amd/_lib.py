@@ -48,6 +48,45 @@ class ProfEntry(C.Structure):
                 ("flops", C.c_double), ("bytes", C.c_double)]
 
 
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
+SIGNATURES = {
+    "wsovod_last_error": [],
+    "wsovod_abi_version": [],
+    "wsovod_profile_enable": [_I],
+    "wsovod_profile_reset": [],
+    "wsovod_profile_collect": [C.POINTER(ProfEntry), _I],
+    "wsovod_roi_pool_forward": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P],
+    "wsovod_roi_pool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "wsovod_roi_align_forward": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P],
+    "wsovod_roi_align_backward": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _I, _P, _P],
+    "wsovod_gemm_nt": [C.POINTER(GemmDesc), _P],
+    "wsovod_preprocess_image": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "wsovod_stem_im2col": [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
+    "wsovod_maxpool2x2_nhwc": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "wsovod_global_avgpool_nhwc": [_P, _I, _I, _I, _I, _P, _P],
+    "wsovod_transpose_cast": [_P, _I, _L, _I, _I, _P, _I, _L, _P],
+    "wsovod_cast": [_P, _I, _P, _I, _L, _P],
+    "wsovod_row_l2norm_scale": [_P, _I, _L, _I, _I, _F, _F, _P, _P],
+    "wsovod_row_l2norm_backward": [_P, _I, _L, _P, _L, _I, _I, _F, _F, _I, _P, _L, _P],
+    "wsovod_segment_colsum": [_P, _I, _L, _P, _I, _I, _I, _P, _L, _I, _P],
+    "wsovod_scale_by_device_scalar": [_P, _L, _P, _P, _P],
+    "wsovod_sgd_momentum": [_P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
+    "wsovod_mil_forward": [_P, _L, _P, _I, _I, _P, _P, _P, _P],
+    "wsovod_mil_backward": [_P, _P, _P, _P, _I, _I, _P, _L, _P],
+    "wsovod_image_bce_forward": [_P, _P, _I, _I, _P, _F, _P, _P, _P, _P],
+    "wsovod_image_bce_backward": [_P, _P, _I, _I, _P, _P, _P],
+    "wsovod_weighted_ce_forward": [_P, _L, _I, _I, _P, _P, _I, _P, _L, _P, _P, _P],
+    "wsovod_weighted_l1_box_forward": [_P, _L, _P, _P, _P, _P, _I, _I, _P, _F, _I, _P, _P, _P, _P],
+    "wsovod_mask_transpose": [_P, _L, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P],
+    "wsovod_add_group_rows": [_P, _L, _I, _P, _P, _L, _I, _I, _P, _L, _P],
+    "wsovod_scale_rows": [_P, _L, _P, _I, _I, _P, _L, _I, _P],
+    "wsovod_data_aware_forward": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
+    "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
+}
+
 _lib = None
 
 
@@ -62,8 +101,11 @@ def lib():
                 "there is no CPU fallback on the product path."
             )
         _lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError here = library older than the header
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
         _lib.wsovod_last_error.restype = C.c_char_p
-        _lib.wsovod_profile_collect.argtypes = [C.POINTER(ProfEntry), C.c_int]
     return _lib
 
 

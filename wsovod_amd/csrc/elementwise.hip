@@ -278,9 +278,122 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------
+// Backward prologue of Linear+ReLU(+Dropout): dA = dy * [y > 0] * scale, written both as
+// [M][N] (operand of the dX contraction) and transposed [N][ldt] (operand of the dW
+// contraction, reduction dim = proposals).  y == NULL means no mask.
+// ---------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restrict__ dy, long long lddy,
+                                                             const TI* __restrict__ y, long long ldy, int M, int N,
+                                                             float scale, TO* __restrict__ dA, long long ldda,
+                                                             TO* __restrict__ dAt, long long ldt) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  for (int i = ty; i < 64; i += 4) {
+    const int m = m0 + i, n = n0 + tx;
+    float v = 0.f;
+    if (m < M && n < N) {
+      v = to_f32(dy[(long long)m * lddy + n]) * scale;
+      if (y && !(to_f32(y[(long long)m * ldy + n]) > 0.f)) v = 0.f;
+      if (dA) dA[(long long)m * ldda + n] = from_f32<TO>(v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (dAt)
+    for (int i = ty; i < 64; i += 4) {
+      const int n = n0 + i, m = m0 + tx;
+      if (n < N && m < M) dAt[(long long)n * ldt + m] = from_f32<TO>(tile[tx][i]);
+    }
+}
+
+// out[m][n] = x[m][n] + add[row_group[m]][n]   (box_features += data_aware_features,
+// roi_heads.py:762-763; the per-proposal repeat of data_aware_features_head.py:117-121 is
+// never materialised)
+template <typename T>
+__global__ void add_group_rows_kernel(const T* __restrict__ x, long long ldx, const int* __restrict__ row_group,
+                                      const float* __restrict__ add, long long lda, int M, int N,
+                                      T* __restrict__ out, long long ldo) {
+  const long long total = (long long)M * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
+    out[(long long)m * ldo + n] = from_f32<T>(to_f32(x[(long long)m * ldx + n]) + add[(long long)row_group[m] * lda + n]);
+  }
+}
+
+// out[r][c] = x[r][c] * row_scale[r]  (L2-normalised class text embeddings,
+// open_vocabulary_classifier.py:59-60,87-89); rows >= R of out are left untouched.
+template <typename TO>
+__global__ void scale_rows_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ row_scale,
+                                  int R, int Cc, TO* __restrict__ out, long long ldo) {
+  const long long total = (long long)R * Cc;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / Cc), c = (int)(i - (long long)r * Cc);
+    out[(long long)r * ldo + c] = from_f32<TO>(x[(long long)r * ldx + c] * row_scale[r]);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype, int M, int N,
+                          float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
+                          wsovod_stream_t stream) {
+  if (M == 0 || N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(dy && (dA || dAt), "wsovod_mask_transpose: null pointer");
+  static int slot = wsovod::prof_slot("mask_transpose");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * 4.0 * 3);
+#define MT(TI, TO) hipLaunchKernelGGL((mask_transpose_kernel<TI, TO>), grid, dim3(256), 0, s, (const TI*)dy, lddy, (const TI*)y, ldy, M, N, scale, (TO*)dA, ldda, (TO*)dAt, ldt)
+  if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_F32) MT(float, float);
+  else if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_BF16) MT(float, bf16_t);
+  else if (in_dtype == WSOVOD_BF16 && out_dtype == WSOVOD_BF16) MT(bf16_t, bf16_t);
+  else if (in_dtype == WSOVOD_BF16 && out_dtype == WSOVOD_F32) MT(bf16_t, float);
+  else { wsovod::set_error("wsovod_mask_transpose: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+#undef MT
+  WS_CHECK_LAUNCH("wsovod_mask_transpose");
+  return WSOVOD_OK;
+}
+
+int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* row_group, const float* add,
+                          long long ld_add, int M, int N, void* out, long long ldo, wsovod_stream_t stream) {
+  if (M == 0 || N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(x && row_group && add && out, "wsovod_add_group_rows: null pointer");
+  static int slot = wsovod::prof_slot("add_group_rows");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 4.0 : 8.0));
+  const int grid = grid_for((long long)M * N, 256);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(add_group_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, row_group, add, ld_add, M, N, (bf16_t*)out, ldo);
+  else if (dtype == WSOVOD_F32)
+    hipLaunchKernelGGL(add_group_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, row_group, add, ld_add, M, N, (float*)out, ldo);
+  else { wsovod::set_error("wsovod_add_group_rows: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+  WS_CHECK_LAUNCH("wsovod_add_group_rows");
+  return WSOVOD_OK;
+}
+
+int wsovod_scale_rows(const float* x, long long ldx, const float* row_scale, int R, int C, void* out, long long ldo,
+                      int out_dtype, wsovod_stream_t stream) {
+  if (R == 0 || C == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(x && row_scale && out, "wsovod_scale_rows: null pointer");
+  static int slot = wsovod::prof_slot("scale_rows");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)R * C * 8.0);
+  const int grid = grid_for((long long)R * C, 256);
+  if (out_dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(scale_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, x, ldx, row_scale, R, C, (bf16_t*)out, ldo);
+  else if (out_dtype == WSOVOD_F32)
+    hipLaunchKernelGGL(scale_rows_kernel<float>, dim3(grid), dim3(256), 0, s, x, ldx, row_scale, R, C, (float*)out, ldo);
+  else { wsovod::set_error("wsovod_scale_rows: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+  WS_CHECK_LAUNCH("wsovod_scale_rows");
+  return WSOVOD_OK;
+}
 
 int wsovod_preprocess_image(const unsigned char* img, const int* sizes, const float* mean_host,
                             const float* std_host, int N, int Hp, int Wp, float* out, wsovod_stream_t stream) {

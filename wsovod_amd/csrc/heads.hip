@@ -353,6 +353,101 @@ __global__ __launch_bounds__(256) void pgt_mine_label_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------
+// DataAwareFeaturesHead (class_heads/data_aware_features_head.py:103-129) on the pooled
+// (N,C) GAP vector:  h1 = relu(W1 g + b1) (Hd = C/16);  h2 = tanh(W2 h1 + b2) (P prototypes);
+// daf = h2 @ E (P x F).  Workgroup per image forward; the backward (sums over images) is one
+// workgroup -- the whole head is a few hundred KFLOP.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void data_aware_fwd_kernel(const float* __restrict__ gap, int Cc,
+                                                             const float* __restrict__ W1,
+                                                             const float* __restrict__ b1, int Hd,
+                                                             const float* __restrict__ W2,
+                                                             const float* __restrict__ b2, int P,
+                                                             const float* __restrict__ E, int F,
+                                                             float* __restrict__ h1, float* __restrict__ h2,
+                                                             float* __restrict__ daf) {
+  extern __shared__ float sm[];
+  float* s1 = sm;        // Hd
+  float* s2 = sm + Hd;   // P
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* g = gap + (long long)n * Cc;
+  for (int j = wave; j < Hd; j += 4) {
+    float a = 0.f;
+    for (int c = lane; c < Cc; c += 64) a += W1[(long long)j * Cc + c] * g[c];
+    a = wave_reduce_sum(a);
+    if (lane == 0) {
+      a = fmaxf(a + b1[j], 0.f);
+      s1[j] = a;
+      h1[(long long)n * Hd + j] = a;
+    }
+  }
+  __syncthreads();
+  for (int p = wave; p < P; p += 4) {
+    float a = 0.f;
+    for (int j = lane; j < Hd; j += 64) a += W2[(long long)p * Hd + j] * s1[j];
+    a = wave_reduce_sum(a);
+    if (lane == 0) {
+      a = tanhf(a + b2[p]);
+      s2[p] = a;
+      h2[(long long)n * P + p] = a;
+    }
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < F; f += blockDim.x) {
+    float a = 0.f;
+    for (int p = 0; p < P; ++p) a += s2[p] * E[(long long)p * F + f];
+    daf[(long long)n * F + f] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void data_aware_bwd_kernel(const float* __restrict__ ddaf, int N,
+                                                             const float* __restrict__ gap, int Cc,
+                                                             const float* __restrict__ W2,
+                                                             const float* __restrict__ E, int F,
+                                                             const float* __restrict__ h1, int Hd,
+                                                             const float* __restrict__ h2, int P,
+                                                             float* __restrict__ dW1, float* __restrict__ db1,
+                                                             float* __restrict__ dW2, float* __restrict__ db2,
+                                                             float* __restrict__ dE) {
+  extern __shared__ float sm[];
+  float* dpre2 = sm;        // P
+  float* dh1 = sm + P;      // Hd
+  __shared__ float sh[4];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < Hd * Cc; i += blockDim.x) dW1[i] = 0.f;
+  for (int i = tid; i < Hd; i += blockDim.x) db1[i] = 0.f;
+  for (int i = tid; i < P * Hd; i += blockDim.x) dW2[i] = 0.f;
+  for (int i = tid; i < P; i += blockDim.x) db2[i] = 0.f;
+  for (int i = tid; i < P * F; i += blockDim.x) dE[i] = 0.f;
+  __syncthreads();
+  for (int n = 0; n < N; ++n) {
+    const float* dd = ddaf + (long long)n * F;
+    for (int p = 0; p < P; ++p) {
+      float a = 0.f;
+      for (int f = tid; f < F; f += blockDim.x) a += dd[f] * E[(long long)p * F + f];
+      a = block_reduce(a, sh, false);
+      if (tid == 0) {
+        const float t = h2[(long long)n * P + p];
+        dpre2[p] = a * (1.f - t * t);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < P * F; i += blockDim.x) dE[i] += h2[(long long)n * P + i / F] * dd[i % F];
+    for (int i = tid; i < P * Hd; i += blockDim.x) dW2[i] += dpre2[i / Hd] * h1[(long long)n * Hd + i % Hd];
+    for (int i = tid; i < P; i += blockDim.x) db2[i] += dpre2[i];
+    for (int j = tid; j < Hd; j += blockDim.x) {
+      float a = 0.f;
+      for (int p = 0; p < P; ++p) a += W2[(long long)p * Hd + j] * dpre2[p];
+      dh1[j] = h1[(long long)n * Hd + j] > 0.f ? a : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < Hd * Cc; i += blockDim.x) dW1[i] += dh1[i / Cc] * gap[(long long)n * Cc + i % Cc];
+    for (int j = tid; j < Hd; j += blockDim.x) db1[j] += dh1[j];
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -463,6 +558,33 @@ int wsovod_pgt_mine_and_label(const float* scores, long long ld_scores, const fl
                      gt_classes_img, gt_offsets, img_scores, K, iou_threshold, pgt_boxes, pgt_classes, pgt_scores,
                      pgt_weights, pgt_index, pgt_count, out_classes, out_boxes, out_scores, out_weights, out_matched);
   WS_CHECK_LAUNCH("wsovod_pgt_mine_and_label");
+  return WSOVOD_OK;
+}
+
+int wsovod_data_aware_forward(const float* gap, int N, int C, const float* W1, const float* b1, int Hd, const float* W2,
+                               const float* b2, int P, const float* E, int F, float* h1, float* h2, float* daf,
+                               wsovod_stream_t stream) {
+  if (N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(gap && W1 && b1 && W2 && b2 && E && h1 && h2 && daf, "wsovod_data_aware_forward: null pointer");
+  static int slot = wsovod::prof_slot("data_aware_fwd");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, 0.0);
+  hipLaunchKernelGGL(data_aware_fwd_kernel, dim3(N), dim3(256), (Hd + P) * sizeof(float), s, gap, C, W1, b1, Hd, W2,
+                     b2, P, E, F, h1, h2, daf);
+  WS_CHECK_LAUNCH("wsovod_data_aware_forward");
+  return WSOVOD_OK;
+}
+
+int wsovod_data_aware_backward(const float* ddaf, int N, const float* gap, int C, const float* W2, const float* E,
+                               int F, const float* h1, int Hd, const float* h2, int P, float* dW1, float* db1,
+                               float* dW2, float* db2, float* dE, wsovod_stream_t stream) {
+  WS_CHECK_ARG(dW1 && db1 && dW2 && db2 && dE, "wsovod_data_aware_backward: null pointer");
+  static int slot = wsovod::prof_slot("data_aware_bwd");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, 0.0);
+  hipLaunchKernelGGL(data_aware_bwd_kernel, dim3(1), dim3(256), (Hd + P) * sizeof(float), s, ddaf, N, gap, C, W2, E,
+                     F, h1, Hd, h2, P, dW1, db1, dW2, db2, dE);
+  WS_CHECK_LAUNCH("wsovod_data_aware_backward");
   return WSOVOD_OK;
 }
 

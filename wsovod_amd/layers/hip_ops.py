@@ -376,3 +376,65 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
         ptr(o["gt_boxes"]), ptr(o["gt_scores"]), ptr(o["gt_weights"]), ptr(o["matched"]), stream()),
         "pgt_mine_and_label")
     return o
+
+
+def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None):
+    """dA = dy * [y>0] * scale -> (dA (M,N) or None, dAt (N, ld_t>=M) zero padded or None)."""
+    require_gpu(dy, y)
+    M, N = dy.shape
+    dA = torch.empty((M, N), dtype=out_dtype, device=dy.device) if want_plain else None
+    dAt = None
+    if want_t:
+        ld = ld_t or M
+        dAt = (torch.zeros if ld != M else torch.empty)((N, ld), dtype=out_dtype, device=dy.device)
+    check(lib().wsovod_mask_transpose(ptr(dy), _ld(dy), ptr(y), _ld(y) if y is not None else 0, dtype_code(dy.dtype),
+                                      M, N, C.c_float(scale), ptr(dA), N, ptr(dAt), _ld(dAt) if want_t else 0,
+                                      dtype_code(out_dtype), stream()), "mask_transpose")
+    return dA, dAt
+
+
+def add_group_rows(x, row_group, add):
+    require_gpu(x, row_group, add)
+    M, N = x.shape
+    out = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    check(lib().wsovod_add_group_rows(ptr(x), _ld(x), dtype_code(x.dtype), ptr(row_group), ptr(add), _ld(add), M, N,
+                                      ptr(out), N, stream()), "add_group_rows")
+    return out
+
+
+def scale_rows(x, row_scale, out):
+    """out[:R, :C] = x * row_scale[:, None] (out may be wider/taller and of another dtype)."""
+    require_gpu(x, row_scale, out)
+    R, Cc = x.shape
+    check(lib().wsovod_scale_rows(ptr(x), _ld(x), ptr(row_scale), R, Cc, ptr(out), _ld(out), dtype_code(out.dtype),
+                                  stream()), "scale_rows")
+    return out
+
+
+def data_aware_forward(gap, W1, b1, W2, b2, E):
+    require_gpu(gap, W1, b1, W2, b2, E)
+    N, Cc = gap.shape
+    Hd, P, F = W1.size(0), W2.size(0), E.size(1)
+    dev = gap.device
+    h1 = torch.empty((N, Hd), dtype=torch.float32, device=dev)
+    h2 = torch.empty((N, P), dtype=torch.float32, device=dev)
+    daf = torch.empty((N, F), dtype=torch.float32, device=dev)
+    check(lib().wsovod_data_aware_forward(ptr(gap), N, Cc, ptr(W1), ptr(b1), Hd, ptr(W2), ptr(b2), P, ptr(E), F,
+                                          ptr(h1), ptr(h2), ptr(daf), stream()), "data_aware_forward")
+    return daf, h1, h2
+
+
+def data_aware_backward(ddaf, gap, W2, E, h1, h2):
+    require_gpu(ddaf, gap, W2, E, h1, h2)
+    N, Cc = gap.shape
+    Hd, P, F = h1.size(1), h2.size(1), E.size(1)
+    dev = gap.device
+    dW1 = torch.empty((Hd, Cc), dtype=torch.float32, device=dev)
+    db1 = torch.empty((Hd,), dtype=torch.float32, device=dev)
+    dW2 = torch.empty((P, Hd), dtype=torch.float32, device=dev)
+    db2 = torch.empty((P,), dtype=torch.float32, device=dev)
+    dE = torch.empty((P, F), dtype=torch.float32, device=dev)
+    check(lib().wsovod_data_aware_backward(ptr(ddaf.contiguous()), N, ptr(gap), Cc, ptr(W2), ptr(E), F, ptr(h1), Hd,
+                                           ptr(h2), P, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(dE), stream()),
+          "data_aware_backward")
+    return dW1, db1, dW2, db2, dE
