@@ -1,0 +1,269 @@
+"""torch.autograd fronts of the HIP kernels -- the counterpart of the reference's
+`wsovod/layers/roi_loop_pool.py:9-35` (autograd.Function over the native op, `save_for_backward`,
+`once_differentiable`) extended to every op on the hot path.  Forward AND backward run on the
+C-ABI kernels; torch only carries tensors, streams and the autograd graph.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import hip_ops as H
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def _contig2d(t):
+    return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
+
+
+class _Linear(Function):
+    """y = dropout(relu(x @ W^T + b)); x (M,K) in the compute dtype, W fp32 master (N,K)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype):
+        cd = x.dtype
+        wq = weight if cd == torch.float32 else H.cast(weight, cd)
+        y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, out_dtype=out_dtype)
+        ctx.relu, ctx.dropout_p = relu, dropout_p
+        ctx.save_for_backward(x, weight, y if (relu or dropout_p > 0) else None)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        cd = x.dtype
+        M, K = x.shape
+        N = weight.size(0)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dy = _contig2d(dy)
+        scale = 1.0 / (1.0 - ctx.dropout_p) if ctx.dropout_p > 0 else 1.0
+        Mp, Np = _pad(M, 64), _pad(N, 8)
+        dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or need_db, want_t=need_dw, ld_t=Mp,
+                                   ld_plain=Np)
+        dx = dw = db = None
+        if need_dw:
+            xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
+            dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
+        if need_db:
+            seg = torch.tensor([0, M], dtype=torch.int32, device=x.device)
+            db = H.segment_colsum(dA[:, :N] if Np != N else dA, seg).view(N)
+        if need_dx:
+            wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
+            dx = H.gemm_nt(dA, wt, out_dtype=cd)  # (M,K)
+        return dx, dw, db, None, None, None, None
+
+
+def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=None):
+    return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype)
+
+
+class _RoIPool(Function):
+    @staticmethod
+    def forward(ctx, feat, rois, output_size, spatial_scale, roi_scale, out_dtype):
+        need_grad = feat.requires_grad
+        out, argmax = H.roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=roi_scale,
+                                         out_dtype=out_dtype, need_argmax=need_grad)
+        ctx.shape = tuple(feat.shape)
+        ctx.cl = not feat.is_contiguous()
+        ctx.in_dtype = feat.dtype
+        if need_grad:
+            ctx.save_for_backward(rois, argmax, roi_scale)
+            ctx.mark_non_differentiable(argmax)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        rois, argmax, roi_scale = ctx.saved_tensors
+        g = H.roi_pool_backward(grad_output, rois, argmax, ctx.shape, channels_last=ctx.cl, roi_scale=roi_scale)
+        return g.to(ctx.in_dtype), None, None, None, None, None
+
+
+def roi_pool(feat, rois, output_size, spatial_scale, roi_scale=None, out_dtype=None):
+    return _RoIPool.apply(feat, rois, tuple(output_size), float(spatial_scale), roi_scale, out_dtype or feat.dtype)
+
+
+class _RoIAlign(Function):
+    @staticmethod
+    def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned, roi_scale, out_dtype):
+        out = H.roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned,
+                                  roi_scale=roi_scale, out_dtype=out_dtype)
+        ctx.cfg = (tuple(feat.shape), not feat.is_contiguous(), spatial_scale, sampling_ratio, aligned, feat.dtype)
+        ctx.save_for_backward(rois, roi_scale)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        rois, roi_scale = ctx.saved_tensors
+        shape, cl, scale, sr, aligned, dt = ctx.cfg
+        g = H.roi_align_backward(grad_output, rois, scale, sr, aligned, shape, channels_last=cl, roi_scale=roi_scale)
+        return g.to(dt), None, None, None, None, None, None, None
+
+
+def roi_align(feat, rois, output_size, spatial_scale, sampling_ratio, aligned, roi_scale=None, out_dtype=None):
+    return _RoIAlign.apply(feat, rois, tuple(output_size), float(spatial_scale), int(sampling_ratio), bool(aligned),
+                           roi_scale, out_dtype or feat.dtype)
+
+
+class _CosineLogits(Function):
+    """logits = (T * z/||z||) @ Wn^T (+ bias); Wn (K1,D) already L2-normalised with its zero
+    background row, WnT (D, K1 padded) its transpose (open_vocabulary_classifier.py:91-104)."""
+
+    @staticmethod
+    def forward(ctx, z, wn, wnT, temperature, normalize, bias_vec):
+        rs = H.row_l2norm_scale(z, temperature) if normalize else None
+        logits = H.gemm_nt(z, wn, row_scale=rs, bias=bias_vec, out_dtype=torch.float32)
+        ctx.save_for_backward(z, wnT)
+        ctx.cfg = (temperature, normalize, bias_vec is not None)
+        return logits
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dl):
+        z, wnT = ctx.saved_tensors
+        temperature, normalize, has_bias = ctx.cfg
+        cd = z.dtype
+        dl = _contig2d(dl)
+        M, K1 = dl.shape
+        dA, _ = H.mask_transpose(dl, None, 1.0, cd, want_plain=True, want_t=False, ld_plain=wnT.size(1))
+        u = H.gemm_nt(dA, wnT, out_dtype=torch.float32)  # (M,D) = dL/d(zn)
+        dz = H.row_l2norm_backward(z, u, temperature, relu_mask=False) if normalize else u
+        if cd != torch.float32:
+            dz = H.cast(dz, cd)
+        db = None
+        if has_bias and ctx.needs_input_grad[5]:
+            seg = torch.tensor([0, M], dtype=torch.int32, device=z.device)
+            db = H.segment_colsum(dl, seg).view(K1)
+        return dz, None, None, None, None, db
+
+
+def cosine_logits(z, wn, wnT, temperature, normalize=True, bias_vec=None):
+    return _CosineLogits.apply(z, wn, wnT, float(temperature), bool(normalize), bias_vec)
+
+
+class _MilScores(Function):
+    @staticmethod
+    def forward(ctx, logits2k, seg_offsets, K):
+        scores, P, Q = H.mil_forward(logits2k, seg_offsets, K)
+        ctx.save_for_backward(P, Q, seg_offsets)
+        ctx.K = K
+        return scores
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dscores):
+        P, Q, seg = ctx.saved_tensors
+        return H.mil_backward(dscores, P, Q, seg, ctx.K), None, None
+
+
+def mil_scores(logits2k, seg_offsets, K):
+    """softmax(C, dim=1) * softmax(D, dim=0) per image segment on logits (M,2K) = [C | D]."""
+    return _MilScores.apply(_contig2d(logits2k), seg_offsets, int(K))
+
+
+class _ImageBCE(Function):
+    @staticmethod
+    def forward(ctx, scores, seg_offsets, labels_onehot, norm):
+        loss, img, dS = H.image_bce_forward(scores, seg_offsets, labels_onehot, norm)
+        ctx.save_for_backward(dS, seg_offsets)
+        ctx.M = scores.size(0)
+        ctx.mark_non_differentiable(img)
+        return loss.view(()), img
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout, _gimg):
+        dS, seg = ctx.saved_tensors
+        return H.image_bce_backward(dS, seg, ctx.M, gout.reshape(1).contiguous()), None, None, None
+
+
+def image_bce(scores, seg_offsets, labels_onehot, norm):
+    """-> (loss scalar, clamped image-level scores (N,K))."""
+    return _ImageBCE.apply(_contig2d(scores), seg_offsets, labels_onehot.to(torch.float32).contiguous(), float(norm))
+
+
+class _WeightedCE(Function):
+    @staticmethod
+    def forward(ctx, logits, gt_classes, weights, weighted):
+        loss, dl, accum = H.weighted_ce_forward(logits, gt_classes, weights, weighted)
+        ctx.save_for_backward(dl, accum)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        dl, accum = ctx.saved_tensors
+        H.scale_by_device_scalar(dl, gout.reshape(1).contiguous(), accum[1:2])
+        return dl, None, None, None
+
+
+def weighted_cross_entropy(logits, gt_classes, weights=None, weighted=True):
+    return _WeightedCE.apply(_contig2d(logits), gt_classes.contiguous(),
+                             None if weights is None else weights.to(torch.float32).contiguous(), bool(weighted))
+
+
+class _WeightedL1Box(Function):
+    @staticmethod
+    def forward(ctx, pred, proposal_boxes, gt_boxes, gt_classes, weights, K, bbox_weights, beta, weighted):
+        loss, dp = H.weighted_l1_box_forward(pred, proposal_boxes, gt_boxes, gt_classes, weights, K, bbox_weights,
+                                             beta, weighted)
+        ctx.save_for_backward(dp)
+        return loss.view(())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (dp,) = ctx.saved_tensors
+        H.scale_by_device_scalar(dp, gout.reshape(1).contiguous(), None)
+        return dp, None, None, None, None, None, None, None, None
+
+
+def weighted_l1_box_loss(pred, proposal_boxes, gt_boxes, gt_classes, weights, K, bbox_weights, beta, weighted=True):
+    return _WeightedL1Box.apply(_contig2d(pred), proposal_boxes.to(torch.float32).contiguous(),
+                                gt_boxes.to(torch.float32).contiguous(), gt_classes.contiguous(),
+                                None if weights is None else weights.to(torch.float32).contiguous(), int(K),
+                                tuple(bbox_weights), float(beta), bool(weighted))
+
+
+class _DataAware(Function):
+    @staticmethod
+    def forward(ctx, gap, W1, b1, W2, b2, E):
+        daf, h1, h2 = H.data_aware_forward(gap, W1, b1, W2, b2, E)
+        ctx.save_for_backward(gap, W2, E, h1, h2)
+        return daf
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ddaf):
+        gap, W2, E, h1, h2 = ctx.saved_tensors
+        dW1, db1, dW2, db2, dE = H.data_aware_backward(ddaf, gap, W2, E, h1, h2)
+        return None, dW1, db1, dW2, db2, dE
+
+
+def data_aware_features(gap, W1, b1, W2, b2, E):
+    return _DataAware.apply(gap, W1, b1, W2, b2, E)
+
+
+class _AddGroupRows(Function):
+    @staticmethod
+    def forward(ctx, x, add, row_group, seg_offsets):
+        ctx.save_for_backward(seg_offsets)
+        return H.add_group_rows(x, row_group, add)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (seg,) = ctx.saved_tensors
+        dadd = H.segment_colsum(_contig2d(dy), seg) if ctx.needs_input_grad[1] else None
+        return dy, dadd, None, None
+
+
+def add_group_rows(x, add, row_group, seg_offsets):
+    """x[m] + add[row_group[m]] (box_features += data_aware_features without the per-proposal repeat)."""
+    return _AddGroupRows.apply(x, add, row_group, seg_offsets)

@@ -378,17 +378,20 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
     return o
 
 
-def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None):
-    """dA = dy * [y>0] * scale -> (dA (M,N) or None, dAt (N, ld_t>=M) zero padded or None)."""
+def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None):
+    """dA = dy * [y>0] * scale -> (dA (M, ld_plain>=N) or None, dAt (N, ld_t>=M) or None), zero padded."""
     require_gpu(dy, y)
     M, N = dy.shape
-    dA = torch.empty((M, N), dtype=out_dtype, device=dy.device) if want_plain else None
+    ldp = ld_plain or N
+    dA = None
+    if want_plain:
+        dA = (torch.zeros if ldp != N else torch.empty)((M, ldp), dtype=out_dtype, device=dy.device)
     dAt = None
     if want_t:
         ld = ld_t or M
         dAt = (torch.zeros if ld != M else torch.empty)((N, ld), dtype=out_dtype, device=dy.device)
     check(lib().wsovod_mask_transpose(ptr(dy), _ld(dy), ptr(y), _ld(y) if y is not None else 0, dtype_code(dy.dtype),
-                                      M, N, C.c_float(scale), ptr(dA), N, ptr(dAt), _ld(dAt) if want_t else 0,
+                                      M, N, C.c_float(scale), ptr(dA), ldp, ptr(dAt), _ld(dAt) if want_t else 0,
                                       dtype_code(out_dtype), stream()), "mask_transpose")
     return dA, dAt
 
