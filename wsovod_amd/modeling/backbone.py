@@ -1,0 +1,375 @@
+"""WSL ResNet ("DC5", output stride 8) backbone on the HIP implicit-GEMM convolution.
+
+Host-side mirror of /root/reference/wsovod/modeling/backbone/resnet_wsl.py: same classes
+(`BasicStem`, `BasicBlock`, `BottleneckBlock`, `ResNet`, `build_wsl_resnet_backbone`), same
+constructor arguments, same parameter/buffer names (so reference d2 checkpoints load), same
+`forward(x) -> {"res5": Tensor}` / `output_shape()` / `freeze()` surface.  The compute is not
+torch: every conv (+ folded FrozenBN affine + ReLU + residual add) is one launch of the MFMA
+implicit-GEMM kernel over NHWC activations, pools are the NHWC max-pool kernel.  The returned
+feature map is logically NCHW but stored NHWC (torch.channels_last), which the ROIPooler reads
+directly.
+
+Scope: every shipped WSR config freezes the whole backbone (FREEZE_AT: 5), so only the
+forward exists; a trainable stage raises NotImplementedError instead of silently using torch.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..config import BACKBONE_REGISTRY
+from ..layers import hip_ops as H
+from ..structures import ShapeSpec
+
+__all__ = ["BasicStem", "BasicBlock", "BottleneckBlock", "ResNet", "FrozenBatchNorm2d", "Conv2d",
+           "build_wsl_resnet_backbone", "make_stage"]
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2.layers.FrozenBatchNorm2d: fixed statistics + affine, eps 1e-5 (buffers, not params)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+
+def get_norm(norm, out_channels):
+    if norm is None or (isinstance(norm, str) and len(norm) == 0):
+        return None
+    if norm == "FrozenBN":
+        return FrozenBatchNorm2d(out_channels)
+    raise NotImplementedError(f"wsovod_amd backbone supports NORM 'FrozenBN' or '' (got {norm!r})")
+
+
+def c2_msra_fill(module):
+    nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+class Conv2d(nn.Module):
+    """Parameter holder with detectron2.layers.Conv2d's state-dict layout (weight, bias, norm.*)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, bias=True, norm=None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding, self.dilation = kernel_size, stride, padding, dilation
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.norm = norm
+        self._folded = None
+
+    def folded(self, dtype, cin_pad=None):
+        """(weight [Cout][kh*kw*Cin] in `dtype` with the FrozenBN scale folded in, fp32 bias)."""
+        key = (dtype, cin_pad, self.weight._version, self.weight.device)
+        if self._folded is None or self._folded[0] != key:
+            with torch.no_grad():
+                w = self.weight.float()
+                b = self.bias.float() if self.bias is not None else torch.zeros(self.out_channels, device=w.device)
+                if self.norm is not None:
+                    scale, shift = self.norm.scale_shift()
+                    w = w * scale.view(-1, 1, 1, 1)
+                    b = b * scale + shift
+                w = w.permute(0, 2, 3, 1)  # [Cout][kh][kw][Cin]
+                if cin_pad is not None and cin_pad != self.in_channels:
+                    w = F.pad(w, (0, cin_pad - self.in_channels))
+                wq = w.reshape(self.out_channels, -1).to(dtype).contiguous()
+                self._folded = (key, wq, b.contiguous())
+        return self._folded[1], self._folded[2]
+
+
+def hip_conv(x, conv, relu=False, residual=None):
+    """x: (N,H,W,Cin) NHWC contiguous in the compute dtype -> (N,Ho,Wo,Cout)."""
+    N, Hh, Ww, Cin = x.shape
+    k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    Ho = (Hh + 2 * p - d * (k - 1) - 1) // s + 1
+    Wo = (Ww + 2 * p - d * (k - 1) - 1) // s + 1
+    wq, b = conv.folded(x.dtype, cin_pad=Cin)
+    geom = dict(n_img=N, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=s, pad=p, dil=d)
+    res2d = residual.view(N * Ho * Wo, conv.out_channels) if residual is not None else None
+    out = H.gemm_nt(x, wq, conv=geom, bias=b, relu=relu, residual=res2d, out_dtype=x.dtype)
+    return out.view(N, Ho, Wo, conv.out_channels)
+
+
+class CNNBlockBase(nn.Module):
+    def __init__(self, in_channels, out_channels, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        return self
+
+
+class _PoolMixin:
+    def _init_pool(self, has_pool, pool_stride):
+        self.has_pool, self.pool_stride = has_pool, pool_stride
+
+    def _pool(self, out):
+        if not self.has_pool:
+            return out
+        # stride 1: ZeroPad2d((0,1,0,1)) + MaxPool2d(2, 1); else MaxPool2d(2, stride)  (resnet_wsl.py:85-92)
+        return H.maxpool2x2_nhwc(out, self.pool_stride, zero_pad_br=self.pool_stride == 1)
+
+
+class BasicBlock(CNNBlockBase, _PoolMixin):
+    """resnet_wsl.py:24-110: two 3x3 convs; the block stride lives in the trailing max pool."""
+
+    def __init__(self, in_channels, out_channels, *, stride=1, norm="BN", dilation=1, has_pool=False):
+        super().__init__(in_channels, out_channels, stride)
+        self._init_pool(has_pool, stride)
+        stride = 1
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, 1, stride=stride, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        self.conv1 = Conv2d(in_channels, out_channels, 3, stride=stride, padding=dilation, dilation=dilation,
+                            bias=False, norm=get_norm(norm, out_channels))
+        self.conv2 = Conv2d(out_channels, out_channels, 3, stride=1, padding=dilation, dilation=dilation,
+                            bias=False, norm=get_norm(norm, out_channels))
+        for layer in [self.conv1, self.conv2, self.shortcut]:
+            if layer is not None:
+                c2_msra_fill(layer)
+
+    def forward(self, x):
+        out = hip_conv(x, self.conv1, relu=True)
+        shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
+        out = hip_conv(out, self.conv2, relu=True, residual=shortcut)  # out += shortcut; relu
+        return self._pool(out)
+
+
+class BottleneckBlock(CNNBlockBase, _PoolMixin):
+    """resnet_wsl.py:113-241: 1x1 -> 3x3 (dilated) -> 1x1 + shortcut."""
+
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
+                 stride_in_1x1=False, dilation=1, has_pool=False):
+        super().__init__(in_channels, out_channels, stride)
+        if num_groups != 1:
+            raise NotImplementedError("grouped convolution is not on the WSR hot path")
+        self._init_pool(has_pool, stride)
+        stride = 1
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, 1, stride=stride, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, 1, stride=stride_1x1, bias=False,
+                            norm=get_norm(norm, bottleneck_channels))
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, 3, stride=stride_3x3, padding=dilation,
+                            dilation=dilation, bias=False, norm=get_norm(norm, bottleneck_channels))
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, 1, bias=False, norm=get_norm(norm, out_channels))
+        for layer in [self.conv1, self.conv2, self.conv3, self.shortcut]:
+            if layer is not None:
+                c2_msra_fill(layer)
+
+    def forward(self, x):
+        out = hip_conv(x, self.conv1, relu=True)
+        out = hip_conv(out, self.conv2, relu=True)
+        shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
+        out = hip_conv(out, self.conv3, relu=True, residual=shortcut)
+        return self._pool(out)
+
+
+class BasicStem(CNNBlockBase):
+    """resnet_wsl.py:361-421: conv3x3 s2 -> conv3x3 -> conv3x3 -> maxpool k2 s2 (stride 4)."""
+
+    def __init__(self, in_channels=3, out_channels=64, norm="BN"):
+        super().__init__(in_channels, out_channels, 4)
+        self.conv1 = Conv2d(in_channels, out_channels, 3, stride=2, padding=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        self.conv2 = Conv2d(out_channels, out_channels, 3, stride=1, padding=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        self.conv3 = Conv2d(out_channels, out_channels, 3, stride=1, padding=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for c in (self.conv1, self.conv2, self.conv3):
+            c2_msra_fill(c)
+
+    def _tail(self, x):
+        x = hip_conv(x, self.conv2, relu=True)
+        x = hip_conv(x, self.conv3, relu=True)
+        return H.maxpool2x2_nhwc(x, 2)
+
+    def forward(self, x):
+        """x: NHWC with Cin zero-padded to the kernel's K-step (generic float entry)."""
+        return self._tail(hip_conv(x, self.conv1, relu=True))
+
+    def forward_im2col(self, a, n, ho, wo):
+        """a: (n*ho*wo, 32) fused normalise+im2col operand of conv1 (K = 27 padded to 32)."""
+        assert self.in_channels == 3
+        wq, b = self.conv1.folded(a.dtype)  # [Cout][27]
+        wpad = getattr(self, "_w_im2col", None)
+        if wpad is None or wpad[0] is not wq:
+            w32 = torch.zeros((wq.size(0), 32), dtype=wq.dtype, device=wq.device)
+            w32[:, :27] = wq
+            self._w_im2col = wpad = (wq, w32)
+        x = H.gemm_nt(a, wpad[1], bias=b, relu=True, out_dtype=a.dtype).view(n, ho, wo, self.out_channels)
+        return self._tail(x)
+
+
+class ResNet(nn.Module):
+    """resnet_wsl.py:424-607."""
+
+    def __init__(self, stem, stages, num_classes=None, out_features=None, freeze_at=0, precision="bf16"):
+        super().__init__()
+        if num_classes is not None:
+            raise NotImplementedError("classification head is not on the detection hot path")
+        self.stem = stem
+        self.num_classes = num_classes
+        self.precision = precision
+        current_stride = self.stem.stride
+        self._out_feature_strides = {"stem": current_stride}
+        self._out_feature_channels = {"stem": self.stem.out_channels}
+        self.stage_names, self.stages = [], []
+        if out_features is not None:
+            num_stages = max([{"res2": 1, "res3": 2, "res4": 3, "res5": 4}.get(f, 0) for f in out_features])
+            stages = stages[:num_stages]
+        for i, blocks in enumerate(stages):
+            assert len(blocks) > 0, len(blocks)
+            name = "res" + str(i + 2)
+            stage = nn.Sequential(*blocks)
+            self.add_module(name, stage)
+            self.stage_names.append(name)
+            self.stages.append(stage)
+            self._out_feature_strides[name] = current_stride = int(
+                current_stride * np.prod([k.stride for k in blocks]))
+            self._out_feature_channels[name] = blocks[-1].out_channels
+        self.stage_names = tuple(self.stage_names)
+        if out_features is None:
+            out_features = [name]
+        self._out_features = out_features
+        assert len(self._out_features)
+        children = [x[0] for x in self.named_children()]
+        for out_feature in self._out_features:
+            assert out_feature in children, "Available children: {}".format(", ".join(children))
+        self.freeze(freeze_at)
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    @property
+    def compute_dtype(self):
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+
+    def _check_frozen(self):
+        if any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "wsovod_amd: the HIP backbone is forward-only; all shipped WSR configs use "
+                "MODEL.BACKBONE.FREEZE_AT=5 (conv backward is outside the hot path, SURVEY F3)")
+
+    def _run(self, x):
+        outputs = {}
+        if "stem" in self._out_features:
+            outputs["stem"] = x.permute(0, 3, 1, 2)
+        for name, stage in zip(self.stage_names, self.stages):
+            x = stage(x)
+            if name in self._out_features:
+                outputs[name] = x.permute(0, 3, 1, 2)  # logical NCHW, NHWC memory (channels_last)
+        return outputs
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: (N,C,H,W) normalised float image batch -> {name: (N,C',H/8,W/8) channels_last}."""
+        assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
+        self._check_frozen()
+        cd = self.compute_dtype
+        kstep = 64 if cd == torch.bfloat16 else 32
+        xn = x.permute(0, 2, 3, 1).to(cd)
+        xn = F.pad(xn, (0, kstep - xn.size(-1))).contiguous()  # Cin 3 -> one K-step (generic float entry)
+        return self._run(self.stem(xn))
+
+    @torch.no_grad()
+    def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
+        """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
+        self._check_frozen()
+        a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
+        return self._run(self.stem.forward_im2col(a, images_u8.size(0), ho, wo))
+
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+                for name in self._out_features}
+
+    def freeze(self, freeze_at=0):
+        if freeze_at >= 1:
+            self.stem.freeze()
+        for idx, stage in enumerate(self.stages, start=2):
+            if freeze_at >= idx:
+                for block in stage.children():
+                    block.freeze()
+        return self
+
+    @staticmethod
+    def make_stage(block_class, num_blocks, *, in_channels, out_channels, **kwargs):
+        blocks = []
+        for i in range(num_blocks):
+            curr_kwargs = {}
+            for k, v in kwargs.items():
+                if k.endswith("_per_block"):
+                    assert len(v) == num_blocks
+                    curr_kwargs[k[: -len("_per_block")]] = v[i]
+                else:
+                    curr_kwargs[k] = v
+            blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, **curr_kwargs))
+            in_channels = out_channels
+        return blocks
+
+
+def make_stage(*args, **kwargs):
+    return ResNet.make_stage(*args, **kwargs)
+
+
+@BACKBONE_REGISTRY.register()
+def build_wsl_resnet_backbone(cfg, input_shape):
+    """resnet_wsl.py:623-707 (stage wiring: stride-by-maxpool, dilated res4/res5)."""
+    norm = cfg.MODEL.RESNETS.NORM
+    stem = BasicStem(in_channels=input_shape.channels, out_channels=cfg.MODEL.RESNETS.STEM_OUT_CHANNELS, norm=norm)
+    freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
+    out_features = cfg.MODEL.RESNETS.OUT_FEATURES
+    depth = cfg.MODEL.RESNETS.DEPTH
+    num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
+    width_per_group = cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+    bottleneck_channels = num_groups * width_per_group
+    in_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+    out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+    stride_in_1x1 = cfg.MODEL.RESNETS.STRIDE_IN_1X1
+    res5_dilation = cfg.MODEL.RESNETS.RES5_DILATION
+    assert res5_dilation in {1, 2}, "res5_dilation cannot be {}.".format(res5_dilation)
+    if any(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE):
+        raise NotImplementedError("deformable conv is not used by the WSR configs")
+    num_blocks_per_stage = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3],
+                            152: [3, 8, 36, 3]}[depth]
+    if depth in [18, 34]:
+        assert out_channels == 64, "Must set MODEL.RESNETS.RES2_OUT_CHANNELS = 64 for R18/R34"
+        assert num_groups == 1, "Must set MODEL.RESNETS.NUM_GROUPS = 1 for R18/R34"
+    stages = []
+    for idx, stage_idx in enumerate(range(2, 6)):
+        dilation = res5_dilation if stage_idx == 5 or stage_idx == 4 else 1
+        first_stride = 2 if idx == 0 or (stage_idx == 3 and res5_dilation == 1) else 1
+        has_pool = stage_idx == 2 or stage_idx == 3
+        nb = num_blocks_per_stage[idx]
+        stage_kargs = {"num_blocks": nb, "stride_per_block": [1] * (nb - 1) + [first_stride],
+                       "has_pool_per_block": [False] * (nb - 1) + [has_pool], "in_channels": in_channels,
+                       "out_channels": out_channels, "norm": norm, "dilation": dilation}
+        if depth in [18, 34]:
+            stage_kargs["block_class"] = BasicBlock
+        else:
+            stage_kargs.update(block_class=BottleneckBlock, bottleneck_channels=bottleneck_channels,
+                               stride_in_1x1=stride_in_1x1, num_groups=num_groups)
+        stages.append(ResNet.make_stage(**stage_kargs))
+        in_channels = out_channels
+        out_channels *= 2
+        bottleneck_channels *= 2
+    return ResNet(stem, stages, out_features=out_features, freeze_at=freeze_at,
+                  precision=cfg.MODEL.HIP.PRECISION)

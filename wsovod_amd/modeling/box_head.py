@@ -1,0 +1,72 @@
+"""DiscriminativeAdaptationNeck on the MFMA contraction kernel.
+
+Mirror of /root/reference/wsovod/modeling/roi_heads/box_head.py:18-106: Flatten -> fc1 -> ReLU ->
+Dropout(0.5) -> fc2 -> ReLU -> Dropout(0.5), same child-module names (state-dict keys
+`fc1.weight`, ...), same initialisers (N(0, 0.005), bias 0.1).  Each FC + bias + ReLU + dropout is
+ONE launch (epilogue fused); the backward is the mask/transpose prologue + two contractions.
+"""
+from typing import List
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..config import ROI_BOX_HEAD_REGISTRY, configurable
+from ..layers import functions as Fn
+from ..structures import ShapeSpec
+
+__all__ = ["DiscriminativeAdaptationNeck", "build_box_head"]
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class DiscriminativeAdaptationNeck(nn.Sequential):
+    @configurable
+    def __init__(self, input_shape: ShapeSpec, *, conv_dims: List[int], fc_dims: List[int], conv_norm=""):
+        super().__init__()
+        assert len(conv_dims) + len(fc_dims) > 0
+        if len(conv_dims):
+            raise NotImplementedError("NUM_CONV > 0 is not used by any WSOVOD config (hot path: FC neck only)")
+        self._output_size = (input_shape.channels, input_shape.height, input_shape.width)
+        self.conv_norm_relus = []
+        self.fcs = []
+        for k, fc_dim in enumerate(fc_dims):
+            if k == 0:
+                self.add_module("flatten", nn.Flatten())
+            fc = nn.Linear(int(np.prod(self._output_size)), fc_dim)
+            self.add_module("fc{}".format(k + 1), fc)
+            self.add_module("fc_relu{}".format(k + 1), nn.ReLU(inplace=True))
+            self.add_module("fc_dropout{}".format(k + 1), nn.Dropout(p=0.5, inplace=False))
+            self.fcs.append(fc)
+            self._output_size = fc_dim
+        for layer in self.fcs:
+            torch.nn.init.normal_(layer.weight, std=0.005)
+            torch.nn.init.constant_(layer.bias, 0.1)
+        self._step = 0
+        self.dropout_seed = 0x5EED
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        return {"input_shape": input_shape, "conv_dims": [cfg.MODEL.ROI_BOX_HEAD.CONV_DIM] * cfg.MODEL.ROI_BOX_HEAD.NUM_CONV,
+                "fc_dims": cfg.MODEL.ROI_BOX_HEAD.DAN_DIM, "conv_norm": cfg.MODEL.ROI_BOX_HEAD.NORM}
+
+    def forward(self, x):
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        self._step += 1
+        for k, fc in enumerate(self.fcs):
+            drop = getattr(self, "fc_dropout{}".format(k + 1))
+            p = drop.p if (self.training and drop.training) else 0.0
+            seed = (self.dropout_seed * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF
+            x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed)
+        return x
+
+    @property
+    def output_shape(self):
+        o = self._output_size
+        if isinstance(o, int):
+            return ShapeSpec(channels=o)
+        return ShapeSpec(channels=o[0], height=o[1], width=o[2])
+
+
+def build_box_head(cfg, input_shape):
+    return ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, input_shape)
