@@ -1,0 +1,318 @@
+"""Object-mining (WSDDN MIL) and instance-refinement output layers on HIP kernels.
+
+Mirror of /root/reference/wsovod/modeling/roi_heads/fast_rcnn_open_vocabulary.py: same classes
+(`ObjectMiningOutputLayers` :220-618, `InstanceRefinementOutputLayers` :621-1062), same child
+names (`cls`, `det`, `bbox_pred`), initialisers, `forward` / `losses` / `predict_*` surface and
+loss-dict keys.  Training-path compute (the two softmaxes over ragged per-image segments, image
+BCE, cosine-similarity logits, weighted CE, weighted smooth-L1) runs on the C-ABI kernels.
+The eval tail (`fast_rcnn_inference`: threshold + per-class NMS + top-k) is a SURVEY 8f "next"
+row and is kept as plain torch ops on the device.
+"""
+from typing import Dict, List, Tuple, Union
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from ..config import configurable
+from ..layers import functions as Fn
+from ..structures import Boxes, Instances, ShapeSpec
+from .box_regression import Box2BoxTransform
+
+__all__ = ["fast_rcnn_inference", "ObjectMiningOutputLayers", "InstanceRefinementOutputLayers", "segment_offsets"]
+
+
+def segment_offsets(nums, device):
+    """int32 (G+1) prefix offsets of the per-image proposal counts (host ints -> one tiny H2D copy)."""
+    offs = [0]
+    for n in nums:
+        offs.append(offs[-1] + int(n))
+    return torch.tensor(offs, dtype=torch.int32, device=device)
+
+
+def _nms(boxes, scores, thr):
+    """Plain greedy NMS (eval tail only; 'next' row n2)."""
+    order = scores.argsort(descending=True)
+    boxes = boxes[order]
+    keep = []
+    suppressed = torch.zeros(len(order), dtype=torch.bool, device=boxes.device)
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    for i in range(len(order)):
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        lt = torch.max(boxes[i, :2], boxes[i + 1:, :2])
+        rb = torch.min(boxes[i, 2:], boxes[i + 1:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[:, 0] * wh[:, 1]
+        iou = inter / (area[i] + area[i + 1:] - inter)
+        suppressed[i + 1:] |= iou > thr
+    return order[torch.tensor(keep, dtype=torch.long, device=boxes.device)]
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64, device=boxes.device)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + 1)
+    return _nms(boxes.float() + offsets[:, None], scores, iou_threshold)
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    all_scores, all_boxes = scores.clone(), boxes.clone()
+    valid_mask = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    if not valid_mask.all():
+        boxes, scores = boxes[valid_mask], scores[valid_mask]
+    scores = scores[:, :-1]
+    num_bbox_reg_classes = boxes.shape[1] // 4
+    boxes = Boxes(boxes.reshape(-1, 4))
+    boxes.clip(image_shape)
+    boxes = boxes.tensor.view(-1, num_bbox_reg_classes, 4)
+    filter_mask = scores > score_thresh
+    filter_inds = filter_mask.nonzero()
+    boxes = boxes[filter_inds[:, 0], 0] if num_bbox_reg_classes == 1 else boxes[filter_mask]
+    scores = scores[filter_mask]
+    keep = batched_nms(boxes, scores, filter_inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    boxes, scores, filter_inds = boxes[keep], scores[keep], filter_inds[keep]
+    result = Instances(image_shape)
+    result.pred_boxes = Boxes(boxes)
+    result.scores = scores
+    result.pred_classes = filter_inds[:, 1]
+    return result, filter_inds[:, 0], all_scores, all_boxes
+
+
+def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
+    r = [fast_rcnn_inference_single_image(b, s, shp, score_thresh, nms_thresh, topk_per_image)
+         for s, b, shp in zip(scores, boxes, image_shapes)]
+    return [x[0] for x in r], [x[1] for x in r], [x[2] for x in r], [x[3] for x in r]
+
+
+class ObjectMiningOutputLayers(nn.Module):
+    @configurable
+    def __init__(self, input_shape: ShapeSpec, *, box2box_transform, num_classes: int, class_head: nn.Module = None,
+                 test_score_thresh: float = 0.0, test_nms_thresh: float = 0.5, test_topk_per_image: int = 100,
+                 cls_agnostic_bbox_reg: bool = False, smooth_l1_beta: float = 0.0,
+                 box_reg_loss_type: str = "smooth_l1", loss_weight: Union[float, Dict[str, float]] = 1.0,
+                 mean_loss: bool = True):
+        super().__init__()
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        self.num_classes = num_classes
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.num_bbox_reg_classes = 1 if cls_agnostic_bbox_reg else num_classes
+        self.box_dim = len(box2box_transform.weights)
+        self.det = nn.Linear(input_size, num_classes)
+        nn.init.xavier_uniform_(self.det.weight)
+        nn.init.constant_(self.det.bias, 0)
+        if class_head is not None:
+            raise NotImplementedError("class_head != None is never built by the reference (roi_heads.py:588-590)")
+        self.cls = nn.Linear(input_size, num_classes)
+        nn.init.xavier_uniform_(self.cls.weight)
+        nn.init.constant_(self.cls.bias, 0)
+        self.box2box_transform = box2box_transform
+        self.smooth_l1_beta = smooth_l1_beta
+        self.test_score_thresh, self.test_nms_thresh = test_score_thresh, test_nms_thresh
+        self.test_topk_per_image = test_topk_per_image
+        self.box_reg_loss_type = box_reg_loss_type
+        self.loss_weight = loss_weight
+        self.mean_loss = mean_loss
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, class_head=None, num_classes=None):
+        return {
+            "input_shape": input_shape,
+            "box2box_transform": Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS),
+            "num_classes": num_classes if num_classes else cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+            "class_head": class_head,
+            "cls_agnostic_bbox_reg": cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG,
+            "smooth_l1_beta": cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA,
+            "test_score_thresh": cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+            "test_nms_thresh": cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
+            "test_topk_per_image": cfg.TEST.DETECTIONS_PER_IMAGE,
+            "box_reg_loss_type": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE,
+            "loss_weight": {"loss_box_reg_object_mining": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT,
+                            "loss_cls_object_mining": cfg.WSOVOD.OBJECT_MINING.WEIGHT},
+            "mean_loss": cfg.WSOVOD.OBJECT_MINING.MEAN_LOSS,
+        }
+
+    def forward(self, x, proposals=None, context=False):
+        """-> (scores (R,K) = softmax_classes(C) * softmax_proposals(D) per image, zero deltas)."""
+        if context:
+            raise NotImplementedError("contextlocnet needs POOLER_TYPE ROILoopPool (out of hot-path scope)")
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        K = self.num_classes
+        # one contraction for both heads: rows [cls | det] of a (2K, F) weight
+        w = torch.cat([self.cls.weight, self.det.weight], dim=0)
+        b = torch.cat([self.cls.bias, self.det.bias], dim=0)
+        logits = Fn.linear(x, w, b, out_dtype=torch.float32)  # (R, 2K) = [C | D]
+        if K == 1:  # fast_rcnn_open_vocabulary.py:338-340
+            z = torch.zeros_like(logits[:, :1])
+            logits = torch.cat((logits[:, :1], z, logits[:, 1:], z), dim=1)
+        nums = [x.size(0)] if (proposals is None or len(proposals) == 1) else [len(p) for p in proposals]
+        self._seg = segment_offsets(nums, x.device)
+        scores = Fn.mil_scores(logits, self._seg, max(K, 2) if K == 1 else K)
+        if K == 1:
+            scores = scores[:, :1]
+        proposal_deltas = torch.zeros(scores.shape[0], self.num_bbox_reg_classes * self.box_dim, dtype=scores.dtype,
+                                      device=scores.device, requires_grad=False)
+        return scores, proposal_deltas
+
+    def losses(self, predictions, proposals, gt_classes_img_oh):
+        scores, _ = predictions
+        assert gt_classes_img_oh.dim() == 2
+        seg = segment_offsets([len(p) for p in proposals], scores.device)
+        G, K = gt_classes_img_oh.shape
+        # mean: BCE mean over (N,K); else sum / N   (fast_rcnn_open_vocabulary.py:411-425)
+        norm = float(G * K) if self.mean_loss else float(G)
+        loss, img = Fn.image_bce(scores, seg, gt_classes_img_oh, norm)
+        self._pred_class_img_logits = img
+        losses = {"loss_cls_object_mining": loss}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+    def predict_boxes(self, predictions, proposals):
+        return [p.proposal_boxes.tensor for p in proposals]
+
+    def predict_probs(self, predictions, proposals):
+        scores, _ = predictions
+        num_inst_per_image = [len(p) for p in proposals]
+        probs_bg = torch.zeros(scores.shape[0], 1, dtype=scores.dtype, device=scores.device)
+        return torch.cat((scores, probs_bg), 1).split(num_inst_per_image, dim=0)
+
+    def predict_probs_img(self, predictions, proposals):
+        """Clamped image-level scores (N,K); computed by the BCE kernel when losses() ran first."""
+        cached = getattr(self, "_pred_class_img_logits", None)
+        if cached is not None and self.training:
+            return cached
+        scores, _ = predictions
+        seg = segment_offsets([len(p) for p in proposals], scores.device)
+        zeros = torch.zeros((len(proposals), scores.size(1)), device=scores.device)
+        _, img = Fn.image_bce(scores.detach(), seg, zeros, 1.0)
+        return img
+
+
+class InstanceRefinementOutputLayers(nn.Module):
+    @configurable
+    def __init__(self, input_shape: ShapeSpec, *, box2box_transform, num_classes: int, class_head: nn.Module,
+                 test_score_thresh: float = 0.0, test_nms_thresh: float = 0.5, test_topk_per_image: int = 100,
+                 smooth_l1_beta: float = 0.0, box_reg_loss_type: str = "smooth_l1",
+                 loss_weight: Union[float, Dict[str, float]] = 1.0, refine_k: int = None, refine_reg=False,
+                 cross_entropy_weighted: bool = True):
+        super().__init__()
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        self.num_classes = num_classes
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.cls = class_head
+        self.num_bbox_reg_classes = 1
+        self.box_dim = len(box2box_transform.weights)
+        self.bbox_pred = nn.Linear(input_size, self.num_bbox_reg_classes * self.box_dim)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        nn.init.constant_(self.bbox_pred.bias, 0)
+        self.box2box_transform = box2box_transform
+        self.smooth_l1_beta = smooth_l1_beta
+        self.test_score_thresh, self.test_nms_thresh = test_score_thresh, test_nms_thresh
+        self.test_topk_per_image = test_topk_per_image
+        self.box_reg_loss_type = box_reg_loss_type
+        if isinstance(loss_weight, float):
+            loss_weight = {"loss_cls_r" + str(refine_k): loss_weight, "loss_box_reg_r" + str(refine_k): loss_weight}
+        self.loss_weight = loss_weight
+        self.refine_k, self.refine_reg = refine_k, refine_reg
+        self.cross_entropy_weighted = cross_entropy_weighted
+        if not self.refine_reg[self.refine_k]:
+            del self.bbox_pred
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, refine_k, class_head):
+        return {
+            "input_shape": input_shape,
+            "box2box_transform": Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS),
+            "num_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+            "class_head": class_head,
+            "smooth_l1_beta": cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA,
+            "test_score_thresh": cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+            "test_nms_thresh": cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
+            "test_topk_per_image": cfg.TEST.DETECTIONS_PER_IMAGE,
+            "box_reg_loss_type": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE,
+            "loss_weight": {"loss_box_reg_r" + str(refine_k): cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT,
+                            "loss_cls_r" + str(refine_k): cfg.WSOVOD.INSTANCE_REFINEMENT.WEIGHT},
+            "refine_k": refine_k,
+            "refine_reg": cfg.WSOVOD.INSTANCE_REFINEMENT.REFINE_REG,
+            "cross_entropy_weighted": cfg.WSOVOD.INSTANCE_REFINEMENT.CROSS_ENTROPY_WEIGHTED,
+        }
+
+    def forward(self, x, classifier=None, append_background=True):
+        """-> (logits (R,K+1) with background logit == 0, class-agnostic deltas (R,4))."""
+        if x.dim() > 2:
+            x = torch.flatten(x, start_dim=1)
+        scores = self.cls(x, classifier, append_background=append_background)
+        if self.refine_reg[self.refine_k]:
+            proposal_deltas = Fn.linear(x, self.bbox_pred.weight, self.bbox_pred.bias, out_dtype=torch.float32)
+        else:
+            proposal_deltas = torch.zeros(scores.shape[0], self.num_bbox_reg_classes * self.box_dim,
+                                          dtype=scores.dtype, device=scores.device, requires_grad=False)
+        return scores, proposal_deltas
+
+    def losses(self, predictions, proposals, num_classes=None):
+        scores, proposal_deltas = predictions
+        dev = scores.device
+        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else \
+            torch.empty(0, dtype=torch.int64, device=dev)
+        if len(proposals):
+            proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            assert not proposal_boxes.requires_grad, "Proposals should not require gradients!"
+            gt_boxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals],
+                                 dim=0)
+        else:
+            proposal_boxes = gt_boxes = torch.empty((0, 4), device=dev)
+        weighted_box = self.box_reg_loss_type == "smooth_l1_weighted"
+        weights = None
+        if self.cross_entropy_weighted or weighted_box:
+            weights = torch.cat([p.gt_weights for p in proposals], dim=0)
+        k = str(self.refine_k)
+        losses = {"loss_cls_r" + k: Fn.weighted_cross_entropy(scores, gt_classes, weights,
+                                                            weighted=self.cross_entropy_weighted)}
+        if self.refine_reg[self.refine_k]:
+            if self.box_reg_loss_type not in ("smooth_l1", "smooth_l1_weighted"):
+                raise NotImplementedError(f"box_reg_loss_type {self.box_reg_loss_type} is not on the hot path")
+            losses["loss_box_reg_r" + k] = Fn.weighted_l1_box_loss(
+                proposal_deltas, proposal_boxes, gt_boxes, gt_classes, weights,
+                num_classes if num_classes is not None else self.num_classes, self.box2box_transform.weights,
+                self.smooth_l1_beta, weighted=weighted_box)
+        return {k_: v * self.loss_weight.get(k_, 1.0) for k_, v in losses.items()}
+
+    # ---- eval tail ("next" row n2): plain torch ops on the device ----
+    def inference(self, predictions, proposals):
+        if isinstance(predictions[0], tuple):
+            boxes = self.predict_boxes_K(predictions, proposals)
+            scores = self.predict_probs_K(predictions, proposals)
+        else:
+            boxes = self.predict_boxes(predictions, proposals)
+            scores = self.predict_probs(predictions, proposals)
+        image_shapes = [x.image_size for x in proposals]
+        return fast_rcnn_inference(boxes, scores, image_shapes, self.test_score_thresh, self.test_nms_thresh,
+                                   self.test_topk_per_image)
+
+    def predict_boxes(self, predictions, proposals):
+        if not len(proposals):
+            return []
+        _, proposal_deltas = predictions
+        num_prop_per_image = [len(p) for p in proposals]
+        proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        return self.box2box_transform.apply_deltas(proposal_deltas, proposal_boxes).split(num_prop_per_image)
+
+    def predict_boxes_K(self, predictions, proposals):
+        if not len(proposals):
+            return []
+        deltas = torch.stack([p[1] for p in predictions]).mean(0)
+        return self.predict_boxes((None, deltas), proposals)
+
+    def predict_probs(self, predictions, proposals):
+        scores, _ = predictions
+        return F.softmax(scores, dim=-1).split([len(p) for p in proposals], dim=0)
+
+    def predict_probs_K(self, predictions, proposals):
+        probs = torch.stack([F.softmax(p[0], dim=-1) for p in predictions]).mean(0)
+        return probs.split([len(p) for p in proposals], dim=0)
