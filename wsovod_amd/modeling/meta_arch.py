@@ -1,0 +1,179 @@
+"""GeneralizedRCNN_WSOVOD on the HIP hot path.
+
+Mirror of /root/reference/wsovod/modeling/meta_arch/rcnn_wsovod.py:27-344: same registry name,
+`forward(batched_inputs) -> dict[str, loss]` in training / `inference(...)` in eval, same
+`batched_inputs` format (`image` uint8 CHW BGR, `instances`, `proposals`, `height`/`width`), same
+sub-module names (`backbone`, `data_aware_head`, `roi_heads`) so state dicts are interchangeable.
+The proposals-only branch (rcnn_wsovod.py:198-204) is the hot path; an RPN
+(`MODEL.PROPOSAL_GENERATOR.NAME != "PrecomputedProposals"`) is a SURVEY 8f "next" row.
+"""
+import logging
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..config import BACKBONE_REGISTRY, META_ARCH_REGISTRY, configurable
+from ..layers import hip_ops as H
+from ..structures import ImageList, Instances, ShapeSpec
+from .class_heads import DataAwareFeaturesHead
+from .fast_rcnn_open_vocabulary import segment_offsets
+from .roi_heads import build_roi_heads
+
+__all__ = ["GeneralizedRCNN_WSOVOD", "build_model", "build_backbone"]
+
+
+def build_backbone(cfg, input_shape=None):
+    if input_shape is None:
+        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    return BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, input_shape)
+
+
+def build_model(cfg):
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model
+
+
+def detector_postprocess(results: Instances, output_height: int, output_width: int):
+    """wsovod/modeling/postprocessing.py:8-82 (boxes only): rescale to the requested output size."""
+    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **results.get_fields())
+    boxes = out.pred_boxes.clone()
+    boxes.scale(scale_x, scale_y)
+    boxes.clip(out.image_size)
+    out.pred_boxes = boxes
+    return out[boxes.nonempty()]
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN_WSOVOD(nn.Module):
+    @configurable
+    def __init__(self, *, cfg=None, backbone, data_aware_head=None, proposal_generator, roi_heads,
+                 pixel_mean: Tuple[float], pixel_std: Tuple[float], input_format: Optional[str] = None,
+                 vis_period: int = 0):
+        super().__init__()
+        if proposal_generator is not None:
+            raise NotImplementedError("RPN branch (WSOVODRPN_V2) is a 'next' row; use PrecomputedProposals")
+        self.cfg = cfg
+        self.backbone = backbone
+        self.data_aware_head = data_aware_head
+        self.proposal_generator = None
+        self.roi_heads = roi_heads
+        self.input_format = input_format
+        self.vis_period = 0
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std).view(-1, 1, 1), False)
+        self._mean, self._std = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
+        self.logger = logging.getLogger(__name__)
+        self.classifier = None
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        if cfg.MODEL.PROPOSAL_GENERATOR.NAME != "PrecomputedProposals":
+            raise NotImplementedError(
+                f"MODEL.PROPOSAL_GENERATOR.NAME={cfg.MODEL.PROPOSAL_GENERATOR.NAME}: the RPN branch is a SURVEY 8f "
+                "'next' row; the hot path runs proposals-only (PrecomputedProposals)")
+        return {
+            "cfg": cfg, "backbone": backbone,
+            "data_aware_head": DataAwareFeaturesHead(cfg, backbone.output_shape())
+            if cfg.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.DATA_AWARE else None,
+            "proposal_generator": None, "roi_heads": build_roi_heads(cfg, backbone.output_shape()),
+            "input_format": cfg.INPUT.FORMAT, "vis_period": cfg.VIS_PERIOD,
+            "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
+        }
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    # ---- input staging (H2D + padding are plumbing; normalisation is fused into the stem) ----
+    def _canvas(self, batched_inputs):
+        images = [x["image"] for x in batched_inputs]
+        sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+        Hp, Wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        if len(images) == 1 or all(s == sizes[0] for s in sizes):
+            canvas = torch.stack([im.to(self.device, non_blocking=True) for im in images])
+        else:
+            canvas = torch.zeros((len(images), 3, Hp, Wp), dtype=torch.uint8, device=self.device)
+            for i, im in enumerate(images):
+                canvas[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
+        if canvas.dtype != torch.uint8:
+            raise RuntimeError("GeneralizedRCNN_WSOVOD expects uint8 CHW images (DatasetMapper format)")
+        sizes_t = torch.tensor(sizes, dtype=torch.int32, device=self.device)
+        return canvas.contiguous(), sizes_t, sizes
+
+    def preprocess_image(self, batched_inputs):
+        """rcnn_wsovod.py:321-328: normalise, pad and batch -> ImageList (fp32 NCHW)."""
+        canvas, sizes_t, sizes = self._canvas(batched_inputs)
+        return ImageList(H.preprocess_image(canvas, sizes_t, self._mean, self._std), sizes)
+
+    def _proposals(self, batched_inputs):
+        assert "proposals" in batched_inputs[0]
+        proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+        for p in proposals:
+            p.level_ids = torch.zeros((len(p),), dtype=torch.int64, device=self.device)
+        return proposals
+
+    def _image_level_gt(self, batched_inputs):
+        """get_image_level_gt (roi_heads.py:158-174) on the host copies: no device sync."""
+        K = self.roi_heads.num_classes
+        cls_list, oh = [], torch.zeros((len(batched_inputs), K), dtype=torch.float32)
+        for i, x in enumerate(batched_inputs):
+            gc = x["instances"].gt_classes
+            if gc.is_cuda:
+                return None
+            u = torch.unique(gc, sorted=True).to(torch.int64)
+            cls_list.append(u)
+            oh[i, u] = 1.0
+        cat = torch.cat(cls_list).to(self.device, non_blocking=True)
+        off = segment_offsets([len(u) for u in cls_list], self.device)
+        return cat, off, oh.to(self.device, non_blocking=True)
+
+    def forward(self, batched_inputs, classifier=None):
+        if not self.training:
+            return self.inference(batched_inputs, classifier=classifier)
+        canvas, sizes_t, sizes = self._canvas(batched_inputs)
+        gt_instances = None
+        if "instances" in batched_inputs[0]:
+            self.roi_heads.image_level_gt = self._image_level_gt(batched_inputs)
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+        features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
+        proposals = self._proposals(batched_inputs)
+        daf = self.data_aware_head.forward_per_image(features) if self.data_aware_head is not None else None
+        _, detector_losses = self.roi_heads(ImageList(canvas, sizes), features, proposals, daf, gt_instances,
+                                            append_background=True, loaded_proposals=proposals)
+        losses = {}
+        losses.update(detector_losses)
+        return losses
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, classifier=None):
+        assert not self.training
+        assert detected_instances is None, "forward_with_given_boxes is not on the hot path"
+        canvas, sizes_t, sizes = self._canvas(batched_inputs)
+        features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
+        proposals = self._proposals(batched_inputs)
+        daf = self.data_aware_head.forward_per_image(features) if self.data_aware_head is not None else None
+        if classifier is not None:
+            self.classifier = classifier
+        elif self.classifier is None:
+            weight_path = self.cfg.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_PATH_TEST
+            self.classifier = torch.tensor(np.load(weight_path, encoding="bytes", allow_pickle=True),
+                                           dtype=torch.float32).contiguous().to(self.device)
+        results, _, all_scores, all_boxes = self.roi_heads(ImageList(canvas, sizes), features, proposals, daf, None,
+                                                           self.classifier, append_background=True)
+        if do_postprocess:
+            return GeneralizedRCNN_WSOVOD._postprocess(results, batched_inputs, sizes)
+        return results, all_scores, all_boxes
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        processed_results = []
+        for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
+            height = input_per_image.get("height", image_size[0])
+            width = input_per_image.get("width", image_size[1])
+            processed_results.append({"instances": detector_postprocess(results_per_image, height, width)})
+        return processed_results
