@@ -45,8 +45,8 @@ class OpenVocabularyClassifier(nn.Module):
             nn.init.normal_(class_weight, std=0.01)
         else:
             logger.info("Loading " + weight_path)
-            class_weight = (torch.tensor(np.load(weight_path, encoding="bytes", allow_pickle=True),
-                                         dtype=torch.float32).permute(1, 0).contiguous())  # D x C
+            class_weight = (torch.as_tensor(np.load(weight_path, encoding="bytes", allow_pickle=True))
+                            .to(torch.float32).permute(1, 0).contiguous())  # D x C
         if self.norm_weight:
             class_weight = F.normalize(class_weight, p=2, dim=0)
         # "rand" makes it a Parameter in the reference (a debugging mode); the HIP path treats the

@@ -161,8 +161,8 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             self.classifier = classifier
         elif self.classifier is None:
             weight_path = self.cfg.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_PATH_TEST
-            self.classifier = torch.tensor(np.load(weight_path, encoding="bytes", allow_pickle=True),
-                                           dtype=torch.float32).contiguous().to(self.device)
+            self.classifier = torch.as_tensor(np.load(weight_path, encoding="bytes", allow_pickle=True)).to(
+                torch.float32).contiguous().to(self.device)
         results, _, all_scores, all_boxes = self.roi_heads(ImageList(canvas, sizes), features, proposals, daf, None,
                                                            self.classifier, append_background=True)
         if do_postprocess:

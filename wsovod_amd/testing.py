@@ -1,0 +1,43 @@
+"""Helpers shared by bench.py, smoke() and the tests to build the hot-path model on synthetic inputs."""
+import os
+import pickle
+import tempfile
+
+import torch
+
+from .config import get_cfg
+from .data import make_class_embeddings
+
+_CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
+
+
+def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", device="cuda", weight_path=None,
+                 emb_seed=7):
+    """WSOVOD_WSR_{18,50}_DC5_1x in proposals-only mode: the keys below are the values of
+    /root/reference/configs/PascalVOC-Detection/{Base-RCNN-DilatedC5,WSOVOD_WSR_18_DC5_1x}.yaml
+    that the hot path reads, with PROPOSAL_GENERATOR=PrecomputedProposals, BBOX_REFINE off."""
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(_CONFIG_DIR, f"WSOVOD_WSR_{depth}_DC5_1x.yaml"))
+    if weight_path is None:
+        weight_path = os.path.join(tempfile.mkdtemp(prefix="wsovod_emb_"), f"emb_{K}x{D}.pkl")
+        with open(weight_path, "wb") as f:
+            pickle.dump(make_class_embeddings(K, D, seed=emb_seed), f)
+    cfg.merge_from_list([
+        "MODEL.ROI_HEADS.NUM_CLASSES", K,
+        "MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_DIM", D,
+        "MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_PATH_TRAIN", weight_path,
+        "MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_PATH_TEST", weight_path,
+        "MODEL.ROI_BOX_HEAD.POOLER_TYPE", pooler,
+        "MODEL.HIP.PRECISION", precision,
+        "MODEL.DEVICE", device,
+    ])
+    return cfg
+
+
+def build_hot_path_model(seed=0, **kw):
+    from .modeling import build_model
+
+    cfg = hot_path_cfg(**kw)
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    return cfg, model
