@@ -1,0 +1,351 @@
+"""ORACLE -- test infrastructure only (never imported by wsovod_amd/).
+
+Functional PyTorch-CPU fp32 restatement of the reference's per-image detection hot path
+(SURVEY.md section 8a).  Parameters come in as a state dict with the reference's key names, so
+the same tensors can be loaded into the HIP model and into the reference modules (under shims,
+tests/golden/make_golden.py) and all three compared.  Every function cites the reference lines
+it follows; paths are relative to /root/reference/.
+
+Parity pinning: tests/golden/*.npz hold outputs of the REFERENCE's own code on seeded inputs
+(generated here by tests/golden/make_golden.py); tests/test_oracle_golden.py checks this file
+against them.  Un-vendored pieces (detectron2 / fvcore / torchvision semantics) are restated from
+SURVEY.md Appendix A and cross-checked against torch built-ins where one exists.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from . import roi_ops
+
+# ----------------------------------------------------------------------------------------
+# backbone: wsovod/modeling/backbone/resnet_wsl.py
+# ----------------------------------------------------------------------------------------
+_BLOCKS = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}
+
+
+def conv_frozen_bn(x, sd, prefix, stride=1, padding=0, dilation=1, eps=1e-5):
+    """detectron2 Conv2d(norm=FrozenBatchNorm2d): F.conv2d then F.batch_norm(training=False)."""
+    x = F.conv2d(x, sd[prefix + "weight"], sd.get(prefix + "bias"), stride, padding, dilation)
+    if prefix + "norm.weight" in sd:
+        x = F.batch_norm(x, sd[prefix + "norm.running_mean"], sd[prefix + "norm.running_var"],
+                         sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], training=False, eps=eps)
+    return x
+
+
+def _tail_pool(out, pool_stride):
+    # resnet_wsl.py:85-92
+    if pool_stride == 1:
+        out = F.pad(out, (0, 1, 0, 1))
+        return F.max_pool2d(out, kernel_size=2, stride=1, padding=0)
+    return F.max_pool2d(out, kernel_size=2, stride=pool_stride, padding=0)
+
+
+def basic_block(x, sd, prefix, dilation, has_pool, pool_stride):
+    """resnet_wsl.py:94-110."""
+    out = F.relu(conv_frozen_bn(x, sd, prefix + "conv1.", 1, dilation, dilation))
+    out = conv_frozen_bn(out, sd, prefix + "conv2.", 1, dilation, dilation)
+    shortcut = conv_frozen_bn(x, sd, prefix + "shortcut.") if prefix + "shortcut.weight" in sd else x
+    out = F.relu(out + shortcut)
+    return _tail_pool(out, pool_stride) if has_pool else out
+
+
+def bottleneck_block(x, sd, prefix, dilation, has_pool, pool_stride):
+    """resnet_wsl.py:221-241."""
+    out = F.relu(conv_frozen_bn(x, sd, prefix + "conv1."))
+    out = F.relu(conv_frozen_bn(out, sd, prefix + "conv2.", 1, dilation, dilation))
+    out = conv_frozen_bn(out, sd, prefix + "conv3.")
+    shortcut = conv_frozen_bn(x, sd, prefix + "shortcut.") if prefix + "shortcut.weight" in sd else x
+    out = F.relu(out + shortcut)
+    return _tail_pool(out, pool_stride) if has_pool else out
+
+
+def backbone_forward(sd, x, depth=18, res5_dilation=2, prefix="backbone."):
+    """resnet_wsl.py:410-421 (stem), :497-520 (stages), :674-706 (stride/dilation/pool wiring)."""
+    out = {}
+    x = F.relu(conv_frozen_bn(x, sd, prefix + "stem.conv1.", 2, 1))
+    x = F.relu(conv_frozen_bn(x, sd, prefix + "stem.conv2.", 1, 1))
+    x = F.relu(conv_frozen_bn(x, sd, prefix + "stem.conv3.", 1, 1))
+    x = F.max_pool2d(x, kernel_size=2, stride=2, padding=0)
+    out["stem"] = x
+    block = basic_block if depth in (18, 34) else bottleneck_block
+    for idx, stage_idx in enumerate(range(2, 6)):
+        dilation = res5_dilation if stage_idx in (4, 5) else 1
+        first_stride = 2 if idx == 0 or (stage_idx == 3 and res5_dilation == 1) else 1
+        has_pool = stage_idx in (2, 3)
+        nb = _BLOCKS[depth][idx]
+        for b in range(nb):
+            last = b == nb - 1
+            x = block(x, sd, f"{prefix}res{stage_idx}.{b}.", dilation, has_pool and last, first_stride if last else 1)
+        out[f"res{stage_idx}"] = x
+    return out
+
+
+def preprocess_image(images_u8, pixel_mean, pixel_std):
+    """meta_arch/rcnn_wsovod.py:321-328 + ImageList.from_tensors(size_divisibility=0)."""
+    mean = torch.tensor(pixel_mean).view(-1, 1, 1)
+    std = torch.tensor(pixel_std).view(-1, 1, 1)
+    imgs = [(x.float() - mean) / std for x in images_u8]
+    Hm, Wm = max(i.shape[-2] for i in imgs), max(i.shape[-1] for i in imgs)
+    out = imgs[0].new_zeros((len(imgs), 3, Hm, Wm))
+    for i, im in enumerate(imgs):
+        out[i, :, : im.shape[-2], : im.shape[-1]] = im
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# pooling: wsovod/modeling/poolers.py
+# ----------------------------------------------------------------------------------------
+def pooler_format(boxes_list):
+    """poolers.py:74-108."""
+    return torch.cat([torch.cat((torch.full_like(b[:, :1], i), b), dim=1) for i, b in enumerate(boxes_list)], dim=0)
+
+
+def roi_pooler(feat, boxes_list, pooler_type="ROIPool", output_size=7, scale=0.125, sampling_ratio=0):
+    """poolers.py:169-197,277-284 (single level)."""
+    rois = pooler_format(boxes_list)
+    size = (output_size, output_size)
+    if pooler_type == "ROIPool":
+        return roi_ops.roi_pool_forward(feat, rois, scale, size)[0]
+    if pooler_type == "ROIAlignV2":
+        return roi_ops.roi_align_forward(feat, rois, scale, size, sampling_ratio, True)
+    if pooler_type == "ROIAlign":
+        return roi_ops.roi_align_forward(feat, rois, scale, size, sampling_ratio, False)
+    raise ValueError(pooler_type)
+
+
+# ----------------------------------------------------------------------------------------
+# heads
+# ----------------------------------------------------------------------------------------
+def neck_forward(sd, pooled, prefix="roi_heads.box_head.", dropout_masks=None):
+    """roi_heads/box_head.py:90-93 (Flatten, fc1, ReLU, Dropout, fc2, ReLU, Dropout).
+    dropout_masks: None (eval) or two 0/1 keep masks (inverted dropout, p = 0.5)."""
+    x = torch.flatten(pooled, 1)
+    for k in (1, 2):
+        x = F.relu(F.linear(x, sd[f"{prefix}fc{k}.weight"], sd[f"{prefix}fc{k}.bias"]))
+        if dropout_masks is not None:
+            x = x * dropout_masks[k - 1] * 2.0
+    return x
+
+
+def data_aware_forward(sd, res5, prefix="data_aware_head."):
+    """class_heads/data_aware_features_head.py:123-129 -> one row per image."""
+    x = F.adaptive_avg_pool2d(res5, 1).flatten(start_dim=1)
+    x = F.relu(F.linear(x, sd[prefix + "linear1.weight"], sd[prefix + "linear1.bias"]))
+    x = torch.tanh(F.linear(x, sd[prefix + "linear2.weight"], sd[prefix + "linear2.bias"]))
+    return torch.matmul(x, sd[prefix + "datasets_feat.weight"])
+
+
+def mining_forward(sd, x, nums, prefix="roi_heads.object_miner."):
+    """roi_heads/fast_rcnn_open_vocabulary.py:333-357."""
+    C = F.linear(x, sd[prefix + "cls.weight"], sd[prefix + "cls.bias"])
+    D = F.linear(x, sd[prefix + "det.weight"], sd[prefix + "det.bias"])
+    K = C.shape[1]
+    if K == 1:
+        C = torch.cat((C, torch.zeros_like(C)), dim=1)
+        D = torch.cat((D, torch.zeros_like(D)), dim=1)
+    scores = torch.cat([F.softmax(c, dim=1) * F.softmax(d, dim=0) for c, d in zip(C.split(nums), D.split(nums))], dim=0)
+    if K == 1:
+        scores, _ = torch.split(scores, 1, dim=1)
+    return scores
+
+
+def predict_probs_img(scores, nums):
+    """fast_rcnn_open_vocabulary.py:604-618."""
+    s = torch.cat([t.sum(dim=0, keepdim=True) for t in scores.split(nums)], dim=0)
+    return torch.clamp(s, min=1e-6, max=1.0 - 1e-6)
+
+
+def mining_loss(scores, nums, gt_oh, mean_loss=True):
+    """fast_rcnn_open_vocabulary.py:392-437."""
+    img = predict_probs_img(scores, nums)
+    if mean_loss:
+        return F.binary_cross_entropy(img, gt_oh.float(), reduction="mean")
+    return F.binary_cross_entropy(img, gt_oh.float(), reduction="sum") / gt_oh.size(0)
+
+
+def ov_classifier_forward(sd, x, prefix, temperature=50.0, norm_weight=True, classifier=None,
+                          append_background=True, cls_bias=None):
+    """class_heads/open_vocabulary_classifier.py:79-105.  sd[prefix+'class_weight'] is the (D,K) buffer
+    already normalised at construction (:59-60)."""
+    x = F.relu(F.linear(x, sd[prefix + "projection.0.weight"], sd[prefix + "projection.0.bias"]))
+    x = F.relu(F.linear(x, sd[prefix + "projection.2.weight"], sd[prefix + "projection.2.bias"]))
+    if classifier is not None:
+        class_weight = classifier.permute(1, 0).contiguous()
+        class_weight = F.normalize(class_weight, p=2, dim=0) if norm_weight else class_weight
+    else:
+        class_weight = sd[prefix + "class_weight"]
+    if norm_weight:
+        x = temperature * F.normalize(x, p=2, dim=1)
+    if append_background:
+        class_weight = torch.cat([class_weight, class_weight.new_zeros((class_weight.size(0), 1))], dim=1)
+    x = torch.mm(x, class_weight)
+    if cls_bias is not None:
+        x = x + cls_bias
+    return x
+
+
+def box2box_get_deltas(src, tgt, weights=(10.0, 10.0, 5.0, 5.0)):
+    """detectron2 Box2BoxTransform.get_deltas."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tx, ty = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)),
+                       dim=1)
+
+
+def refinement_losses(logits, deltas, gt_classes, gt_weights, proposal_boxes, gt_boxes, num_classes,
+                      bbox_weights=(10.0, 10.0, 5.0, 5.0), beta=0.0, cross_entropy_weighted=True,
+                      box_loss_type="smooth_l1_weighted"):
+    """fast_rcnn_open_vocabulary.py:754-892 (weighted CE :813-820; weighted smooth-L1 :864-878)."""
+    w = gt_weights.clone()
+    w[gt_classes == -1] = 0.0
+    valid = torch.zeros_like(w)
+    valid[w > 1e-12] = 1.0
+    if cross_entropy_weighted:
+        ce = F.cross_entropy(logits, gt_classes, reduction="none", ignore_index=-1)
+        loss_cls = (ce * w).sum() / valid.sum()
+    else:
+        loss_cls = F.cross_entropy(logits, gt_classes, reduction="mean", ignore_index=-1)
+    fg = ((gt_classes >= 0) & (gt_classes < num_classes)).nonzero().squeeze(1)
+    tgt = box2box_get_deltas(proposal_boxes[fg], gt_boxes[fg], bbox_weights)
+    diff = (deltas[fg] - tgt).abs()
+    l = diff if beta < 1e-5 else torch.where(diff < beta, 0.5 * diff * diff / beta, diff - 0.5 * beta)
+    if box_loss_type == "smooth_l1_weighted":
+        if torch.isnan(tgt).any():
+            loss_box = torch.zeros(())
+        else:
+            loss_box = (l * w[fg, None]).sum() / max(gt_classes.numel(), 1.0)
+    else:
+        loss_box = l.sum() / max(gt_classes.numel(), 1.0)
+    return loss_cls, loss_box
+
+
+# ----------------------------------------------------------------------------------------
+# pseudo-GT mining + labelling (no grad): roi_heads/roi_heads.py
+# ----------------------------------------------------------------------------------------
+def pairwise_iou(b1, b2):
+    """detectron2.structures.pairwise_iou."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    wh = (torch.min(b1[:, None, 2:], b2[:, 2:]) - torch.max(b1[:, None, :2], b2[:, :2])).clamp(min=0)
+    inter = wh.prod(dim=2)
+    return torch.where(inter > 0, inter / (a1[:, None] + a2 - inter), torch.zeros(1))
+
+
+@torch.no_grad()
+def get_pgt_top_k(prev_pred_boxes, prev_pred_scores, gt_classes_img_int, pred_class_img_logits, num_classes):
+    """roi_heads.py:1043-1343 with top_k=1, thres=0, need_weight, sam=None.
+    prev_pred_boxes: list of (R,4); prev_pred_scores: list of (R,>=K).  Returns per image a dict with
+    gt_boxes (G,4), gt_classes (G), gt_scores (G), gt_weights (G)."""
+    out = []
+    for i, (boxes, scores, gt_int) in enumerate(zip(prev_pred_boxes, prev_pred_scores, gt_classes_img_int)):
+        R = boxes.size(0)
+        b = boxes.unsqueeze(1).expand(R, num_classes, 4)
+        s = torch.index_select(scores, 1, gt_int)
+        b = torch.index_select(b, 1, gt_int)
+        keep = (b[:, :, 2] - b[:, :, 0]) * (b[:, :, 3] - b[:, :, 1]) > 20  # :1090-1096
+        b = b.masked_select(keep.unsqueeze(2).expand(-1, gt_int.numel(), 4)).view(-1, gt_int.numel(), 4)
+        s = s.masked_select(keep).view(-1, gt_int.numel())
+        top_k = min(s.size(0), 1)
+        pgt_scores, pgt_idx = torch.topk(s, top_k, dim=0)
+        pgt_boxes = torch.gather(b, 0, pgt_idx.unsqueeze(2).expand(top_k, gt_int.numel(), 4))
+        pgt_classes = gt_int.unsqueeze(0).expand(top_k, gt_int.numel())
+        pgt_weights = torch.index_select(pred_class_img_logits[i:i + 1], 1, gt_int).expand(top_k, gt_int.numel())
+        pgt_scores, pgt_boxes = pgt_scores.reshape(-1), pgt_boxes.reshape(-1, 4)
+        pgt_classes, pgt_weights = pgt_classes.reshape(-1), pgt_weights.reshape(-1)
+        if pgt_weights.numel() == 0:  # :1181-1207 fallbacks
+            pgt_weights = torch.tensor([1], dtype=pgt_weights.dtype)
+        if pgt_scores.numel() == 0:
+            pgt_scores = torch.tensor([1], dtype=pgt_scores.dtype)
+        if pgt_boxes.numel() == 0:
+            pgt_boxes = torch.tensor([[-10000, -10000, 10000, 10000]], dtype=pgt_boxes.dtype)
+        if pgt_classes.numel() == 0:
+            pgt_classes = torch.tensor([0], dtype=pgt_classes.dtype)
+        out.append(dict(gt_boxes=pgt_boxes, gt_classes=pgt_classes, gt_scores=pgt_scores, gt_weights=pgt_weights))
+    return out
+
+
+@torch.no_grad()
+def label_and_sample_proposals_wsl(proposal_boxes_list, targets, num_classes, iou_thr=0.5):
+    """roi_heads.py:1722-1825 + _sample_proposals_wsl :1566-1610 with Matcher([thr],[0,1]) and
+    subsample_labels(4096, 1.0) keeping every proposal (R <= 4096)."""
+    res = []
+    for pb, t in zip(proposal_boxes_list, targets):
+        iou = pairwise_iou(t["gt_boxes"], pb)  # (G,R)
+        matched_vals, matched_idxs = iou.max(dim=0)
+        labels = (matched_vals >= iou_thr).to(torch.int8)
+        gt_classes = t["gt_classes"][matched_idxs].clone()
+        gt_classes[labels == 0] = num_classes
+        res.append(dict(gt_classes=gt_classes, gt_boxes=t["gt_boxes"][matched_idxs],
+                        gt_scores=t["gt_scores"][matched_idxs], gt_weights=t["gt_weights"][matched_idxs],
+                        matched_idxs=matched_idxs))
+    return res
+
+
+def get_image_level_gt(gt_classes_list, num_classes):
+    """roi_heads.py:158-174."""
+    ints = [torch.unique(g, sorted=True).to(torch.int64) for g in gt_classes_list]
+    oh = torch.cat([torch.zeros((1, num_classes)).scatter_(1, g.unsqueeze(0), 1) for g in ints], dim=0)
+    return ints, oh
+
+
+# ----------------------------------------------------------------------------------------
+# the whole training step (rcnn_wsovod.py:137-234 -> roi_heads.py:648-907), proposals-only mode
+# ----------------------------------------------------------------------------------------
+def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool", temperature=50.0,
+                  pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True,
+                  mean_loss=True, sampling_ratio=0, dropout_masks=None, refine_prefix="roi_heads.box_refinery_0."):
+    """batch: list of dicts {image uint8 (3,H,W), boxes (R,4), objectness (R), gt_classes (G)}.
+    Returns (losses dict, intermediates dict).  REFINE_NUM=1, REFINE_REG=[True], SAMPLING_ON."""
+    inter = {}
+    x = preprocess_image([b["image"] for b in batch], pixel_mean, pixel_std)
+    feats = backbone_forward(sd, x, depth)
+    res5 = feats["res5"]
+    inter["res5"] = res5
+    boxes_list = [b["boxes"] for b in batch]
+    nums = [len(b) for b in boxes_list]
+    pooled = roi_pooler(res5.detach(), boxes_list, pooler_type, 7, 0.125, sampling_ratio)
+    objectness = torch.cat([b["objectness"] + 1 for b in batch], dim=0)
+    pooled = pooled * objectness.view(-1, 1, 1, 1)  # roi_heads.py:733-739
+    inter["pooled"] = pooled
+    feat = neck_forward(sd, pooled, dropout_masks=dropout_masks)
+    if data_aware:
+        daf = data_aware_forward(sd, res5)
+        inter["daf"] = daf
+        feat = feat + torch.cat([daf[i].repeat(n, 1) for i, n in enumerate(nums)])  # roi_heads.py:762-763
+    inter["box_features"] = feat
+    scores = mining_forward(sd, feat, nums)
+    inter["mining_scores"] = scores
+    gt_int, gt_oh = get_image_level_gt([b["gt_classes"] for b in batch], num_classes)
+    losses = {"loss_cls_object_mining": mining_loss(scores, nums, gt_oh, mean_loss)}
+    img_logits = predict_probs_img(scores, nums).detach()
+    inter["pred_class_img_logits"] = img_logits
+    targets = get_pgt_top_k(boxes_list, list(scores.detach().split(nums)), gt_int, img_logits, num_classes)
+    labelled = label_and_sample_proposals_wsl(boxes_list, targets, num_classes)
+    inter["targets"], inter["labelled"] = targets, labelled
+    logits = ov_classifier_forward(sd, feat, refine_prefix + "cls.", temperature)
+    deltas = F.linear(feat, sd[refine_prefix + "bbox_pred.weight"], sd[refine_prefix + "bbox_pred.bias"])
+    inter["refine_logits"], inter["refine_deltas"] = logits, deltas
+    lc, lb = refinement_losses(logits, deltas, torch.cat([l["gt_classes"] for l in labelled]),
+                               torch.cat([l["gt_weights"] for l in labelled]), torch.cat(boxes_list),
+                               torch.cat([l["gt_boxes"] for l in labelled]), num_classes)
+    losses["loss_cls_r0"], losses["loss_box_reg_r0"] = lc, lb
+    return losses, inter
+
+
+def batch_from_inputs(batched_inputs):
+    """DatasetMapper-format dicts (with Instances) -> the plain-tensor batch of train_forward."""
+    return [dict(image=x["image"], boxes=x["proposals"].proposal_boxes.tensor.float(),
+                 objectness=x["proposals"].objectness_logits.float(), gt_classes=x["instances"].gt_classes)
+            for x in batched_inputs]
+
+
+def sgd_step(params, grads, bufs, lr, momentum, weight_decay):
+    """torch.optim.SGD (dampening 0) as configured by engine/defaults.py:274-318."""
+    for k in params:
+        g = grads[k] + weight_decay * params[k]
+        bufs[k] = momentum * bufs[k] + g if k in bufs else g.clone()
+        params[k] = params[k] - lr * bufs[k]

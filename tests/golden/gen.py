@@ -1,0 +1,93 @@
+"""Seeded inputs/parameters shared by tests/golden/make_golden.py (which feeds them to the
+REFERENCE) and by the tests (which feed them to the oracle and to the HIP path).  Everything is a
+pure function of (key, seed) on torch's CPU generator, so no weights need to be committed."""
+import hashlib
+import math
+
+import torch
+
+PIXEL_MEAN = [102.9801, 115.9465, 122.7717]
+PIXEL_STD = [57.375, 57.12, 58.395]  # exercises the /std path; keeps activations O(1)
+
+
+def _gen(key, seed):
+    h = int(hashlib.sha256(f"{seed}:{key}".encode()).hexdigest()[:12], 16)
+    return torch.Generator().manual_seed(h)
+
+
+def seeded_state(shapes, seed=0):
+    """shapes: {state_dict key: shape} of a model built from the reference key names.  Initialisers follow the
+    reference's (c2_msra_fill, N(0,.005)/0.1, xavier, N(0,.001), nn.Linear default, U(-.01,.01), N(0,1)) but with
+    non-trivial FrozenBN statistics so that BN folding is exercised."""
+    sd = {}
+    for k, shp in shapes.items():
+        g = _gen(k, seed)
+        shp = tuple(shp)
+        if k.endswith("norm.weight") or k.endswith("norm.running_var"):
+            t = 0.5 + torch.rand(shp, generator=g)
+        elif k.endswith("norm.bias") or k.endswith("norm.running_mean"):
+            t = 0.1 * torch.randn(shp, generator=g)
+        elif k.startswith("backbone.") and k.endswith("weight"):
+            fan_out = shp[0] * shp[2] * shp[3]
+            t = torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_out)
+        elif ".box_head.fc" in k:
+            t = torch.randn(shp, generator=g) * 0.005 if k.endswith("weight") else torch.full(shp, 0.1)
+        elif ".object_miner." in k:
+            if k.endswith("weight"):
+                a = math.sqrt(6.0 / (shp[0] + shp[1]))
+                t = (torch.rand(shp, generator=g) * 2 - 1) * a
+            else:
+                t = 0.01 * torch.randn(shp, generator=g)
+        elif k.endswith("bbox_pred.weight"):
+            t = torch.randn(shp, generator=g) * 0.001
+        elif k.endswith("bbox_pred.bias"):
+            t = 0.01 * torch.randn(shp, generator=g)
+        elif ".projection." in k:
+            fan_in = shp[1] if len(shp) == 2 else None
+            bound = 1.0 / math.sqrt(fan_in) if fan_in else 0.02
+            t = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        elif k.endswith("class_weight"):
+            t = torch.nn.functional.normalize(torch.randn(shp, generator=g), p=2, dim=0)  # (D,K), unit columns
+        elif k.startswith("data_aware_head.datasets_feat"):
+            t = torch.randn(shp, generator=g)
+        elif k.startswith("data_aware_head."):
+            t = (torch.rand(shp, generator=g) * 2 - 1) * (0.3 if k.endswith("weight") else 0.05)
+        elif k.endswith("cls_bias"):
+            t = torch.full(shp, 0.5)
+        else:
+            raise KeyError(f"no initialiser for {k} {shp}")
+        sd[k] = t.float()
+    return sd
+
+
+def seeded_batch(n_images, R, K, H, W, seed=0, edge_cases=True):
+    """Plain-tensor batch (oracle.wsovod_ref.train_forward format)."""
+    batch = []
+    for i in range(n_images):
+        g = _gen(f"img{i}", seed)
+        h, w = (H, W) if i % 2 == 0 else (H - 8 * (i % 3), W - 16)  # ragged sizes -> exercises padding
+        image = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+        r = R if i != n_images - 1 else max(R - 7, 1)  # ragged proposal counts
+        x0 = torch.rand(r, generator=g) * (w - 17)
+        y0 = torch.rand(r, generator=g) * (h - 17)
+        bw = 16 + torch.rand(r, generator=g) * (torch.clamp(w - x0, max=400.0) - 16)
+        bh = 16 + torch.rand(r, generator=g) * (torch.clamp(h - y0, max=300.0) - 16)
+        boxes = torch.stack([x0, y0, x0 + bw, y0 + bh], dim=1)
+        if edge_cases and r >= 4:
+            boxes[0] = torch.tensor([3.0, 3.0, 6.0, 7.0])  # area 12 <= 20: filtered from pseudo-GT mining
+            boxes[1] = torch.tensor([0.0, 0.0, float(w), float(h)])  # whole image
+        obj = (1.0 - torch.rand(r, generator=g)).sort(descending=True).values
+        ncls = 1 if i % 3 == 2 else 2
+        gt_classes = torch.randperm(K, generator=g)[: min(ncls, K)].to(torch.int64)
+        gt_classes = torch.cat([gt_classes, gt_classes[:1]])  # a duplicate: exercises torch.unique
+        batch.append(dict(image=image, boxes=boxes, objectness=obj, gt_classes=gt_classes))
+    return batch
+
+
+def strided_sample(t, n=4096):
+    """Deterministic sub-sample of a big tensor for compact fixtures."""
+    flat = t.detach().reshape(-1)
+    if flat.numel() <= n:
+        return flat.clone()
+    idx = torch.linspace(0, flat.numel() - 1, n).long()
+    return flat[idx].clone()
