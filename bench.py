@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the WSOVOD hot path on MI355X (contract: see the task statement / DESIGN.md).
+
+One "step" = one full training iteration of WSOVOD_WSR_18_DC5 in proposals-only mode on a batch of
+synthetic 800x600 images with 512 proposals each: uint8 image -> fused normalise+stem -> frozen
+backbone -> RoIPool(+objectness) -> neck -> object mining (MIL) -> pseudo-GT mining/labelling ->
+instance refinement (cosine-similarity head) -> losses -> backward -> fused SGD step
+(reference: wsovod/engine/trainer.py:37-84).  Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  `value` = images/sec over all N GPUs (weak scaling: per-GPU batch fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--depth", type=int, default=18)
+    ap.add_argument("--proposals", type=int, default=512)
+    ap.add_argument("--classes", type=int, default=20)
+    ap.add_argument("--embed-dim", type=int, default=512)
+    ap.add_argument("--pooler", default="ROIPool")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    return ap.parse_args()
+
+
+def to_device_batch(batch, dev):
+    out = []
+    for x in batch:
+        out.append({"image": x["image"].to(dev), "proposals": x["proposals"].to(dev),
+                    "instances": x["instances"],  # image-level labels stay on the host (no sync to read them)
+                    "height": x["height"], "width": x["width"]})
+    return out
+
+
+def cpu_baseline(model, batch, args):
+    """The oracle (CPU restatement of the reference path) timed on the host cores: baseline only."""
+    from oracle import wsovod_ref as R
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    sample = R.batch_from_inputs(batch[:1])
+    bufs = {}
+
+    def step():
+        losses, _ = R.train_forward(sd, sample, depth=args.depth, num_classes=args.classes, pooler_type=args.pooler)
+        total = sum(losses.values())
+        grads = torch.autograd.grad(total, [sd[k] for k in train_keys], allow_unused=True)
+        with torch.no_grad():
+            for k, g in zip(train_keys, grads):
+                if g is None:
+                    continue
+                g = g + 5e-4 * sd[k]
+                bufs[k] = g if k not in bufs else bufs[k].mul_(0.9).add_(g)
+                sd[k].sub_(0.01 * bufs[k])
+
+    step()  # warm-up
+    n, t0 = 0, time.time()
+    while True:
+        step()
+        n += 1
+        if time.time() - t0 > args.cpu_seconds or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": f"{n} full fp32 training steps of 1 image x {args.proposals} proposals (oracle/wsovod_ref.py, "
+                      f"torch {torch.__version__} CPU, {ncores} threads; RoIPool = single-thread C oracle)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from wsovod_amd import _lib
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.engine import build_optimizer, run_step, wrap_model_with_ddp
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim,
+                                      precision=args.precision, pooler=args.pooler, device=f"cuda:{local_rank}")
+    model.train()
+    optimizer = build_optimizer(cfg, model)
+    ddp = wrap_model_with_ddp(model, local_rank)
+    host_batch = make_batch(args.batch, args.proposals, args.classes, seed=1234 + rank)
+    batch = to_device_batch(host_batch, dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_step(ddp, optimizer, batch)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run_step(ddp, optimizer, batch)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roofline = None
+    if not args.no_roofline:
+        # second pass over the same K steps with every launch bracketed by hipEvents on its stream
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(args.steps):
+            run_step(ddp, optimizer, batch)
+        torch.cuda.synchronize()
+        table = _lib.profile_collect()
+        _lib.profile_enable(False)
+        table = [e for e in table if e["launches"] > 0]
+        table.sort(key=lambda e: -e["ms"])
+        if rank == 0 and table:
+            top = table[0]
+            mfma = top["flops"] > 0 and ("gemm" in top["name"] or "conv" in top["name"])
+            avg_ms = top["ms"] / top["launches"]
+            if mfma:
+                ach = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+                roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK[args.precision], "unit": "TFLOP/s",
+                            "frac": ach / PEAK[args.precision], "traffic": None}
+            else:
+                ach = top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9
+                roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roofline.update(kernel=top["name"], launches_per_step=top["launches"] / args.steps,
+                            avg_launch_ms=avg_ms, share_of_kernel_time=top["ms"] / sum(e["ms"] for e in table),
+                            kernels=[{"name": e["name"], "ms_per_step": e["ms"] / args.steps,
+                                      "launches_per_step": e["launches"] / args.steps,
+                                      "tflops": (e["flops"] / (e["ms"] * 1e-3) / 1e12) if e["flops"] and e["ms"] else None,
+                                      "gbs": (e["bytes"] / (e["ms"] * 1e-3) / 1e9) if e["bytes"] and e["ms"] else None}
+                                     for e in table[:12]])
+
+    if rank == 0:
+        images = world * args.batch * args.steps
+        out = {
+            "metric": "images/sec (512 proposals/img) WSR_18_DC5 fwd+bwd at 1/2/4/8 MI355X",
+            "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"VOC07 WSOVOD_WSR_{args.depth}_DC5_1x, {args.proposals} proposals/img, "
+                                   f"{args.classes}-class embeddings (D={args.embed_dim}), 800x600 images, "
+                                   f"proposals-only mode, {args.pooler}, full training step (fwd+bwd+SGD)",
+                       "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
+                       "parallelism": f"dp{world}"},
+        }
+        if roofline is not None:
+            out["roofline"] = roofline
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(model, host_batch, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
