@@ -54,13 +54,12 @@ def to_device_batch(batch, dev):
     return out
 
 
-def cpu_baseline(model, batch, args):
+def cpu_baseline(model, sd, batch, args):
     """The oracle (CPU restatement of the reference path) timed on the host cores: baseline only."""
     from oracle import wsovod_ref as R
 
     ncores = os.cpu_count() or 1
     torch.set_num_threads(ncores)
-    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
     for k in train_keys:
         sd[k].requires_grad_(True)
@@ -115,6 +114,9 @@ def main():
     model.train()
     optimizer = build_optimizer(cfg, model)
     ddp = wrap_model_with_ddp(model, local_rank)
+    cpu_state = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # snapshot of the untrained weights for the CPU leg
+        cpu_state = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
     host_batch = make_batch(args.batch, args.proposals, args.classes, seed=1234 + rank)
     batch = to_device_batch(host_batch, dev)
 
@@ -131,6 +133,10 @@ def main():
         run_step(ddp, optimizer, batch)
     sync()
     elapsed = time.perf_counter() - t0
+    last = run_step(ddp, optimizer, batch)  # outside the timed region: the run must have stayed finite
+    final_losses = {k: float(v.detach()) for k, v in last.items()}
+    if not all(v == v and abs(v) != float("inf") for v in final_losses.values()):
+        raise RuntimeError(f"training diverged during the benchmark: {final_losses}")
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,12 +185,12 @@ def main():
                                    f"{args.classes}-class embeddings (D={args.embed_dim}), 800x600 images, "
                                    f"proposals-only mode, {args.pooler}, full training step (fwd+bwd+SGD)",
                        "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}"},
+                       "parallelism": f"dp{world}", "final_losses": final_losses},
         }
         if roofline is not None:
             out["roofline"] = roofline
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, host_batch, args)
+            out["cpu_baseline"] = cpu_baseline(model, cpu_state, host_batch, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

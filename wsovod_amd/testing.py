@@ -34,10 +34,17 @@ def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", devi
     return cfg
 
 
-def build_hot_path_model(seed=0, **kw):
+def build_hot_path_model(seed=0, calibrate_synthetic=True, **kw):
+    """Random-init model of the named architecture (reference initialisers).  With
+    `calibrate_synthetic` the frozen stem's first FrozenBN scale is set to 1/64 so that the random
+    backbone maps raw-scale pixels (PIXEL_STD = 1: inputs of +-128) to O(1) features, as a trained
+    checkpoint would; it changes no arithmetic, only keeps synthetic training finite."""
     from .modeling import build_model
 
     cfg = hot_path_cfg(**kw)
     torch.manual_seed(seed)
     model = build_model(cfg)
+    if calibrate_synthetic:
+        with torch.no_grad():
+            model.backbone.stem.conv1.norm.weight.fill_(1.0 / 64.0)
     return cfg, model
