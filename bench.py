@@ -58,8 +58,7 @@ def cpu_baseline(model, sd, batch, args):
     """The oracle (CPU restatement of the reference path) timed on the host cores: baseline only."""
     from oracle import wsovod_ref as R
 
-    ncores = os.cpu_count() or 1
-    torch.set_num_threads(ncores)
+    host_cores = os.cpu_count() or 1
     train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
     for k in train_keys:
         sd[k].requires_grad_(True)
@@ -78,7 +77,19 @@ def cpu_baseline(model, sd, batch, args):
                 bufs[k] = g if k not in bufs else bufs[k].mul_(0.9).add_(g)
                 sd[k].sub_(0.01 * bufs[k])
 
-    step()  # warm-up
+    # pick the thread count the host runs this path fastest at (all cores oversubscribe the small ops)
+    best = None
+    for nt in sorted({host_cores, min(host_cores, 64), min(host_cores, 32), min(host_cores, 16)}, reverse=True):
+        torch.set_num_threads(nt)
+        if best is None:
+            step()  # warm-up (also builds/loads the C oracle)
+        t0 = time.time()
+        step()
+        dt = time.time() - t0
+        if best is None or dt < best[1]:
+            best = (nt, dt)
+    ncores = best[0]
+    torch.set_num_threads(ncores)
     n, t0 = 0, time.time()
     while True:
         step()
@@ -88,7 +99,7 @@ def cpu_baseline(model, sd, batch, args):
     dt = time.time() - t0
     return {"value": n / dt, "unit": "images/sec", "cores": ncores, "kind": "port",
             "sample": f"{n} full fp32 training steps of 1 image x {args.proposals} proposals (oracle/wsovod_ref.py, "
-                      f"torch {torch.__version__} CPU, {ncores} threads; RoIPool = single-thread C oracle)"}
+                      f"torch {torch.__version__} CPU, {ncores} of {host_cores} host threads = fastest of 16/32/64/all; RoIPool = single-thread C oracle)"}
 
 
 def main():
