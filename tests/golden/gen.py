@@ -89,5 +89,5 @@ def strided_sample(t, n=4096):
     flat = t.detach().reshape(-1)
     if flat.numel() <= n:
         return flat.clone()
-    idx = torch.linspace(0, flat.numel() - 1, n).long()
+    idx = (torch.arange(n, dtype=torch.int64) * (flat.numel() - 1)) // (n - 1)
     return flat[idx].clone()

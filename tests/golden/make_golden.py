@@ -1,0 +1,398 @@
+"""Generate the golden vectors in tests/golden/*.npz by running the REFERENCE's own code.
+
+Runs only in the authoring container (needs /root/reference).  detectron2 / fvcore / torchvision /
+cv2 / clip are not installed, so the reference's hot-path files are loaded by path with small
+stand-in modules registered in sys.modules (semantics: SURVEY.md Appendix A).  The stand-ins for
+containers/config/matcher/box-transform are the repo's own compat layer (wsovod_amd.structures,
+.config, .modeling.{matcher,box_regression,sampling}); torchvision.ops.RoIPool is the REFERENCE's
+own C++ RoIPool compiled where it lies (oracle/_ref).  No reference source is copied: the
+fixtures hold only inputs-by-seed and outputs.
+
+    python tests/golden/make_golden.py
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import roi_ops  # noqa: E402
+from tests.golden import gen  # noqa: E402
+from wsovod_amd import config as C  # noqa: E402
+from wsovod_amd import structures as S  # noqa: E402
+from wsovod_amd.modeling import box_regression, matcher, sampling  # noqa: E402
+
+
+# --------------------------------------------------------------------------------------
+# stand-in modules
+# --------------------------------------------------------------------------------------
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []  # behave as a package
+    sys.modules[name] = m
+    parent, _, child = name.rpartition(".")
+    if parent and parent in sys.modules:
+        setattr(sys.modules[parent], child, m)
+    return m
+
+
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, training=False,
+                            eps=self.eps)
+
+
+def get_norm(norm, out_channels):
+    if norm is None or (isinstance(norm, str) and len(norm) == 0):
+        return None
+    assert norm == "FrozenBN", norm
+    return FrozenBatchNorm2d(out_channels)
+
+
+class D2Conv2d(nn.Conv2d):
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+
+    def forward(self, x):
+        x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        if self.norm is not None:
+            x = self.norm(x)
+        if self.activation is not None:
+            x = self.activation(x)
+        return x
+
+
+class CNNBlockBase(nn.Module):
+    def __init__(self, in_channels, out_channels, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        return self
+
+
+class Backbone(nn.Module):
+    @property
+    def size_divisibility(self):
+        return 0
+
+
+def c2_msra_fill(module):
+    nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+def cat(tensors, dim=0):
+    assert isinstance(tensors, (list, tuple))
+    if len(tensors) == 1:
+        return tensors[0]
+    return torch.cat(tensors, dim)
+
+
+def d2_cross_entropy(input, target, *, reduction="mean", **kwargs):
+    if target.numel() == 0 and reduction == "mean":
+        return input.sum() * 0.0
+    return F.cross_entropy(input, target, reduction=reduction, **kwargs)
+
+
+def smooth_l1_loss(input, target, beta, reduction="none"):
+    if beta < 1e-5:
+        loss = torch.abs(input - target)
+    else:
+        n = torch.abs(input - target)
+        loss = torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+    if reduction == "mean":
+        return loss.mean() if loss.numel() > 0 else 0.0 * loss.sum()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+class RefRoIPool(nn.Module):
+    """torchvision.ops.RoIPool stand-in = the reference's own compiled C++ RoIPool (oracle/_ref)."""
+
+    def __init__(self, output_size, spatial_scale):
+        super().__init__()
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.spatial_scale = spatial_scale
+
+    def forward(self, input, rois):
+        assert not input.requires_grad  # backbone is frozen on this path
+        return roi_ops.ref_roi_pool_forward(input, rois, self.spatial_scale, self.output_size)[0]
+
+
+class OracleROIAlign(nn.Module):
+    def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
+        super().__init__()
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.spatial_scale, self.sampling_ratio, self.aligned = spatial_scale, sampling_ratio, aligned
+
+    def forward(self, input, rois):
+        return roi_ops.roi_align_forward(input, rois, self.spatial_scale, self.output_size, self.sampling_ratio,
+                                         self.aligned)
+
+
+class _Storage:
+    iter = 0
+
+    def put_scalar(self, *a, **k):
+        pass
+
+    def put_image(self, *a, **k):
+        pass
+
+
+class _Unsupported:
+    def __init__(self, *a, **k):
+        raise RuntimeError("not available in the golden harness")
+
+
+def install_shims():
+    _mod("cv2")
+    _mod("clip")
+    _mod("fvcore")
+    _mod("fvcore.nn", giou_loss=None, smooth_l1_loss=smooth_l1_loss)
+    _mod("fvcore.nn.weight_init", c2_msra_fill=c2_msra_fill, c2_xavier_fill=None)
+    _mod("torchvision")
+    _mod("torchvision.ops", RoIPool=RefRoIPool)
+    _mod("detectron2")
+    _mod("detectron2.layers", CNNBlockBase=CNNBlockBase, Conv2d=D2Conv2d, DeformConv=_Unsupported,
+         ModulatedDeformConv=_Unsupported, ShapeSpec=S.ShapeSpec, get_norm=get_norm, Linear=nn.Linear, cat=cat,
+         nonzero_tuple=sampling.nonzero_tuple, cross_entropy=d2_cross_entropy, batched_nms=None, ciou_loss=None,
+         diou_loss=None, ROIAlign=OracleROIAlign, ROIAlignRotated=_Unsupported)
+    _mod("detectron2.config", configurable=C.configurable, CfgNode=C.CfgNode)
+    _mod("detectron2.structures", Boxes=S.Boxes, Instances=S.Instances, ImageList=S.ImageList,
+         pairwise_iou=S.pairwise_iou, PolygonMasks=_Unsupported)
+    _mod("detectron2.utils")
+    _mod("detectron2.utils.comm", get_world_size=lambda: 1)
+    _mod("detectron2.utils.events", get_event_storage=lambda: _Storage())
+    _mod("detectron2.utils.visualizer", Visualizer=_Unsupported)
+    _mod("detectron2.utils.logger", log_first_n=lambda *a, **k: None)
+    _mod("detectron2.data", MetadataCatalog=types.SimpleNamespace(get=lambda name: None), DatasetCatalog=None)
+    _mod("detectron2.data.detection_utils", convert_image_to_rgb=None)
+    _mod("detectron2.modeling")
+    _mod("detectron2.modeling.backbone", Backbone=Backbone,
+         build_backbone=lambda cfg: C.BACKBONE_REGISTRY_REF.get(cfg.MODEL.BACKBONE.NAME)(
+             cfg, S.ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))))
+    _mod("detectron2.modeling.backbone.backbone", Backbone=Backbone)
+    C.BACKBONE_REGISTRY_REF = C.Registry("REF_BACKBONE")
+    C.ROI_BOX_HEAD_REGISTRY_REF = C.Registry("REF_ROI_BOX_HEAD")
+    C.ROI_HEADS_REGISTRY_REF = C.Registry("REF_ROI_HEADS")
+    C.META_ARCH_REGISTRY_REF = C.Registry("REF_META_ARCH")
+    _mod("detectron2.modeling.backbone.build", BACKBONE_REGISTRY=C.BACKBONE_REGISTRY_REF)
+    _mod("detectron2.modeling.box_regression", Box2BoxTransform=box_regression.Box2BoxTransform)
+    _mod("detectron2.modeling.matcher", Matcher=matcher.Matcher)
+    _mod("detectron2.modeling.sampling", subsample_labels=sampling.subsample_labels)
+    _mod("detectron2.modeling.meta_arch")
+    _mod("detectron2.modeling.meta_arch.build", META_ARCH_REGISTRY=C.META_ARCH_REGISTRY_REF)
+    _mod("detectron2.modeling.proposal_generator", build_proposal_generator=lambda cfg, shape: None)
+    _mod("detectron2.modeling.proposal_generator.proposal_utils", add_ground_truth_to_proposals=None)
+    _mod("detectron2.modeling.roi_heads", ROI_BOX_HEAD_REGISTRY=C.ROI_BOX_HEAD_REGISTRY_REF,
+         ROI_HEADS_REGISTRY=C.ROI_HEADS_REGISTRY_REF)
+    _mod("detectron2.modeling.roi_heads.box_head",
+         build_box_head=lambda cfg, shape: C.ROI_BOX_HEAD_REGISTRY_REF.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, shape))
+    # the reference package skeleton (real files are loaded into it by path)
+    for name in ("wsovod", "wsovod.modeling", "wsovod.modeling.backbone", "wsovod.modeling.roi_heads",
+                 "wsovod.modeling.class_heads", "wsovod.modeling.meta_arch"):
+        _mod(name)
+    _mod("wsovod.layers", ROILoopPool=_Unsupported)
+    _mod("wsovod.modeling.proposal_generator", WSOVODRPN_V2=type("WSOVODRPN_V2", (), {}))
+    _mod("wsovod.modeling.postprocessing", detector_postprocess=None)
+
+
+def load_ref(modname, relpath):
+    spec = importlib.util.spec_from_file_location(modname, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[modname] = m
+    parent, _, child = modname.rpartition(".")
+    setattr(sys.modules[parent], child, m)
+    spec.loader.exec_module(m)
+    return m
+
+
+def load_reference():
+    install_shims()
+    r = types.SimpleNamespace()
+    r.resnet = load_ref("wsovod.modeling.backbone.resnet_wsl", "wsovod/modeling/backbone/resnet_wsl.py")
+    r.box_head = load_ref("wsovod.modeling.roi_heads.box_head", "wsovod/modeling/roi_heads/box_head.py")
+    r.ovc = load_ref("wsovod.modeling.class_heads.open_vocabulary_classifier",
+                     "wsovod/modeling/class_heads/open_vocabulary_classifier.py")
+    sys.modules["wsovod.modeling.class_heads"].OpenVocabularyClassifier = r.ovc.OpenVocabularyClassifier
+    r.daf = load_ref("wsovod.modeling.class_heads.data_aware_features_head",
+                     "wsovod/modeling/class_heads/data_aware_features_head.py")
+    r.frcnn = load_ref("wsovod.modeling.roi_heads.fast_rcnn_open_vocabulary",
+                       "wsovod/modeling/roi_heads/fast_rcnn_open_vocabulary.py")
+    r.poolers = load_ref("wsovod.modeling.poolers", "wsovod/modeling/poolers.py")
+    r.roi_heads = load_ref("wsovod.modeling.roi_heads.roi_heads", "wsovod/modeling/roi_heads/roi_heads.py")
+    r.meta = load_ref("wsovod.modeling.meta_arch.rcnn_wsovod", "wsovod/modeling/meta_arch/rcnn_wsovod.py")
+    return r
+
+
+# --------------------------------------------------------------------------------------
+# fixtures
+# --------------------------------------------------------------------------------------
+def ref_cfg(depth, K, D, emb_path, pooler="ROIPool"):
+    from wsovod_amd.testing import hot_path_cfg
+
+    cfg = hot_path_cfg(depth=depth, K=K, D=D, pooler=pooler, device="cpu", weight_path=emb_path)
+    cfg.MODEL.PIXEL_STD = list(gen.PIXEL_STD)
+    cfg.MODEL.ROI_HEADS.NAME = "WSOVODROIHeads"
+    cfg.DATASETS.TRAIN = ("synthetic",)
+    return cfg
+
+
+def to_inputs(batch):
+    out = []
+    for b in batch:
+        h, w = b["image"].shape[-2:]
+        props = S.Instances((h, w), proposal_boxes=S.Boxes(b["boxes"].clone()), objectness_logits=b["objectness"].clone())
+        nb = len(b["gt_classes"])
+        inst = S.Instances((h, w), gt_boxes=S.Boxes(b["boxes"][:nb].clone()), gt_classes=b["gt_classes"].clone())
+        out.append({"image": b["image"], "instances": inst, "proposals": props, "height": h, "width": w})
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def build_ref_model(r, depth, K, D, seed):
+    import pickle
+    import tempfile
+
+    shapes_probe = None
+    emb = os.path.join(tempfile.mkdtemp(prefix="golden_"), "emb.pkl")
+    with open(emb, "wb") as f:
+        pickle.dump(torch.randn(K, D), f)  # placeholder; class_weight is overwritten from the seeded state
+    cfg = ref_cfg(depth, K, D, emb)
+    model = r.meta.GeneralizedRCNN_WSOVOD(cfg)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gen.seeded_state(shapes, seed)
+    missing, unexpected = model.load_state_dict(sd, strict=True), None
+    return cfg, model, sd, shapes
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    r = load_reference()
+
+    # ---------------- G2: RoIPool / ROIAlign (reference C++ op) ----------------
+    from tests.util import random_rois
+
+    feat = torch.randn(2, 8, 75, 100, generator=torch.Generator().manual_seed(11))
+    rois = random_rois(64, 2, 600, 800, seed=3)
+    out, arg = roi_ops.ref_roi_pool_forward(feat, rois, 0.125, (7, 7))
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(12))
+    gi = roi_ops.ref_roi_pool_backward(g, rois, arg, 0.125, feat.shape)
+    save("g2_roi_pool", feat=feat, rois=rois, out=out, argmax=arg, grad_out=g, grad_in=gi)
+
+    # ---------------- G1/G3-G9: whole model at the plumbing scale ----------------
+    K, D = 20, 512
+    cfg, model, sd, shapes = build_ref_model(r, 18, K, D, seed=1)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 1e-12  # dropout RNG cannot be reproduced: golden vectors are taken with p = 1e-12 ~ off;
+            # (kept in training mode so it still returns a fresh tensor for the reference's in-place `+=`)
+    save("shapes_r18_k20", keys=np.array(list(shapes.keys())), shapes=np.array([str(v) for v in shapes.values()]))
+
+    # G1 backbone on a small image pair
+    x = torch.randn(2, 3, 96, 128, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        feats = model.backbone(x)
+    save("g1_backbone_small", x=x, res5=feats["res5"])
+
+    # G8 whole training step: 4 ragged images ~ 320x416, R = 64 (last image 57), K = 20
+    batch = gen.seeded_batch(4, 64, K, 320, 416, seed=2)
+    inputs = to_inputs(batch)
+    captured = {}
+    rh = model.roi_heads
+    orig_miner, orig_ref, orig_head = rh.object_miner.forward, rh.box_refinery[0].forward, rh.box_head.forward
+
+    def cap(name, fn):
+        def wrapped(*a, **k):
+            o = fn(*a, **k)
+            captured[name] = o
+            return o
+        return wrapped
+
+    rh.object_miner.forward = cap("miner", orig_miner)
+    rh.box_refinery[0].forward = cap("refine", orig_ref)
+    rh.box_head.forward = cap("neck", orig_head)
+    orig_label = rh.label_and_sample_proposals_wsl
+    rh.label_and_sample_proposals_wsl = cap("proposals_k", orig_label)
+    orig_pgt = rh.get_pgt_top_k
+    rh.get_pgt_top_k = cap("targets", orig_pgt)
+    loss_dict = model(inputs)
+    total = sum(loss_dict.values())
+    total.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+    arrays = {f"loss/{k}": v for k, v in loss_dict.items()}
+    arrays["mining_scores"] = captured["miner"][0]
+    arrays["refine_logits"] = captured["refine"][0]
+    arrays["refine_deltas"] = captured["refine"][1]
+    arrays["neck_out_sample"] = gen.strided_sample(captured["neck"], 8192)
+    arrays["pred_class_img_logits"] = rh.pred_class_img_logits
+    arrays["label/gt_classes"] = torch.cat([p.gt_classes for p in captured["proposals_k"]])
+    arrays["label/gt_boxes"] = torch.cat([p.gt_boxes.tensor for p in captured["proposals_k"]])
+    arrays["label/gt_weights"] = torch.cat([p.gt_weights for p in captured["proposals_k"]])
+    arrays["label/gt_scores"] = torch.cat([p.gt_scores for p in captured["proposals_k"]])
+    arrays["pgt/num"] = np.array([len(t) for t in captured["targets"]])
+    arrays["pgt/gt_boxes"] = torch.cat([t.gt_boxes.tensor for t in captured["targets"]])
+    arrays["pgt/gt_classes"] = torch.cat([t.gt_classes for t in captured["targets"]])
+    arrays["pgt/gt_weights"] = torch.cat([t.gt_weights for t in captured["targets"]])
+    for k, gth in grads.items():
+        arrays[f"gradnorm/{k}"] = gth.norm()
+        arrays[f"gradsample/{k}"] = gen.strided_sample(gth, 2048)
+    save("g8_train_step_r18_k20", **arrays)
+
+    # G5: OV classifier variants on a fixed feature matrix
+    feat_x = torch.randn(48, 4096, generator=torch.Generator().manual_seed(21)) * 0.5
+    head = rh.box_refinery[0].cls
+    with torch.no_grad():
+        l_default = head(feat_x, None, append_background=True)
+        l_nobg = head(feat_x, None, append_background=False)
+        clsf = torch.randn(33, D, generator=torch.Generator().manual_seed(22))
+        l_call = head(feat_x, clsf, append_background=True)
+    save("g5_ov_classifier", x=feat_x, classifier=clsf, logits_default=l_default, logits_nobg=l_nobg,
+         logits_classifier=l_call)
+
+    # G9: data-aware head on a fixed feature map
+    fm = torch.randn(3, 512, 9, 13, generator=torch.Generator().manual_seed(31))
+    props = [S.Instances((72, 104), proposal_boxes=S.Boxes(torch.zeros(n, 4))) for n in (3, 1, 2)]
+    with torch.no_grad():
+        daf = model.data_aware_head({"res5": fm}, props)
+    save("g9_data_aware", res5=fm, daf=daf, nums=np.array([3, 1, 2]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,101 @@
+"""CPU: pin the oracle (oracle/wsovod_ref.py, oracle/roi_ops_ref.c) against the golden vectors that
+tests/golden/make_golden.py produced by running the REFERENCE's own code."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import roi_ops
+from oracle import wsovod_ref as R
+from tests.golden import gen
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    d = np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+    return {k: torch.from_numpy(d[k]) if d[k].dtype.kind in "fiub" else d[k] for k in d.files}
+
+
+def seeded_sd(seed=1):
+    d = np.load(os.path.join(G, "shapes_r18_k20.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    return gen.seeded_state(shapes, seed)
+
+
+def test_roi_pool_c_oracle_matches_reference_op():
+    g = load("g2_roi_pool")
+    out, arg = roi_ops.roi_pool_forward(g["feat"], g["rois"], 0.125, (7, 7))
+    assert torch.equal(arg, g["argmax"]) and torch.equal(out, g["out"])  # bit-exact
+    gi = roi_ops.roi_pool_backward(g["grad_out"], g["rois"], arg, tuple(g["feat"].shape))
+    assert torch.equal(gi, g["grad_in"])
+
+
+@pytest.mark.skipif(not roi_ops.ref_available(), reason="oracle/_ref not built and /root/reference absent")
+def test_roi_pool_c_oracle_matches_compiled_reference_random():
+    from tests.util import random_rois
+
+    feat = torch.randn(3, 5, 40, 50)
+    rois = random_rois(128, 3, 320, 400, seed=77)
+    for size in [(7, 7), (3, 5), (1, 1)]:
+        a = roi_ops.roi_pool_forward(feat, rois, 0.125, size)
+        b = roi_ops.ref_roi_pool_forward(feat, rois, 0.125, size)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_backbone_matches_reference():
+    g = load("g1_backbone_small")
+    res5 = R.backbone_forward(seeded_sd(), g["x"], depth=18)["res5"]
+    torch.testing.assert_close(res5, g["res5"], rtol=1e-4, atol=1e-5)
+
+
+def test_ov_classifier_matches_reference():
+    g = load("g5_ov_classifier")
+    sd = seeded_sd()
+    p = "roi_heads.box_refinery_0.cls."
+    torch.testing.assert_close(R.ov_classifier_forward(sd, g["x"], p), g["logits_default"], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(R.ov_classifier_forward(sd, g["x"], p, append_background=False), g["logits_nobg"],
+                               rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(R.ov_classifier_forward(sd, g["x"], p, classifier=g["classifier"]),
+                               g["logits_classifier"], rtol=1e-5, atol=1e-4)
+    assert torch.all(g["logits_default"][:, -1] == 0)  # background logit is identically zero
+
+
+def test_data_aware_head_matches_reference():
+    g = load("g9_data_aware")
+    per_image = R.data_aware_forward(seeded_sd(), g["res5"])
+    rep = torch.cat([per_image[i].repeat(int(n), 1) for i, n in enumerate(g["nums"])])
+    torch.testing.assert_close(rep, g["daf"], rtol=1e-5, atol=1e-6)
+
+
+def test_full_training_step_matches_reference():
+    """Losses, MIL scores, refinement logits (<=1e-5), pseudo-GT / labels (exact) and parameter
+    gradients of one whole step at the plumbing scale (4 ragged images, R=64/57, K=20)."""
+    g = load("g8_train_step_r18_k20")
+    sd = seeded_sd()
+    train_keys = [k[len("gradnorm/"):] for k in g if k.startswith("gradnorm/")]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    batch = gen.seeded_batch(4, 64, 20, 320, 416, seed=2)
+    losses, inter = R.train_forward(sd, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD)
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+        torch.testing.assert_close(losses[k].detach(), g["loss/" + k], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(inter["mining_scores"].detach(), g["mining_scores"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(inter["refine_logits"].detach(), g["refine_logits"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(inter["refine_deltas"].detach(), g["refine_deltas"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(inter["pred_class_img_logits"], g["pred_class_img_logits"], rtol=1e-5, atol=1e-8)
+    # indices / labels: exact
+    lab = inter["labelled"]
+    assert torch.equal(torch.cat([l["gt_classes"] for l in lab]), g["label/gt_classes"])
+    assert torch.equal(torch.cat([l["gt_boxes"] for l in lab]), g["label/gt_boxes"])
+    torch.testing.assert_close(torch.cat([l["gt_weights"] for l in lab]), g["label/gt_weights"], rtol=1e-5, atol=1e-8)
+    tg = inter["targets"]
+    assert [len(t["gt_classes"]) for t in tg] == g["pgt/num"].tolist()
+    assert torch.equal(torch.cat([t["gt_boxes"] for t in tg]), g["pgt/gt_boxes"])
+    assert torch.equal(torch.cat([t["gt_classes"] for t in tg]), g["pgt/gt_classes"])
+    total = sum(losses.values())
+    grads = torch.autograd.grad(total, [sd[k] for k in train_keys])
+    for k, gr in zip(train_keys, grads):
+        torch.testing.assert_close(gr.norm(), g["gradnorm/" + k], rtol=2e-4, atol=1e-9)
+        torch.testing.assert_close(gen.strided_sample(gr, 2048), g["gradsample/" + k], rtol=2e-3, atol=1e-7)
