@@ -1,0 +1,241 @@
+"""GPU parity of the individual head kernels against the oracle / plain torch fp32 on the CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import wsovod_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _seg(nums, dev):
+    o = [0]
+    for n in nums:
+        o.append(o[-1] + n)
+    return torch.tensor(o, dtype=torch.int32, device=dev)
+
+
+@pytest.mark.parametrize("nums,K", [([64, 57, 1, 30], 20), ([512], 80), ([300, 212], 1203), ([5], 2)])
+def test_mil_forward_backward(gpu, nums, K):
+    from wsovod_amd.layers import functions as Fn
+
+    torch.manual_seed(0)
+    M = sum(nums)
+    logits = torch.randn(M, 2 * K) * 3
+    y = (torch.rand(len(nums), K) < 0.1).float()
+    lc = logits.clone().requires_grad_(True)
+    scores_ref = torch.cat([F.softmax(c, 1) * F.softmax(d, 0)
+                            for c, d in zip(lc[:, :K].split(nums), lc[:, K:].split(nums))])
+    loss_ref = R.mining_loss(scores_ref, nums, y)
+    loss_ref.backward()
+    lg = logits.clone().to(gpu).requires_grad_(True)
+    seg = _seg(nums, gpu)
+    scores = Fn.mil_scores(lg, seg, K)
+    loss, img = Fn.image_bce(scores, seg, y.to(gpu), float(len(nums) * K))
+    loss.backward()
+    torch.testing.assert_close(scores.detach().cpu(), scores_ref.detach(), rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(img.cpu(), R.predict_probs_img(scores_ref.detach(), nums), rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(lg.grad.cpu(), lc.grad, rtol=2e-3, atol=1e-7)
+
+
+def test_mil_k1_special_case(gpu):
+    from tests.helpers import seeded_sd
+    from wsovod_amd.modeling.fast_rcnn_open_vocabulary import ObjectMiningOutputLayers
+    from wsovod_amd.modeling.box_regression import Box2BoxTransform
+
+    torch.manual_seed(1)
+    layer = ObjectMiningOutputLayers(4096, box2box_transform=Box2BoxTransform((10., 10., 5., 5.)), num_classes=1).to(gpu)
+    x = torch.randn(40, 4096)
+    sd = {"p.cls.weight": layer.cls.weight.detach().cpu(), "p.cls.bias": layer.cls.bias.detach().cpu(),
+          "p.det.weight": layer.det.weight.detach().cpu(), "p.det.bias": layer.det.bias.detach().cpu()}
+    ref = R.mining_forward(sd, x, [25, 15], prefix="p.")
+
+    class P:  # only len() is used
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    scores, _ = layer(x.to(gpu), [P(25), P(15)])
+    torch.testing.assert_close(scores.detach().cpu(), ref, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("K1,weighted", [(21, True), (81, True), (1201, True), (21, False)])
+def test_weighted_cross_entropy(gpu, K1, weighted):
+    from wsovod_amd.layers import functions as Fn
+
+    torch.manual_seed(2)
+    M = 333
+    logits = torch.randn(M, K1) * 4
+    gt = torch.randint(-1, K1, (M,))
+    gt[:5] = -1
+    w = torch.rand(M)
+    w[7] = 0.0
+    lc = logits.clone().requires_grad_(True)
+    ref_c, _ = R.refinement_losses(lc, torch.zeros(M, 4), gt, w, torch.tensor([[0., 0., 10., 10.]]).repeat(M, 1),
+                                   torch.tensor([[0., 0., 10., 10.]]).repeat(M, 1), K1 - 1,
+                                   cross_entropy_weighted=weighted)
+    (ref_c * 0.7).backward()
+    lg = logits.clone().to(gpu).requires_grad_(True)
+    loss = Fn.weighted_cross_entropy(lg, gt.to(gpu), w.to(gpu), weighted)
+    (loss * 0.7).backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref_c.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(lg.grad.cpu(), lc.grad, rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("beta,kind", [(0.0, "smooth_l1_weighted"), (0.5, "smooth_l1_weighted"), (0.0, "smooth_l1")])
+def test_weighted_l1_box_loss(gpu, beta, kind):
+    from wsovod_amd.layers import functions as Fn
+
+    torch.manual_seed(3)
+    M, K = 257, 20
+    pb = torch.rand(M, 4) * 100
+    pb[:, 2:] += pb[:, :2] + 5
+    gb = torch.rand(M, 4) * 100
+    gb[:, 2:] += gb[:, :2] + 5
+    gt = torch.randint(-1, K + 1, (M,))
+    w = torch.rand(M)
+    pred = torch.randn(M, 4)
+    pc = pred.clone().requires_grad_(True)
+    _, ref = R.refinement_losses(torch.randn(M, K + 1), pc, gt, w, pb, gb, K, beta=beta, box_loss_type=kind)
+    ref.backward()
+    pg = pred.clone().to(gpu).requires_grad_(True)
+    wk = w.clone()
+    wk[gt == -1] = 0
+    loss = Fn.weighted_l1_box_loss(pg, pb.to(gpu), gb.to(gpu), gt.to(gpu), wk.to(gpu), K, (10., 10., 5., 5.), beta,
+                                   weighted=kind == "smooth_l1_weighted")
+    loss.backward()
+    torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(pg.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-8)
+
+
+def test_weighted_l1_nan_guard(gpu):
+    from wsovod_amd.layers import functions as Fn
+
+    pb = torch.tensor([[0., 0., 10., 10.], [5., 5., 20., 20.]])
+    gb = torch.tensor([[0., 0., 10., 10.], [8., 8., 8., 30.]])  # zero-width target -> log(0) = -inf, not NaN
+    gb[1] = torch.tensor([9., 9., 5., 30.])  # negative width -> log(<0) = NaN
+    gt = torch.tensor([1, 2])
+    pred = torch.zeros(2, 4, device=gpu, requires_grad=True)
+    loss = Fn.weighted_l1_box_loss(pred, pb.to(gpu), gb.to(gpu), gt.to(gpu), torch.ones(2, device=gpu), 20,
+                                   (10., 10., 5., 5.), 0.0)
+    loss.backward()
+    assert float(loss) == 0.0 and torch.all(pred.grad == 0)  # reference guard: fast_rcnn_open_vocabulary.py:868-871
+
+
+@pytest.mark.parametrize("case", ["normal", "all_small", "no_gt", "single"])
+def test_pgt_mining_and_labelling_exact(gpu, case):
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(4)
+    K = 20
+    nums = [60, 45, 1] if case != "single" else [1]
+    boxes_list, scores_list, gts = [], [], []
+    for i, n in enumerate(nums):
+        x0, y0 = torch.rand(n) * 300, torch.rand(n) * 200
+        b = torch.stack([x0, y0, x0 + 10 + torch.rand(n) * 200, y0 + 10 + torch.rand(n) * 150], 1)
+        if case == "all_small" and i == 1:
+            b[:, 2:] = b[:, :2] + 3.0  # every box has area 9 <= 20
+        if n > 3:
+            b[2] = b[1]  # duplicate boxes: IoU ties
+        boxes_list.append(b)
+        scores_list.append(torch.rand(n, K) * 0.05)
+        gts.append(torch.tensor([], dtype=torch.int64) if (case == "no_gt" and i == 0)
+                   else torch.unique(torch.randint(0, K, (2,))))
+    img_logits = torch.rand(len(nums), K).clamp(1e-6, 1 - 1e-6)
+    targets = R.get_pgt_top_k(boxes_list, scores_list, gts, img_logits, K)
+    lab = R.label_and_sample_proposals_wsl(boxes_list, targets, K)
+    dev = gpu
+    seg = torch.tensor([0] + list(torch.tensor(nums).cumsum(0)), dtype=torch.int32, device=dev)
+    goff = torch.tensor([0] + list(torch.tensor([len(g) for g in gts]).cumsum(0)), dtype=torch.int32, device=dev)
+    o = H.pgt_mine_and_label(torch.cat(scores_list).to(dev), torch.cat(boxes_list).to(dev), seg,
+                             torch.cat(gts).to(dev), goff, img_logits.to(dev), K, 0.5)
+    torch.cuda.synchronize()
+    assert o["pgt_count"].cpu().tolist() == [len(t["gt_classes"]) for t in targets]
+    assert torch.equal(o["gt_classes"].cpu(), torch.cat([l["gt_classes"] for l in lab]))
+    assert torch.equal(o["gt_boxes"].cpu(), torch.cat([l["gt_boxes"] for l in lab]))
+    assert torch.equal(o["gt_weights"].cpu(), torch.cat([l["gt_weights"] for l in lab]))
+    assert torch.equal(o["gt_scores"].cpu(), torch.cat([l["gt_scores"] for l in lab]))
+    assert torch.equal(o["matched"].cpu().long(), torch.cat([l["matched_idxs"] for l in lab]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_fn_forward_backward(gpu, dtype):
+    from wsovod_amd.layers import functions as Fn
+
+    torch.manual_seed(5)
+    M, K, N = 150, 256, 44
+    x = torch.randn(M, K).to(dtype)
+    w = torch.randn(N, K) * 0.1
+    b = torch.randn(N)
+    xr = x.float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    wq = w.to(dtype).float() if dtype == torch.bfloat16 else wr
+    yr = F.relu(F.linear(xr, wr if dtype == torch.float32 else wq.requires_grad_(True), br))
+    g = torch.randn(M, N)
+    yr.backward(g)
+    xg = x.to(gpu).requires_grad_(True)
+    wg, bg = w.to(gpu).requires_grad_(True), b.to(gpu).requires_grad_(True)
+    y = Fn.linear(xg, wg, bg, relu=True, out_dtype=torch.float32)
+    y.backward(g.to(gpu))
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(y.detach().cpu(), yr.detach(), **tol)
+    wref = wr.grad if dtype == torch.float32 else wq.grad
+    torch.testing.assert_close(wg.grad.cpu(), wref, **(tol if dtype == torch.float32 else dict(rtol=5e-2, atol=0.3)))
+    torch.testing.assert_close(bg.grad.cpu(), br.grad, **(tol if dtype == torch.float32 else dict(rtol=5e-2, atol=0.3)))
+    torch.testing.assert_close(xg.grad.float().cpu(), xr.grad, **(tol if dtype == torch.float32 else dict(rtol=5e-2, atol=0.1)))
+
+
+def test_dropout_linear_backward_uses_same_mask(gpu):
+    from wsovod_amd.layers import functions as Fn
+
+    x = torch.randn(64, 128, device=gpu).abs().requires_grad_(True)
+    w = torch.rand(96, 128, device=gpu).requires_grad_(True)
+    y = Fn.linear(x, w, None, relu=True, dropout_p=0.5, seed=42)
+    kept = (y > 0)
+    assert 0.4 < kept.float().mean().item() < 0.6
+    y.sum().backward()
+    # d/dx of sum(y) = 2 * kept @ w   (inverted dropout scale 2, relu always active: inputs and weights positive)
+    torch.testing.assert_close(x.grad, 2.0 * kept.float() @ w.detach(), rtol=1e-4, atol=1e-3)
+
+
+def test_elementwise_kernels(gpu):
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(6)
+    # 2x2 max pools incl. the zero-padded stride-1 variant
+    x = torch.randn(2, 9, 11, 64)
+    for stride, pad in [(2, False), (1, True)]:
+        xc = x.permute(0, 3, 1, 2)
+        ref = F.max_pool2d(F.pad(xc, (0, 1, 0, 1)) if pad else xc, 2, stride).permute(0, 2, 3, 1)
+        for dt in (torch.float32, torch.bfloat16):
+            out = H.maxpool2x2_nhwc(x.to(dt).to(gpu).contiguous(), stride, zero_pad_br=pad)
+            torch.testing.assert_close(out.float().cpu(), ref.to(dt).float())
+    # GAP
+    torch.testing.assert_close(H.global_avgpool_nhwc(x.to(gpu)).cpu(), x.mean(dim=(1, 2)), rtol=1e-5, atol=1e-6)
+    # preprocess + stem im2col
+    img = torch.randint(0, 256, (2, 3, 21, 30), dtype=torch.uint8)
+    sizes = torch.tensor([[21, 30], [17, 25]], dtype=torch.int32)
+    mean, std = [102.9801, 115.9465, 122.7717], [57.375, 57.12, 58.395]
+    ref = R.preprocess_image([img[0], img[1][:, :17, :25]], mean, std)
+    out = H.preprocess_image(img.to(gpu), sizes.to(gpu), mean, std)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-6, atol=1e-6)
+    a, ho, wo = H.stem_im2col(img.to(gpu), sizes.to(gpu), mean, std, torch.float32)
+    cols = F.unfold(ref, 3, padding=1, stride=2)  # (N, 27 [c,r,q], L)
+    cols = cols.view(2, 3, 9, -1).permute(0, 3, 2, 1).reshape(2 * ho * wo, 27)  # -> k = (r*3+q)*3 + c
+    torch.testing.assert_close(a.cpu()[:, :27], cols, rtol=1e-6, atol=1e-6)
+    assert torch.all(a.cpu()[:, 27:] == 0)
+    # data-aware head vs oracle
+    from tests.helpers import seeded_sd
+
+    sd = seeded_sd()
+    fm = torch.randn(3, 512, 6, 7)
+    ref = R.data_aware_forward(sd, fm)
+    gap = H.global_avgpool_nhwc(fm.permute(0, 2, 3, 1).contiguous().to(gpu))
+    p = "data_aware_head."
+    daf, _, _ = H.data_aware_forward(gap, *(sd[p + k].to(gpu) for k in
+                                            ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
+                                             "datasets_feat.weight")))
+    torch.testing.assert_close(daf.cpu(), ref, rtol=1e-4, atol=1e-5)
