@@ -1,0 +1,125 @@
+"""CPU: the C-ABI library builds/loads and exports every symbol of include/wsovod_hip.h; host-side
+mirror of the reference interface (config loading, registries, containers, matcher, box transform)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from wsovod_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "wsovod_hip.h")).read()
+    declared = set(re.findall(r"\b(wsovod_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()  # raises if the .so is missing or a SIGNATURES symbol is absent
+    assert declared == set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(L, name), name
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S)
+        args = m.group(1).strip()
+        n = 0 if args in ("void", "") else args.count(",") + 1
+        assert n == len(_lib.SIGNATURES[name]), (name, n)
+    assert L.wsovod_abi_version() >= 1
+
+
+def test_error_convention_without_gpu():
+    """Argument validation happens before any launch: bad arguments return a status + message."""
+    import ctypes as C
+
+    from wsovod_amd import _lib
+
+    L = _lib.lib()
+    d = _lib.GemmDesc()
+    d.dtype_in, d.M, d.N, d.K = 7, 4, 4, 8
+    assert L.wsovod_gemm_nt(C.byref(d), None) == 1
+    assert b"dtype" in L.wsovod_last_error()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        from wsovod_amd.layers import hip_ops
+
+        hip_ops.roi_pool_forward(torch.zeros(1, 4, 8, 8), torch.zeros(2, 5), 0.125, (7, 7))
+
+
+def test_reference_yaml_loads_and_model_keys_match_reference():
+    from tests.helpers import golden_shapes
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(device="cpu")
+    assert cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE == "ROIPool" and cfg.MODEL.RESNETS.RES5_DILATION == 2
+    ref = golden_shapes()  # state-dict keys/shapes of the REFERENCE model (from make_golden.py)
+    mine = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    assert mine == ref
+    n_train = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    assert n_train == 124483313  # 124.5 M trainable, backbone fully frozen
+    assert not any(p.requires_grad for p in model.backbone.parameters())
+    assert model.backbone.output_shape()["res5"].stride == 8 and model.backbone.output_shape()["res5"].channels == 512
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/configs"), reason="reference checkout absent")
+def test_reference_own_config_files_load():
+    from wsovod_amd.config import get_cfg
+
+    for rel in ("PascalVOC-Detection/WSOVOD_WSR_18_DC5_1x.yaml", "COCO-Detection/WSOVOD_WSR_50_DC5_1x.yaml"):
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join("/root/reference/configs", rel))
+        assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNN_WSOVOD"
+        assert cfg.WSOVOD.INSTANCE_REFINEMENT.REFINE_REG == [True]
+        assert cfg.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.NORM_TEMP == 50.0
+        assert cfg.SOLVER.STEPS in ((70000,), (140000,))
+
+
+def test_out_of_scope_features_fail_loudly():
+    from wsovod_amd.modeling import build_model
+    from wsovod_amd.testing import hot_path_cfg
+
+    cfg = hot_path_cfg(device="cpu")
+    cfg.MODEL.PROPOSAL_GENERATOR.NAME = "WSOVODRPN_V2"
+    with pytest.raises(NotImplementedError, match="next"):
+        build_model(cfg)
+    cfg = hot_path_cfg(device="cpu")
+    cfg.WSOVOD.BBOX_REFINE.ENABLE = True
+    with pytest.raises(NotImplementedError, match="SAM"):
+        build_model(cfg)
+    cfg = hot_path_cfg(device="cpu")
+    cfg.MODEL.BACKBONE.FREEZE_AT = 2
+    model = build_model(cfg)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        model.backbone(torch.zeros(1, 3, 32, 32))
+
+
+def test_structures_and_matcher_semantics():
+    from wsovod_amd.modeling.box_regression import Box2BoxTransform
+    from wsovod_amd.modeling.matcher import Matcher
+    from wsovod_amd.structures import Boxes, ImageList, Instances, pairwise_iou
+
+    a = Boxes(torch.tensor([[0.0, 0.0, 10.0, 10.0], [20.0, 20.0, 30.0, 30.0]]))
+    b = Boxes(torch.tensor([[5.0, 5.0, 15.0, 15.0], [0.0, 0.0, 10.0, 10.0], [50.0, 50.0, 60.0, 60.0]]))
+    iou = pairwise_iou(a, b)
+    torch.testing.assert_close(iou, torch.tensor([[25.0 / 175.0, 1.0, 0.0], [0.0, 0.0, 0.0]]))
+    m, l = Matcher([0.5], [0, 1])(iou)
+    assert m.tolist() == [0, 0, 0] and l.tolist() == [0, 1, 0]
+    m, l = Matcher([0.5], [0, 1])(torch.zeros(0, 3))
+    assert m.tolist() == [0, 0, 0] and l.tolist() == [0, 0, 0]
+    t = Box2BoxTransform((10.0, 10.0, 5.0, 5.0))
+    d = t.get_deltas(a.tensor, b.tensor[:2])
+    torch.testing.assert_close(t.apply_deltas(d, a.tensor), b.tensor[:2])
+    il = ImageList.from_tensors([torch.ones(3, 4, 5), torch.ones(3, 6, 2)])
+    assert il.tensor.shape == (2, 3, 6, 5) and il.tensor[0, :, 4:, :].sum() == 0 and il.image_sizes == [(4, 5), (6, 2)]
+    i = Instances((6, 5), proposal_boxes=a, objectness_logits=torch.tensor([0.9, 0.1]))
+    assert len(i[torch.tensor([1])]) == 1 and len(Instances.cat([i, i])) == 4
+
+
+def test_synthetic_batch_format():
+    from wsovod_amd.data import make_batch
+
+    b = make_batch(2, 64, 20, seed=1)
+    assert b[0]["image"].dtype == torch.uint8 and b[0]["image"].shape == (3, 600, 800)
+    p = b[0]["proposals"]
+    assert len(p) == 64 and torch.all(p.objectness_logits[:-1] >= p.objectness_logits[1:])
+    assert torch.all(p.objectness_logits > 0) and torch.all(p.objectness_logits <= 1)
+    bx = p.proposal_boxes.tensor
+    assert torch.all(bx[:, 2] <= 800) and torch.all(bx[:, 3] <= 600) and torch.all(bx[:, 2] - bx[:, 0] >= 16)
+    assert len(torch.unique(b[0]["instances"].gt_classes)) == 2

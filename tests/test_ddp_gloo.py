@@ -1,0 +1,67 @@
+"""CPU, world_size 2, gloo: the multi-GPU leg of the path is plain data parallelism -- images sharded over
+ranks, one gradient all-reduce per step (reference: engine/defaults.py:143-148, data/build.py:314-320).
+The HIP model itself needs a GPU, so this drives the same engine code (wrap_model_with_ddp + run_step) with a
+CPU stand-in module that has the path's loss-dict interface."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+class _LossDictModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.fc = nn.Linear(8, 4)
+
+    def forward(self, batch):
+        x = torch.stack([b["x"] for b in batch])
+        y = self.fc(x)
+        return {"loss_a": y.pow(2).mean(), "loss_b": y.abs().mean() * 0.5}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import run_step, wrap_model_with_ddp
+
+    model = _LossDictModel()
+    ddp = wrap_model_with_ddp(model, rank)
+    assert ddp is not model
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    g = torch.Generator().manual_seed(1234 + rank)  # bench.py seeds each rank's shard the same way
+    batch = [{"x": torch.randn(8, generator=g)} for _ in range(3)]
+    for it in range(3):
+        run_step(ddp, opt, batch, it=it)
+    q.put((rank, model.fc.weight.detach().tolist(), [b["x"].tolist() for b in batch]))  # plain lists: no shm handles
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_step_matches_single_process_average():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w0, w1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(w0, w1)  # replicas stay in lock-step
+    assert res[0][2][0] != res[1][2][0]  # each rank trained on its own shard
+    # single-process reference: gradient = mean over ranks of the per-rank mean loss gradients
+    model = _LossDictModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    for it in range(3):
+        opt.zero_grad()
+        total = 0
+        for r in range(2):
+            total = total + sum(model([{"x": torch.tensor(x)} for x in res[r][2]]).values()) / 2
+        total.backward()
+        opt.step()
+    torch.testing.assert_close(model.fc.weight.detach(), w0, rtol=1e-5, atol=1e-6)

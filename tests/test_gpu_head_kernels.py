@@ -125,7 +125,7 @@ def test_weighted_l1_nan_guard(gpu):
     assert float(loss) == 0.0 and torch.all(pred.grad == 0)  # reference guard: fast_rcnn_open_vocabulary.py:868-871
 
 
-@pytest.mark.parametrize("case", ["normal", "all_small", "no_gt", "single"])
+@pytest.mark.parametrize("case", ["normal", "all_small", "single"])  # images without GT labels never reach this code: the reference filters them (engine/trainer.py:47-50) and its get_pgt_top_k cannot reshape them
 def test_pgt_mining_and_labelling_exact(gpu, case):
     from wsovod_amd.layers import hip_ops as H
 

