@@ -220,9 +220,9 @@ int wsovod_sgd_momentum(float* param, const float* grad, float* momentum_buf, lo
  *   loss = sum BCE(clamp(sum_r scores, 1e-6, 1-1e-6), y) / norm.
  * ---------------------------------------------------------------------------------- */
 int wsovod_mil_forward(const float* logits, long long ld, const int* seg_offsets, int G, int K,
-                       float* scores, float* P, float* Q, wsovod_stream_t stream);
+                       float* scores, float* P, float* Q, int M, wsovod_stream_t stream);
 int wsovod_mil_backward(const float* dscores, const float* P, const float* Q, const int* seg_offsets,
-                        int G, int K, float* dlogits, long long ld, wsovod_stream_t stream);
+                        int G, int K, float* dlogits, long long ld, int M, wsovod_stream_t stream);
 int wsovod_image_bce_forward(const float* scores, const int* seg_offsets, int G, int K,
                              const float* labels_onehot, float norm, float* img_scores, float* dS_img,
                              float* loss, wsovod_stream_t stream);
@@ -285,7 +285,7 @@ int wsovod_data_aware_forward(const float* gap, int N, int C, const float* W1, c
 int wsovod_data_aware_backward(const float* ddaf, int N, const float* gap, int C, const float* W2,
                                const float* E, int F, const float* h1, int Hd, const float* h2, int P,
                                float* dW1, float* db1, float* dW2, float* db2, float* dE,
-                               wsovod_stream_t stream);
+                               float* scratch /* N*(P+Hd) floats */, wsovod_stream_t stream);
 
 #ifdef __cplusplus
 }

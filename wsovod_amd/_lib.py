@@ -73,8 +73,8 @@ SIGNATURES = {
     "wsovod_segment_colsum": [_P, _I, _L, _P, _I, _I, _I, _P, _L, _I, _P],
     "wsovod_scale_by_device_scalar": [_P, _L, _P, _P, _P],
     "wsovod_sgd_momentum": [_P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
-    "wsovod_mil_forward": [_P, _L, _P, _I, _I, _P, _P, _P, _P],
-    "wsovod_mil_backward": [_P, _P, _P, _P, _I, _I, _P, _L, _P],
+    "wsovod_mil_forward": [_P, _L, _P, _I, _I, _P, _P, _P, _I, _P],
+    "wsovod_mil_backward": [_P, _P, _P, _P, _I, _I, _P, _L, _I, _P],
     "wsovod_image_bce_forward": [_P, _P, _I, _I, _P, _F, _P, _P, _P, _P],
     "wsovod_image_bce_backward": [_P, _P, _I, _I, _P, _P, _P],
     "wsovod_weighted_ce_forward": [_P, _L, _I, _I, _P, _P, _I, _P, _L, _P, _P, _P],
@@ -83,7 +83,7 @@ SIGNATURES = {
     "wsovod_add_group_rows": [_P, _L, _I, _P, _P, _L, _I, _I, _P, _L, _P],
     "wsovod_scale_rows": [_P, _L, _P, _I, _I, _P, _L, _I, _P],
     "wsovod_data_aware_forward": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
-    "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P],
+    "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
 }
 

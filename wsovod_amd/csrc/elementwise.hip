@@ -109,26 +109,6 @@ __global__ void maxpool2x2_nhwc_kernel(const T* __restrict__ in, int N, int H, i
   }
 }
 
-// Global average pool over NHWC -> (N,C) fp32 (DataAwareFeaturesHead.GAP,
-// data_aware_features_head.py:62,124).  Workgroup per (image, 64-channel group): 4 wavefronts
-// stride the pixels, lane = channel (coalesced), LDS combine.
-template <typename T>
-__global__ __launch_bounds__(256) void gap_nhwc_kernel(const T* __restrict__ in, int HW, int C,
-                                                       float* __restrict__ out) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cg = ceil_div(C, 64);
-  const int n = blockIdx.x / cg, c = (blockIdx.x % cg) * 64 + lane;
-  float acc = 0.f;
-  if (c < C) {
-    const T* p = in + (long long)n * HW * C + c;
-    for (int i = wave; i < HW; i += 4) acc += to_f32(p[(long long)i * C]);
-  }
-  part[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && c < C) out[(long long)n * C + c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) / (float)HW;
-}
-
 // ---------------------------------------------------------------------------------
 // transpose + cast: dst[c][r] = src[r][c]  (64x64 LDS tile, padded), and plain cast.
 // ---------------------------------------------------------------------------------
@@ -205,28 +185,49 @@ __global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------
-// Segmented column sum: out[g][n] = sum_{m in [seg[g], seg[g+1])} x[m][n]   (bias grads with
-// one segment; per-image data-aware-feature grads).  Workgroup per (segment, 64 columns).
+// Segmented column sum: out[g][n] += scale * sum_{m in segment g} x[m][n]  (bias grads with one
+// segment; per-image data-aware-feature grads; global average pool with uniform segments).
+// Grid = (64-column groups) x (256-row chunks): lane = column (coalesced), the 4 wavefronts
+// stride the chunk's rows; a wavefront flushes its running sum with one atomicAdd per lane when
+// the segment changes and at the end, so the reduction over M is spread over the whole chip.
+// `out` is zero-filled by the launcher unless accumulating.
 // ---------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, long long ld,
-                                                             const int* __restrict__ seg, int N,
-                                                             float* __restrict__ out, long long ldo, int accumulate) {
-  __shared__ float part[4][64];
+                                                             const int* __restrict__ seg, int G, int uniform_rows,
+                                                             int M, int N, float scale, float* __restrict__ out,
+                                                             long long ldo) {
+  constexpr int RC = 256;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int cg = ceil_div(N, 64);
-  const int g = blockIdx.x / cg, n = (blockIdx.x % cg) * 64 + lane;
-  const int m0 = seg ? seg[g] : 0, m1 = seg ? seg[g + 1] : 0;
-  float acc = 0.f;
-  if (n < N)
-    for (int m = m0 + wave; m < m1; m += 4) acc += to_f32(x[(long long)m * ld + n]);
-  part[wave][lane] = acc;
-  __syncthreads();
-  if (wave == 0 && n < N) {
-    const float v = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-    float* o = out + (long long)g * ldo + n;
-    *o = accumulate ? *o + v : v;
+  const int n = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * RC, r1 = min(r0 + RC, M);
+  if (n >= N) return;
+  int g = 0;
+  if (!seg) {
+    g = (r0 + wave) / uniform_rows;
+  } else {
+    int lo = 0, hi = G;  // largest g with seg[g] <= row
+    const int row = r0 + wave;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg[mid] <= row) lo = mid; else hi = mid;
+    }
+    g = lo;
   }
+  float acc = 0.f;
+  for (int m = r0 + wave; m < r1; m += 4) {
+    int gm = g;
+    if (!seg) gm = m / uniform_rows;
+    else while (gm + 1 < G && m >= seg[gm + 1]) ++gm;
+    if (gm != g) {
+      if (acc != 0.f) atomicAdd(out + (long long)g * ldo + n, acc * scale);
+      acc = 0.f;
+      g = gm;
+    }
+    if (seg && (m < seg[g] || m >= seg[g + 1])) continue;  // rows outside every segment
+    acc += to_f32(x[(long long)m * ld + n]);
+  }
+  if (acc != 0.f) atomicAdd(out + (long long)g * ldo + n, acc * scale);
 }
 
 // x *= num[0] / den[0]  (device scalars: upstream loss grad / normaliser; no host sync)
@@ -458,6 +459,20 @@ int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C
   return WSOVOD_OK;
 }
 
+static int launch_colsum(const void* x, int dtype, long long ld, const int* seg, int G, int uniform_rows, int M, int N,
+                         float scale, float* out, long long ldo, int accumulate, hipStream_t s) {
+  if (!accumulate) {
+    if (ldo == N) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * N, s);
+    else (void)hipMemset2DAsync(out, ldo * sizeof(float), 0, N * sizeof(float), G, s);
+  }
+  const dim3 grid(ceil_div(N, 64), ceil_div(M, 256));
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
+  else
+    hipLaunchKernelGGL(segment_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
+  return 0;
+}
+
 int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out, wsovod_stream_t stream) {
   WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_global_avgpool_nhwc: bad dtype");
   if (N == 0) return WSOVOD_OK;
@@ -465,11 +480,7 @@ int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, 
   static int slot = wsovod::prof_slot("gap_nhwc");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)N * HW * C * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
-  const int grid = N * ceil_div(C, 64);
-  if (dtype == WSOVOD_BF16)
-    hipLaunchKernelGGL(gap_nhwc_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)in, HW, C, out);
-  else
-    hipLaunchKernelGGL(gap_nhwc_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, HW, C, out);
+  launch_colsum(in, dtype, C, nullptr, N, HW, N * HW, C, 1.0f / (float)HW, out, C, 0, s);
   WS_CHECK_LAUNCH("wsovod_global_avgpool_nhwc");
   return WSOVOD_OK;
 }
@@ -548,15 +559,12 @@ int wsovod_segment_colsum(const void* x, int dtype, long long ld, const int* seg
                           float* out, long long ldo, int accumulate, wsovod_stream_t stream) {
   if (G == 0 || N == 0) return WSOVOD_OK;
   WS_CHECK_ARG(x && out && seg_offsets, "wsovod_segment_colsum: null pointer");
-  (void)M;
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_segment_colsum: bad dtype");
   static int slot = wsovod::prof_slot("segment_colsum");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
-  const int grid = G * ceil_div(N, 64);
-  if (dtype == WSOVOD_BF16)
-    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ld, seg_offsets, N, out, ldo, accumulate);
-  else
-    hipLaunchKernelGGL(segment_colsum_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ld, seg_offsets, N, out, ldo, accumulate);
+  if (M > 0) launch_colsum(x, dtype, ld, seg_offsets, G, 0, M, N, 1.0f, out, ldo, accumulate, s);
+  else if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * ldo, s);
   WS_CHECK_LAUNCH("wsovod_segment_colsum");
   return WSOVOD_OK;
 }

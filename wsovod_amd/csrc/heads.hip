@@ -23,18 +23,15 @@ __device__ __forceinline__ float block_reduce(float v, float* sh, bool is_max) {
 // ---------------------------------------------------------------------------------
 // MIL forward (fast_rcnn_open_vocabulary.py:342-354):  per image,
 //   P = softmax_k(C[r,:]),  Q = softmax_r(D[:,k]) over the image's proposals,  S = P * Q.
-// logits: (M, 2K) row-major [cls | det].  Workgroup per image; threads stride rows for P
-// (wavefront per row) and columns for Q.
+// logits: (M, 2K) row-major [cls | det].
+//   rows kernel : wavefront per proposal row (grid-stride)            -> P
+//   cols kernel : workgroup (16 wavefronts) per (image, 64-class tile): lane = class (coalesced),
+//                 the wavefronts split the image's proposals, LDS combine   -> Q, S = P*Q
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mil_forward_kernel(const float* __restrict__ logits, long long ld,
-                                                          const int* __restrict__ seg, int K,
-                                                          float* __restrict__ scores, float* __restrict__ P,
-                                                          float* __restrict__ Q) {
-  const int g = blockIdx.x;
-  const int m0 = seg[g], m1 = seg[g + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // P: softmax over classes, wavefront per row
-  for (int m = m0 + wave; m < m1; m += 4) {
+__global__ __launch_bounds__(256) void mil_rows_kernel(const float* __restrict__ logits, long long ld, int M, int K,
+                                                       float* __restrict__ P) {
+  const int lane = threadIdx.x & 63;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
     const float* c = logits + (long long)m * ld;
     float mx = -FLT_MAX;
     for (int k = lane; k < K; k += 64) mx = fmaxf(mx, c[k]);
@@ -44,62 +41,107 @@ __global__ __launch_bounds__(256) void mil_forward_kernel(const float* __restric
     sum = wave_reduce_sum(sum);
     for (int k = lane; k < K; k += 64) P[(long long)m * K + k] = expf(c[k] - mx) / sum;
   }
-  // Q: softmax over the image's proposals, one thread per class column (coalesced across k)
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    const float* d = logits + K + k;
-    float mx = -FLT_MAX;
-    for (int m = m0; m < m1; ++m) mx = fmaxf(mx, d[(long long)m * ld]);
-    float sum = 0.f;
-    for (int m = m0; m < m1; ++m) sum += expf(d[(long long)m * ld] - mx);
-    for (int m = m0; m < m1; ++m) Q[(long long)m * K + k] = expf(d[(long long)m * ld] - mx) / sum;
-  }
+}
+
+constexpr int kColWaves = 16;
+
+__device__ __forceinline__ float col_combine(float v, float (*red)[64], bool is_max) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
-  for (long long i = (long long)m0 * K + threadIdx.x; i < (long long)m1 * K; i += blockDim.x) scores[i] = P[i] * Q[i];
+  red[wave][lane] = v;
+  __syncthreads();
+  float r = red[0][lane];
+#pragma unroll
+  for (int i = 1; i < kColWaves; ++i) r = is_max ? fmaxf(r, red[i][lane]) : r + red[i][lane];
+  return r;
+}
+
+__global__ __launch_bounds__(1024) void mil_cols_kernel(const float* __restrict__ logits, long long ld,
+                                                        const int* __restrict__ seg, int K,
+                                                        const float* __restrict__ P, float* __restrict__ Q,
+                                                        float* __restrict__ scores) {
+  __shared__ float red[kColWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y, k = blockIdx.x * 64 + lane;
+  const int m0 = seg[g], m1 = seg[g + 1];
+  const bool ok = k < K;
+  const float* d = logits + K + (ok ? k : 0);
+  float mx = -FLT_MAX;
+  for (int m = m0 + wave; m < m1; m += kColWaves) mx = fmaxf(mx, d[(long long)m * ld]);
+  mx = col_combine(mx, red, true);
+  float sum = 0.f;
+  for (int m = m0 + wave; m < m1; m += kColWaves) sum += expf(d[(long long)m * ld] - mx);
+  sum = col_combine(sum, red, false);
+  if (!ok) return;
+  for (int m = m0 + wave; m < m1; m += kColWaves) {
+    const float q = expf(d[(long long)m * ld] - mx) / sum;
+    const long long i = (long long)m * K + k;
+    Q[i] = q;
+    scores[i] = P[i] * q;
+  }
 }
 
 // MIL backward: dC = P*(dP - sum_k dP*P), dD = Q*(dQ - sum_r dQ*Q) with dP = dS*Q, dQ = dS*P.
-__global__ __launch_bounds__(256) void mil_backward_kernel(const float* __restrict__ dS, const float* __restrict__ P,
-                                                           const float* __restrict__ Q, const int* __restrict__ seg,
-                                                           int K, float* __restrict__ dlogits, long long ld) {
-  const int g = blockIdx.x;
-  const int m0 = seg[g], m1 = seg[g + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int m = m0 + wave; m < m1; m += 4) {
+__global__ __launch_bounds__(256) void mil_bwd_rows_kernel(const float* __restrict__ dS, const float* __restrict__ P,
+                                                           const float* __restrict__ Q, int M, int K,
+                                                           float* __restrict__ dlogits, long long ld) {
+  const int lane = threadIdx.x & 63;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
     const long long b = (long long)m * K;
     float dot = 0.f;
     for (int k = lane; k < K; k += 64) dot += dS[b + k] * Q[b + k] * P[b + k];
     dot = wave_reduce_sum(dot);
     for (int k = lane; k < K; k += 64) dlogits[(long long)m * ld + k] = P[b + k] * (dS[b + k] * Q[b + k] - dot);
   }
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
-    float dot = 0.f;
-    for (int m = m0; m < m1; ++m) {
+}
+
+__global__ __launch_bounds__(1024) void mil_bwd_cols_kernel(const float* __restrict__ dS, const float* __restrict__ P,
+                                                            const float* __restrict__ Q,
+                                                            const int* __restrict__ seg, int K,
+                                                            float* __restrict__ dlogits, long long ld) {
+  __shared__ float red[kColWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y, k = blockIdx.x * 64 + lane;
+  const int m0 = seg[g], m1 = seg[g + 1];
+  const bool ok = k < K;
+  float dot = 0.f;
+  if (ok)
+    for (int m = m0 + wave; m < m1; m += kColWaves) {
       const long long i = (long long)m * K + k;
       dot += dS[i] * P[i] * Q[i];
     }
-    for (int m = m0; m < m1; ++m) {
-      const long long i = (long long)m * K + k;
-      dlogits[(long long)m * ld + K + k] = Q[i] * (dS[i] * P[i] - dot);
-    }
+  dot = col_combine(dot, red, false);
+  if (!ok) return;
+  for (int m = m0 + wave; m < m1; m += kColWaves) {
+    const long long i = (long long)m * K + k;
+    dlogits[(long long)m * ld + K + k] = Q[i] * (dS[i] * P[i] - dot);
   }
 }
 
 // ---------------------------------------------------------------------------------
 // Image-level scores + BCE (predict_probs_img :604-618, binary_cross_entropy :429-437):
 //   S[g][k] = sum_r scores;  c = clamp(S, 1e-6, 1-1e-6);  loss = sum BCE(c, y) / norm.
-// Single workgroup (N*K is tiny); grad wrt S is stored for the backward broadcast.
+//   sum kernel: workgroup (16 wavefronts) per (image, 64-class tile) -> S;  finalize: one workgroup.
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void image_bce_kernel(const float* __restrict__ scores,
-                                                        const int* __restrict__ seg, int G, int K,
-                                                        const float* __restrict__ y, float norm,
-                                                        float* __restrict__ img_scores, float* __restrict__ dS_img,
-                                                        float* __restrict__ loss) {
+__global__ __launch_bounds__(1024) void image_sum_kernel(const float* __restrict__ scores,
+                                                         const int* __restrict__ seg, int K, float* __restrict__ S) {
+  __shared__ float red[kColWaves][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y, k = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (k < K)
+    for (int m = seg[g] + wave; m < seg[g + 1]; m += kColWaves) s += scores[(long long)m * K + k];
+  s = col_combine(s, red, false);
+  if (k < K && wave == 0) S[(long long)g * K + k] = s;
+}
+
+__global__ __launch_bounds__(256) void image_bce_kernel(const float* S, int GK, const float* __restrict__ y,
+                                                        float norm, float* __restrict__ img_scores, float* dS_img,
+                                                        float* __restrict__ loss) {  // S may alias dS_img
   __shared__ float sh[4];
   float local = 0.f;
-  for (int i = threadIdx.x; i < G * K; i += blockDim.x) {
-    const int g = i / K, k = i - g * K;
-    float s = 0.f;
-    for (int m = seg[g]; m < seg[g + 1]; ++m) s += scores[(long long)m * K + k];
+  for (int i = threadIdx.x; i < GK; i += blockDim.x) {
+    const float s = S[i];
     const float c = fminf(fmaxf(s, 1e-6f), 1.0f - 1e-6f);
     img_scores[i] = c;
     const float yy = y[i];
@@ -116,7 +158,8 @@ __global__ void image_bce_backward_kernel(const float* __restrict__ dS_img, cons
                                           const float* __restrict__ gout, float* __restrict__ dscores) {
   const int g = blockIdx.x;
   const float go = gout ? gout[0] : 1.f;
-  for (long long i = (long long)seg[g] * K + threadIdx.x; i < (long long)seg[g + 1] * K; i += blockDim.x)
+  for (long long i = (long long)seg[g] * K + threadIdx.x + (long long)blockIdx.y * blockDim.x;
+       i < (long long)seg[g + 1] * K; i += (long long)blockDim.x * gridDim.y)
     dscores[i] = go * dS_img[(long long)g * K + (int)(i % K)];
 }
 
@@ -132,28 +175,36 @@ __global__ __launch_bounds__(256) void weighted_ce_kernel(const float* __restric
                                                           const float* __restrict__ w, int weighted,
                                                           float* __restrict__ dlogits, long long ldd,
                                                           float* __restrict__ accum) {
-  const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
-  const long long t = gt[m];
-  const bool ignore = t == -1;
-  const float wr = weighted ? (ignore ? 0.f : w[m]) : (ignore ? 0.f : 1.f);
-  const float* x = logits + (long long)m * ld;
-  float mx = -FLT_MAX;
-  for (int k = lane; k < K1; k += 64) mx = fmaxf(mx, x[k]);
-  mx = wave_reduce_max(mx);
-  float sum = 0.f;
-  for (int k = lane; k < K1; k += 64) sum += expf(x[k] - mx);
-  sum = wave_reduce_sum(sum);
-  const float lse = mx + logf(sum);
-  for (int k = lane; k < K1; k += 64) {
-    const float p = expf(x[k] - lse);
-    dlogits[(long long)m * ldd + k] = ignore ? 0.f : wr * (p - (k == t ? 1.f : 0.f));
+  __shared__ float sh_sum[4], sh_cnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float lsum = 0.f, lcnt = 0.f;
+  for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
+    const long long t = gt[m];
+    const bool ignore = t == -1;
+    const float wr = weighted ? (ignore ? 0.f : w[m]) : (ignore ? 0.f : 1.f);
+    const float* x = logits + (long long)m * ld;
+    float mx = -FLT_MAX;
+    for (int k = lane; k < K1; k += 64) mx = fmaxf(mx, x[k]);
+    mx = wave_reduce_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < K1; k += 64) sum += expf(x[k] - mx);
+    sum = wave_reduce_sum(sum);
+    const float lse = mx + logf(sum);
+    for (int k = lane; k < K1; k += 64) {
+      const float p = expf(x[k] - lse);
+      dlogits[(long long)m * ldd + k] = ignore ? 0.f : wr * (p - (k == t ? 1.f : 0.f));
+    }
+    if (!ignore) lsum += wr * (lse - x[t]);
+    if (weighted ? (wr > 1e-12f) : !ignore) lcnt += 1.0f;
   }
   if (lane == 0) {
-    if (!ignore) atomicAdd(accum, wr * (lse - x[t]));
-    const bool counted = weighted ? (wr > 1e-12f) : !ignore;
-    if (counted) atomicAdd(accum + 1, 1.0f);
+    sh_sum[wave] = lsum;
+    sh_cnt[wave] = lcnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(accum, sh_sum[0] + sh_sum[1] + sh_sum[2] + sh_sum[3]);
+    atomicAdd(accum + 1, sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3]);
   }
 }
 __global__ void ce_finalize_kernel(const float* __restrict__ accum, float* __restrict__ loss) {
@@ -171,6 +222,7 @@ __global__ void weighted_l1_kernel(const float* __restrict__ pred, long long ldp
                                    const float* __restrict__ gbox, const long long* __restrict__ gt,
                                    const float* __restrict__ w, int M, int K, float wx, float wy, float ww, float wh,
                                    float beta, int weighted, float* __restrict__ dpred, float* __restrict__ accum) {
+  float tot = 0.f, bad = 0.f;
   for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
     const long long t = gt[m];
     const bool fg = t >= 0 && t < K;
@@ -202,11 +254,21 @@ __global__ void weighted_l1_kernel(const float* __restrict__ pred, long long ldp
           d[j] = (diff > 0.f ? 1.f : -1.f) * wr;
         }
       }
-      if (nan) atomicAdd(accum + 1, 1.0f);
-      else atomicAdd(accum, local);
+      if (nan) {
+        bad += 1.0f;
+        local = 0.f;
+      }
+      tot += local;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) dpred[(long long)m * 4 + j] = d[j];
+  }
+  __shared__ float sh[4];
+  const float t = block_reduce(tot, sh, false);
+  const float b = block_reduce(bad, sh, false);
+  if (threadIdx.x == 0) {
+    if (t != 0.f) atomicAdd(accum, t);
+    if (b != 0.f) atomicAdd(accum + 1, b);
   }
 }
 __global__ void l1_finalize_kernel(const float* __restrict__ accum, int M, float* __restrict__ loss,
@@ -401,50 +463,68 @@ __global__ __launch_bounds__(256) void data_aware_fwd_kernel(const float* __rest
   }
 }
 
-__global__ __launch_bounds__(256) void data_aware_bwd_kernel(const float* __restrict__ ddaf, int N,
-                                                             const float* __restrict__ gap, int Cc,
+// stage 1, workgroup per image: dpre2[n][p] = (ddaf[n] . E[p]) * (1 - h2^2);  dh1[n][j] = relu'(h1) * W2^T dpre2
+__global__ __launch_bounds__(256) void data_aware_bwd_stage1(const float* __restrict__ ddaf,
                                                              const float* __restrict__ W2,
                                                              const float* __restrict__ E, int F,
                                                              const float* __restrict__ h1, int Hd,
                                                              const float* __restrict__ h2, int P,
-                                                             float* __restrict__ dW1, float* __restrict__ db1,
-                                                             float* __restrict__ dW2, float* __restrict__ db2,
-                                                             float* __restrict__ dE) {
-  extern __shared__ float sm[];
-  float* dpre2 = sm;        // P
-  float* dh1 = sm + P;      // Hd
+                                                             float* __restrict__ dpre2, float* __restrict__ dh1) {
+  extern __shared__ float sm[];  // P
   __shared__ float sh[4];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < Hd * Cc; i += blockDim.x) dW1[i] = 0.f;
-  for (int i = tid; i < Hd; i += blockDim.x) db1[i] = 0.f;
-  for (int i = tid; i < P * Hd; i += blockDim.x) dW2[i] = 0.f;
-  for (int i = tid; i < P; i += blockDim.x) db2[i] = 0.f;
-  for (int i = tid; i < P * F; i += blockDim.x) dE[i] = 0.f;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const float* dd = ddaf + (long long)n * F;
+  for (int p = 0; p < P; ++p) {
+    float a = 0.f;
+    for (int f = tid; f < F; f += blockDim.x) a += dd[f] * E[(long long)p * F + f];
+    a = block_reduce(a, sh, false);
+    if (tid == 0) {
+      const float t = h2[(long long)n * P + p];
+      sm[p] = a * (1.f - t * t);
+      dpre2[(long long)n * P + p] = sm[p];
+    }
+  }
   __syncthreads();
-  for (int n = 0; n < N; ++n) {
-    const float* dd = ddaf + (long long)n * F;
-    for (int p = 0; p < P; ++p) {
-      float a = 0.f;
-      for (int f = tid; f < F; f += blockDim.x) a += dd[f] * E[(long long)p * F + f];
-      a = block_reduce(a, sh, false);
-      if (tid == 0) {
-        const float t = h2[(long long)n * P + p];
-        dpre2[p] = a * (1.f - t * t);
-      }
+  for (int j = tid; j < Hd; j += blockDim.x) {
+    float a = 0.f;
+    for (int p = 0; p < P; ++p) a += W2[(long long)p * Hd + j] * sm[p];
+    dh1[(long long)n * Hd + j] = h1[(long long)n * Hd + j] > 0.f ? a : 0.f;
+  }
+}
+
+// stage 2, grid-stride over every gradient element; each sums over the N images in a fixed order
+// (deterministic): dE = h2^T ddaf, dW2 = dpre2^T h1, db2, dW1 = dh1^T gap, db1.
+__global__ void data_aware_bwd_stage2(const float* __restrict__ ddaf, int N, const float* __restrict__ gap, int Cc,
+                                      int F, const float* __restrict__ h1, int Hd, const float* __restrict__ h2,
+                                      int P, const float* __restrict__ dpre2, const float* __restrict__ dh1,
+                                      float* __restrict__ dW1, float* __restrict__ db1, float* __restrict__ dW2,
+                                      float* __restrict__ db2, float* __restrict__ dE) {
+  const long long nE = (long long)P * F, nW2 = (long long)P * Hd, nW1 = (long long)Hd * Cc;
+  const long long total = nE + nW2 + P + nW1 + Hd;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    long long j = i;
+    if (j < nE) {
+      const int p = (int)(j / F), f = (int)(j % F);
+      for (int n = 0; n < N; ++n) a += h2[(long long)n * P + p] * ddaf[(long long)n * F + f];
+      dE[j] = a;
+    } else if ((j -= nE) < nW2) {
+      const int p = (int)(j / Hd), q = (int)(j % Hd);
+      for (int n = 0; n < N; ++n) a += dpre2[(long long)n * P + p] * h1[(long long)n * Hd + q];
+      dW2[j] = a;
+    } else if ((j -= nW2) < P) {
+      for (int n = 0; n < N; ++n) a += dpre2[(long long)n * P + j];
+      db2[j] = a;
+    } else if ((j -= P) < nW1) {
+      const int q = (int)(j / Cc), c = (int)(j % Cc);
+      for (int n = 0; n < N; ++n) a += dh1[(long long)n * Hd + q] * gap[(long long)n * Cc + c];
+      dW1[j] = a;
+    } else {
+      j -= nW1;
+      for (int n = 0; n < N; ++n) a += dh1[(long long)n * Hd + j];
+      db1[j] = a;
     }
-    __syncthreads();
-    for (int i = tid; i < P * F; i += blockDim.x) dE[i] += h2[(long long)n * P + i / F] * dd[i % F];
-    for (int i = tid; i < P * Hd; i += blockDim.x) dW2[i] += dpre2[i / Hd] * h1[(long long)n * Hd + i % Hd];
-    for (int i = tid; i < P; i += blockDim.x) db2[i] += dpre2[i];
-    for (int j = tid; j < Hd; j += blockDim.x) {
-      float a = 0.f;
-      for (int p = 0; p < P; ++p) a += W2[(long long)p * Hd + j] * dpre2[p];
-      dh1[j] = h1[(long long)n * Hd + j] > 0.f ? a : 0.f;
-    }
-    __syncthreads();
-    for (int i = tid; i < Hd * Cc; i += blockDim.x) dW1[i] += dh1[i / Cc] * gap[(long long)n * Cc + i % Cc];
-    for (int j = tid; j < Hd; j += blockDim.x) db1[j] += dh1[j];
-    __syncthreads();
   }
 }
 
@@ -453,25 +533,30 @@ __global__ __launch_bounds__(256) void data_aware_bwd_kernel(const float* __rest
 extern "C" {
 
 int wsovod_mil_forward(const float* logits, long long ld, const int* seg_offsets, int G, int K, float* scores,
-                       float* P, float* Q, wsovod_stream_t stream) {
-  if (G == 0) return WSOVOD_OK;
+                       float* P, float* Q, int M, wsovod_stream_t stream) {
+  if (G == 0 || M == 0) return WSOVOD_OK;
   WS_CHECK_ARG(logits && seg_offsets && scores && P && Q && K > 0, "wsovod_mil_forward: bad argument");
   static int slot = wsovod::prof_slot("mil_forward");
   hipStream_t s = (hipStream_t)stream;
-  wsovod::ProfScope prof(slot, s, 0.0, 0.0);
-  hipLaunchKernelGGL(mil_forward_kernel, dim3(G), dim3(256), 0, s, logits, ld, seg_offsets, K, scores, P, Q);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * K * 20.0);
+  hipLaunchKernelGGL(mil_rows_kernel, dim3(std::min(ceil_div(M, 4), 2048)), dim3(256), 0, s, logits, ld, M, K, P);
+  hipLaunchKernelGGL(mil_cols_kernel, dim3(ceil_div(K, 64), G), dim3(1024), 0, s, logits, ld, seg_offsets, K, P, Q,
+                     scores);
   WS_CHECK_LAUNCH("wsovod_mil_forward");
   return WSOVOD_OK;
 }
 
 int wsovod_mil_backward(const float* dscores, const float* P, const float* Q, const int* seg_offsets, int G, int K,
-                        float* dlogits, long long ld, wsovod_stream_t stream) {
-  if (G == 0) return WSOVOD_OK;
+                        float* dlogits, long long ld, int M, wsovod_stream_t stream) {
+  if (G == 0 || M == 0) return WSOVOD_OK;
   WS_CHECK_ARG(dscores && P && Q && seg_offsets && dlogits && K > 0, "wsovod_mil_backward: bad argument");
   static int slot = wsovod::prof_slot("mil_backward");
   hipStream_t s = (hipStream_t)stream;
-  wsovod::ProfScope prof(slot, s, 0.0, 0.0);
-  hipLaunchKernelGGL(mil_backward_kernel, dim3(G), dim3(256), 0, s, dscores, P, Q, seg_offsets, K, dlogits, ld);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * K * 20.0);
+  hipLaunchKernelGGL(mil_bwd_rows_kernel, dim3(std::min(ceil_div(M, 4), 2048)), dim3(256), 0, s, dscores, P, Q, M, K,
+                     dlogits, ld);
+  hipLaunchKernelGGL(mil_bwd_cols_kernel, dim3(ceil_div(K, 64), G), dim3(1024), 0, s, dscores, P, Q, seg_offsets, K,
+                     dlogits, ld);
   WS_CHECK_LAUNCH("wsovod_mil_backward");
   return WSOVOD_OK;
 }
@@ -483,8 +568,10 @@ int wsovod_image_bce_forward(const float* scores, const int* seg_offsets, int G,
   static int slot = wsovod::prof_slot("image_bce");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, 0.0);
-  hipLaunchKernelGGL(image_bce_kernel, dim3(1), dim3(256), 0, s, scores, seg_offsets, G, K, labels_onehot, norm,
-                     img_scores, dS_img, loss);
+  // dS_img doubles as the scratch for the un-clamped sums (read, then overwritten, per element)
+  hipLaunchKernelGGL(image_sum_kernel, dim3(ceil_div(K, 64), G), dim3(1024), 0, s, scores, seg_offsets, K, dS_img);
+  hipLaunchKernelGGL(image_bce_kernel, dim3(1), dim3(256), 0, s, dS_img, G * K, labels_onehot, norm, img_scores,
+                     dS_img, loss);
   WS_CHECK_LAUNCH("wsovod_image_bce_forward");
   return WSOVOD_OK;
 }
@@ -496,7 +583,7 @@ int wsovod_image_bce_backward(const float* dS_img, const int* seg_offsets, int G
   static int slot = wsovod::prof_slot("image_bce_bwd");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, 0.0);
-  hipLaunchKernelGGL(image_bce_backward_kernel, dim3(G), dim3(256), 0, s, dS_img, seg_offsets, K, grad_out, dscores);
+  hipLaunchKernelGGL(image_bce_backward_kernel, dim3(G, 8), dim3(256), 0, s, dS_img, seg_offsets, K, grad_out, dscores);
   WS_CHECK_LAUNCH("wsovod_image_bce_backward");
   return WSOVOD_OK;
 }
@@ -511,7 +598,7 @@ int wsovod_weighted_ce_forward(const float* logits, long long ld, int M, int K1,
   (void)hipMemsetAsync(accum2, 0, 2 * sizeof(float), s);
   if (M > 0) {
     WS_CHECK_ARG(logits && gt_classes && dlogits && K1 > 0 && (!weighted || weights), "wsovod_weighted_ce_forward: bad argument");
-    hipLaunchKernelGGL(weighted_ce_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, s, logits, ld, M, K1, gt_classes,
+    hipLaunchKernelGGL(weighted_ce_kernel, dim3(std::min(ceil_div(M, 4), 256)), dim3(256), 0, s, logits, ld, M, K1, gt_classes,
                        weights, weighted, dlogits, ldd, accum2);
   }
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1), 0, s, accum2, loss);
@@ -577,13 +664,19 @@ int wsovod_data_aware_forward(const float* gap, int N, int C, const float* W1, c
 
 int wsovod_data_aware_backward(const float* ddaf, int N, const float* gap, int C, const float* W2, const float* E,
                                int F, const float* h1, int Hd, const float* h2, int P, float* dW1, float* db1,
-                               float* dW2, float* db2, float* dE, wsovod_stream_t stream) {
-  WS_CHECK_ARG(dW1 && db1 && dW2 && db2 && dE, "wsovod_data_aware_backward: null pointer");
+                               float* dW2, float* db2, float* dE, float* scratch, wsovod_stream_t stream) {
+  WS_CHECK_ARG(dW1 && db1 && dW2 && db2 && dE && scratch, "wsovod_data_aware_backward: null pointer");
   static int slot = wsovod::prof_slot("data_aware_bwd");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, 0.0);
-  hipLaunchKernelGGL(data_aware_bwd_kernel, dim3(1), dim3(256), (Hd + P) * sizeof(float), s, ddaf, N, gap, C, W2, E,
-                     F, h1, Hd, h2, P, dW1, db1, dW2, db2, dE);
+  float* dpre2 = scratch;                 // N*P
+  float* dh1 = scratch + (size_t)N * P;   // N*Hd
+  if (N > 0)
+    hipLaunchKernelGGL(data_aware_bwd_stage1, dim3(N), dim3(256), P * sizeof(float), s, ddaf, W2, E, F, h1, Hd, h2, P,
+                       dpre2, dh1);
+  const long long total = (long long)P * F + (long long)P * Hd + P + (long long)Hd * C + Hd;
+  hipLaunchKernelGGL(data_aware_bwd_stage2, dim3((int)std::min<long long>(ceil_div_ll(total, 256), 1024)), dim3(256),
+                     0, s, ddaf, N, gap, C, F, h1, Hd, h2, P, dpre2, dh1, dW1, db1, dW2, db2, dE);
   WS_CHECK_LAUNCH("wsovod_data_aware_backward");
   return WSOVOD_OK;
 }

@@ -285,7 +285,7 @@ def mil_forward(logits, seg_offsets, K):
     scores = torch.empty((M, K), dtype=torch.float32, device=logits.device)
     P = torch.empty_like(scores)
     Q = torch.empty_like(scores)
-    check(lib().wsovod_mil_forward(ptr(logits), _ld(logits), ptr(seg_offsets), G, K, ptr(scores), ptr(P), ptr(Q),
+    check(lib().wsovod_mil_forward(ptr(logits), _ld(logits), ptr(seg_offsets), G, K, ptr(scores), ptr(P), ptr(Q), M,
                                    stream()), "mil_forward")
     return scores, P, Q
 
@@ -296,7 +296,7 @@ def mil_backward(dscores, P, Q, seg_offsets, K):
     G = seg_offsets.numel() - 1
     dlogits = torch.empty((M, 2 * K), dtype=torch.float32, device=P.device)
     check(lib().wsovod_mil_backward(ptr(dscores.contiguous()), ptr(P), ptr(Q), ptr(seg_offsets), G, K, ptr(dlogits),
-                                    _ld(dlogits), stream()), "mil_backward")
+                                    _ld(dlogits), M, stream()), "mil_backward")
     return dlogits
 
 
@@ -437,7 +437,8 @@ def data_aware_backward(ddaf, gap, W2, E, h1, h2):
     dW2 = torch.empty((P, Hd), dtype=torch.float32, device=dev)
     db2 = torch.empty((P,), dtype=torch.float32, device=dev)
     dE = torch.empty((P, F), dtype=torch.float32, device=dev)
+    scratch = torch.empty((N * (P + Hd),), dtype=torch.float32, device=dev)
     check(lib().wsovod_data_aware_backward(ptr(ddaf.contiguous()), N, ptr(gap), Cc, ptr(W2), ptr(E), F, ptr(h1), Hd,
-                                           ptr(h2), P, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(dE), stream()),
+                                           ptr(h2), P, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(dE), ptr(scratch), stream()),
           "data_aware_backward")
     return dW1, db1, dW2, db2, dE
