@@ -90,7 +90,9 @@ def test_bf16_step_close_to_fp32_reference(gpu):
         if p.requires_grad:
             assert torch.isfinite(p.grad).all(), k
             ref = g["gradnorm/" + k]
-            assert abs(float(p.grad.float().norm()) - float(ref)) <= 0.15 * float(ref) + 1e-6, k
+            # det.bias has a mathematically zero gradient (softmax over proposals ignores a per-class shift):
+            # both sides are rounding noise there, hence the absolute term
+            assert abs(float(p.grad.float().norm()) - float(ref)) <= 0.15 * float(ref) + 1e-4, k
 
 
 @pytest.mark.parametrize("pooler", ["ROIPool", "ROIAlignV2"])
