@@ -11,7 +11,7 @@ def _ref_mm(A, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 128128, 128064, 64128, 64064])
+@pytest.mark.parametrize("tile", [0, 128128, 128064, 64128, 64064, 256256, 256128, 1128128])
 @pytest.mark.parametrize("shape", [(512, 4096, 1024), (100, 40, 256), (333, 129, 192), (64, 4, 4096)])
 def test_gemm_nt_plain(gpu, dtype, tile, shape):
     from wsovod_amd.layers import hip_ops
@@ -84,7 +84,8 @@ def test_gemm_dropout_statistics(gpu):
     dict(Cin=64, Cout=128, H=19, W=25, k=1, stride=1, pad=0, dil=1),
     dict(Cin=64, Cout=96, H=20, W=26, k=3, stride=2, pad=1, dil=1),
 ])
-def test_conv_implicit_gemm(gpu, dtype, cfg):
+@pytest.mark.parametrize("tile", [0, 256256, 256128, 1128128])
+def test_conv_implicit_gemm(gpu, dtype, cfg, tile):
     from wsovod_amd.layers import hip_ops
 
     torch.manual_seed(2)
@@ -98,7 +99,7 @@ def test_conv_implicit_gemm(gpu, dtype, cfg):
     w_k = w.permute(0, 2, 3, 1).reshape(cfg["Cout"], -1).contiguous().to(gpu)
     geom = dict(n_img=n, H=cfg["H"], W=cfg["W"], Cin=cfg["Cin"], Ho=Ho, Wo=Wo, KH=cfg["k"], KW=cfg["k"],
                 stride=cfg["stride"], pad=cfg["pad"], dil=cfg["dil"])
-    out = hip_ops.gemm_nt(x_nhwc, w_k, conv=geom, bias=bias.to(gpu), relu=True, out_dtype=torch.float32)
+    out = hip_ops.gemm_nt(x_nhwc, w_k, conv=geom, bias=bias.to(gpu), relu=True, out_dtype=torch.float32, tile_hint=tile)
     out = out.view(n, Ho, Wo, cfg["Cout"]).permute(0, 3, 1, 2).cpu()
     torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-3)
 

@@ -36,7 +36,7 @@ def main():
             A = torch.randn(M, K, device=dev).to(dt)
             B = torch.randn(N, K, device=dev).to(dt)
             out = torch.empty(M, N, device=dev, dtype=torch.float32)
-            for tile in (128128, 64064):
+            for tile in (128128, 1128128, 256128, 256256):
                 ms = timeit(lambda: hip_ops.gemm_nt(A, B, out=out, tile_hint=tile), iters=iters)
                 print(f"gemm {str(dt)[6:]:9s} {name:12s} tile {tile:6d}  {ms:8.3f} ms  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s")
             del A, B, out
@@ -48,10 +48,11 @@ def main():
             w = torch.randn(Cout, 9 * Cin, device=dev).to(dt)
             geom = dict(n_img=n, H=H, W=W, Cin=Cin, Ho=H, Wo=W, KH=3, KW=3, stride=1, pad=dil, dil=dil)
             out = torch.empty(n * H * W, Cout, device=dev, dtype=dt)
-            ms = timeit(lambda: hip_ops.gemm_nt(x, w, conv=geom, out=out, relu=True), iters=5)
             fl = 2.0 * n * H * W * Cout * 9 * Cin
-            print(f"conv {str(dt)[6:]:9s} {nm:10s} {ms:8.3f} ms  {fl/ms/1e9:8.1f} TFLOP/s")
-    # roi pool
+            for tile in (0, 1128128, 256128, 256256):
+                ms = timeit(lambda: hip_ops.gemm_nt(x, w, conv=geom, out=out, relu=True, tile_hint=tile), iters=5)
+                print(f"conv {str(dt)[6:]:9s} {nm:10s} tile {tile:7d} {ms:8.3f} ms  {fl/ms/1e9:8.1f} TFLOP/s")
+    return
     from tests.util import random_rois
     for n, R in [(1, 512), (8, 4096)]:
         feat = torch.randn(n, 75, 100, 512, device=dev).permute(0, 3, 1, 2)

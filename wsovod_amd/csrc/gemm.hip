@@ -93,14 +93,17 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-template <typename T, int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p) {
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BKE = Traits<T>::BKE;
-  constexpr int TM = BM / 32;  // 16x16 tiles per wavefront along M
-  constexpr int TN = BN / 32;
-  constexpr int RA = BM / 32;  // 16-B chunks each thread stages per K-step (A)
-  constexpr int RB = BN / 32;
+  constexpr int NT = 64 * WM * WN;       // threads: WM x WN wavefronts
+  constexpr int TM = BM / (WM * 16);     // 16x16 tiles per wavefront along M
+  constexpr int TN = BN / (WN * 16);
+  constexpr int LR = NT / 8;             // rows staged per loader pass (8 x 16-B chunks per row)
+  constexpr int RA = BM / LR;            // 16-B chunks each thread stages per K-step (A)
+  constexpr int RB = BN / LR;
+  static_assert(BM % LR == 0 && BN % LR == 0, "tile rows must be a multiple of the loader pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
   char* sB = smem + 2 * BM * 128;
@@ -119,8 +122,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lrow = tid >> 3, lchunk = tid & 7;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lrow = tid >> 3;
+  // DMA staging writes LDS linearly (wave base + lane*16 B), so the XOR swizzle moves to the SOURCE:
+  // the lane that lands in slot (tid&7) of its row fetches logical chunk slot ^ ((row>>1)&7).
+  // (LR is a multiple of 16, so the swizzle term is the same for every loader pass.)
+  const int lchunk = DMA ? ((tid & 7) ^ ((lrow >> 1) & 7)) : (tid & 7);
 
   // ---- per-thread loader state.  All global reads are raw buffer loads: a lane whose row
   // or K-chunk is out of range gets voffset = -1, which the hardware range check turns into
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int m = m0 + lrow + 32 * i;
+    const int m = m0 + lrow + LR * i;
     const bool ok = m < p.M;
     if (CONV) {
       const int hw = p.Ho * p.Wo;
@@ -158,14 +165,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
       a_off[i] = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
     } else {
       hi0[i] = wi0[i] = 0;
-      a_off[i] = ok ? (int)(((long long)(lrow + 32 * i) * p.lda + lchunk * EPC) * esz) : -1;
+      a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
     }
   }
   int b_off[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int n = n0 + lrow + 32 * i;
-    b_off[i] = n < p.N ? (int)(((long long)(lrow + 32 * i) * p.ldb + lchunk * EPC) * esz) : -1;
+    const int n = n0 + lrow + LR * i;
+    b_off[i] = n < p.N ? (int)(((long long)(lrow + LR * i) * p.ldb + lchunk * EPC) * esz) : -1;
   }
 
   const int nk = (p.K + BKE - 1) / BKE;
@@ -200,9 +207,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     char* dA = sA + buf * BM * 128;
     char* dB = sB + buf * BN * 128;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *(u32x4*)(dA + lds_off(lrow + 32 * i, lchunk)) = ra[i];
+    for (int i = 0; i < RA; ++i) *(u32x4*)(dA + lds_off(lrow + LR * i, lchunk)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *(u32x4*)(dB + lds_off(lrow + 32 * i, lchunk)) = rb[i];
+    for (int i = 0; i < RB; ++i) *(u32x4*)(dB + lds_off(lrow + LR * i, lchunk)) = rb[i];
+  };
+
+  // LDS-direct staging (buffer_load ... lds): no staging VGPRs, no ds_write pass.  Each wave
+  // instruction lands 8 rows x 128 B contiguously at a wave-uniform LDS base.
+  typedef __attribute__((address_space(3))) void lds_void;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_dma = [&](int kt, int buf) {
+    const int kbase = kt * BKE;
+    const bool k_ok = kbase + lchunk * EPC < p.K;
+    char* dA = sA + buf * BM * 128 + wave_u * 1024;
+    char* dB = sB + buf * BN * 128 + wave_u * 1024;
+    if (CONV) {
+      const int cpt = p.Cin / BKE;
+      const int tap = kt / cpt;
+      const int c0 = (kt - tap * cpt) * BKE;
+      const int r = tap / p.KW;
+      const int q = tap - r * p.KW;
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int hi = hi0[i] + r * p.dil;
+        const int wi = wi0[i] + q * p.dil;
+        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + c0) * esz;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dA + LR * i * 128), 16, ok ? off : -1, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dA + LR * i * 128), 16,
+                                                 (k_ok && a_off[i] >= 0) ? a_off[i] + kbase * esz : -1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(dB + LR * i * 128), 16,
+                                               (k_ok && b_off[i] >= 0) ? b_off[i] + kbase * esz : -1, 0, 0, 0);
   };
 
   f32x4 acc[TM][TN];
@@ -213,15 +255,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
 
   const int frow = lane & 15, fq = lane >> 4;
   auto compute = [&](int cur) {
-    const char* cA = sA + cur * BM * 128 + (wm * (BM / 2)) * 128;
-    const char* cB = sB + cur * BN * 128 + (wn * (BN / 2)) * 128;
+    const char* cA = sA + cur * BM * 128 + (wm * (BM / WM)) * 128;
+    const char* cB = sB + cur * BN * 128 + (wn * (BN / WN)) * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = fq + 4 * ks;
       uint4 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int row = i * 16 + frow;  // wm*(BM/2) is a multiple of 16: the swizzle term is unchanged
+        const int row = i * 16 + frow;  // the wavefront's row base is a multiple of 16: swizzle term unchanged
         af[i] = *(const uint4*)(cA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
@@ -249,6 +291,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     }
   };
 
+  if constexpr (DMA) {
+    // ---- LDS-direct pipeline: next K-step's DMA is issued before the MFMAs of the current one;
+    // the barrier (with the vmcnt(0) hipcc puts in front of it) retires it.  One barrier per K-step.
+    stage_dma(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      if (kt + 1 < nk) stage_dma(kt + 1, cur ^ 1);
+      compute(cur);
+      __syncthreads();
+    }
+  } else {
   // ---- software pipeline: two K-steps of global loads in flight (register sets 0/1),
   // LDS double buffered, one barrier per K-step.
   u32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
@@ -269,6 +323,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
     if (kt + 2 < nk) store_lds(0, ra0, rb0);
     __syncthreads();
   }
+  }
 
   // ---- epilogue (fp32): D[row=(lane>>4)*4+reg][col=lane&15]
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
@@ -276,8 +331,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + frow;
-      const int mb = m0 + wm * (BM / 2) + i * 16 + fq * 4;
+      const int n = n0 + wn * (BN / WN) + j * 16 + frow;
+      const int mb = m0 + wm * (BM / WM) + i * 16 + fq * 4;
       if (n >= p.N) continue;
       const float bias = p.bias ? p.bias[n] : 0.f;
       float v[4];
@@ -313,12 +368,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs p) {
   }
 }
 
-template <typename T, int BM, int BN, bool CONV>
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false>
 int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
   static int slot = wsovod::prof_slot(slot_name);
   static bool attr_set = false;
   constexpr int lds_bytes = 2 * (BM + BN) * 128;
-  auto kfn = gemm_nt_kernel<T, BM, BN, CONV>;
+  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
@@ -327,7 +382,7 @@ int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops
   args.tiles_m = ceil_div(a.M, BM);
   args.tiles_n = ceil_div(a.N, BN);
   wsovod::ProfScope prof(slot, s, flops, bytes);
-  hipLaunchKernelGGL(kfn, dim3(args.tiles_m * args.tiles_n), dim3(256), lds_bytes, s, args);
+  hipLaunchKernelGGL(kfn, dim3(args.tiles_m * args.tiles_n), dim3(64 * WM * WN), lds_bytes, s, args);
   WS_CHECK_LAUNCH(slot_name);
   return WSOVOD_OK;
 }
@@ -336,6 +391,18 @@ template <typename T, bool CONV>
 int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, double bytes) {
   constexpr bool bf = sizeof(T) == 2;
   switch (tile) {
+    case 256256:  // 16 wavefronts (4x4), 128 KiB LDS, one workgroup per CU: 128 FLOP per staged byte
+      return launch<T, 256, 256, CONV, 4, 4, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x256" : "conv_igemm_f32_256x256")
+                                                       : (bf ? "gemm_nt_bf16_256x256" : "gemm_nt_f32_256x256"),
+                                             flops, bytes);
+    case 256128:
+      return launch<T, 256, 128, CONV, 4, 2, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x128" : "conv_igemm_f32_256x128")
+                                                       : (bf ? "gemm_nt_bf16_256x128" : "gemm_nt_f32_256x128"),
+                                             flops, bytes);
+    case 1128128:  // 128x128 with LDS-direct staging (A/B comparison against the register-staged form)
+      return launch<T, 128, 128, CONV, 2, 2, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x128_dma" : "conv_igemm_f32_128x128_dma")
+                                                             : (bf ? "gemm_nt_bf16_128x128_dma" : "gemm_nt_f32_128x128_dma"),
+                                                   flops, bytes);
     case 128128:
       return launch<T, 128, 128, CONV>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x128" : "conv_igemm_f32_128x128")
                                                  : (bf ? "gemm_nt_bf16_128x128" : "gemm_nt_f32_128x128"),
