@@ -21,7 +21,7 @@
 // share the B (weight) slab in their private L2.
 #include "common.h"
 
-namespace {
+namespace wsovod_gemm {
 
 struct GemmArgs {
   const char* A;
@@ -214,9 +214,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 
   // LDS-direct staging (buffer_load ... lds): no staging VGPRs, no ds_write pass.  Each wave
   // instruction lands 8 rows x 128 B contiguously at a wave-uniform LDS base.
-  typedef __attribute__((address_space(3))) void lds_void;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto stage_dma = [&](int kt, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)  // LDS address-space pointers / LDS-DMA builtins exist in the device pass only
     const int kbase = kt * BKE;
     const bool k_ok = kbase + lchunk * EPC < p.K;
     char* dA = sA + buf * BM * 128 + wave_u * 1024;
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     for (int i = 0; i < RB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(dB + LR * i * 128), 16,
                                                (k_ok && b_off[i] >= 0) ? b_off[i] + kbase * esz : -1, 0, 0, 0);
+#endif
   };
 
   f32x4 acc[TM][TN];
@@ -443,7 +445,8 @@ int auto_tile(int M, int N) {
   return 64064;
 }
 
-}  // namespace
+}  // namespace wsovod_gemm
+using namespace wsovod_gemm;
 
 extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream) {
   WS_CHECK_ARG(d != nullptr, "wsovod_gemm_nt: null descriptor");
