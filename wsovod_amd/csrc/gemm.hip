@@ -401,6 +401,14 @@ int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, doub
       return launch<T, 256, 128, CONV, 4, 2, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x128" : "conv_igemm_f32_256x128")
                                                        : (bf ? "gemm_nt_bf16_256x128" : "gemm_nt_f32_256x128"),
                                              flops, bytes);
+    case 1256064:  // few output columns (stem / res2 convs, Cout = 64): tall LDS-direct tile
+      return launch<T, 256, 64, CONV, 4, 1, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x64_dma" : "conv_igemm_f32_256x64_dma")
+                                                            : (bf ? "gemm_nt_bf16_256x64_dma" : "gemm_nt_f32_256x64_dma"),
+                                                  flops, bytes);
+    case 1128064:
+      return launch<T, 128, 64, CONV, 2, 2, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x64_dma" : "conv_igemm_f32_128x64_dma")
+                                                            : (bf ? "gemm_nt_bf16_128x64_dma" : "gemm_nt_f32_128x64_dma"),
+                                                  flops, bytes);
     case 1128128:  // 128x128 with LDS-direct staging (A/B comparison against the register-staged form)
       return launch<T, 128, 128, CONV, 2, 2, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x128_dma" : "conv_igemm_f32_128x128_dma")
                                                              : (bf ? "gemm_nt_bf16_128x128_dma" : "gemm_nt_f32_128x128_dma"),
@@ -427,21 +435,20 @@ int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, doub
   }
 }
 
-// Pick the largest tile that still gives the 256 CUs >= ~2 workgroups each; fall back to
-// the smallest tile (most workgroups) for small problems.
+// Tile choice (measured on MI355X, tools/probe_kernels.py): the 256x256 LDS-direct tile moves 128 FLOP
+// per staged byte and wins whenever it still yields about one workgroup per CU; smaller problems
+// step down to tiles that keep the 256 CUs busy.
 int auto_tile(int M, int N) {
-  const int cands[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-  for (int c = 0; c < 4; ++c) {
-    const int bm = cands[c][0], bn = cands[c][1];
-    if (N <= 64 && bn == 128) continue;
-    if (M <= 64 && bm == 128) continue;
-    const long long tiles = (long long)ceil_div(M, bm) * ceil_div(N, bn);
-    if (tiles >= 512) return bm * 1000 + bn;
+  auto tiles = [&](int bm, int bn) { return (long long)ceil_div(M, bm) * ceil_div(N, bn); };
+  if (N <= 64) {
+    if (tiles(256, 64) >= 230) return 1256064;
+    if (tiles(128, 64) >= 230) return 1128064;
+    return 64064;
   }
-  if (N <= 64 && M > 64) {
-    // few columns: keep rows big only if that still fills the chip
-    return (long long)ceil_div(M, 128) >= 256 ? 128064 : 64064;
-  }
+  if (M > 128 && N > 128 && tiles(256, 256) >= 230) return 256256;
+  if (M > 128 && tiles(256, 128) >= 230) return 256128;
+  if (tiles(128, 128) >= 230) return 1128128;
+  if (N <= 128 && tiles(128, 64) >= 230) return 1128064;
   return 64064;
 }
 
