@@ -117,14 +117,20 @@ def main():
 
     from wsovod_amd import _lib
     from wsovod_amd.data import make_batch
-    from wsovod_amd.engine import build_optimizer, run_step, wrap_model_with_ddp
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
     from wsovod_amd.testing import build_hot_path_model
 
     cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim,
                                       precision=args.precision, pooler=args.pooler, device=f"cuda:{local_rank}")
     model.train()
     optimizer = build_optimizer(cfg, model)
-    ddp = wrap_model_with_ddp(model, local_rank)
+    trainer = HotPathTrainer(model, optimizer)  # per-tensor async all-reduce overlapped with the frozen forward
+    trainer.broadcast_parameters()
+
+    def run_step(_m, _o, data):
+        return trainer.run_step(data)
+
+    ddp = model
     cpu_state = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # snapshot of the untrained weights for the CPU leg
         cpu_state = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}

@@ -17,9 +17,41 @@ class _LossDictModel(nn.Module):
         self.fc = nn.Linear(8, 4)
 
     def forward(self, batch):
+        if hasattr(self, "forward_frozen"):
+            return self.forward_trainable(self.forward_frozen(batch))
         x = torch.stack([b["x"] for b in batch])
         y = self.fc(x)
         return {"loss_a": y.pow(2).mean(), "loss_b": y.abs().mean() * 0.5}
+
+
+class _TwoPhaseModel(_LossDictModel):
+    """Stand-in with the hot path's forward_frozen / forward_trainable split."""
+
+    def forward_frozen(self, batch):
+        return {"x": torch.stack([b["x"] for b in batch]) * 2.0}  # parameter-free work
+
+    def forward_trainable(self, st):
+        y = self.fc(st["x"])
+        return {"loss_a": y.pow(2).mean(), "loss_b": y.abs().mean() * 0.5}
+
+
+def _worker_overlap(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import HotPathTrainer
+
+    model = _TwoPhaseModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True)
+    tr.broadcast_parameters()
+    g = torch.Generator().manual_seed(1234 + rank)
+    batch = [{"x": torch.randn(8, generator=g)} for _ in range(3)]
+    for it in range(3):
+        tr.run_step(batch)
+    tr.flush()
+    q.put((rank, model.fc.weight.detach().tolist(), [b["x"].tolist() for b in batch]))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, q):
@@ -56,6 +88,32 @@ def test_two_rank_data_parallel_step_matches_single_process_average():
     assert res[0][2][0] != res[1][2][0]  # each rank trained on its own shard
     # single-process reference: gradient = mean over ranks of the per-rank mean loss gradients
     model = _LossDictModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    for it in range(3):
+        opt.zero_grad()
+        total = 0
+        for r in range(2):
+            total = total + sum(model([{"x": torch.tensor(x)} for x in res[r][2]]).values()) / 2
+        total.backward()
+        opt.step()
+    torch.testing.assert_close(model.fc.weight.detach(), w0, rtol=1e-5, atol=1e-6)
+
+
+def test_overlapped_trainer_matches_plain_data_parallel():
+    """HotPathTrainer (async per-tensor all-reduce finished after the next frozen forward) == averaged SGD."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w0, w1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(w0, w1)
+    model = _TwoPhaseModel()
     opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
     for it in range(3):
         opt.zero_grad()

@@ -149,3 +149,27 @@ def test_product_path_fails_loudly_without_gpu_tensors(gpu):
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         hip_ops.gemm_nt(torch.randn(8, 8), torch.randn(8, 8))
+
+
+def test_overlapped_trainer_equals_plain_run_step(gpu):
+    """HotPathTrainer's deferred-update schedule gives the same parameters as run_step (single GPU)."""
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer, run_step
+
+    batch = to_inputs(gen.seeded_batch(2, 32, 20, 256, 352, seed=6))
+    outs = []
+    for mode in ("plain", "overlap"):
+        cfg, model, sd = build_seeded_hip_model("fp32")
+        cfg.SOLVER.BASE_LR = 1e-4
+        opt = build_optimizer(cfg, model)
+        if mode == "plain":
+            for it in range(3):
+                run_step(model, opt, batch, it=it)
+        else:
+            tr = HotPathTrainer(model, opt)
+            for it in range(3):
+                tr.run_step(batch)
+            tr.flush()
+        torch.cuda.synchronize()
+        outs.append({k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
+    for k in outs[0]:
+        torch.testing.assert_close(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")

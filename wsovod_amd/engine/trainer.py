@@ -17,6 +17,7 @@ class HipSGD(torch.optim.Optimizer):
 
     def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.grad_scale = 1.0  # 1/world_size when gradients arrive as a SUM over ranks
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -30,7 +31,7 @@ class HipSGD(torch.optim.Optimizer):
                     state["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 H.sgd_momentum(p.data, g, state["momentum_buffer"], group["lr"], group["momentum"],
-                               group["weight_decay"])
+                               group["weight_decay"], grad_scale=self.grad_scale)
 
 
 def build_optimizer(cfg, model):
@@ -72,3 +73,68 @@ def run_step(model, optimizer, data, iter_size=1, it=0):
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return loss_dict
+
+
+class HotPathTrainer:
+    """Data-parallel training loop of the hot path with the gradient exchange hidden behind compute.
+
+    Same arithmetic as `run_step` + DistributedDataParallel (gradients averaged over ranks, then the
+    SGD update; reference: engine/trainer.py:37-84, engine/defaults.py:143-148), different schedule:
+
+        step t:  frozen forward(t)  ||  all-reduce of step t-1's gradients (RCCL, its own stream)
+                 wait -> SGD update(t-1) (grad_scale = 1/world)  -> heads forward/backward(t)
+                 -> launch all-reduce(t) asynchronously
+
+    The frozen part (backbone, GAP, RoI pooling) reads no trainable parameter, so running it before the
+    previous update lands changes nothing numerically; the update still precedes every use of the weights.
+    Gradients are exchanged tensor-by-tensor (`all_reduce(async_op=True)`), so there is no bucket copy and
+    `fc1.weight`'s 411 MB -- produced last in backward -- overlaps the next step's backbone instead of
+    stalling the step.  Call `flush()` after the last step.
+    """
+
+    def __init__(self, model, optimizer, overlap=True):
+        self.model = model
+        self.optimizer = optimizer
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.overlap = overlap
+        self._pending = None  # list of (work, param) of the in-flight exchange
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        if isinstance(optimizer, HipSGD):
+            optimizer.grad_scale = 1.0 / self.world
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                dist.broadcast(t.data, src)
+
+    def _finish_pending(self):
+        if self._pending is None:
+            return
+        for work in self._pending:
+            if work is not None:
+                work.wait()
+        if self.world > 1 and not isinstance(self.optimizer, HipSGD):
+            for p in self.params:
+                if p.grad is not None:
+                    p.grad.div_(self.world)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        self._pending = None
+
+    def run_step(self, data):
+        st = self.model.forward_frozen(data)
+        self._finish_pending()
+        loss_dict = self.model.forward_trainable(st)
+        sum(loss_dict.values()).backward()
+        works = []
+        if self.world > 1:
+            for p in self.params:
+                if p.grad is not None:
+                    works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        self._pending = works
+        if not self.overlap:
+            self._finish_pending()
+        return loss_dict
+
+    def flush(self):
+        self._finish_pending()

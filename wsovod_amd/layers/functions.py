@@ -50,7 +50,7 @@ class _Linear(Function):
             xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
             dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
         if need_db:
-            seg = torch.tensor([0, M], dtype=torch.int32, device=x.device)
+            seg = H.const_tensor((0, M), torch.int32, x.device)
             db = H.segment_colsum(dA[:, :N] if Np != N else dA, seg).view(N)
         if need_dx:
             wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
@@ -138,7 +138,7 @@ class _CosineLogits(Function):
             dz = H.cast(dz, cd)
         db = None
         if has_bias and ctx.needs_input_grad[5]:
-            seg = torch.tensor([0, M], dtype=torch.int32, device=z.device)
+            seg = H.const_tensor((0, M), torch.int32, z.device)
             db = H.segment_colsum(dl, seg).view(K1)
         return dz, None, None, None, None, db
 

@@ -11,6 +11,22 @@ from .. import _lib
 from .._lib import BF16, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
 
 
+_CONST_CACHE = {}
+
+
+def const_tensor(values, dtype, device):
+    """Small constant index tensors (segment offsets, sizes, row->image maps) keyed by value: built and
+    copied to the device once, so steady-state steps issue no tiny blocking H2D copies."""
+    key = (tuple(values), dtype, str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 4096:
+            _CONST_CACHE.clear()
+        t = torch.tensor(list(values), dtype=dtype, device=device)
+        _CONST_CACHE[key] = t
+    return t
+
+
 def feature_layout(feat):
     """(layout code, N, C, H, W) of a logical-NCHW feature tensor; NHWC == torch.channels_last."""
     if feat.dim() != 4:

@@ -130,18 +130,24 @@ class DataAwareFeaturesHead(nn.Module):
                 "features_dim": cfg.MODEL.ROI_BOX_HEAD.DAN_DIM[-1], "mrrp_on": cfg.MODEL.MRRP.MRRP_ON,
                 "mrrp_num_branch": cfg.MODEL.MRRP.NUM_BRANCH}
 
-    def forward_per_image(self, features):
-        feats = [features[f] for f in self.cls_in_features]
-        outs = []
-        for f in feats:
+    def pooled_stats(self, features):
+        """Parameter-free part: GAP of every input feature map -> list of (N,C) fp32."""
+        gaps = []
+        for f in [features[k] for k in self.cls_in_features]:
             if f.is_contiguous(memory_format=torch.channels_last):
                 nhwc = f.permute(0, 2, 3, 1)
             else:
                 nhwc = f.permute(0, 2, 3, 1).contiguous()
-            gap = H.global_avgpool_nhwc(nhwc)
-            outs.append(Fn.data_aware_features(gap, self.linear1.weight, self.linear1.bias, self.linear2.weight,
-                                               self.linear2.bias, self.datasets_feat.weight))
+            gaps.append(H.global_avgpool_nhwc(nhwc))
+        return gaps
+
+    def from_stats(self, gaps):
+        outs = [Fn.data_aware_features(g, self.linear1.weight, self.linear1.bias, self.linear2.weight,
+                                       self.linear2.bias, self.datasets_feat.weight) for g in gaps]
         return outs[0] if len(outs) == 1 else torch.stack(outs).mean(0)
+
+    def forward_per_image(self, features):
+        return self.from_stats(self.pooled_stats(features))
 
     def forward(self, features, proposals):
         """Reference signature: one feature row per proposal (repeat materialised)."""

@@ -24,10 +24,12 @@ __all__ = ["fast_rcnn_inference", "ObjectMiningOutputLayers", "InstanceRefinemen
 
 def segment_offsets(nums, device):
     """int32 (G+1) prefix offsets of the per-image proposal counts (host ints -> one tiny H2D copy)."""
+    from ..layers.hip_ops import const_tensor
+
     offs = [0]
     for n in nums:
         offs.append(offs[-1] + int(n))
-    return torch.tensor(offs, dtype=torch.int32, device=device)
+    return const_tensor(offs, torch.int32, device)
 
 
 def _nms(boxes, scores, thr):

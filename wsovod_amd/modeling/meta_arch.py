@@ -102,7 +102,7 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
                 canvas[i, :, : sizes[i][0], : sizes[i][1]].copy_(im, non_blocking=True)
         if canvas.dtype != torch.uint8:
             raise RuntimeError("GeneralizedRCNN_WSOVOD expects uint8 CHW images (DatasetMapper format)")
-        sizes_t = torch.tensor(sizes, dtype=torch.int32, device=self.device)
+        sizes_t = H.const_tensor([v for s in sizes for v in s], torch.int32, self.device).view(-1, 2)
         return canvas.contiguous(), sizes_t, sizes
 
     def preprocess_image(self, batched_inputs):
@@ -135,16 +135,33 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
     def forward(self, batched_inputs, classifier=None):
         if not self.training:
             return self.inference(batched_inputs, classifier=classifier)
+        return self.forward_trainable(self.forward_frozen(batched_inputs))
+
+    @torch.no_grad()
+    def forward_frozen(self, batched_inputs):
+        """Everything of the training forward that touches NO trainable parameter: input staging, the
+        frozen backbone, GAP for the data-aware head, RoI pooling with the objectness scale.  Because it
+        does not depend on the weights being updated, a data-parallel trainer may run it while the previous
+        step's gradient all-reduce is still in flight (wsovod_amd/engine/trainer.py)."""
         canvas, sizes_t, sizes = self._canvas(batched_inputs)
-        gt_instances = None
+        st = {"canvas": canvas, "sizes": sizes, "gt_instances": None, "image_level_gt": None}
         if "instances" in batched_inputs[0]:
-            self.roi_heads.image_level_gt = self._image_level_gt(batched_inputs)
-            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            st["image_level_gt"] = self._image_level_gt(batched_inputs)
+            st["gt_instances"] = [x["instances"].to(self.device) for x in batched_inputs]
         features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
-        proposals = self._proposals(batched_inputs)
-        daf = self.data_aware_head.forward_per_image(features) if self.data_aware_head is not None else None
-        _, detector_losses = self.roi_heads(ImageList(canvas, sizes), features, proposals, daf, gt_instances,
-                                            append_background=True, loaded_proposals=proposals)
+        st["features"] = features
+        st["proposals"] = self._proposals(batched_inputs)
+        st["gaps"] = self.data_aware_head.pooled_stats(features) if self.data_aware_head is not None else None
+        st["pooled"] = self.roi_heads.pool_features(features, st["proposals"])
+        return st
+
+    def forward_trainable(self, st):
+        """The trainable remainder: data-aware MLP, neck, object mining, refinement, losses."""
+        self.roi_heads.image_level_gt = st["image_level_gt"]
+        daf = self.data_aware_head.from_stats(st["gaps"]) if self.data_aware_head is not None else None
+        _, detector_losses = self.roi_heads(ImageList(st["canvas"], st["sizes"]), st["features"], st["proposals"],
+                                            daf, st["gt_instances"], append_background=True,
+                                            loaded_proposals=st["proposals"], pooled=st["pooled"])
         losses = {}
         losses.update(detector_losses)
         return losses

@@ -180,7 +180,7 @@ class WSOVODROIHeads(ROIHeads):
     # ------------------------------------------------------------------------------
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances],
                 data_aware_features=None, targets: Optional[List[Instances]] = None, classifier=None,
-                append_background=True, file_names=None, loaded_proposals=None):
+                append_background=True, file_names=None, loaded_proposals=None, pooled=None):
         if self.training:
             assert targets, "'targets' argument is required during training"
             if self.image_level_gt is not None:
@@ -197,7 +197,8 @@ class WSOVODROIHeads(ROIHeads):
         del targets
         self.images = images
         if self.training:
-            losses = self._forward_box(features, proposals, data_aware_features, classifier, append_background)
+            losses = self._forward_box(features, proposals, data_aware_features, classifier, append_background,
+                                       pooled=pooled)
             self.iter = self.iter + 1
             if self.iter_test > 0:
                 self.epoch_test = self.epoch_test + 1
@@ -208,30 +209,33 @@ class WSOVODROIHeads(ROIHeads):
         self.iter_test = self.iter_test + 1
         return pred_instances, {}, all_scores, all_boxes
 
-    def get_features(self, features, proposals, data_aware_features=None):
-        """roi_heads.py:1827-1857: pooled -> objectness scale -> neck -> (+ data-aware features)."""
+    def pool_features(self, features, proposals):
+        """Parameter-free part of the box branch: RoI pooling with the fused `* (objectness + 1)` scale
+        (roi_heads.py:727-739)."""
         feats = [features[f] for f in self.box_in_features]
-        cd = self.compute_dtype
         roi_scale = torch.cat([x.objectness_logits + 1 for x in proposals], dim=0).to(torch.float32)
-        box_features = self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
-                                       out_dtype=cd)
+        return self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
+                               out_dtype=self.compute_dtype)
+
+    def get_features(self, features, proposals, data_aware_features=None, pooled=None):
+        """roi_heads.py:1827-1857: pooled -> objectness scale -> neck -> (+ data-aware features)."""
+        box_features = pooled if pooled is not None else self.pool_features(features, proposals)
         box_features = self.box_head(box_features)
         if data_aware_features is not None:
             nums = [len(p) for p in proposals]
             dev = box_features.device
             if data_aware_features.size(0) == len(proposals) and data_aware_features.size(0) != sum(nums):
                 seg = segment_offsets(nums, dev)  # per-image rows, broadcast in-kernel
-                row_group = torch.repeat_interleave(
-                    torch.arange(len(nums), dtype=torch.int32, device=dev),
-                    torch.tensor(nums, device=dev), output_size=sum(nums))
+                row_group = H.const_tensor([i for i, n in enumerate(nums) for _ in range(n)], torch.int32, dev)
             else:  # reference form: one row per proposal
                 seg = torch.arange(sum(nums) + 1, dtype=torch.int32, device=dev)
                 row_group = torch.arange(sum(nums), dtype=torch.int32, device=dev)
             box_features = Fn.add_group_rows(box_features, data_aware_features.to(torch.float32), row_group, seg)
         return box_features
 
-    def _forward_box(self, features, proposals, data_aware_features=None, classifier=None, append_background=True):
-        box_features = self.get_features(features, proposals, data_aware_features)
+    def _forward_box(self, features, proposals, data_aware_features=None, classifier=None, append_background=True,
+                     pooled=None):
+        box_features = self.get_features(features, proposals, data_aware_features, pooled=pooled)
         predictions = self.object_miner(box_features, proposals)
         if not self.training:
             if self.refine_K <= 0:
