@@ -198,10 +198,12 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
                                                              int M, int N, float scale, float* __restrict__ out,
                                                              long long ldo) {
   constexpr int RC = 256;
+  constexpr int V = 16 / sizeof(T);  // columns per lane: one 16-B load per row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + lane;
+  const int n0 = (blockIdx.x * 64 + lane) * V;
   const int r0 = blockIdx.y * RC, r1 = min(r0 + RC, M);
-  if (n >= N) return;
+  if (n0 >= N) return;
+  const bool vec = (n0 + V <= N) && ((ld * sizeof(T)) % 16 == 0) && (((uintptr_t)x & 15) == 0);
   int g = 0;
   if (!seg) {
     g = (r0 + wave) / uniform_rows;
@@ -214,20 +216,38 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
     }
     g = lo;
   }
-  float acc = 0.f;
+  float acc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  auto flush = [&](int gg) {
+#pragma unroll
+    for (int j = 0; j < V; ++j)
+      if (n0 + j < N && acc[j] != 0.f) atomicAdd(out + (long long)gg * ldo + n0 + j, acc[j] * scale);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  };
   for (int m = r0 + wave; m < r1; m += 4) {
     int gm = g;
     if (!seg) gm = m / uniform_rows;
     else while (gm + 1 < G && m >= seg[gm + 1]) ++gm;
     if (gm != g) {
-      if (acc != 0.f) atomicAdd(out + (long long)g * ldo + n, acc * scale);
-      acc = 0.f;
+      flush(g);
       g = gm;
     }
     if (seg && (m < seg[g] || m >= seg[g + 1])) continue;  // rows outside every segment
-    acc += to_f32(x[(long long)m * ld + n]);
+    const T* row = x + (long long)m * ld + n0;
+    if (vec) {
+      const uint4 raw = *(const uint4*)row;
+      const T* e = (const T*)&raw;
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc[j] += to_f32(e[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        if (n0 + j < N) acc[j] += to_f32(row[j]);
+    }
   }
-  if (acc != 0.f) atomicAdd(out + (long long)g * ldo + n, acc * scale);
+  flush(g);
 }
 
 // x *= num[0] / den[0]  (device scalars: upstream loss grad / normaliser; no host sync)
@@ -465,7 +485,7 @@ static int launch_colsum(const void* x, int dtype, long long ld, const int* seg,
     if (ldo == N) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * N, s);
     else (void)hipMemset2DAsync(out, ldo * sizeof(float), 0, N * sizeof(float), G, s);
   }
-  const dim3 grid(ceil_div(N, 64), ceil_div(M, 256));
+  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 256));
   if (dtype == WSOVOD_BF16)
     hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
   else

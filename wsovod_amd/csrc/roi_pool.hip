@@ -144,56 +144,67 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
                                        const float* __restrict__ roi_scale, int C, int H, int W, int PH,
                                        float spatial_scale, void* out, int out_dtype, int* __restrict__ argmax,
                                        int cgroups) {
+  // lane = 2 adjacent channels (one 4-B bf16x2 / 8-B float2 load), workgroup = 128 channels of one roi
+  typedef T vec2 __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int nbins = PH * PWT;
   float* sval = (float*)smem;
-  int* sarg = (int*)(sval + 64 * nbins);
+  int* sarg = (int*)(sval + 128 * nbins);
   const int r = blockIdx.x / cgroups;
-  const int c0 = (blockIdx.x - r * cgroups) * 64;
-  const int c = c0 + lane;
+  const int c0 = (blockIdx.x - r * cgroups) * 128;
+  const int c = c0 + lane * 2;
   const RoiBox b = decode_roi(rois + (long long)r * 5, spatial_scale, PH, PWT);
   const float scale = roi_scale ? roi_scale[r] : 1.0f;
   const T* base = feat + (long long)b.batch * H * W * C + (c < C ? c : 0);
   int hs, he, ws[PWT], we[PWT];
-  float maxv[PWT];
-  int maxi[PWT];
+  float maxv[PWT][2];
+  int maxi[PWT][2];
   int bw = 0;
 #pragma unroll
   for (int pw = 0; pw < PWT; ++pw) {
     bin_window(b, ph, pw, H, W, hs, he, ws[pw], we[pw]);
     const bool empty = (he <= hs) || (we[pw] <= ws[pw]);
-    maxv[pw] = empty ? 0.f : -FLT_MAX;
-    maxi[pw] = -1;
+    maxv[pw][0] = maxv[pw][1] = empty ? 0.f : -FLT_MAX;
+    maxi[pw][0] = maxi[pw][1] = -1;
     bw = max(bw, we[pw] - ws[pw]);
   }
   for (int h = hs; h < he; ++h) {
     const T* row = base + (long long)h * W * C;
     for (int j = 0; j < bw; ++j) {
-      float v[PWT];
+      vec2 v[PWT];
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
         const int w = min(ws[pw] + j, W - 1);  // clamped: lanes past the bin load a valid cell and ignore it
-        v[pw] = to_f32(row[(long long)w * C]);
+        v[pw] = *(const vec2*)(row + (long long)w * C);
       }
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
         const int w = ws[pw] + j;
-        if (w < we[pw] && v[pw] > maxv[pw]) {
-          maxv[pw] = v[pw];
-          maxi[pw] = h * W + w;
+        if (w < we[pw]) {
+          const float v0 = to_f32(v[pw][0]), v1 = to_f32(v[pw][1]);
+          if (v0 > maxv[pw][0]) {
+            maxv[pw][0] = v0;
+            maxi[pw][0] = h * W + w;
+          }
+          if (v1 > maxv[pw][1]) {
+            maxv[pw][1] = v1;
+            maxi[pw][1] = h * W + w;
+          }
         }
       }
     }
   }
 #pragma unroll
-  for (int pw = 0; pw < PWT; ++pw) {
-    sval[lane * nbins + ph * PWT + pw] = roi_scale ? maxv[pw] * scale : maxv[pw];
-    if (ARGMAX) sarg[lane * nbins + ph * PWT + pw] = maxi[pw];
-  }
+  for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      sval[(lane * 2 + q) * nbins + ph * PWT + pw] = roi_scale ? maxv[pw][q] * scale : maxv[pw][q];
+      if (ARGMAX) sarg[(lane * 2 + q) * nbins + ph * PWT + pw] = maxi[pw][q];
+    }
   __syncthreads();
   const int nthreads = blockDim.x, tid = threadIdx.x;
-  const int nvalid = min(64, C - c0) * nbins;
+  const int nvalid = min(128, C - c0) * nbins;
   const long long obase = ((long long)r * C + c0) * nbins;
   const bool vec = (nvalid & 3) == 0 && (obase & 3) == 0;
   if (out_dtype == WSOVOD_F32) {
@@ -494,7 +505,7 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     const int grid = (int)ceil_div_ll(items, 4);
     const int lds = 4 * 64 * ph * pw * 4 * (argmax ? 2 : 1);
     wsovod::ProfScope prof(slot, s, 0.0, bytes);
-    if (lds > 160 * 1024 && !(pw == 7 && ph <= 16)) {
+    if (lds > 160 * 1024 && !(pw == 7 && ph <= 16 && (C & 1) == 0)) {
       // pooled tile does not fit the per-wavefront LDS transpose: thread-per-bin fallback
       const long long total = (long long)R * C * ph * pw;
       const int g = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
@@ -514,10 +525,15 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)feat, rois, roi_scale, R, C, H, W, ph, pw,      \
                        spatial_scale, out, out_dtype, argmax, cgroups);                                           \
   } while (0)
-    if (pw == 7 && ph <= 16) {
-      // fast path: workgroup per (roi, channel group), wavefront per pooled row
-      const int lds7 = 64 * ph * pw * 4 * (argmax ? 2 : 1);
+    if (pw == 7 && ph <= 16 && (C & 1) == 0 && (((uintptr_t)feat) & 7) == 0) {
+      // fast path: workgroup per (roi, 128-channel group), wavefront per pooled row, 2 channels per lane
+      const int cgroups = ceil_div(C, 128);
+      const int lds7 = 128 * ph * pw * 4 * (argmax ? 2 : 1);
       const int grid7 = R * cgroups;
+      if (lds7 > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)roi_pool_fwd_nhwc_rows<float, true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        (void)hipFuncSetAttribute((const void*)roi_pool_fwd_nhwc_rows<bf16_t, true, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+      }
 #define LAUNCH_ROWS(T, AM)                                                                                   \
   hipLaunchKernelGGL((roi_pool_fwd_nhwc_rows<T, AM, 7>), dim3(grid7), dim3(64 * ph), lds7, s, (const T*)feat, \
                      rois, roi_scale, C, H, W, ph, spatial_scale, out, out_dtype, argmax, cgroups)

@@ -30,8 +30,10 @@ class HipSGD(torch.optim.Optimizer):
                 if "momentum_buffer" not in state:
                     state["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                sh = getattr(p, "_hip_shadow", None)  # bf16 copy used by the MFMA kernels: refreshed in the same pass
+                shadow = sh[0] if (sh is not None and sh[1] == p._version and sh[0].dtype == torch.bfloat16) else None
                 H.sgd_momentum(p.data, g, state["momentum_buffer"], group["lr"], group["momentum"],
-                               group["weight_decay"], grad_scale=self.grad_scale)
+                               group["weight_decay"], grad_scale=self.grad_scale, bf16_shadow=shadow)
 
 
 def build_optimizer(cfg, model):

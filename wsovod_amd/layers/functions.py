@@ -18,13 +18,29 @@ def _contig2d(t):
     return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
 
 
+def weight_shadow(weight, cd):
+    """Compute-dtype copy of an fp32 master weight.  For leaf parameters the bf16 copy is cached on the
+    parameter (`_hip_shadow` = (tensor, version)); HipSGD refreshes it inside the fused update kernel, so in
+    steady state no separate cast pass over the weights runs.  Any other in-place change of the parameter
+    bumps `_version` and invalidates the cache."""
+    if cd == torch.float32:
+        return weight
+    sh = getattr(weight, "_hip_shadow", None)
+    if sh is not None and sh[1] == weight._version and sh[0].dtype == cd:
+        return sh[0]
+    t = H.cast(weight.detach(), cd)
+    if weight.is_leaf:
+        weight._hip_shadow = (t, weight._version)
+    return t
+
+
 class _Linear(Function):
     """y = dropout(relu(x @ W^T + b)); x (M,K) in the compute dtype, W fp32 master (N,K)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype):
         cd = x.dtype
-        wq = weight if cd == torch.float32 else H.cast(weight, cd)
+        wq = weight_shadow(weight, cd)
         y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, out_dtype=out_dtype)
         ctx.relu, ctx.dropout_p = relu, dropout_p
         ctx.save_for_backward(x, weight, y if (relu or dropout_p > 0) else None)
