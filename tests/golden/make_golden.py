@@ -375,6 +375,15 @@ def main():
         arrays[f"gradsample/{k}"] = gen.strided_sample(gth, 2048)
     save("g8_train_step_r18_k20", **arrays)
 
+    # G1b: R50 (BottleneckBlock) backbone on a small image pair, random init with seeded FrozenBN stats
+    cfg50, model50, sd50, shapes50 = build_ref_model(r, 50, 20, 512, seed=3)
+    bshapes = {k: v for k, v in shapes50.items() if k.startswith("backbone.")}
+    save("shapes_r50_backbone", keys=np.array(list(bshapes.keys())), shapes=np.array([str(v) for v in bshapes.values()]))
+    x50 = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        f50 = model50.backbone(x50)
+    save("g1_backbone_r50_small", x=x50, res5=f50["res5"])
+
     # G5: OV classifier variants on a fixed feature matrix
     feat_x = torch.randn(48, 4096, generator=torch.Generator().manual_seed(21)) * 0.5
     head = rh.box_refinery[0].cls

@@ -173,3 +173,26 @@ def test_overlapped_trainer_equals_plain_run_step(gpu):
         outs.append({k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
     for k in outs[0]:
         torch.testing.assert_close(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])
+def test_r50_backbone_matches_reference_golden(gpu, precision, tol):
+    """WSR_50 (BottleneckBlock, 1x1 / dilated 3x3 / 1x1, 2048-channel res5) forward vs the reference."""
+    import numpy as np
+    import os
+    from tests.helpers import G
+    from wsovod_amd.modeling.meta_arch import build_backbone
+    from wsovod_amd.testing import hot_path_cfg
+
+    g = load_golden("g1_backbone_r50_small")
+    d = np.load(os.path.join(G, "shapes_r50_backbone.npz"))
+    shapes = {str(k)[len("backbone."):]: eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    sd = {k[len("backbone."):]: v for k, v in gen.seeded_state({"backbone." + k: s for k, s in shapes.items()}, 3).items()}
+    cfg = hot_path_cfg(depth=50, precision=precision)
+    bb = build_backbone(cfg).to(gpu)
+    bb.load_state_dict(sd, strict=True)
+    out = bb(g["x"].to(gpu))["res5"]
+    assert out.shape == g["res5"].shape and out.is_contiguous(memory_format=torch.channels_last)
+    ref = g["res5"]
+    err = (out.float().cpu() - ref).abs().max() / ref.abs().max()
+    assert err < tol, err  # relative to the map's peak value

@@ -99,3 +99,13 @@ def test_full_training_step_matches_reference():
     for k, gr in zip(train_keys, grads):
         torch.testing.assert_close(gr.norm(), g["gradnorm/" + k], rtol=2e-4, atol=1e-9)
         torch.testing.assert_close(gen.strided_sample(gr, 2048), g["gradsample/" + k], rtol=2e-3, atol=1e-7)
+
+
+def test_r50_bottleneck_backbone_matches_reference():
+    g = load("g1_backbone_r50_small")
+    d = np.load(os.path.join(G, "shapes_r50_backbone.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    sd = gen.seeded_state(shapes, 3)
+    res5 = R.backbone_forward(sd, g["x"], depth=50)["res5"]
+    assert res5.shape[1] == 2048
+    torch.testing.assert_close(res5, g["res5"], rtol=1e-4, atol=1e-5)

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
                                                              const int* __restrict__ seg, int G, int uniform_rows,
                                                              int M, int N, float scale, float* __restrict__ out,
                                                              long long ldo) {
-  constexpr int RC = 256;
+  constexpr int RC = 32;  // rows per workgroup: small chunks -> thousands of workgroups even for M = 4096
   constexpr int V = 16 / sizeof(T);  // columns per lane: one 16-B load per row
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 64 + lane) * V;
@@ -485,7 +485,7 @@ static int launch_colsum(const void* x, int dtype, long long ld, const int* seg,
     if (ldo == N) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * N, s);
     else (void)hipMemset2DAsync(out, ldo * sizeof(float), 0, N * sizeof(float), G, s);
   }
-  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 256));
+  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 32));
   if (dtype == WSOVOD_BF16)
     hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
   else
