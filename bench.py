@@ -45,6 +45,27 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_name, args):
+    """HBM/fabric bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE cannot be collected from inside this process).  Only returned when the run matches the
+    profiled workload; otherwise null."""
+    import re
+
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b8_bf16.json")
+    if not (os.path.exists(path) and args.batch == 8 and args.precision == "bf16" and args.depth == 18
+            and args.proposals == 512):
+        return None
+    m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma)?$", kernel_name)
+    if not m:
+        return None
+    tag = "gemm_nt_kernelI%sLi%sELi%sELb%d" % ("DF16b" if m.group(2) == "bf16" else "f", m.group(3), m.group(4),
+                                             1 if m.group(1) == "conv_igemm" else 0)
+    with open(path) as f:
+        table = json.load(f)["kernels"]
+    hits = [v for k, v in table.items() if tag in k]
+    return hits[0]["traffic_bytes_per_launch"] if len(hits) == 1 else None
+
+
 def to_device_batch(batch, dev):
     out = []
     for x in batch:
@@ -183,6 +204,8 @@ def main():
                 ach = top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9
                 roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": ach / HBM_PEAK_GBS, "traffic": None}
+            roofline["traffic"] = pmc_traffic(top["name"], args)
+            roofline["algorithmic_per_launch"] = (top["flops"] if mfma else top["bytes"]) / top["launches"]
             roofline.update(kernel=top["name"], launches_per_step=top["launches"] / args.steps,
                             avg_launch_ms=avg_ms, share_of_kernel_time=top["ms"] / sum(e["ms"] for e in table),
                             kernels=[{"name": e["name"], "ms_per_step": e["ms"] / args.steps,
