@@ -55,6 +55,7 @@ struct GemmArgs {
   int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
   long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
   int tiles_m, tiles_n;
+  int group_m;  // tile-order group height (see the XCD remap in the kernel)
 };
 
 template <typename T>
@@ -117,8 +118,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tile_m = wg % p.tiles_m;
-  const int tile_n = wg / p.tiles_m;
+  // Grouped order: ids sweep `group_m` M-tiles for every N-tile before moving on, so the contiguous
+  // run of ids one XCD executes is a near-square block of the tile grid and re-reads neither operand
+  // more than ~sqrt(run) times through its private L2 (measured: FETCH_SIZE, profiles/).
+  const int group_size = p.group_m * p.tiles_n;
+  const int group_id = wg / group_size;
+  const int first_m = group_id * p.group_m;
+  const int gm = min(p.tiles_m - first_m, p.group_m);
+  const int in_group = wg - group_id * group_size;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -383,6 +392,12 @@ int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops
   GemmArgs args = a;
   args.tiles_m = ceil_div(a.M, BM);
   args.tiles_n = ceil_div(a.N, BN);
+  {
+    const int run = std::max(1, args.tiles_m * args.tiles_n / 8);  // tiles per XCD
+    int g = 1;
+    while ((g + 1) * (g + 1) <= run) ++g;
+    args.group_m = std::max(1, std::min(g, args.tiles_m));
+  }
   wsovod::ProfScope prof(slot, s, flops, bytes);
   hipLaunchKernelGGL(kfn, dim3(args.tiles_m * args.tiles_n), dim3(64 * WM * WN), lds_bytes, s, args);
   WS_CHECK_LAUNCH(slot_name);
