@@ -11,7 +11,7 @@ def _ref_mm(A, B):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("tile", [0, 128128, 128064, 64128, 64064, 256256, 256128, 1128128, 1128064, 1256064])
+@pytest.mark.parametrize("tile", [0, 128128, 128064, 64128, 64064, 256256, 256128, 1128128, 1128064, 1256064, 3256128, 4128128, 3128128])
 @pytest.mark.parametrize("shape", [(512, 4096, 1024), (100, 40, 256), (333, 129, 192), (64, 4, 4096)])
 def test_gemm_nt_plain(gpu, dtype, tile, shape):
     from wsovod_amd.layers import hip_ops
@@ -84,7 +84,7 @@ def test_gemm_dropout_statistics(gpu):
     dict(Cin=64, Cout=128, H=19, W=25, k=1, stride=1, pad=0, dil=1),
     dict(Cin=64, Cout=96, H=20, W=26, k=3, stride=2, pad=1, dil=1),
 ])
-@pytest.mark.parametrize("tile", [0, 256256, 256128, 1128128, 1128064, 1256064])
+@pytest.mark.parametrize("tile", [0, 256256, 256128, 1128128, 1128064, 1256064, 3256128, 4128128])
 def test_conv_implicit_gemm(gpu, dtype, cfg, tile):
     from wsovod_amd.layers import hip_ops
 

@@ -94,7 +94,7 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
 
-template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false>
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p) {
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BKE = Traits<T>::BKE;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   static_assert(BM % LR == 0 && BN % LR == 0, "tile rows must be a multiple of the loader pass");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
-  char* sB = smem + 2 * BM * 128;
+  char* sB = smem + STAGES * BM * 128;
 
   // ---- XCD-aware tile id: blocks b, b+8, ... share an XCD; give each XCD a contiguous
   // run of tile ids (M fastest), i.e. tiles that stream the same weight slab. Bijective.
@@ -271,16 +271,42 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = fq + 4 * ks;
-      uint4 af[TM], bfr[TN];
+      u32x4 af[TM], bfr[TN];
+      if constexpr (DMA && STAGES >= 3) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // Deep pipeline: hipcc would put `s_waitcnt vmcnt(0)` in front of any ds_read it can see while
+        // LDS-DMA is in flight (it cannot tell the ring slots apart) and so drain the ring every K-step.
+        // The fragment reads are therefore issued as asm (invisible to that pass) and retired by an
+        // explicit lgkmcnt(0) that names every destination (cdna_hip_programming.md 5.7 item 1, form ii).
+        typedef __attribute__((address_space(3))) const char lds_cchar;
+        const unsigned baseA = (unsigned)(size_t)(lds_cchar*)cA, baseB = (unsigned)(size_t)(lds_cchar*)cB;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = i * 16 + frow;  // the wavefront's row base is a multiple of 16: swizzle term unchanged
-        af[i] = *(const uint4*)(cA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-      }
+        for (int i = 0; i < TM; ++i) {
+          const int row = i * 16 + frow;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(af[i]) : "v"(baseA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));
+        }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = j * 16 + frow;
-        bfr[j] = *(const uint4*)(cB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 16 + frow;
+          asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[j]) : "v"(baseB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));
+        }
+        static_assert(TM == 4 && TN == 4, "the lgkmcnt wait statement names 8 fragment registers");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]),
+                       "+v"(bfr[3]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int row = i * 16 + frow;  // the wavefront's row base is a multiple of 16: swizzle term unchanged
+          af[i] = *(const u32x4*)(cA + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int row = j * 16 + frow;
+          bfr[j] = *(const u32x4*)(cB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+        }
       }
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -302,7 +328,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     }
   };
 
-  if constexpr (DMA) {
+  if constexpr (DMA && STAGES >= 3) {
+    // ---- deep LDS-direct pipeline: STAGES-1 K-steps of DMA in flight.  A counted s_waitcnt retires only
+    // the oldest stage, a raw s_barrier (no vmcnt(0) drain) publishes it, the freed buffer is re-staged at
+    // once, then the MFMAs run -- one barrier per K-step, loads span STAGES-1 compute phases.
+    //   RAW: own vmcnt wait, then the barrier every wave passes only after ITS wait => stage kt is complete.
+    //   WAR: the buffer re-staged after the barrier of step kt was last read in compute(kt-1), which every
+    //        wave finished before reaching that barrier.
+    [[maybe_unused]] constexpr int LPS = RA + RB;  // DMA instructions per thread per stage
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+      if (st < nk) stage_dma(st, st);
+    for (int kt = 0; kt < nk; ++kt) {
+      [[maybe_unused]] const int newer = min(nk - 1 - kt, STAGES - 2);  // stages issued after kt that may still be in flight
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (newer >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * LPS) : "memory");
+      else if (STAGES > 3 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      __builtin_amdgcn_s_barrier();
+      if (kt + STAGES - 1 < nk) stage_dma(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
+      compute(kt % STAGES);
+    }
+  } else if constexpr (DMA) {
     // ---- LDS-direct pipeline: next K-step's DMA is issued before the MFMAs of the current one;
     // the barrier (with the vmcnt(0) hipcc puts in front of it) retires it.  One barrier per K-step.
     stage_dma(0, 0);
@@ -379,12 +427,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   }
 }
 
-template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false>
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
 int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
   static int slot = wsovod::prof_slot(slot_name);
   static bool attr_set = false;
-  constexpr int lds_bytes = 2 * (BM + BN) * 128;
-  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA>;
+  constexpr int lds_bytes = STAGES * (BM + BN) * 128;
+  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA, STAGES>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
@@ -412,6 +460,18 @@ int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, doub
       return launch<T, 256, 256, CONV, 4, 4, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x256" : "conv_igemm_f32_256x256")
                                                        : (bf ? "gemm_nt_bf16_256x256" : "gemm_nt_f32_256x256"),
                                              flops, bytes);
+    case 3256128:  // 256x128, 3-stage deep pipeline (144 KiB LDS)
+      return launch<T, 256, 128, CONV, 4, 2, true, 3>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x128_s3" : "conv_igemm_f32_256x128_s3")
+                                                                : (bf ? "gemm_nt_bf16_256x128_s3" : "gemm_nt_f32_256x128_s3"),
+                                                      flops, bytes);
+    case 4128128:  // 128x128, 4-stage deep pipeline (128 KiB LDS)
+      return launch<T, 128, 128, CONV, 2, 2, true, 4>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x128_s4" : "conv_igemm_f32_128x128_s4")
+                                                                : (bf ? "gemm_nt_bf16_128x128_s4" : "gemm_nt_f32_128x128_s4"),
+                                                      flops, bytes);
+    case 3128128:  // 128x128, 3-stage (96 KiB LDS)
+      return launch<T, 128, 128, CONV, 2, 2, true, 3>(a, s, CONV ? (bf ? "conv_igemm_bf16_128x128_s3" : "conv_igemm_f32_128x128_s3")
+                                                                : (bf ? "gemm_nt_bf16_128x128_s3" : "gemm_nt_f32_128x128_s3"),
+                                                      flops, bytes);
     case 256128:
       return launch<T, 256, 128, CONV, 4, 2, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x128" : "conv_igemm_f32_256x128")
                                                        : (bf ? "gemm_nt_bf16_256x128" : "gemm_nt_f32_256x128"),
