@@ -110,22 +110,78 @@ __global__ void maxpool2x2_nhwc_kernel(const T* __restrict__ in, int N, int H, i
 }
 
 // ---------------------------------------------------------------------------------
-// transpose + cast: dst[c][r] = src[r][c]  (64x64 LDS tile, padded), and plain cast.
+// transpose + cast: dst[c][r] = src[r][c]  (64x64 LDS tile; 8 elements = 16/32 B per lane on both
+// the load and the store side), and plain cast.
 // ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, bool vec, int nvalid, float (&v)[8]) {
+  if (vec) {
+    if constexpr (sizeof(T) == 2) {
+      const uint4 raw = *(const uint4*)p;
+      const T* e = (const T*)&raw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = to_f32(e[j]);
+    } else {
+      const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = j < nvalid ? to_f32(p[j]) : 0.f;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, bool vec, int nvalid, const float (&v)[8]) {
+  if (vec) {
+    if constexpr (sizeof(T) == 2) {
+      uint4 raw;
+      T* e = (T*)&raw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) e[j] = from_f32<T>(v[j]);
+      *(uint4*)p = raw;
+    } else {
+      *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < nvalid) p[j] = from_f32<T>(v[j]);
+  }
+}
+
 template <typename TS, typename TD>
 __global__ __launch_bounds__(256) void transpose_cast_kernel(const TS* __restrict__ src, long long lds_, int R, int C,
                                                              TD* __restrict__ dst, long long ldd) {
   __shared__ float tile[64][65];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < R && c < C) ? to_f32(src[(long long)r * lds_ + c]) : 0.f;
+  const bool src_al = ((lds_ * sizeof(TS)) % 16 == 0) && (((uintptr_t)src & 15) == 0);
+  const bool dst_al = ((ldd * sizeof(TD)) % 16 == 0) && (((uintptr_t)dst & 15) == 0);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = (tid >> 3) + 32 * it, cg = (tid & 7) * 8;
+    const int r = r0 + row, c = c0 + cg;
+    float v[8];
+    if (r < R && c < C) load8(src + (long long)r * lds_ + c, src_al && c + 8 <= C, C - c, v);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[row][cg + j] = v[j];
   }
   __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < C && r < R) dst[(long long)c * ldd + r] = from_f32<TD>(tile[tx][i]);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int col = (tid >> 3) + 32 * it, rg = (tid & 7) * 8;
+    const int c = c0 + col, r = r0 + rg;
+    if (c < C && r < R) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = tile[rg + j][col];
+      store8(dst + (long long)c * ldd + r, dst_al && r + 8 <= R, R - r, v);
+    }
   }
 }
 
@@ -197,25 +253,26 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
                                                              const int* __restrict__ seg, int G, int uniform_rows,
                                                              int M, int N, float scale, float* __restrict__ out,
                                                              long long ldo) {
-  constexpr int RC = 32;  // rows per workgroup: small chunks -> thousands of workgroups even for M = 4096
+  constexpr int RC = 128;            // rows per workgroup
   constexpr int V = 16 / sizeof(T);  // columns per lane: one 16-B load per row
+  __shared__ float part[3][64][V + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 64 + lane) * V;
   const int r0 = blockIdx.y * RC, r1 = min(r0 + RC, M);
-  if (n0 >= N) return;
+  const bool col_ok = n0 < N;
   const bool vec = (n0 + V <= N) && ((ld * sizeof(T)) % 16 == 0) && (((uintptr_t)x & 15) == 0);
-  int g = 0;
-  if (!seg) {
-    g = (r0 + wave) / uniform_rows;
-  } else {
+  auto seg_of = [&](int row) {
+    if (!seg) return row / uniform_rows;
     int lo = 0, hi = G;  // largest g with seg[g] <= row
-    const int row = r0 + wave;
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
       if (seg[mid] <= row) lo = mid; else hi = mid;
     }
-    g = lo;
-  }
+    return lo;
+  };
+  const int g_first = seg_of(r0), g_last = seg_of(r1 - 1);
+  const bool one_seg = g_first == g_last && (!seg || (r0 >= seg[g_first] && r1 <= seg[g_first + 1]));
+  int g = one_seg ? g_first : seg_of(min(r0 + wave, r1 - 1));
   float acc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -226,28 +283,46 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
   };
-  for (int m = r0 + wave; m < r1; m += 4) {
-    int gm = g;
-    if (!seg) gm = m / uniform_rows;
-    else while (gm + 1 < G && m >= seg[gm + 1]) ++gm;
-    if (gm != g) {
-      flush(g);
-      g = gm;
-    }
-    if (seg && (m < seg[g] || m >= seg[g + 1])) continue;  // rows outside every segment
-    const T* row = x + (long long)m * ld + n0;
-    if (vec) {
-      const uint4 raw = *(const uint4*)row;
-      const T* e = (const T*)&raw;
+  if (col_ok)
+    for (int m = r0 + wave; m < r1; m += 4) {
+      if (!one_seg) {
+        int gm = g;
+        if (!seg) gm = m / uniform_rows;
+        else while (gm + 1 < G && m >= seg[gm + 1]) ++gm;
+        if (gm != g) {
+          flush(g);
+          g = gm;
+        }
+        if (seg && (m < seg[g] || m >= seg[g + 1])) continue;  // rows outside every segment
+      }
+      const T* row = x + (long long)m * ld + n0;
+      if (vec) {
+        const uint4 raw = *(const uint4*)row;
+        const T* e = (const T*)&raw;
 #pragma unroll
-      for (int j = 0; j < V; ++j) acc[j] += to_f32(e[j]);
-    } else {
+        for (int j = 0; j < V; ++j) acc[j] += to_f32(e[j]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < V; ++j)
-        if (n0 + j < N) acc[j] += to_f32(row[j]);
+        for (int j = 0; j < V; ++j)
+          if (n0 + j < N) acc[j] += to_f32(row[j]);
+      }
     }
+  if (!one_seg) {  // chunk straddles a segment boundary (rare): per-wavefront atomics
+    if (col_ok) flush(g);
+    return;
   }
-  flush(g);
+  // common case: combine the 4 wavefronts through LDS, ONE atomic per column per workgroup (atomics that
+  // all target the same few rows serialise at the memory side, so their count is what matters)
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) part[wave - 1][lane][j] = acc[j];
+  }
+  __syncthreads();
+  if (wave == 0 && col_ok) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] += part[0][lane][j] + part[1][lane][j] + part[2][lane][j];
+    flush(g);
+  }
 }
 
 // x *= num[0] / den[0]  (device scalars: upstream loss grad / normaliser; no host sync)
@@ -310,24 +385,50 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restric
                                                              float scale, TO* __restrict__ dA, long long ldda,
                                                              TO* __restrict__ dAt, long long ldt) {
   __shared__ float tile[64][65];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tid = threadIdx.x;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  for (int i = ty; i < 64; i += 4) {
-    const int m = m0 + i, n = n0 + tx;
-    float v = 0.f;
+  const bool dy_al = ((lddy * sizeof(TI)) % 16 == 0) && (((uintptr_t)dy & 15) == 0);
+  const bool y_al = y && ((ldy * sizeof(TI)) % 16 == 0) && (((uintptr_t)y & 15) == 0);
+  const bool da_al = dA && ((ldda * sizeof(TO)) % 16 == 0) && (((uintptr_t)dA & 15) == 0);
+  const bool dt_al = dAt && ((ldt * sizeof(TO)) % 16 == 0) && (((uintptr_t)dAt & 15) == 0);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int row = (tid >> 3) + 32 * it, cg = (tid & 7) * 8;
+    const int m = m0 + row, n = n0 + cg;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
     if (m < M && n < N) {
-      v = to_f32(dy[(long long)m * lddy + n]) * scale;
-      if (y && !(to_f32(y[(long long)m * ldy + n]) > 0.f)) v = 0.f;
-      if (dA) dA[(long long)m * ldda + n] = from_f32<TO>(v);
+      const bool full = n + 8 <= N;
+      load8(dy + (long long)m * lddy + n, dy_al && full, N - n, v);
+      if (y) {
+        float yv[8];
+        load8(y + (long long)m * ldy + n, y_al && full, N - n, yv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = yv[j] > 0.f ? v[j] * scale : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= scale;
+      }
+      if (dA) store8(dA + (long long)m * ldda + n, da_al && full, N - n, v);
     }
-    tile[i][tx] = v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[row][cg + j] = v[j];
   }
   __syncthreads();
-  if (dAt)
-    for (int i = ty; i < 64; i += 4) {
-      const int n = n0 + i, m = m0 + tx;
-      if (n < N && m < M) dAt[(long long)n * ldt + m] = from_f32<TO>(tile[tx][i]);
+  if (dAt) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int col = (tid >> 3) + 32 * it, rg = (tid & 7) * 8;
+      const int n = n0 + col, m = m0 + rg;
+      if (n < N && m < M) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[rg + j][col];
+        store8(dAt + (long long)n * ldt + m, dt_al && m + 8 <= M, M - m, v);
+      }
     }
+  }
 }
 
 // out[m][n] = x[m][n] + add[row_group[m]][n]   (box_features += data_aware_features,
@@ -485,7 +586,7 @@ static int launch_colsum(const void* x, int dtype, long long ld, const int* seg,
     if (ldo == N) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * N, s);
     else (void)hipMemset2DAsync(out, ldo * sizeof(float), 0, N * sizeof(float), G, s);
   }
-  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 32));
+  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 128));
   if (dtype == WSOVOD_BF16)
     hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
   else
