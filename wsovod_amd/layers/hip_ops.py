@@ -27,6 +27,46 @@ def const_tensor(values, dtype, device):
     return t
 
 
+class _PinnedRing:
+    """Small page-locked staging ring for per-step host data (image-level labels ...): a pageable
+    `tensor.to(device)` blocks the host until the stream drains, which would serialise host and GPU once per
+    step; copies from pinned memory are truly asynchronous.  A slot is reused only after its copy event."""
+
+    def __init__(self, slots=16, nbytes=1 << 16):
+        self.bufs = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.i = 0
+
+    def stage(self, t_cpu, device):
+        nb = t_cpu.numel() * t_cpu.element_size()
+        if nb == 0 or nb > self.bufs[0].numel():
+            return t_cpu.to(device)
+        k = self.i
+        self.i = (self.i + 1) % len(self.bufs)
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        view = self.bufs[k][:nb].view(t_cpu.dtype).view(t_cpu.shape)
+        view.copy_(t_cpu)
+        out = view.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return out
+
+
+_RING = None
+
+
+def h2d_small(t_cpu, device):
+    """Asynchronous host->device copy of a small CPU tensor through the pinned staging ring."""
+    global _RING
+    if not torch.device(device).type == "cuda":
+        return t_cpu.to(device)
+    if _RING is None:
+        _RING = _PinnedRing()
+    return _RING.stage(t_cpu.contiguous(), device)
+
+
 def feature_layout(feat):
     """(layout code, N, C, H, W) of a logical-NCHW feature tensor; NHWC == torch.channels_last."""
     if feat.dim() != 4:

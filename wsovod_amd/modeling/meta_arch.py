@@ -128,9 +128,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             u = torch.unique(gc, sorted=True).to(torch.int64)
             cls_list.append(u)
             oh[i, u] = 1.0
-        cat = torch.cat(cls_list).to(self.device, non_blocking=True)
+        cat = H.h2d_small(torch.cat(cls_list), self.device)
         off = segment_offsets([len(u) for u in cls_list], self.device)
-        return cat, off, oh.to(self.device, non_blocking=True)
+        return cat, off, H.h2d_small(oh, self.device)
 
     def forward(self, batched_inputs, classifier=None):
         if not self.training:
@@ -147,7 +147,11 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         st = {"canvas": canvas, "sizes": sizes, "gt_instances": None, "image_level_gt": None}
         if "instances" in batched_inputs[0]:
             st["image_level_gt"] = self._image_level_gt(batched_inputs)
-            st["gt_instances"] = [x["instances"].to(self.device) for x in batched_inputs]
+            # With the image-level labels already extracted on the host, the heads never read the dataset
+            # boxes (weak supervision), so the instances are not copied to the device (a pageable H2D copy
+            # would block the host until the stream drains).
+            st["gt_instances"] = [x["instances"] if st["image_level_gt"] is not None else x["instances"].to(self.device)
+                                  for x in batched_inputs]
         features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
         st["features"] = features
         st["proposals"] = self._proposals(batched_inputs)
