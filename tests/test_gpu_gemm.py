@@ -83,6 +83,7 @@ def test_gemm_dropout_statistics(gpu):
     dict(Cin=128, Cout=256, H=19, W=25, k=3, stride=1, pad=2, dil=2),
     dict(Cin=64, Cout=128, H=19, W=25, k=1, stride=1, pad=0, dil=1),
     dict(Cin=64, Cout=96, H=20, W=26, k=3, stride=2, pad=1, dil=1),
+    dict(Cin=64, Cout=64, H=37, W=71, k=3, stride=1, pad=1, dil=1),  # halo-tile kernel with ragged tiles
 ])
 @pytest.mark.parametrize("tile", [0, 256256, 256128, 1128128, 1128064, 1256064, 3256128, 4128128])
 def test_conv_implicit_gemm(gpu, dtype, cfg, tile):
@@ -113,3 +114,29 @@ def test_gemm_argument_errors(gpu):
         hip_ops.gemm_nt(A, B)  # K=30 is not a multiple of 4 fp32 elements (16-B chunks)
     with pytest.raises(RuntimeError):
         hip_ops.gemm_nt(A.cpu(), B.cpu())
+
+
+def test_conv3x3_c64_halo_kernel_with_residual(gpu):
+    """The Cin=Cout=64 halo-tile kernel (auto dispatch, bf16) incl. residual add, vs fp64 conv."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(7)
+    n, H, W = 3, 41, 67
+    x = torch.randn(n, 64, H, W).to(torch.bfloat16)
+    w = (torch.randn(64, 64, 3, 3) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(64)
+    res = torch.randn(n, H, W, 64).to(torch.bfloat16)
+    ref = F.relu(F.conv2d(x.double(), w.double(), bias.double(), 1, 1) + res.double().permute(0, 3, 1, 2)).float()
+    geom = dict(n_img=n, H=H, W=W, Cin=64, Ho=H, Wo=W, KH=3, KW=3, stride=1, pad=1, dil=1)
+    out = hip_ops.gemm_nt(x.permute(0, 2, 3, 1).contiguous().to(gpu), w.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(gpu),
+                          conv=geom, bias=bias.to(gpu), relu=True, residual=res.view(-1, 64).to(gpu),
+                          out_dtype=torch.float32)
+    torch.testing.assert_close(out.view(n, H, W, 64).permute(0, 3, 1, 2).cpu(), ref, rtol=1e-3, atol=5e-3)
+    from wsovod_amd import _lib
+    _lib.profile_reset(); _lib.profile_enable(True)
+    hip_ops.gemm_nt(x.permute(0, 2, 3, 1).contiguous().to(gpu), w.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(gpu),
+                    conv=geom, out_dtype=torch.bfloat16)
+    torch.cuda.synchronize()
+    names = [e["name"] for e in _lib.profile_collect() if e["launches"] > 0]
+    _lib.profile_enable(False)
+    assert "conv3x3_c64_halo_bf16" in names  # the dedicated kernel is the one that ran

@@ -427,6 +427,125 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   }
 }
 
+// ---------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 / Cin = Cout = 64 convolution (stem conv2, conv3 and the four res2 convs,
+// resnet_wsl.py:386-405,59-79) in bf16.  With only 64 output channels the generic implicit GEMM stages
+// every input pixel nine times (once per tap) for a 64-wide B tile: 51 FLOP per staged byte, L2-bound.
+// Here a workgroup owns an 8x32 block of output pixels of one image: the 10x34 input halo patch is
+// DMA-staged into LDS ONCE (zero-filled outside the image by the buffer range check) and all nine taps
+// read their A fragments from it at shifted pixel offsets; the 64x64 weight slice of each tap streams
+// through a double-buffered 8-KiB LDS tile.  LDS rows are 128 B (64 bf16 channels of one pixel) with the
+// same XOR swizzle as the GEMM image, keyed by the patch pixel index, so 16 consecutive pixels read
+// conflict-free.  4 wavefronts, each 64 pixels (2 rows x 32) x 64 channels = 4x4 MFMA tiles.
+// ---------------------------------------------------------------------------------
+constexpr int C64_TH = 8, C64_TW = 32, C64_PW = C64_TW + 2, C64_PH = C64_TH + 2, C64_NPIX = C64_PW * C64_PH;
+constexpr int C64_PATCH_BYTES = ((C64_NPIX + 31) / 32 * 32) * 128;  // padded to whole 32-pixel DMA passes
+
+__global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sP = smem;                    // halo patch [pixel][128 B]
+  char* sW = smem + C64_PATCH_BYTES;  // 2 x [64 cout][128 B] weight slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpi = tiles_x * tiles_y;
+  const int img = blockIdx.x / tpi;
+  const int t = blockIdx.x - img * tpi;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int y0 = ty * C64_TH, x0 = tx * C64_TW;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(64 * p.ldb * 2), 0x00020000);
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+
+  auto stage_weights = [&](int tap, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid >> 3) + 32 * i;                 // cout
+      const int chunk = (tid & 7) ^ ((row >> 1) & 7);      // swizzle on the source
+      const int off = (int)((row * p.ldb + tap * 64 + chunk * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + buf * 8192 + i * 4096 + wave_u * 1024), 16,
+                                               off, 0, 0, 0);
+    }
+#endif
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  // halo patch: pixel q of the patch = image pixel (y0-1 + q/PW, x0-1 + q%PW); 8 pixels per wave DMA
+  for (int base = 0; base < C64_NPIX; base += 32) {
+    const int q = base + (tid >> 3);
+    const int py = q / C64_PW, px = q - py * C64_PW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool ok = q < C64_NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const int chunk = (tid & 7) ^ ((q >> 1) & 7);
+    const int off = (((img * p.H + y) * p.W + x) * 64 + chunk * 8) * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sP + (base + wave_u * 8) * 128), 16, ok ? off : -1, 0,
+                                             0, 0);
+  }
+#endif
+  stage_weights(0, 0);
+  __syncthreads();
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int cur = tap & 1;
+    if (tap + 1 < 9) stage_weights(tap + 1, cur ^ 1);
+    const int r = tap / 3, s3 = tap - r * 3;
+    const char* cW = sW + cur * 8192;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int chunk = fq + 4 * ks;
+      u32x4 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int yy = wave * 2 + (i >> 1) + r;          // patch row of this 16-pixel group, shifted by the tap
+        const int q = yy * C64_PW + (i & 1) * 16 + frow + s3;
+        af[i] = *(const u32x4*)(sP + q * 128 + ((chunk ^ ((q >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = j * 16 + frow;
+        bfr[j] = *(const u32x4*)(cW + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
+                                                              __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // epilogue: bias + residual + ReLU; D[row=(lane>>4)*4+reg][col=lane&15]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + wave * 2 + (i >> 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = j * 16 + frow;
+      const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int x = x0 + (i & 1) * 16 + fq * 4 + rr;
+        if (y < p.H && x < p.W) {
+          const long long m = ((long long)img * p.H + y) * p.W + x;
+          float v = acc[i][j][rr] * p.alpha + bias;
+          if (p.residual) v += load_as_f32(p.residual, m * p.ldr + n, p.dtype_r);
+          if (p.relu) v = fmaxf(v, 0.f);
+          store_from_f32(p.C, m * p.ldc + n, p.dtype_c, v);
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
 int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
   static int slot = wsovod::prof_slot(slot_name);
@@ -608,8 +727,20 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   }
   bytes += (double)d->M * d->N * ((d->C ? (d->dtype_c == WSOVOD_BF16 ? 2 : 4) : 0) + (d->Ct ? (d->dtype_ct == WSOVOD_BF16 ? 2 : 4) : 0));
   const double flops = 2.0 * d->M * d->N * d->K;
-  const int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
   hipStream_t s = (hipStream_t)stream;
+  if (d->conv && d->tile_hint == 0 && d->dtype_in == WSOVOD_BF16 && a.Cin == 64 && d->N == 64 && a.KH == 3 &&
+      a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W && d->C && !d->Ct &&
+      !d->row_scale && !d->group_add && !d->mask_src && !d->accumulate && d->dropout_p == 0.f) {
+    static int slot = wsovod::prof_slot("conv3x3_c64_halo_bf16");
+    const int lds_bytes = C64_PATCH_BYTES + 2 * 8192;
+    const int tiles_x = ceil_div(a.W, C64_TW), tiles_y = ceil_div(a.H, C64_TH);
+    wsovod::ProfScope prof(slot, s, flops, bytes);
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(d->geom.n_img * tiles_x * tiles_y), dim3(256), lds_bytes, s, a, tiles_x,
+                       tiles_y);
+    WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64)");
+    return WSOVOD_OK;
+  }
+  const int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
   if (d->dtype_in == WSOVOD_BF16)
     return d->conv ? dispatch_tile<bf16_t, true>(a, tile, s, flops, bytes) : dispatch_tile<bf16_t, false>(a, tile, s, flops, bytes);
   return d->conv ? dispatch_tile<float, true>(a, tile, s, flops, bytes) : dispatch_tile<float, false>(a, tile, s, flops, bytes);
