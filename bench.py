@@ -32,7 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="debug: every rank uses cuda:0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--depth", type=int, default=18)
     ap.add_argument("--proposals", type=int, default=512)
@@ -51,9 +54,8 @@ def pmc_traffic(kernel_name, args):
     profiled workload; otherwise null."""
     import re
 
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_b8_bf16.json")
-    if not (os.path.exists(path) and args.batch == 8 and args.precision == "bf16" and args.depth == 18
-            and args.proposals == 512):
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}_bf16.json")
+    if not (os.path.exists(path) and args.precision == "bf16" and args.depth == 18 and args.proposals == 512):
         return None
     m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma)?$", kernel_name)
     if not m:
@@ -130,11 +132,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback on the product path)")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from wsovod_amd import _lib
     from wsovod_amd.data import make_batch
