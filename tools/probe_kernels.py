@@ -36,7 +36,7 @@ def main():
             A = torch.randn(M, K, device=dev).to(dt)
             B = torch.randn(N, K, device=dev).to(dt)
             out = torch.empty(M, N, device=dev, dtype=torch.float32)
-            for tile in (1128128, 3128128, 4128128, 256128, 3256128, 256256):
+            for tile in (0, 256256):
                 ms = timeit(lambda: hip_ops.gemm_nt(A, B, out=out, tile_hint=tile), iters=iters)
                 print(f"gemm {str(dt)[6:]:9s} {name:12s} tile {tile:6d}  {ms:8.3f} ms  {2.0*M*N*K/ms/1e9:8.1f} TFLOP/s")
             del A, B, out
@@ -49,7 +49,7 @@ def main():
             geom = dict(n_img=n, H=H, W=W, Cin=Cin, Ho=H, Wo=W, KH=3, KW=3, stride=1, pad=dil, dil=dil)
             out = torch.empty(n * H * W, Cout, device=dev, dtype=dt)
             fl = 2.0 * n * H * W * Cout * 9 * Cin
-            for tile in (0, 3256128, 256256):
+            for tile in (0, 256256):
                 ms = timeit(lambda: hip_ops.gemm_nt(x, w, conv=geom, out=out, relu=True, tile_hint=tile), iters=5)
                 print(f"conv {str(dt)[6:]:9s} {nm:10s} tile {tile:7d} {ms:8.3f} ms  {fl/ms/1e9:8.1f} TFLOP/s")
     return
