@@ -196,3 +196,36 @@ def test_r50_backbone_matches_reference_golden(gpu, precision, tol):
     ref = g["res5"]
     err = (out.float().cpu() - ref).abs().max() / ref.abs().max()
     assert err < tol, err  # relative to the map's peak value
+
+
+@pytest.mark.parametrize("depth,K,D,R", [(18, 80, 768, 48), (50, 80, 512, 40)])
+def test_other_baseline_configs_match_oracle(gpu, depth, K, D, R):
+    """BASELINE.json configs 3/4 as parity cases (scaled-down R and image size): COCO-style K=80 with
+    ViT-L/14 D=768 embeddings on R18, and WSR_50 (BottleneckBlock backbone, fc1 100352->4096) -- whole
+    training step in the fp32 parity mode against the oracle on identical seeded parameters."""
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, depth=depth, K=K, D=D, precision="fp32", device="cuda:0",
+                                      calibrate_synthetic=False)
+    model._std = [float(v) for v in gen.PIXEL_STD]
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gen.seeded_state(shapes, seed=11)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    batch = gen.seeded_batch(2, R, K, 256, 352, seed=13)
+    ref_losses, inter = R_train(sd, batch, depth, K)
+    losses, cap, pgt = _run(model, batch)
+    for k, v in ref_losses.items():
+        torch.testing.assert_close(losses[k].detach().cpu(), v.detach(), rtol=2e-3, atol=1e-5)
+    assert (cap["miner"][0].detach().cpu() - inter["mining_scores"]).abs().max() < 1e-3
+    assert (cap["refine"][0].detach().cpu() - inter["refine_logits"]).abs().max() < 1e-3
+    assert cap["refine"][0].shape[1] == K + 1
+    assert torch.equal(pgt["gt_classes"].cpu(), torch.cat([l["gt_classes"] for l in inter["labelled"]]))
+
+
+def R_train(sd, batch, depth, K):
+    sdc = {k: v.clone() for k, v in sd.items()}
+    return R.train_forward(sdc, batch, depth=depth, num_classes=K, pixel_std=gen.PIXEL_STD)
