@@ -198,8 +198,8 @@ def test_r50_backbone_matches_reference_golden(gpu, precision, tol):
     assert err < tol, err  # relative to the map's peak value
 
 
-@pytest.mark.parametrize("depth,K,D,R", [(18, 80, 768, 48), (50, 80, 512, 40)])
-def test_other_baseline_configs_match_oracle(gpu, depth, K, D, R):
+@pytest.mark.parametrize("depth,K,D,NR", [(18, 80, 768, 48), (50, 80, 512, 40)])
+def test_other_baseline_configs_match_oracle(gpu, depth, K, D, NR):
     """BASELINE.json configs 3/4 as parity cases (scaled-down R and image size): COCO-style K=80 with
     ViT-L/14 D=768 embeddings on R18, and WSR_50 (BottleneckBlock backbone, fc1 100352->4096) -- whole
     training step in the fp32 parity mode against the oracle on identical seeded parameters."""
@@ -215,7 +215,7 @@ def test_other_baseline_configs_match_oracle(gpu, depth, K, D, R):
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.eval()
-    batch = gen.seeded_batch(2, R, K, 256, 352, seed=13)
+    batch = gen.seeded_batch(2, NR, K, 256, 352, seed=13)
     ref_losses, inter = R_train(sd, batch, depth, K)
     losses, cap, pgt = _run(model, batch)
     torch.testing.assert_close(losses["loss_cls_object_mining"].detach().cpu(),
