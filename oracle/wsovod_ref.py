@@ -297,7 +297,8 @@ def get_image_level_gt(gt_classes_list, num_classes):
 # ----------------------------------------------------------------------------------------
 def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool", temperature=50.0,
                   pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True,
-                  mean_loss=True, sampling_ratio=0, dropout_masks=None, refine_prefix="roi_heads.box_refinery_0."):
+                  mean_loss=True, sampling_ratio=0, dropout_masks=None, refine_prefix="roi_heads.box_refinery_0.",
+                  miner_prefix="roi_heads.object_miner.", classifier=None):
     """batch: list of dicts {image uint8 (3,H,W), boxes (R,4), objectness (R), gt_classes (G)}.
     Returns (losses dict, intermediates dict).  REFINE_NUM=1, REFINE_REG=[True], SAMPLING_ON."""
     inter = {}
@@ -317,7 +318,7 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
         inter["daf"] = daf
         feat = feat + torch.cat([daf[i].repeat(n, 1) for i, n in enumerate(nums)])  # roi_heads.py:762-763
     inter["box_features"] = feat
-    scores = mining_forward(sd, feat, nums)
+    scores = mining_forward(sd, feat, nums, prefix=miner_prefix)
     inter["mining_scores"] = scores
     gt_int, gt_oh = get_image_level_gt([b["gt_classes"] for b in batch], num_classes)
     losses = {"loss_cls_object_mining": mining_loss(scores, nums, gt_oh, mean_loss)}
@@ -326,7 +327,8 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
     targets = get_pgt_top_k(boxes_list, list(scores.detach().split(nums)), gt_int, img_logits, num_classes)
     labelled = label_and_sample_proposals_wsl(boxes_list, targets, num_classes)
     inter["targets"], inter["labelled"] = targets, labelled
-    logits = ov_classifier_forward(sd, feat, refine_prefix + "cls.", temperature)
+    # mixed-dataset mode hands the dataset's raw text embeddings in per call (rcnn_wsovod_mixed_datasets.py:237)
+    logits = ov_classifier_forward(sd, feat, refine_prefix + "cls.", temperature, classifier=classifier)
     deltas = F.linear(feat, sd[refine_prefix + "bbox_pred.weight"], sd[refine_prefix + "bbox_pred.bias"])
     inter["refine_logits"], inter["refine_deltas"] = logits, deltas
     lc, lb = refinement_losses(logits, deltas, torch.cat([l["gt_classes"] for l in labelled]),

@@ -32,7 +32,7 @@ def seeded_state(shapes, seed=0):
             t = torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_out)
         elif ".box_head.fc" in k:
             t = torch.randn(shp, generator=g) * 0.005 if k.endswith("weight") else torch.full(shp, 0.1)
-        elif ".object_miner." in k:
+        elif ".object_miner." in k or ".object_miners." in k:
             if k.endswith("weight"):
                 a = math.sqrt(6.0 / (shp[0] + shp[1]))
                 t = (torch.rand(shp, generator=g) * 2 - 1) * a
@@ -58,6 +58,28 @@ def seeded_state(shapes, seed=0):
             raise KeyError(f"no initialiser for {k} {shp}")
         sd[k] = t.float()
     return sd
+
+
+def mixed_seeded_state(shapes, seed):
+    """seeded_state for the mixed-dataset model: miners shared per dataset family appear under every index of
+    `object_miners` in the state dict and must hold the same tensors."""
+    sd = seeded_state(shapes, seed)
+    for k in list(sd):
+        if k.startswith("roi_heads.object_miners.1."):
+            sd[k] = sd[k.replace("object_miners.1.", "object_miners.0.")]
+    return sd
+
+
+def sampler_dataset_dicts(sizes=(7, 5, 30), num_categories=6, seed=3):
+    """Concatenated dataset dicts (id order) with random category sets, as the multi-dataset sampler sees them."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for ds, n in enumerate(sizes):
+        for i in range(n):
+            k = int(torch.randint(1, 4, (1,), generator=g))
+            cats = torch.randint(0, num_categories, (k,), generator=g).tolist()
+            out.append({"dataset_id": ds, "annotations": [{"category_id": c} for c in cats]})
+    return out
 
 
 def seeded_batch(n_images, R, K, H, W, seed=0, edge_cases=True):

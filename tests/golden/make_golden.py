@@ -300,10 +300,108 @@ def build_ref_model(r, depth, K, D, seed):
     return cfg, model, sd, shapes
 
 
+def golden_mixed(r):
+    """G10: the REFERENCE's mixed-dataset meta-arch + ROI heads (rcnn_wsovod_mixed_datasets.py, roi_heads.py:1860+)
+    on two sources with different class counts (voc-like K=20 through the shared voc miner, coco-like K=80)."""
+    from wsovod_amd.testing import mixed_datasets_cfg
+
+    r.meta_mixed = load_ref("wsovod.modeling.meta_arch.rcnn_wsovod_mixed_datasets",
+                            "wsovod/modeling/meta_arch/rcnn_wsovod_mixed_datasets.py")
+    Ks = (20, 20, 80)
+    cfg = mixed_datasets_cfg(Ks=Ks, device="cpu")
+    cfg.MODEL.PIXEL_STD = list(gen.PIXEL_STD)
+    cfg.DATASETS.TRAIN = ("synthetic",)
+    torch.manual_seed(0)
+    model = r.meta_mixed.GeneralizedRCNN_WSOVOD_MixedDatasets(cfg)
+    assert type(model.roi_heads).__name__ == "WSOVODMixedDatasetsROIHeads"
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gen.mixed_seeded_state(shapes, seed=17)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 1e-12
+    save("shapes_mixed_r18", keys=np.array(list(shapes.keys())), shapes=np.array([str(v) for v in shapes.values()]))
+    arrays = {}
+    for source_id in (2, 0):
+        K = Ks[source_id]
+        batch = gen.seeded_batch(2, 40, K, 256, 352, seed=19 + source_id)
+        inputs = to_inputs(batch)
+        for d in inputs:
+            d["dataset_id"] = source_id
+        captured = {}
+        rh = model.roi_heads
+        miner = rh.object_miners[source_id]
+        orig_miner, orig_ref, orig_label = miner.forward, rh.box_refinery[0].forward, rh.label_and_sample_proposals_wsl
+
+        def cap(name, fn):
+            def wrapped(*a, **k):
+                o = fn(*a, **k)
+                captured[name] = o
+                return o
+            return wrapped
+
+        miner.forward = cap("miner", orig_miner)
+        rh.box_refinery[0].forward = cap("refine", orig_ref)
+        rh.label_and_sample_proposals_wsl = cap("proposals_k", orig_label)
+        model.zero_grad(set_to_none=True)
+        loss_dict = model(inputs)
+        sum(loss_dict.values()).backward()
+        miner.forward, rh.box_refinery[0].forward, rh.label_and_sample_proposals_wsl = orig_miner, orig_ref, orig_label
+        p = f"s{source_id}/"
+        for k, v in loss_dict.items():
+            arrays[p + "loss/" + k] = v
+        arrays[p + "mining_scores"] = captured["miner"][0]
+        arrays[p + "refine_logits"] = captured["refine"][0]
+        arrays[p + "refine_deltas"] = captured["refine"][1]
+        arrays[p + "label/gt_classes"] = torch.cat([q.gt_classes for q in captured["proposals_k"]])
+        arrays[p + "label/gt_boxes"] = torch.cat([q.gt_boxes.tensor for q in captured["proposals_k"]])
+        arrays[p + "label/gt_weights"] = torch.cat([q.gt_weights for q in captured["proposals_k"]])
+        for k, q in model.named_parameters():
+            if q.requires_grad:
+                arrays[p + "gradnorm/" + k] = q.grad.norm() if q.grad is not None else torch.tensor(-1.0)
+    save("g10_mixed_datasets_step", **arrays)
+
+
+def golden_sampler():
+    """G11: the REFERENCE's MultiDatasetTrainingSampler (repeat factors with class-aware sampling on one dataset,
+    and the per-rank index streams of a 2-rank job)."""
+    import itertools
+
+    rank_box = {"rank": 0, "world": 2}
+    _mod("detectron2")
+    _mod("detectron2.data")
+    _mod("detectron2.data.samplers", RepeatFactorTrainingSampler=_Unsupported)
+    _mod("detectron2.utils")
+    _mod("detectron2.utils.comm", get_world_size=lambda: rank_box["world"], get_rank=lambda: rank_box["rank"],
+         shared_random_seed=lambda: 0)
+    for name in ("wsovod", "wsovod.data", "wsovod.data.samplers"):
+        if name not in sys.modules:
+            _mod(name)
+    m = load_ref("wsovod.data.samplers.distributed_sampler_multi_dataset",
+                 "wsovod/data/samplers/distributed_sampler_multi_dataset.py")
+    dicts = gen.sampler_dataset_dicts()
+    rf = m.MultiDatasetTrainingSampler.get_repeat_factors(dicts, 3, [1, 1.5, 2], [False] * 3, [False, False, True],
+                                                          0.001, 1.0)
+    arrays = {"repeat_factors": rf}
+    for rank in (0, 1):
+        rank_box["rank"] = rank
+        arrays[f"stream_rank{rank}"] = np.array(list(itertools.islice(iter(
+            m.MultiDatasetTrainingSampler(rf, seed=42)), 400)))
+    rank_box.update(rank=0, world=1)
+    arrays["stream_noshuffle"] = np.array(list(itertools.islice(iter(
+        m.MultiDatasetTrainingSampler(rf, shuffle=False, seed=7)), 300)))
+    save("g11_multi_dataset_sampler", **arrays)
+
+
 def main():
+    if "--only-sampler" in sys.argv:
+        return golden_sampler()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     r = load_reference()
+    if "--only-mixed" in sys.argv:
+        return golden_mixed(r)
 
     # ---------------- G2: RoIPool / ROIAlign (reference C++ op) ----------------
     from tests.util import random_rois
@@ -401,6 +499,9 @@ def main():
     with torch.no_grad():
         daf = model.data_aware_head({"res5": fm}, props)
     save("g9_data_aware", res5=fm, daf=daf, nums=np.array([3, 1, 2]))
+
+    golden_mixed(r)
+    golden_sampler()
 
 
 if __name__ == "__main__":

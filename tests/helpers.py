@@ -32,6 +32,8 @@ def to_inputs(batch):
         nb = len(b["gt_classes"])
         inst = Instances((h, w), gt_boxes=Boxes(b["boxes"][:nb].clone()), gt_classes=b["gt_classes"].clone())
         out.append({"image": b["image"], "instances": inst, "proposals": props, "height": h, "width": w})
+        if "dataset_id" in b:  # mixed-dataset batches carry their source (reference: data/build_multi_dataset.py:270-272)
+            out[-1]["dataset_id"] = b["dataset_id"]
     return out
 
 

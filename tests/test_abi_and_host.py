@@ -123,3 +123,49 @@ def test_synthetic_batch_format():
     bx = p.proposal_boxes.tensor
     assert torch.all(bx[:, 2] <= 800) and torch.all(bx[:, 3] <= 600) and torch.all(bx[:, 2] - bx[:, 0] >= 16)
     assert len(torch.unique(b[0]["instances"].gt_classes)) == 2
+
+
+def test_multi_dataset_sampler_matches_reference_golden():
+    """Index work: the per-rank draw order is bit-identical to the reference's sampler (fixture g11)."""
+    import itertools
+    import os
+
+    import numpy as np
+    from tests.golden import gen
+    from wsovod_amd.data import MultiDatasetTrainingSampler
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_multi_dataset_sampler.npz"))
+    dicts = gen.sampler_dataset_dicts()
+    rf = MultiDatasetTrainingSampler.get_repeat_factors(dicts, 3, [1, 1.5, 2], [False] * 3, [False, False, True],
+                                                        0.001, 1.0)
+    assert np.array_equal(rf.numpy(), g["repeat_factors"])
+    streams = []
+    for rank in (0, 1):
+        s = MultiDatasetTrainingSampler(rf, seed=42, rank=rank, world_size=2)
+        streams.append(list(itertools.islice(iter(s), 400)))
+        assert streams[-1] == g[f"stream_rank{rank}"].tolist()
+    s = MultiDatasetTrainingSampler(rf, shuffle=False, seed=7, rank=0, world_size=1)
+    assert list(itertools.islice(iter(s), 300)) == g["stream_noshuffle"].tolist()
+    # dataset mix follows the ratios: equalised sizes x [1, 1.5, 2]
+    ds = np.array([dicts[i]["dataset_id"] for i in streams[0] + streams[1]])
+    share = np.bincount(ds, minlength=3) / len(ds)
+    assert abs(share[1] / share[0] - 1.5) < 0.2 and abs(share[2] / share[0] - 2.0) < 0.25
+
+
+def test_repeat_factor_and_batcher_semantics():
+    from wsovod_amd.data import MultiDatasetAspectRatioGroupedDataset, repeat_factors_from_category_frequency
+
+    dicts = [{"annotations": [{"category_id": 0}]}] * 99 + [{"annotations": [{"category_id": 0}, {"category_id": 1}]}]
+    rf = repeat_factors_from_category_frequency(dicts, 0.04)
+    assert rf[0] == 1.0 and abs(float(rf[-1]) - 2.0) < 1e-6  # f(1) = 0.01 -> sqrt(0.04 / 0.01)
+    stream = [{"dataset_id": i % 2, "width": 4 + (i % 3), "height": 5, "i": i} for i in range(40)]
+    batches = list(MultiDatasetAspectRatioGroupedDataset(stream, batch_size=[2, 3], num_datasets=2))
+    assert batches
+    seen = []
+    for b in batches:
+        ids = {d["dataset_id"] for d in b}
+        assert len(ids) == 1 and len(b) == [2, 3][ids.pop()]  # one dataset per batch, its own batch size
+        assert len({d["width"] > d["height"] for d in b}) == 1  # one orientation per batch
+        seen += [d["i"] for d in b]
+    assert len(seen) == len(set(seen))
+    assert seen[:2] == [d["i"] for d in batches[0]]

@@ -123,3 +123,67 @@ def test_overlapped_trainer_matches_plain_data_parallel():
         total.backward()
         opt.step()
     torch.testing.assert_close(model.fc.weight.detach(), w0, rtol=1e-5, atol=1e-6)
+
+
+class _TwoSourceModel(nn.Module):
+    """Mixed-dataset stand-in: the batch's dataset id picks one of two heads, the other gets no gradient."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.heads = nn.ModuleList([nn.Linear(8, 4), nn.Linear(8, 6)])
+
+    def forward_frozen(self, batch):
+        return {"x": torch.stack([b["x"] for b in batch]), "source": batch[0]["dataset_id"]}
+
+    def forward_trainable(self, st):
+        return {"loss": self.heads[st["source"]](st["x"]).pow(2).mean()}
+
+
+def _worker_mixed(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import HotPathTrainer
+
+    model = _TwoSourceModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True, reduce_unused=True)
+    tr.broadcast_parameters()
+    g = torch.Generator().manual_seed(77 + rank)
+    xs = [torch.randn(8, generator=g) for _ in range(3)]
+    for it in range(3):
+        src = (rank + it) % 2  # the two ranks always draw from DIFFERENT datasets
+        tr.run_step([{"x": x, "dataset_id": src} for x in xs])
+    tr.flush()
+    q.put((rank, [h.weight.detach().tolist() for h in model.heads], [x.tolist() for x in xs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mixed_dataset_ranks_with_different_sources_stay_in_lockstep():
+    """Ranks whose batches come from different datasets touch different object miners; with
+    reduce_unused the exchange still lines up (no hang) and equals the averaged single-process update."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_mixed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(torch.tensor(a), torch.tensor(b))
+    model = _TwoSourceModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    for it in range(3):
+        opt.zero_grad()
+        total = 0
+        for r in range(2):
+            st = model.forward_frozen([{"x": torch.tensor(x), "dataset_id": (r + it) % 2} for x in res[r][2]])
+            total = total + model.forward_trainable(st)["loss"] / 2
+        total.backward()
+        opt.step()
+    for h, w in zip(model.heads, res[0][1]):
+        torch.testing.assert_close(h.weight.detach(), torch.tensor(w), rtol=1e-5, atol=1e-6)

@@ -242,6 +242,55 @@ def test_other_baseline_configs_match_oracle(gpu, depth, K, D, NR):
         assert pgt["pgt_count"].cpu().tolist() == [len(t["gt_classes"]) for t in tg]
 
 
+def test_mixed_datasets_step_matches_reference_golden(gpu):
+    """SURVEY 8f n3 / BASELINE config 5: batches alternate between datasets with different class counts; the
+    dataset id selects the object miner (shared per family) and the text embeddings of the refinement head.
+    Checked against the REFERENCE's mixed-dataset model (fixture g10) in the fp32 parity mode."""
+    from wsovod_amd.modeling import build_model
+    from wsovod_amd.testing import mixed_datasets_cfg
+
+    g = load_golden("g10_mixed_datasets_step")
+    Ks = (20, 20, 80)
+    cfg = mixed_datasets_cfg(Ks=Ks, precision="fp32", device="cuda:0")
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    assert type(model).__name__ == "GeneralizedRCNN_WSOVOD_MixedDatasets"
+    miners = model.roi_heads.object_miners
+    assert miners[0] is miners[1] and miners[0] is not miners[2]  # voc train/val share, coco has its own
+    assert miners[2].cls.out_features == 80
+    model._std = [float(v) for v in gen.PIXEL_STD]
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gen.mixed_seeded_state(shapes, seed=17)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    for source_id in (2, 0, 2):
+        K, p = Ks[source_id], f"s{source_id}/"
+        batch = gen.seeded_batch(2, 40, K, 256, 352, seed=19 + source_id)
+        for b in batch:
+            b["dataset_id"] = source_id
+        model.zero_grad(set_to_none=True)
+        model.roi_heads.select_source(source_id)
+        losses, cap, pgt = _run(model, batch)
+        assert cap["miner"][0].shape[1] == K and cap["refine"][0].shape[1] == K + 1
+        assert (cap["miner"][0].detach().cpu() - g[p + "mining_scores"]).abs().max() < 1e-3
+        assert (cap["refine"][0].detach().cpu() - g[p + "refine_logits"]).abs().max() < 1e-3
+        for name in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+            torch.testing.assert_close(losses[name].detach().cpu(), g[p + "loss/" + name], rtol=2e-3, atol=1e-5,
+                                       msg=lambda m: f"{name} (source {source_id}): {m}")
+        assert torch.equal(pgt["gt_classes"].cpu(), g[p + "label/gt_classes"])
+        assert torch.equal(pgt["gt_boxes"].cpu(), g[p + "label/gt_boxes"])
+        for k, q in model.named_parameters():
+            if q.requires_grad:
+                ref = float(g[p + "gradnorm/" + k])
+                if ref < 0:
+                    assert q.grad is None, k  # the other family's miner is untouched
+                else:
+                    assert abs(float(q.grad.float().norm()) - ref) <= 5e-3 * ref + 1e-6, (k, float(q.grad.norm()), ref)
+
+
 def R_train(sd, batch, depth, K):
     sdc = {k: v.clone() for k, v in sd.items()}
     return R.train_forward(sdc, batch, depth=depth, num_classes=K, pixel_std=gen.PIXEL_STD)

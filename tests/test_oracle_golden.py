@@ -101,6 +101,37 @@ def test_full_training_step_matches_reference():
         torch.testing.assert_close(gen.strided_sample(gr, 2048), g["gradsample/" + k], rtol=2e-3, atol=1e-7)
 
 
+def test_mixed_datasets_step_matches_reference():
+    """G10: the reference's mixed-dataset meta-arch/ROI heads; dataset 2 (K=80, own miner) and dataset 0
+    (K=20, the shared voc miner), per-call text embeddings."""
+    from wsovod_amd.data import make_class_embeddings
+
+    g = load("g10_mixed_datasets_step")
+    d = np.load(os.path.join(G, "shapes_mixed_r18.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    sd = gen.mixed_seeded_state(shapes, 17)
+    Ks = (20, 20, 80)
+    for source_id in (2, 0):
+        K, p = Ks[source_id], f"s{source_id}/"
+        batch = gen.seeded_batch(2, 40, K, 256, 352, seed=19 + source_id)
+        sdc = {k: v.clone() for k, v in sd.items()}
+        losses, inter = R.train_forward(sdc, batch, depth=18, num_classes=K, pixel_std=gen.PIXEL_STD,
+                                        miner_prefix=f"roi_heads.object_miners.{source_id}.",
+                                        classifier=make_class_embeddings(K, 512, seed=100 + K))
+        assert inter["refine_logits"].shape[1] == K + 1
+        for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+            torch.testing.assert_close(losses[k].detach(), g[p + "loss/" + k], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(inter["mining_scores"].detach(), g[p + "mining_scores"], rtol=1e-4, atol=1e-8)
+        torch.testing.assert_close(inter["refine_logits"].detach(), g[p + "refine_logits"], rtol=1e-4, atol=1e-4)
+        lab = inter["labelled"]
+        assert torch.equal(torch.cat([l["gt_classes"] for l in lab]), g[p + "label/gt_classes"])
+        assert torch.equal(torch.cat([l["gt_boxes"] for l in lab]), g[p + "label/gt_boxes"])
+        # the reference leaves the other family's miner without a gradient (find_unused_parameters)
+        other = 0 if source_id == 2 else 2
+        assert float(g[p + f"gradnorm/roi_heads.object_miners.{other}.cls.weight"]) == -1.0
+        assert float(g[p + f"gradnorm/roi_heads.object_miners.{source_id}.cls.weight"]) > 0
+
+
 def test_r50_bottleneck_backbone_matches_reference():
     g = load("g1_backbone_r50_small")
     d = np.load(os.path.join(G, "shapes_r50_backbone.npz"))

@@ -202,6 +202,12 @@ def add_wsovod_config(cfg):
     _C.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.PROTOTYPE_NUM = 5
     _C.MODEL.MRRP = C({"MRRP_ON": False, "NUM_BRANCH": 3, "BRANCH_DILATIONS": [1, 2, 3],
                        "MRRP_STAGE": "res4", "TEST_BRANCH_IDX": 1})
+    _C.DATASETS.MIXED_DATASETS = C()
+    _C.DATASETS.MIXED_DATASETS.NAMES = ["coco_2017_train"]
+    _C.DATASETS.MIXED_DATASETS.WEIGHT_PATH_TRAINS = ["models/coco_text_embedding_single_prompt.pkl"]
+    _C.DATASETS.MIXED_DATASETS.NUM_CLASSES = [80]
+    _C.DATASETS.MIXED_DATASETS.PROPOSAL_FILES = [""]
+    _C.DATASETS.MIXED_DATASETS.RATIOS = [1]
     _C.TEST.EVAL_TRAIN = False
     _C.VIS_TEST = False
     _C.SOLVER.OPTIMIZER = "SGD"
@@ -236,7 +242,8 @@ def configurable(init_func=None, *, from_config=None):
 def _called_with_cfg(*args, **kwargs):
     if len(args) and isinstance(args[0], CfgNode):
         return True
-    if isinstance(kwargs.pop("cfg", None), CfgNode):
+    # a lone `cfg=` keyword; explicit construction (a subclass forwarding from_config's dict) may carry cfg too
+    if len(kwargs) == 1 and isinstance(kwargs.get("cfg"), CfgNode):
         return True
     return False
 

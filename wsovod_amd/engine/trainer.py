@@ -94,7 +94,11 @@ class HotPathTrainer:
     stalling the step.  Call `flush()` after the last step.
     """
 
-    def __init__(self, model, optimizer, overlap=True):
+    def __init__(self, model, optimizer, overlap=True, reduce_unused=False):
+        """reduce_unused: parameters that received no gradient this step (mixed-dataset mode: the other
+        datasets' object miners) still take part in the exchange with zeros, so that every rank issues the same
+        collectives -- the job `find_unused_parameters=True` does in the reference (engine/defaults.py:146-148)."""
+        self.reduce_unused = reduce_unused
         self.model = model
         self.optimizer = optimizer
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -131,6 +135,8 @@ class HotPathTrainer:
         works = []
         if self.world > 1:
             for p in self.params:
+                if p.grad is None and self.reduce_unused:
+                    p.grad = torch.zeros_like(p)
                 if p.grad is not None:
                     works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
         self._pending = works

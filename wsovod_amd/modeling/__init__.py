@@ -1,4 +1,4 @@
 from .backbone import build_wsl_resnet_backbone  # noqa: F401  (registers)
 from .box_head import DiscriminativeAdaptationNeck  # noqa: F401
-from .roi_heads import WSOVODROIHeads  # noqa: F401
-from .meta_arch import GeneralizedRCNN_WSOVOD, build_model  # noqa: F401
+from .roi_heads import WSOVODMixedDatasetsROIHeads, WSOVODROIHeads  # noqa: F401
+from .meta_arch import GeneralizedRCNN_WSOVOD, GeneralizedRCNN_WSOVOD_MixedDatasets, build_model  # noqa: F401

@@ -70,8 +70,9 @@ class OpenVocabularyClassifier(nn.Module):
         """(Wn (K1,D), WnT (D,K1 padded to 8)) in the compute dtype, L2-normalised, bg row zero."""
         src = classifier if classifier is not None else self.class_weight
         key = (src.data_ptr(), src._version, classifier is not None, append_background, dtype)
-        if self._cache is not None and self._cache[0] == key:
-            return self._cache[1], self._cache[2]
+        hit = self._cache.get(key) if self._cache else None
+        if hit is not None:
+            return hit
         with torch.no_grad():
             rows = (classifier if classifier is not None else self.class_weight.t()).to(torch.float32).contiguous()
             C, D = rows.shape  # (C', D)
@@ -84,7 +85,9 @@ class OpenVocabularyClassifier(nn.Module):
             H.scale_rows(rows, rs, wn)
             wnT = H.transpose_cast(wn, dtype, ld_dst=(K1 + 7) // 8 * 8)  # (D, K1p)
             # transpose_cast(src (K1,D)) -> (D, ld): rows of wnT are embedding dims
-        self._cache = (key, wn, wnT)
+        if self._cache is None or len(self._cache) >= 8:  # one entry per dataset in mixed-dataset mode
+            self._cache = {}
+        self._cache[key] = (wn, wnT)
         return wn, wnT
 
     def forward(self, x, classifier=None, append_background=False):

@@ -21,7 +21,7 @@ from .class_heads import DataAwareFeaturesHead
 from .fast_rcnn_open_vocabulary import segment_offsets
 from .roi_heads import build_roi_heads
 
-__all__ = ["GeneralizedRCNN_WSOVOD", "build_model", "build_backbone"]
+__all__ = ["GeneralizedRCNN_WSOVOD", "GeneralizedRCNN_WSOVOD_MixedDatasets", "build_model", "build_backbone"]
 
 
 def build_backbone(cfg, input_shape=None):
@@ -145,6 +145,7 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         step's gradient all-reduce is still in flight (wsovod_amd/engine/trainer.py)."""
         canvas, sizes_t, sizes = self._canvas(batched_inputs)
         st = {"canvas": canvas, "sizes": sizes, "gt_instances": None, "image_level_gt": None}
+        self._select_source(batched_inputs, st)
         if "instances" in batched_inputs[0]:
             st["image_level_gt"] = self._image_level_gt(batched_inputs)
             # With the image-level labels already extracted on the host, the heads never read the dataset
@@ -159,13 +160,20 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         st["pooled"] = self.roi_heads.pool_features(features, st["proposals"])
         return st
 
+    def _heads_kwargs(self, st):
+        return {}
+
+    def _select_source(self, batched_inputs, st):
+        pass
+
     def forward_trainable(self, st):
         """The trainable remainder: data-aware MLP, neck, object mining, refinement, losses."""
         self.roi_heads.image_level_gt = st["image_level_gt"]
         daf = self.data_aware_head.from_stats(st["gaps"]) if self.data_aware_head is not None else None
         _, detector_losses = self.roi_heads(ImageList(st["canvas"], st["sizes"]), st["features"], st["proposals"],
                                             daf, st["gt_instances"], append_background=True,
-                                            loaded_proposals=st["proposals"], pooled=st["pooled"])
+                                            loaded_proposals=st["proposals"], pooled=st["pooled"],
+                                            **self._heads_kwargs(st))
         losses = {}
         losses.update(detector_losses)
         return losses
@@ -198,3 +206,39 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             width = input_per_image.get("width", image_size[1])
             processed_results.append({"instances": detector_postprocess(results_per_image, height, width)})
         return processed_results
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN_WSOVOD_MixedDatasets(GeneralizedRCNN_WSOVOD):
+    """meta_arch/rcnn_wsovod_mixed_datasets.py:28-367: a batch comes from ONE dataset (`dataset_id`); its class
+    count selects the object miner and its CLIP text embeddings are handed to the refinement head per call."""
+
+    @configurable
+    def __init__(self, *, classifier_train=(), classifier_test=None, **kwargs):
+        super().__init__(**kwargs)
+        self.classifier_train = list(classifier_train)
+        self.classifier = classifier_test
+
+    @property
+    def classifier_test(self):  # the reference's attribute name (rcnn_wsovod_mixed_datasets.py:81,319-331)
+        return self.classifier
+
+    @classmethod
+    def from_config(cls, cfg):
+        ret = super().from_config(cfg)
+
+        def load(path):
+            return torch.as_tensor(np.load(path, encoding="bytes", allow_pickle=True)).to(torch.float32).contiguous().to(
+                cfg.MODEL.DEVICE)
+
+        ret["classifier_train"] = [load(p) for p in cfg.DATASETS.MIXED_DATASETS.WEIGHT_PATH_TRAINS]
+        ret["classifier_test"] = load(cfg.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_PATH_TEST)
+        return ret
+
+    def _select_source(self, batched_inputs, st):
+        st["source_id"] = int(batched_inputs[0].get("dataset_id", 0))
+        if self.training:
+            self.roi_heads.select_source(st["source_id"])
+
+    def _heads_kwargs(self, st):
+        return {"classifier": self.classifier_train[st["source_id"]], "source_id": st["source_id"]}

@@ -181,6 +181,11 @@ class WSOVODROIHeads(ROIHeads):
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances],
                 data_aware_features=None, targets: Optional[List[Instances]] = None, classifier=None,
                 append_background=True, file_names=None, loaded_proposals=None, pooled=None):
+        return self._forward_impl(images, features, proposals, data_aware_features, targets, classifier,
+                                  append_background, pooled)
+
+    def _forward_impl(self, images, features, proposals, data_aware_features, targets, classifier, append_background,
+                      pooled):
         if self.training:
             assert targets, "'targets' argument is required during training"
             if self.image_level_gt is not None:
@@ -255,7 +260,7 @@ class WSOVODROIHeads(ROIHeads):
             targets, proposals_k = self.mine_and_label(k, prev_pred_scores, prev_pred_boxes, proposals, seg, nums)
             predictions_k = self.box_refinery[k](box_features, classifier=classifier,
                                                  append_background=append_background)
-            losses.update(self.box_refinery[k].losses(predictions_k, proposals_k))
+            losses.update(self.box_refinery[k].losses(predictions_k, proposals_k, self.num_classes))
             if k + 1 < self.refine_K:
                 prev_pred_scores = torch.softmax(predictions_k[0].detach(), dim=-1)
                 prev_pred_boxes = torch.cat(self.box_refinery[k].predict_boxes(
@@ -295,3 +300,56 @@ class WSOVODROIHeads(ROIHeads):
             proposals_k.append(q)
             start += n
         return o, proposals_k
+
+
+@ROI_HEADS_REGISTRY.register()
+class WSOVODMixedDatasetsROIHeads(WSOVODROIHeads):
+    """Mixed-dataset variant (reference roi_heads.py:1860-3324): one object miner per dataset
+    family (`object_miners[source_id]`, voc/coco/lvis share by name), the class count and the text-embedding
+    `classifier` of the refinement head chosen per call.  Everything else is the single-dataset path."""
+
+    @configurable
+    def __init__(self, *, object_miners: nn.ModuleList, num_classes_list: List[int], **kwargs):
+        self._source_id = 0
+        super().__init__(object_miner=None, **kwargs)
+        self.object_miners = object_miners
+        self.num_classes_list = list(num_classes_list)
+
+    @property
+    def object_miner(self):
+        return self.object_miners[self._source_id]
+
+    @object_miner.setter
+    def object_miner(self, value):  # the base class assigns None; the active miner is selected per call
+        pass
+
+    @classmethod
+    def _init_box_head(cls, cfg, input_shape):
+        ret = super()._init_box_head(cfg, input_shape)
+        box_head = ret["box_head"]
+        keys_map = {}
+        for name in cfg.DATASETS.MIXED_DATASETS.NAMES:
+            for fam in ("voc", "coco", "lvis"):
+                if fam in name:
+                    keys_map[name] = fam
+        miner_dict = {}
+        for name, num_classes in zip(cfg.DATASETS.MIXED_DATASETS.NAMES, cfg.DATASETS.MIXED_DATASETS.NUM_CLASSES):
+            k = keys_map[name]
+            if k not in miner_dict:
+                miner_dict[k] = ObjectMiningOutputLayers(cfg, box_head.output_shape, class_head=None,
+                                                         num_classes=num_classes)
+        ret.pop("object_miner")
+        ret["object_miners"] = nn.ModuleList([miner_dict[keys_map[n]] for n in cfg.DATASETS.MIXED_DATASETS.NAMES])
+        ret["num_classes_list"] = cfg.DATASETS.MIXED_DATASETS.NUM_CLASSES
+        return ret
+
+    def select_source(self, source_id):
+        self._source_id = int(source_id)
+        self.num_classes = self.num_classes_list[self._source_id]
+
+    def forward(self, images, features, proposals, data_aware_features=None, targets=None, classifier=None,
+                source_id=0, append_background=True, file_names=None, loaded_proposals=None, pooled=None):
+        if self.training:
+            self.select_source(source_id)
+        return self._forward_impl(images, features, proposals, data_aware_features, targets, classifier,
+                                  append_background, pooled)

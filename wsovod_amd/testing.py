@@ -34,6 +34,26 @@ def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", devi
     return cfg
 
 
+def mixed_datasets_cfg(names=("voc_2007_train", "voc_2007_val", "coco_2017_train"), Ks=(20, 20, 80), D=512, **kw):
+    """The mixed-dataset variant (BASELINE config 5): one text-embedding file per dataset,
+    object miners shared per dataset family."""
+    cfg = hot_path_cfg(K=max(Ks), D=D, **kw)
+    cfg.merge_from_file(os.path.join(_CONFIG_DIR, "MixedDatasets_WSOVOD_WSR_18_DC5_1x.yaml"))
+    tmp = tempfile.mkdtemp(prefix="wsovod_emb_")
+    paths = []
+    for i, K in enumerate(Ks):
+        paths.append(os.path.join(tmp, f"emb{i}_{K}x{D}.pkl"))
+        with open(paths[-1], "wb") as f:
+            pickle.dump(make_class_embeddings(K, D, seed=100 + K), f)
+    cfg.merge_from_list([
+        "DATASETS.MIXED_DATASETS.NAMES", list(names),
+        "DATASETS.MIXED_DATASETS.NUM_CLASSES", list(Ks),
+        "DATASETS.MIXED_DATASETS.WEIGHT_PATH_TRAINS", paths,
+        "MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.WEIGHT_PATH_TEST", paths[-1],
+    ])
+    return cfg
+
+
 def build_hot_path_model(seed=0, calibrate_synthetic=True, **kw):
     """Random-init model of the named architecture (reference initialisers).  With
     `calibrate_synthetic` the frozen stem's first FrozenBN scale is set to 1/64 so that the random
