@@ -288,7 +288,50 @@ def test_mixed_datasets_step_matches_reference_golden(gpu):
                 if ref < 0:
                     assert q.grad is None, k  # the other family's miner is untouched
                 else:
-                    assert abs(float(q.grad.float().norm()) - ref) <= 5e-3 * ref + 1e-6, (k, float(q.grad.norm()), ref)
+                    got = float(q.grad.double().norm())
+                    assert abs(got - ref) <= 2e-3 * ref + 1e-6, (k, got, ref)
+
+
+def test_mixed_large_vocabulary_matches_oracle(gpu):
+    """BASELINE config 5's vocabulary scale: an LVIS-sized dataset (K = 1203 text embeddings, its own miner)
+    next to VOC.  The only place where the region x text cos-sim GEMM and the K-wide MIL / CE kernels see a
+    four-digit class count; fp32 parity mode against the oracle on identical seeded parameters."""
+    from wsovod_amd.modeling import build_model
+    from wsovod_amd.testing import mixed_datasets_cfg
+
+    Ks = (20, 1203)
+    cfg = mixed_datasets_cfg(names=("voc_2007_train", "lvis_v1_train"), Ks=Ks, precision="fp32", device="cuda:0")
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model._std = [float(v) for v in gen.PIXEL_STD]
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gen.seeded_state(shapes, seed=23)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    for source_id in (1, 0):
+        K = Ks[source_id]
+        batch = gen.seeded_batch(2, 48, K, 256, 352, seed=29 + source_id)
+        for b in batch:
+            b["dataset_id"] = source_id
+        sdc = {k: v.clone() for k, v in sd.items()}
+        ref_losses, inter = R.train_forward(sdc, batch, depth=18, num_classes=K, pixel_std=gen.PIXEL_STD,
+                                            miner_prefix=f"roi_heads.object_miners.{source_id}.",
+                                            classifier=model.classifier_train[source_id].cpu())
+        model.zero_grad(set_to_none=True)
+        model.roi_heads.select_source(source_id)
+        losses, cap, pgt = _run(model, batch)
+        assert cap["miner"][0].shape[1] == K and cap["refine"][0].shape[1] == K + 1
+        assert (cap["miner"][0].detach().cpu() - inter["mining_scores"]).abs().max() < 1e-3
+        assert (cap["refine"][0].detach().cpu() - inter["refine_logits"]).abs().max() < 1e-3
+        for name, v in ref_losses.items():
+            torch.testing.assert_close(losses[name].detach().cpu(), v.detach(), rtol=2e-3, atol=1e-5,
+                                       msg=lambda m: f"{name} (source {source_id}): {m}")
+        lab = inter["labelled"]
+        assert torch.equal(pgt["gt_classes"].cpu(), torch.cat([l["gt_classes"] for l in lab]))
+        assert torch.equal(pgt["gt_boxes"].cpu(), torch.cat([l["gt_boxes"] for l in lab]))
 
 
 def R_train(sd, batch, depth, K):
