@@ -157,7 +157,7 @@ def test_overlapped_trainer_equals_plain_run_step(gpu):
 
     batch = to_inputs(gen.seeded_batch(2, 32, 20, 256, 352, seed=6))
     outs = []
-    for mode in ("plain", "overlap"):
+    for mode in ("plain", "overlap", "rccl"):
         cfg, model, sd = build_seeded_hip_model("fp32")
         cfg.SOLVER.BASE_LR = 1e-4
         opt = build_optimizer(cfg, model)
@@ -165,14 +165,27 @@ def test_overlapped_trainer_equals_plain_run_step(gpu):
             for it in range(3):
                 run_step(model, opt, batch, it=it)
         else:
-            tr = HotPathTrainer(model, opt)
-            for it in range(3):
-                tr.run_step(batch)
-            tr.flush()
+            if mode == "rccl":  # the exchange through a real RCCL communicator (one rank: the sum is the identity)
+                import os
+                import torch.distributed as dist
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            try:
+                tr = HotPathTrainer(model, opt)
+                assert tr.exchange == (mode == "rccl")
+                tr.broadcast_parameters()
+                for it in range(3):
+                    tr.run_step(batch)
+                tr.flush()
+                torch.cuda.synchronize()
+            finally:
+                if mode == "rccl":
+                    dist.destroy_process_group()
         torch.cuda.synchronize()
         outs.append({k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
-    for k in outs[0]:
-        torch.testing.assert_close(outs[0][k], outs[1][k], rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
+    for other in outs[1:]:
+        for k in outs[0]:
+            torch.testing.assert_close(outs[0][k], other[k], rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])

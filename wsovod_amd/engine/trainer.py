@@ -102,6 +102,7 @@ class HotPathTrainer:
         self.model = model
         self.optimizer = optimizer
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = dist.is_initialized()  # a 1-rank group still goes through RCCL (exercised by the GPU tests)
         self.overlap = overlap
         self._pending = None  # list of (work, param) of the in-flight exchange
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -109,7 +110,7 @@ class HotPathTrainer:
             optimizer.grad_scale = 1.0 / self.world
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.exchange:
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, src)
 
@@ -133,7 +134,7 @@ class HotPathTrainer:
         loss_dict = self.model.forward_trainable(st)
         sum(loss_dict.values()).backward()
         works = []
-        if self.world > 1:
+        if self.exchange:
             for p in self.params:
                 if p.grad is None and self.reduce_unused:
                     p.grad = torch.zeros_like(p)
