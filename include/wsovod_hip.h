@@ -245,6 +245,34 @@ int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, cons
                                    float beta, int weighted, float* dpred, float* accum2, float* loss,
                                    wsovod_stream_t stream);
 
+/* Greedy non-maximum suppression over G independent segments of boxes that are already sorted by
+ * descending score inside each segment.  Replaces torchvision.ops.nms / batched_nms (un-vendored; SURVEY
+ * Appendix A) at the reference's call sites: find_top_rpn_proposals (proposal_utils.py:123; one segment per
+ * image, idxs = level) and fast_rcnn_inference_single_image (fast_rcnn_open_vocabulary.py:176; one segment per
+ * class = the exact per-class form of batched_nms).  A box suppresses a later one of its segment when
+ * inter / (area_a + area_b - inter) > iou_threshold, all in fp32 in that operation order (bit-exact keep sets).
+ *   boxes       : (N,4) f32 xyxy, 16-byte aligned; segment g owns rows [seg_offsets[g], seg_offsets[g+1])
+ *   valid       : optional (N) bytes; a zero marks a box that was filtered out (never kept, never suppresses)
+ *   max_seg_len : longest segment (host value; sizes the bitmap, <= 16384)
+ *   max_keep    : stop after this many kept boxes per segment (<= 0: no limit)
+ *   workspace   : N * max(1, ceil(max_seg_len / 64)) 64-bit words
+ *   keep_idx    : (N) int32; segment g's kept positions (relative to its start, ascending = by score) are
+ *                 written to keep_idx[seg_offsets[g] ...]; keep_count : (G) int32 how many. */
+int wsovod_nms_segments(const float* boxes, const int* seg_offsets, const unsigned char* valid, int G, int N,
+                        int max_seg_len, float iou_threshold, int max_keep, unsigned long long* workspace,
+                        int* keep_idx, int* keep_count, wsovod_stream_t stream);
+
+/* RPN proposal decode for the selected anchors of every image: Box2BoxTransform.apply_deltas (detectron2,
+ * un-vendored; called from WSOVODRPN_V2._decode_proposals, rpn.py:495-515), then Boxes.clip
+ * and the nonempty(threshold = min_size) test of find_top_rpn_proposals (proposal_utils.py:101-121).
+ *   anchors (A,4) f32; deltas (num_images, A, 4) f32; index (num_images*per_image) int64 anchor ids per image
+ *   (NULL: the first per_image anchors); image_sizes (num_images,2) f32 (h,w) on the device;
+ *   weights: HOST array of the 4 Box2BoxTransform weights; boxes (num_images*per_image,4) out;
+ *   valid (num_images*per_image) out: finite before clipping and both sides > min_size after. */
+int wsovod_rpn_decode(const float* anchors, const float* deltas, const long long* index, int num_images, int per_image,
+                      long long anchors_per_image, const float* image_sizes, const float* weights, float scale_clamp,
+                      float min_size, float* boxes, unsigned char* valid, wsovod_stream_t stream);
+
 /* Pseudo-ground-truth mining + proposal labelling, no grad.  Replaces
  * WSOVODROIHeads.get_pgt_top_k (roi_heads.py:1043-1343; top_k=1, sam=None) followed by
  * label_and_sample_proposals_wsl (roi_heads.py:1722-1825) with Matcher([thr],[0,1]) when every

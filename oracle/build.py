@@ -1,6 +1,6 @@
 """ORACLE build recipe -- test infrastructure only.
 
-* `build_c()` compiles oracle/roi_ops_ref.c (our plain-C restatement) with gcc into
+* `build_c()` compiles oracle/roi_ops_ref.c + oracle/det_ops_ref.c (our plain-C restatements) with gcc into
   oracle/_build/liboracle_roi.so.
 * `build_ref()` compiles the REFERENCE's own CPU RoIPool from its sources where they lie
   under /root/reference (never copied) plus our C-ABI shim into oracle/_ref/libref_roi_pool.so.
@@ -23,10 +23,10 @@ def _stale(out, srcs):
 
 
 def build_c(force=False):
-    src = os.path.join(HERE, "roi_ops_ref.c")
+    srcs = [os.path.join(HERE, "roi_ops_ref.c"), os.path.join(HERE, "det_ops_ref.c")]
     os.makedirs(os.path.dirname(C_LIB), exist_ok=True)
-    if force or _stale(C_LIB, [src]):
-        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", C_LIB, src, "-lm"],
+    if force or _stale(C_LIB, srcs):
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", C_LIB] + srcs + ["-lm"],
                        check=True)
     return C_LIB
 

@@ -119,3 +119,20 @@ def ref_roi_pool_backward(grad, rois, argmax, spatial_scale, input_shape):
         _reflib().ref_roi_pool_backward(_p(grad), _p(rois), _p(argmax.contiguous()), R,
                                         C.c_float(spatial_scale), ph, pw, N, Cc, H, W, _p(gi))
     return gi
+
+
+def nms_segments(boxes, seg_offsets, iou_threshold, max_keep=0, valid=None):
+    """oracle/det_ops_ref.c: greedy NMS per segment over score-sorted boxes.
+    -> list (per segment) of int64 tensors of kept positions relative to the segment start."""
+    boxes = boxes.detach().to(torch.float32).contiguous()
+    seg = torch.as_tensor(seg_offsets, dtype=torch.int32).contiguous()
+    G, N = seg.numel() - 1, boxes.shape[0]
+    keep = torch.zeros(max(N, 1), dtype=torch.int32)
+    count = torch.zeros(max(G, 1), dtype=torch.int32)
+    v = None
+    if valid is not None:
+        v = valid.detach().to(torch.uint8).contiguous()
+    if G:
+        _clib().nms_segments(_p(boxes), _p(seg), _p(v) if v is not None else None, G, C.c_float(iou_threshold),
+                             int(max_keep), _p(keep), _p(count))
+    return [keep[int(seg[g]):int(seg[g]) + int(count[g])].to(torch.int64) for g in range(G)]

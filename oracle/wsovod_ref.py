@@ -196,6 +196,82 @@ def box2box_get_deltas(src, tgt, weights=(10.0, 10.0, 5.0, 5.0)):
                        dim=1)
 
 
+SCALE_CLAMP = math.log(1000.0 / 16)  # detectron2 box_regression._DEFAULT_SCALE_CLAMP
+
+
+def box2box_apply_deltas(deltas, boxes, weights=(10.0, 10.0, 5.0, 5.0), scale_clamp=SCALE_CLAMP):
+    """detectron2 Box2BoxTransform.apply_deltas (un-vendored)."""
+    deltas = deltas.float()
+    boxes = boxes.to(deltas.dtype)
+    widths = boxes[:, 2] - boxes[:, 0]
+    heights = boxes[:, 3] - boxes[:, 1]
+    ctr_x = boxes[:, 0] + 0.5 * widths
+    ctr_y = boxes[:, 1] + 0.5 * heights
+    wx, wy, ww, wh = weights
+    dx = deltas[:, 0::4] / wx
+    dy = deltas[:, 1::4] / wy
+    dw = torch.clamp(deltas[:, 2::4] / ww, max=scale_clamp)
+    dh = torch.clamp(deltas[:, 3::4] / wh, max=scale_clamp)
+    pred_ctr_x = dx * widths[:, None] + ctr_x[:, None]
+    pred_ctr_y = dy * heights[:, None] + ctr_y[:, None]
+    pred_w = torch.exp(dw) * widths[:, None]
+    pred_h = torch.exp(dh) * heights[:, None]
+    x1 = pred_ctr_x - 0.5 * pred_w
+    y1 = pred_ctr_y - 0.5 * pred_h
+    x2 = pred_ctr_x + 0.5 * pred_w
+    y2 = pred_ctr_y + 0.5 * pred_h
+    return torch.stack((x1, y1, x2, y2), dim=-1).reshape(deltas.shape)
+
+
+def rpn_decode_clip(anchors, deltas, image_size, weights=(1.0, 1.0, 1.0, 1.0), min_size=0.0):
+    """rpn.py:495-515 (_decode_proposals) + proposal_utils.py:101-121 (finite check, Boxes.clip,
+    nonempty(threshold=min_size)) for one image.  -> (clipped boxes, keep flags)."""
+    boxes = box2box_apply_deltas(deltas, anchors, weights)
+    finite = torch.isfinite(boxes).all(dim=1)
+    h, w = image_size
+    boxes = boxes.clone()
+    boxes[:, 0::2] = boxes[:, 0::2].clamp(min=0, max=w)
+    boxes[:, 1::2] = boxes[:, 1::2].clamp(min=0, max=h)
+    keep = finite & ((boxes[:, 2] - boxes[:, 0]) > min_size) & ((boxes[:, 3] - boxes[:, 1]) > min_size)
+    return boxes, keep
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """detectron2.layers.batched_nms -> torchvision.ops.batched_nms (un-vendored): per-category greedy NMS,
+    result sorted by descending score (oracle/det_ops_ref.c does the suppression)."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    by_score = scores.argsort(descending=True, stable=True)
+    order = by_score[idxs[by_score].argsort(stable=True)]
+    cats, counts = torch.unique_consecutive(idxs[order], return_counts=True)
+    offs = [0] + counts.cumsum(0).tolist()
+    keeps = roi_ops.nms_segments(boxes.float()[order], offs, iou_threshold)
+    kept = torch.cat([order[offs[g] + k] for g, k in enumerate(keeps)])
+    return kept[scores[kept].argsort(descending=True, stable=True)]
+
+
+def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    """fast_rcnn_open_vocabulary.py:149-217 -> (boxes, scores, classes, proposal index) of the detections."""
+    valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+    pred_inds = torch.arange(scores.size(0))[valid]
+    boxes, scores = boxes[valid], scores[valid]
+    scores = scores[:, :-1]
+    nreg = boxes.shape[1] // 4
+    boxes = boxes.reshape(-1, 4).clone()
+    h, w = image_shape
+    boxes[:, 0::2] = boxes[:, 0::2].clamp(min=0, max=w)
+    boxes[:, 1::2] = boxes[:, 1::2].clamp(min=0, max=h)
+    boxes = boxes.view(-1, nreg, 4)
+    filter_mask = scores > score_thresh
+    filter_inds = filter_mask.nonzero()
+    boxes = boxes[filter_inds[:, 0], 0] if nreg == 1 else boxes[filter_mask]
+    scores = scores[filter_mask]
+    keep = batched_nms(boxes, scores, filter_inds[:, 1], nms_thresh)
+    if topk_per_image >= 0:
+        keep = keep[:topk_per_image]
+    return boxes[keep], scores[keep], filter_inds[keep, 1], pred_inds[filter_inds[keep, 0]]
+
+
 def refinement_losses(logits, deltas, gt_classes, gt_weights, proposal_boxes, gt_boxes, num_classes,
                       bbox_weights=(10.0, 10.0, 5.0, 5.0), beta=0.0, cross_entropy_weighted=True,
                       box_loss_type="smooth_l1_weighted"):

@@ -144,6 +144,26 @@ def test_eval_inference_runs(gpu):
     assert inst.pred_boxes.tensor.shape[1] == 4 and len(inst.scores) == len(inst.pred_classes)
 
 
+def test_eval_tail_matches_oracle(gpu):
+    """Threshold + per-class NMS + top-k (n2): given the HIP model's own per-proposal scores and boxes the
+    detections are index work -- the same boxes / classes / proposal ids as the oracle tail, in the same order."""
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    model.eval()
+    batch = gen.seeded_batch(3, 200, 20, 256, 352, seed=15)
+    results, all_scores, all_boxes = model.inference(to_inputs(batch), do_postprocess=False,
+                                                     classifier=torch.randn(20, 512, device=gpu))
+    pred = model.roi_heads.box_refinery[-1]
+    checked = 0
+    for b, res, sc, bx in zip(batch, results, all_scores, all_boxes):
+        rb, rs, rc, ri = R.fast_rcnn_inference_single_image(bx[0].cpu(), sc[0].cpu(), tuple(b["image"].shape[-2:]),
+                                                            pred.test_score_thresh, pred.test_nms_thresh,
+                                                            pred.test_topk_per_image)
+        assert torch.equal(res.pred_classes.cpu(), rc) and torch.equal(res.pred_inds.cpu(), ri)
+        assert torch.equal(res.pred_boxes.tensor.cpu(), rb) and torch.equal(res.scores.cpu(), rs)
+        checked += len(rc)
+    assert checked > 0
+
+
 def test_product_path_fails_loudly_without_gpu_tensors(gpu):
     from wsovod_amd.layers import hip_ops
 

@@ -498,3 +498,43 @@ def data_aware_backward(ddaf, gap, W2, E, h1, h2):
                                            ptr(h2), P, ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(dE), ptr(scratch), stream()),
           "data_aware_backward")
     return dW1, db1, dW2, db2, dE
+
+
+def nms_segments(boxes, seg_offsets, max_seg_len, iou_threshold, max_keep=0, valid=None):
+    """Greedy NMS per segment over boxes sorted by descending score inside each segment.
+    boxes (N,4) f32; seg_offsets (G+1) int32 on the device; max_seg_len: host int.  Returns
+    (keep_idx (N) int32 -- segment g's kept positions, relative to its start, at [seg_offsets[g], ...),
+     keep_count (G) int32)."""
+    require_gpu(boxes, seg_offsets)
+    boxes = boxes.contiguous()
+    assert boxes.dtype == torch.float32 and seg_offsets.dtype == torch.int32
+    N, G = boxes.shape[0], seg_offsets.numel() - 1
+    W = max(1, (int(max_seg_len) + 63) // 64)
+    ws = torch.empty((max(N, 1) * W,), dtype=torch.int64, device=boxes.device)
+    keep_idx = torch.empty((max(N, 1),), dtype=torch.int32, device=boxes.device)
+    keep_count = torch.zeros((max(G, 1),), dtype=torch.int32, device=boxes.device)
+    if valid is not None:
+        valid = valid.contiguous().view(torch.uint8)
+    check(lib().wsovod_nms_segments(ptr(boxes), ptr(seg_offsets), ptr(valid), G, N, int(max_seg_len),
+                                    C.c_float(iou_threshold), int(max_keep), ptr(ws), ptr(keep_idx), ptr(keep_count),
+                                    stream()), "nms_segments")
+    return keep_idx[:N], keep_count[:G]
+
+
+def rpn_decode(anchors, deltas, index, image_sizes, weights, scale_clamp, min_size):
+    """anchors (A,4), deltas (B,A,4), index (B,k) int64 or None, image_sizes (B,2) f32 device tensor (h,w).
+    Returns (boxes (B,k,4) clipped, valid (B,k) bool)."""
+    require_gpu(anchors, deltas, image_sizes)
+    anchors, deltas = anchors.contiguous(), deltas.contiguous()
+    B, A = deltas.shape[0], deltas.shape[1]
+    k = index.shape[1] if index is not None else A
+    if index is not None:
+        index = index.contiguous()
+        assert index.dtype == torch.int64
+    boxes = torch.empty((B, k, 4), dtype=torch.float32, device=deltas.device)
+    valid = torch.empty((B, k), dtype=torch.uint8, device=deltas.device)
+    w = (C.c_float * 4)(*[float(v) for v in weights])
+    check(lib().wsovod_rpn_decode(ptr(anchors), ptr(deltas), ptr(index), B, k, A, ptr(image_sizes), w,
+                                  C.c_float(scale_clamp), C.c_float(min_size), ptr(boxes), ptr(valid), stream()),
+          "rpn_decode")
+    return boxes, valid.bool()

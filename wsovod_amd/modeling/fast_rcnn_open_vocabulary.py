@@ -32,56 +32,56 @@ def segment_offsets(nums, device):
     return const_tensor(offs, torch.int32, device)
 
 
-def _nms(boxes, scores, thr):
-    """Plain greedy NMS (eval tail only; 'next' row n2)."""
-    order = scores.argsort(descending=True)
-    boxes = boxes[order]
-    keep = []
-    suppressed = torch.zeros(len(order), dtype=torch.bool, device=boxes.device)
-    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
-    for i in range(len(order)):
-        if suppressed[i]:
-            continue
-        keep.append(i)
-        lt = torch.max(boxes[i, :2], boxes[i + 1:, :2])
-        rb = torch.min(boxes[i, 2:], boxes[i + 1:, 2:])
-        wh = (rb - lt).clamp(min=0)
-        inter = wh[:, 0] * wh[:, 1]
-        iou = inter / (area[i] + area[i + 1:] - inter)
-        suppressed[i + 1:] |= iou > thr
-    return order[torch.tensor(keep, dtype=torch.long, device=boxes.device)]
-
-
 def batched_nms(boxes, scores, idxs, iou_threshold):
+    """detectron2.layers.batched_nms (-> torchvision): NMS inside each category `idxs`, result sorted by
+    descending score.  Boxes are ordered by (category, score), each category becomes one segment of the HIP
+    segment-NMS kernel (the exact per-category form; torchvision's coordinate-offset shortcut approximates it)."""
+    from ..layers import hip_ops as H
+
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
-    max_coordinate = boxes.max()
-    offsets = idxs.to(boxes) * (max_coordinate + 1)
-    return _nms(boxes.float() + offsets[:, None], scores, iou_threshold)
+    by_score = scores.argsort(descending=True, stable=True)
+    order = by_score[idxs[by_score].argsort(stable=True)]
+    _, counts = torch.unique_consecutive(idxs[order], return_counts=True)
+    seg = torch.zeros(counts.numel() + 1, dtype=torch.int32, device=boxes.device)
+    seg[1:] = counts.cumsum(0)
+    keep_rel, keep_count = H.nms_segments(boxes.float()[order], seg, int(counts.max()), float(iou_threshold))
+    pos = torch.arange(order.numel(), device=boxes.device, dtype=torch.int32)
+    start = torch.repeat_interleave(seg[:-1], counts)  # segment start of every slot
+    kept_slots = pos - start < torch.repeat_interleave(keep_count, counts)  # slot s of segment g holds its s-th keep
+    kept = order[(start + keep_rel)[kept_slots].long()]
+    return kept[scores[kept].argsort(descending=True, stable=True)]
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
-    all_scores, all_boxes = scores.clone(), boxes.clone()
+    """fast_rcnn_open_vocabulary.py:149-217: finite filter, clip, score threshold, per-class NMS, top-k.
+    Index plumbing in torch on the device; the suppression itself is the HIP segment-NMS kernel."""
+    all_scores, all_boxes = scores.clone().unsqueeze(0), boxes.clone().unsqueeze(0)
+    pred_inds = torch.arange(scores.size(0), device=scores.device, dtype=torch.long).unsqueeze(1).repeat(
+        1, scores.size(1))
     valid_mask = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
     if not valid_mask.all():
-        boxes, scores = boxes[valid_mask], scores[valid_mask]
+        boxes, scores, pred_inds = boxes[valid_mask], scores[valid_mask], pred_inds[valid_mask]
     scores = scores[:, :-1]
     num_bbox_reg_classes = boxes.shape[1] // 4
     boxes = Boxes(boxes.reshape(-1, 4))
     boxes.clip(image_shape)
     boxes = boxes.tensor.view(-1, num_bbox_reg_classes, 4)
+    pred_inds = pred_inds[:, :-1]
     filter_mask = scores > score_thresh
     filter_inds = filter_mask.nonzero()
     boxes = boxes[filter_inds[:, 0], 0] if num_bbox_reg_classes == 1 else boxes[filter_mask]
     scores = scores[filter_mask]
+    pred_inds = pred_inds[filter_mask]
     keep = batched_nms(boxes, scores, filter_inds[:, 1], nms_thresh)
     if topk_per_image >= 0:
         keep = keep[:topk_per_image]
-    boxes, scores, filter_inds = boxes[keep], scores[keep], filter_inds[keep]
+    boxes, scores, filter_inds, pred_inds = boxes[keep], scores[keep], filter_inds[keep], pred_inds[keep]
     result = Instances(image_shape)
     result.pred_boxes = Boxes(boxes)
     result.scores = scores
     result.pred_classes = filter_inds[:, 1]
+    result.pred_inds = pred_inds
     return result, filter_inds[:, 0], all_scores, all_boxes
 
 
