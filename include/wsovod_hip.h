@@ -273,6 +273,13 @@ int wsovod_rpn_decode(const float* anchors, const float* deltas, const long long
                       long long anchors_per_image, const float* image_sizes, const float* weights, float scale_clamp,
                       float min_size, float* boxes, unsigned char* valid, wsovod_stream_t stream);
 
+/* im2col rows of selected output pixels of an NHWC convolution input (weight gradient of the RPN's 3x3 conv,
+ * detectron2 StandardRPNHead.conv, un-vendored; only the sampled anchors of rpn.py:217-233 carry a loss).
+ *   x (n_img,H,W,Cin) NHWC in `dtype`; rows (n_rows) int64 flat output-pixel ids (img*Ho*Wo + ho*Wo + wo), a
+ *   negative id yields a zero row; out (n_rows, KH*KW*Cin) in `dtype`, tap-major then channel. */
+int wsovod_im2col_rows(const void* x, int dtype, const long long* rows, int n_rows, int H, int W, int Cin, int Ho, int Wo,
+                       int KH, int KW, int stride, int pad, int dil, void* out, wsovod_stream_t stream);
+
 /* Pseudo-ground-truth mining + proposal labelling, no grad.  Replaces
  * WSOVODROIHeads.get_pgt_top_k (roi_heads.py:1043-1343; top_k=1, sam=None) followed by
  * label_and_sample_proposals_wsl (roi_heads.py:1722-1825) with Matcher([thr],[0,1]) when every

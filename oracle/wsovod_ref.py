@@ -369,12 +369,96 @@ def get_image_level_gt(gt_classes_list, num_classes):
 
 
 # ----------------------------------------------------------------------------------------
+# RPN branch: proposal_generator/rpn.py, proposal_utils.py, detectron2 pieces restated
+# ----------------------------------------------------------------------------------------
+def anchor_grid(h, w, stride=8, sizes=(32, 64, 128, 256, 512, 768), aspect_ratios=(1.0, 2.0, 0.5), offset=0.0):
+    """detectron2 DefaultAnchorGenerator (un-vendored): (H*W*A, 4), A = sizes x ratios."""
+    cell = []
+    for size in sizes:
+        area = size ** 2.0
+        for ar in aspect_ratios:
+            ww = math.sqrt(area / ar)
+            hh = ar * ww
+            cell.append([-ww / 2.0, -hh / 2.0, ww / 2.0, hh / 2.0])
+    cell = torch.tensor(cell)
+    sx = torch.arange(offset * stride, w * stride, step=stride, dtype=torch.float32)
+    sy = torch.arange(offset * stride, h * stride, step=stride, dtype=torch.float32)
+    yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+    xx, yy = xx.reshape(-1), yy.reshape(-1)
+    shifts = torch.stack((xx, yy, xx, yy), dim=1)
+    return (shifts.view(-1, 1, 4) + cell.view(1, -1, 4)).reshape(-1, 4)
+
+
+def rpn_head_forward(sd, feat, prefix="proposal_generator.rpn_head."):
+    """detectron2 StandardRPNHead + the permutes of rpn.py:403-417 -> ((N, H*W*A), (N, H*W*A, 4))."""
+    t = F.relu(F.conv2d(feat, sd[prefix + "conv.weight"], sd[prefix + "conv.bias"], padding=1))
+    lo = F.conv2d(t, sd[prefix + "objectness_logits.weight"], sd[prefix + "objectness_logits.bias"])
+    de = F.conv2d(t, sd[prefix + "anchor_deltas.weight"], sd[prefix + "anchor_deltas.bias"])
+    N = feat.shape[0]
+    lo = lo.permute(0, 2, 3, 1).flatten(1)
+    de = de.view(N, -1, 4, de.shape[-2], de.shape[-1]).permute(0, 3, 4, 1, 2).flatten(1, -2)
+    return lo, de
+
+
+@torch.no_grad()
+def find_top_rpn_proposals(anchors, logits, deltas, image_sizes, nms_thresh=0.7, pre_nms_topk=2048,
+                           post_nms_topk=1024, min_box_size=40.0, weights=(1.0, 1.0, 1.0, 1.0)):
+    """rpn.py:495-515 + proposal_utils.py:26-144, single level.  -> per image (boxes, objectness logits)."""
+    out = []
+    k = min(logits.shape[1], pre_nms_topk)
+    for n, image_size in enumerate(image_sizes):
+        sc, idx = logits[n].sort(descending=True)
+        sc, idx = sc[:k], idx[:k]
+        boxes, keep = rpn_decode_clip(anchors[idx], deltas[n][idx], image_size, weights, min_box_size)
+        keep = keep & torch.isfinite(sc)
+        boxes, sc = boxes[keep], sc[keep]
+        kept = roi_ops.nms_segments(boxes, [0, len(boxes)], nms_thresh, post_nms_topk)[0]
+        out.append((boxes[kept], sc[kept]))
+    return out
+
+
+def rpn_match_anchors(anchors, gt_boxes, thresholds=(0.2, 0.6), labels=(0, -1, 1)):
+    """detectron2 Matcher(allow_low_quality_matches=True) on pairwise_iou(gt, anchors) (rpn.py:268-269)."""
+    iou = pairwise_iou(gt_boxes, anchors)
+    vals, matches = iou.max(dim=0)
+    lab = torch.ones_like(matches, dtype=torch.int8)
+    bounds = [-float("inf")] + list(thresholds) + [float("inf")]
+    for l, lo, hi in zip(labels, bounds[:-1], bounds[1:]):
+        lab[(vals >= lo) & (vals < hi)] = l
+    best = iou.max(dim=1).values
+    lab[(iou == best[:, None]).nonzero()[:, 1]] = 1
+    return matches, lab
+
+
+def rpn_losses(anchors, logits, deltas, targets, subsample, batch_size_per_image=512, positive_fraction=0.5,
+               weights=(1.0, 1.0, 1.0, 1.0), thresholds=(0.2, 0.6)):
+    """rpn.py:237-375 (label_and_sample_anchors + losses, smooth_l1 beta 0).  `subsample(labels, n, frac, bg)` is
+    detectron2's subsample_labels (random there; the tests inject a deterministic one on both sides)."""
+    gt_labels, gt_deltas = [], []
+    for t in targets:
+        matches, lab = rpn_match_anchors(anchors, t["gt_boxes"], thresholds)
+        pos_idx, neg_idx = subsample(lab, batch_size_per_image, positive_fraction, 0)
+        lab = torch.full_like(lab, -1)
+        lab[pos_idx] = 1
+        lab[neg_idx] = 0
+        gt_labels.append(lab)
+        gt_deltas.append(box2box_get_deltas(anchors, t["gt_boxes"][matches], weights))
+    gt_labels, gt_deltas = torch.stack(gt_labels), torch.stack(gt_deltas)
+    pos = gt_labels == 1
+    loc = (deltas[pos] - gt_deltas[pos]).abs().sum()
+    valid = gt_labels >= 0
+    obj = F.binary_cross_entropy_with_logits(logits[valid], gt_labels[valid].float(), reduction="sum")
+    norm = batch_size_per_image * len(targets)
+    return {"loss_rpn_cls": obj / norm, "loss_rpn_loc": loc / norm}, gt_labels
+
+
+# ----------------------------------------------------------------------------------------
 # the whole training step (rcnn_wsovod.py:137-234 -> roi_heads.py:648-907), proposals-only mode
 # ----------------------------------------------------------------------------------------
 def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool", temperature=50.0,
                   pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True,
                   mean_loss=True, sampling_ratio=0, dropout_masks=None, refine_prefix="roi_heads.box_refinery_0.",
-                  miner_prefix="roi_heads.object_miner.", classifier=None):
+                  miner_prefix="roi_heads.object_miner.", classifier=None, rpn=None):
     """batch: list of dicts {image uint8 (3,H,W), boxes (R,4), objectness (R), gt_classes (G)}.
     Returns (losses dict, intermediates dict).  REFINE_NUM=1, REFINE_REG=[True], SAMPLING_ON."""
     inter = {}
@@ -383,9 +467,22 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
     res5 = feats["res5"]
     inter["res5"] = res5
     boxes_list = [b["boxes"] for b in batch]
+    obj_list = [b["objectness"] for b in batch]
+    if rpn is not None:
+        # rcnn_wsovod.py:177-197: RPN boxes (sigmoid objectness ramped by iter / MAX_ITER) ahead of the loaded ones.
+        # rpn = dict(cur_iter, max_iter, subsample[, proposals = precomputed (boxes, logits) per image])
+        anchors = anchor_grid(res5.shape[-2], res5.shape[-1])
+        rpn_logits, rpn_deltas = rpn_head_forward(sd, res5.detach())
+        inter["rpn_logits"], inter["rpn_deltas"] = rpn_logits, rpn_deltas
+        sizes = [tuple(b["image"].shape[-2:]) for b in batch]
+        props = rpn.get("proposals") or find_top_rpn_proposals(anchors, rpn_logits.detach(), rpn_deltas.detach(), sizes)
+        inter["rpn_proposals"] = props
+        ramp = rpn["cur_iter"] / rpn["max_iter"]
+        boxes_list = [torch.cat([pb, b]) for (pb, _), b in zip(props, boxes_list)]
+        obj_list = [torch.cat([torch.sigmoid(ps) * ramp, o]) for (_, ps), o in zip(props, obj_list)]
     nums = [len(b) for b in boxes_list]
     pooled = roi_pooler(res5.detach(), boxes_list, pooler_type, 7, 0.125, sampling_ratio)
-    objectness = torch.cat([b["objectness"] + 1 for b in batch], dim=0)
+    objectness = torch.cat([o + 1 for o in obj_list], dim=0)
     pooled = pooled * objectness.view(-1, 1, 1, 1)  # roi_heads.py:733-739
     inter["pooled"] = pooled
     feat = neck_forward(sd, pooled, dropout_masks=dropout_masks)
@@ -411,6 +508,16 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
                                torch.cat([l["gt_weights"] for l in labelled]), torch.cat(boxes_list),
                                torch.cat([l["gt_boxes"] for l in labelled]), num_classes)
     losses["loss_cls_r0"], losses["loss_box_reg_r0"] = lc, lb
+    if rpn is not None:
+        # roi_heads.py:862-881: pseudo GT for the RPN from the refinement head's own predictions
+        probs = torch.softmax(logits.detach(), dim=-1)
+        pred_boxes = box2box_apply_deltas(deltas.detach(), torch.cat(boxes_list))
+        rpn_targets = get_pgt_top_k(list(pred_boxes.split(nums)), list(probs.split(nums)), gt_int, img_logits,
+                                    num_classes)
+        inter["rpn_targets"] = rpn_targets
+        rl, rpn_labels = rpn_losses(anchors, rpn_logits, rpn_deltas, rpn_targets, rpn["subsample"])
+        inter["rpn_labels"] = rpn_labels
+        losses.update(rl)
     return losses, inter
 
 

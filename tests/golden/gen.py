@@ -27,6 +27,8 @@ def seeded_state(shapes, seed=0):
             t = 0.5 + torch.rand(shp, generator=g)
         elif k.endswith("norm.bias") or k.endswith("norm.running_mean"):
             t = 0.1 * torch.randn(shp, generator=g)
+        elif k.startswith("proposal_generator."):
+            t = torch.randn(shp, generator=g) * (0.02 if k.endswith("weight") else 0.05)
         elif k.startswith("backbone.") and k.endswith("weight"):
             fan_out = shp[0] * shp[2] * shp[3]
             t = torch.randn(shp, generator=g) * math.sqrt(2.0 / fan_out)
@@ -80,6 +82,16 @@ def sampler_dataset_dicts(sizes=(7, 5, 30), num_categories=6, seed=3):
             cats = torch.randint(0, num_categories, (k,), generator=g).tolist()
             out.append({"dataset_id": ds, "annotations": [{"category_id": c} for c in cats]})
     return out
+
+
+def first_k_subsample(labels, num_samples, positive_fraction, bg_label):
+    """Deterministic stand-in for detectron2's subsample_labels (random there): the FIRST num_pos positives and
+    the FIRST num_neg negatives in index order.  Injected on both sides of the RPN parity tests."""
+    positive = ((labels != -1) & (labels != bg_label)).nonzero().flatten()
+    negative = (labels == bg_label).nonzero().flatten()
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    return positive[:num_pos], negative[:num_neg]
 
 
 def seeded_batch(n_images, R, K, H, W, seed=0, edge_cases=True):

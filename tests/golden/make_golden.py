@@ -364,6 +364,131 @@ def golden_mixed(r):
     save("g10_mixed_datasets_step", **arrays)
 
 
+class RefStandardRPNHead(nn.Module):
+    """detectron2 StandardRPNHead stand-in (un-vendored) in plain torch."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        from wsovod_amd.modeling.anchor_generator import build_anchor_generator
+
+        in_channels = input_shape[0].channels
+        A = build_anchor_generator(cfg, input_shape).num_anchors[0]
+        self.conv = D2Conv2d(in_channels, in_channels, kernel_size=3, stride=1, padding=1, activation=nn.ReLU())
+        self.objectness_logits = nn.Conv2d(in_channels, A, kernel_size=1, stride=1)
+        self.anchor_deltas = nn.Conv2d(in_channels, A * 4, kernel_size=1, stride=1)
+        for layer in (self.conv, self.objectness_logits, self.anchor_deltas):
+            nn.init.normal_(layer.weight, std=0.01)
+            nn.init.constant_(layer.bias, 0)
+
+    def forward(self, features):
+        lo, de = [], []
+        for x in features:
+            t = self.conv(x)
+            lo.append(self.objectness_logits(t))
+            de.append(self.anchor_deltas(t))
+        return lo, de
+
+
+def golden_rpn(r):
+    """G12: the REFERENCE's WSOVODRPN_V2 + find_top_rpn_proposals + the meta-arch / ROI-heads RPN branches on one
+    training step (RPN boxes + loaded boxes, pseudo-GT from the refinement head, RPN losses).  detectron2's
+    anchor generator / matcher / box transform / RPN head are the restated stand-ins, batched_nms is the oracle's;
+    subsample_labels is replaced by the deterministic first-k rule of tests/golden/gen.py on both sides."""
+    from oracle import wsovod_ref as R
+    from wsovod_amd.modeling import anchor_generator as AG
+    from wsovod_amd.testing import hot_path_cfg
+
+    C.PROPOSAL_GENERATOR_REGISTRY_REF = C.Registry("REF_PROPOSAL_GENERATOR")
+    C.RPN_HEAD_REGISTRY_REF = C.Registry("REF_RPN_HEAD")
+    C.RPN_HEAD_REGISTRY_REF._obj_map["StandardRPNHead"] = RefStandardRPNHead
+    L = sys.modules["detectron2.layers"]
+    L.CycleBatchNormList = _Unsupported
+    L.batched_nms = R.batched_nms
+    L.move_device_like = lambda src, dst: src.to(dst.device)
+    _mod("detectron2.modeling.anchor_generator", build_anchor_generator=AG.build_anchor_generator,
+         DefaultAnchorGenerator=AG.DefaultAnchorGenerator)
+    B = sys.modules["detectron2.modeling.box_regression"]
+    B.Box2BoxTransformLinear = _Unsupported
+    B._dense_box_regression_loss = None
+    _mod("detectron2.modeling.proposal_generator.build", PROPOSAL_GENERATOR_REGISTRY=C.PROPOSAL_GENERATOR_REGISTRY_REF)
+    _mod("detectron2.modeling.proposal_generator.rpn", RPN_HEAD_REGISTRY=C.RPN_HEAD_REGISTRY_REF,
+         build_rpn_head=lambda cfg, shape: C.RPN_HEAD_REGISTRY_REF.get(cfg.MODEL.RPN.HEAD_NAME)(cfg, shape))
+    _mod("detectron2.modeling.poolers", convert_boxes_to_pooler_format=None)
+    _mod("detectron2.utils.env", TORCH_VERSION=(2, 10))
+    _mod("detectron2.utils.memory", retry_if_cuda_oom=lambda f: f)
+    sys.modules["detectron2.structures"].pairwise_point_box_distance = None
+    sys.modules["fvcore.nn"].giou_loss = None
+    sys.modules["wsovod.layers"].csc = None
+    pg = _mod("wsovod.modeling.proposal_generator")
+    r.putils = load_ref("wsovod.modeling.proposal_generator.proposal_utils",
+                        "wsovod/modeling/proposal_generator/proposal_utils.py")
+    r.rpn = load_ref("wsovod.modeling.proposal_generator.rpn", "wsovod/modeling/proposal_generator/rpn.py")
+    r.rpn.subsample_labels = gen.first_k_subsample
+    pg.WSOVODRPN_V2, pg.WSOVODRPN = r.rpn.WSOVODRPN_V2, r.rpn.WSOVODRPN
+    r.meta.WSOVODRPN_V2 = r.rpn.WSOVODRPN_V2
+    r.meta.build_proposal_generator = lambda cfg, shape: C.PROPOSAL_GENERATOR_REGISTRY_REF.get(
+        cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shape)
+    _Storage.iter = 1000
+
+    import pickle
+    import tempfile
+    K, D = 20, 512
+    emb = os.path.join(tempfile.mkdtemp(prefix="golden_"), "emb.pkl")
+    with open(emb, "wb") as f:
+        pickle.dump(torch.randn(K, D), f)
+    cfg = hot_path_cfg(depth=18, K=K, D=D, device="cpu", weight_path=emb, rpn=True)
+    cfg.MODEL.PIXEL_STD = list(gen.PIXEL_STD)
+    cfg.MODEL.ROI_HEADS.NAME = "WSOVODROIHeads"
+    cfg.DATASETS.TRAIN = ("synthetic",)
+    cfg.SOLVER.MAX_ITER = 4000
+    torch.manual_seed(0)
+    model = r.meta.GeneralizedRCNN_WSOVOD(cfg)
+    assert type(model.proposal_generator).__name__ == "WSOVODRPN_V2" and model.roi_heads.rpn_on
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    sd = gen.seeded_state(shapes, seed=41)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 1e-12
+    save("shapes_rpn_r18", keys=np.array(list(shapes.keys())), shapes=np.array([str(v) for v in shapes.values()]))
+    batch = gen.seeded_batch(2, 40, K, 256, 352, seed=43)
+    inputs = to_inputs(batch)
+    captured = {}
+    pgm = model.proposal_generator
+    orig = pgm.predict_proposals
+
+    def cap_props(*a, **k):
+        o = orig(*a, **k)
+        captured["proposals"] = [(p.proposal_boxes.tensor.clone(), p.objectness_logits.clone()) for p in o]
+        return o
+
+    pgm.predict_proposals = cap_props
+    orig_label = pgm.label_and_sample_anchors
+
+    def cap_label(*a, **k):
+        o = orig_label(*a, **k)
+        captured["anchor_labels"] = torch.stack(o[0])
+        return o
+
+    pgm.label_and_sample_anchors = cap_label
+    loss_dict = model(inputs)
+    sum(loss_dict.values()).backward()
+    arrays = {f"loss/{k}": v for k, v in loss_dict.items()}
+    arrays["rpn_logits"] = pgm.pred_objectness_logits[0]
+    arrays["rpn_deltas_sample"] = gen.strided_sample(pgm.pred_anchor_deltas[0], 8192)
+    for i, (bx, sc) in enumerate(captured["proposals"]):
+        arrays[f"prop{i}/boxes"], arrays[f"prop{i}/logits"] = bx, sc
+    arrays["anchor_labels"] = captured["anchor_labels"]
+    for i, t in enumerate(model.roi_heads.proposal_targets):
+        arrays[f"target{i}/gt_boxes"] = t.gt_boxes.tensor
+        arrays[f"target{i}/gt_classes"] = t.gt_classes
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            arrays["gradnorm/" + k] = q.grad.double().norm() if q.grad is not None else torch.tensor(-1.0)
+    save("g12_rpn_train_step", **arrays)
+
+
 def golden_sampler():
     """G11: the REFERENCE's MultiDatasetTrainingSampler (repeat factors with class-aware sampling on one dataset,
     and the per-rank index streams of a 2-rank job)."""
@@ -403,6 +528,8 @@ def main():
     r = load_reference()
     if "--only-mixed" in sys.argv:
         return golden_mixed(r)
+    if "--only-rpn" in sys.argv:
+        return golden_rpn(r)
 
     # ---------------- G2: RoIPool / ROIAlign (reference C++ op) ----------------
     from tests.util import random_rois
@@ -503,6 +630,7 @@ def main():
 
     golden_mixed(r)
     golden_sampler()
+    golden_rpn(r)
 
 
 if __name__ == "__main__":

@@ -75,9 +75,9 @@ def test_out_of_scope_features_fail_loudly():
     from wsovod_amd.modeling import build_model
     from wsovod_amd.testing import hot_path_cfg
 
-    cfg = hot_path_cfg(device="cpu")
-    cfg.MODEL.PROPOSAL_GENERATOR.NAME = "WSOVODRPN_V2"
-    with pytest.raises(NotImplementedError, match="next"):
+    cfg = hot_path_cfg(device="cpu", rpn=True)
+    cfg.MODEL.MRRP.MRRP_ON = True
+    with pytest.raises(NotImplementedError, match="MRRP"):
         build_model(cfg)
     cfg = hot_path_cfg(device="cpu")
     cfg.WSOVOD.BBOX_REFINE.ENABLE = True
@@ -88,6 +88,31 @@ def test_out_of_scope_features_fail_loudly():
     model = build_model(cfg)
     with pytest.raises(NotImplementedError, match="forward-only"):
         model.backbone(torch.zeros(1, 3, 32, 32))
+
+
+def test_rpn_host_pieces():
+    """Anchor grid (detectron2 DefaultAnchorGenerator restated) against the oracle's, state-dict names of the RPN,
+    and the low-quality-match rule of the anchor matcher."""
+    from oracle import wsovod_ref as R
+    from wsovod_amd.modeling import build_model
+    from wsovod_amd.modeling.matcher import Matcher
+    from wsovod_amd.testing import hot_path_cfg
+
+    model = build_model(hot_path_cfg(device="cpu", rpn=True))
+    pg = model.proposal_generator
+    assert type(pg).__name__ == "WSOVODRPN_V2" and model.roi_heads.rpn_on
+    keys = {k for k in model.state_dict() if k.startswith("proposal_generator.")}
+    assert keys == {f"proposal_generator.rpn_head.{m}.{p}" for m in ("conv", "objectness_logits", "anchor_deltas")
+                    for p in ("weight", "bias")}
+    assert pg.rpn_head.objectness_logits.weight.shape == (18, 512, 1, 1)
+    assert pg.rpn_head.anchor_deltas.weight.shape == (72, 512, 1, 1)
+    grid = pg.anchor_generator([torch.zeros(1, 512, 5, 7)])[0].tensor
+    assert torch.equal(grid, R.anchor_grid(5, 7))
+    assert grid.shape == (5 * 7 * 18, 4)
+    torch.testing.assert_close(grid[18:36] - grid[:18], torch.tensor([8.0, 0, 8.0, 0]).expand(18, 4))
+    iou = torch.tensor([[0.1, 0.15, 0.7], [0.05, 0.0, 0.1]])
+    m, lab = Matcher([0.2, 0.6], [0, -1, 1], allow_low_quality_matches=True)(iou)
+    assert lab.tolist() == [1, 0, 1] and m.tolist() == [0, 0, 0]  # anchor 0 is GT 1's best match despite IoU 0.05
 
 
 def test_structures_and_matcher_semantics():

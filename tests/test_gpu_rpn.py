@@ -1,0 +1,138 @@
+"""-m gpu: the RPN branch on the HIP kernels against the reference's golden step (g12) and the
+oracle.  fp32 parity mode; detectron2's random anchor sub-sampling is replaced by gen.first_k_subsample on both
+sides (the golden was generated the same way)."""
+import numpy as np
+import os
+import pytest
+import torch
+
+from oracle import wsovod_ref as R
+from tests.conftest import *  # noqa: F401,F403
+from tests.golden import gen
+from tests.helpers import G, load_golden, to_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def build_rpn_model(precision="fp32"):
+    from wsovod_amd.modeling import build_model, sampling
+    from wsovod_amd.testing import hot_path_cfg
+
+    cfg = hot_path_cfg(precision=precision, device="cuda:0", rpn=True)
+    cfg.SOLVER.MAX_ITER = 4000
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model._std = [float(v) for v in gen.PIXEL_STD]
+    d = np.load(os.path.join(G, "shapes_rpn_r18.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    assert {k: tuple(v.shape) for k, v in model.state_dict().items()} == {k: tuple(v) for k, v in shapes.items()}
+    sd = gen.seeded_state(shapes, 41)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    model.roi_heads.iter = 1000  # the reference reads the trainer's iteration counter (rcnn_wsovod.py:181-184)
+    return cfg, model, sd, sampling
+
+
+def match_fraction(a, b, tol=0.05):
+    """fraction of rows of a that have a row of b within tol (max abs coordinate difference)."""
+    if len(a) == 0:
+        return 1.0
+    d = (a[:, None, :] - b[None, :, :]).abs().amax(dim=2)
+    return float((d.min(dim=1).values < tol).float().mean())
+
+
+def test_rpn_step_matches_reference_golden(gpu, monkeypatch):
+    g = load_golden("g12_rpn_train_step")
+    cfg, model, sd, sampling = build_rpn_model("fp32")
+    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
+    losses = model(to_inputs(batch))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    pg = model.proposal_generator
+    torch.testing.assert_close(pg.pred_objectness_logits[0].detach().cpu(), g["rpn_logits"], rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(gen.strided_sample(pg.pred_anchor_deltas[0].detach().cpu(), 8192), g["rpn_deltas_sample"],
+                               rtol=1e-4, atol=2e-4)
+    # proposals: decoded through expf and selected by sort + NMS from logits that differ in the last bits, so the
+    # set is compared geometrically (the index kernels themselves are bit-exact: tests/test_gpu_proposals.py)
+    for i, p in enumerate(model.rpn_proposals):
+        ref_b, ref_s = g[f"prop{i}/boxes"], g[f"prop{i}/logits"]
+        got_b = p.proposal_boxes.tensor.cpu()
+        assert abs(len(got_b) - len(ref_b)) <= 2
+        assert match_fraction(ref_b, got_b) >= 0.95 and match_fraction(got_b, ref_b) >= 0.95
+        assert float(p.objectness_logits.max()) <= 0.25 + 1e-6  # sigmoid * iter / MAX_ITER
+    for i, t in enumerate(model.roi_heads.proposal_targets):
+        torch.testing.assert_close(t.gt_boxes.tensor.cpu(), g[f"target{i}/gt_boxes"], rtol=1e-4, atol=1e-2)
+        assert torch.equal(t.gt_classes.cpu(), g[f"target{i}/gt_classes"])
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0", "loss_rpn_cls", "loss_rpn_loc"):
+        torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=5e-3, atol=1e-5,
+                                   msg=lambda m: f"{k}: {m}")
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            ref = float(g["gradnorm/" + k])
+            got = float(q.grad.double().norm())
+            assert abs(got - ref) <= 1e-2 * ref + 1e-6, (k, got, ref)
+
+
+def test_rpn_head_gradients_match_oracle(gpu, monkeypatch):
+    """Given identical proposals (the oracle is fed the HIP path's own RPN boxes), every loss and the RPN-head
+    gradients agree tightly -- isolates the sparse-row weight-gradient path (im2col rows + GEMMs)."""
+    cfg, model, sd, sampling = build_rpn_model("fp32")
+    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=47)
+    losses = model(to_inputs(batch))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    pg = model.proposal_generator
+    k = pg.pre_nms_topk[True]
+    props = []
+    for p in model.rpn_proposals:  # undo sigmoid * ramp: the oracle applies it itself
+        s = p.objectness_logits.cpu() / 0.25
+        props.append((p.proposal_boxes.tensor.cpu(), torch.log(s / (1 - s))))
+    sdc = {kk: v.clone() for kk, v in sd.items()}
+    keys = [kk for kk in sdc if kk.startswith("proposal_generator.")]
+    for kk in keys:
+        sdc[kk].requires_grad_(True)
+    ref_losses, inter = R.train_forward(sdc, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD,
+                                        rpn=dict(cur_iter=1000, max_iter=4000, subsample=gen.first_k_subsample,
+                                                 proposals=props))
+    for name, v in ref_losses.items():
+        torch.testing.assert_close(losses[name].detach().cpu(), v.detach(), rtol=2e-3, atol=1e-5,
+                                   msg=lambda m: f"{name}: {m}")
+    grads = torch.autograd.grad(ref_losses["loss_rpn_cls"] + ref_losses["loss_rpn_loc"], [sdc[kk] for kk in keys])
+    P = dict(model.named_parameters())
+    for kk, gr in zip(keys, grads):
+        got = P[kk].grad.detach().float().cpu()
+        assert (got - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-7, kk
+
+
+def test_rpn_eval_inference_runs(gpu):
+    cfg, model, sd, _ = build_rpn_model("fp32")
+    model.eval()
+    batch = gen.seeded_batch(2, 30, 20, 256, 352, seed=49)
+    out = model(to_inputs(batch), classifier=torch.randn(20, 512, device=gpu))
+    assert len(out) == 2 and len(model.rpn_proposals[0]) > 0
+    inst = out[0]["instances"]
+    assert inst.pred_boxes.tensor.shape[1] == 4 and len(inst.scores) == len(inst.pred_classes)
+
+
+def test_bf16_rpn_step_is_finite_and_close(gpu, monkeypatch):
+    g = load_golden("g12_rpn_train_step")
+    cfg, model, sd, sampling = build_rpn_model("bf16")
+    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
+    losses = model(to_inputs(batch))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    lo = model.proposal_generator.pred_objectness_logits[0].detach().float().cpu()
+    assert (lo - g["rpn_logits"]).abs().max() < 0.05 * g["rpn_logits"].abs().max()  # bf16 conv inputs: ~1e-2 relative
+    # the localisation loss depends on WHICH proposal the heads pick as pseudo ground truth; bf16 scores may pick a
+    # neighbouring box, so it is only bounded loosely (observed 10 %)
+    torch.testing.assert_close(losses["loss_rpn_cls"].detach().cpu(), g["loss/loss_rpn_cls"], rtol=0.1, atol=1e-3)
+    torch.testing.assert_close(losses["loss_rpn_loc"].detach().cpu(), g["loss/loss_rpn_loc"], rtol=0.3, atol=1e-3)
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            assert torch.isfinite(q.grad).all(), k

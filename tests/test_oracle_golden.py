@@ -132,6 +132,36 @@ def test_mixed_datasets_step_matches_reference():
         assert float(g[p + f"gradnorm/roi_heads.object_miners.{source_id}.cls.weight"]) > 0
 
 
+def test_rpn_train_step_matches_reference():
+    """G12: the reference's RPN branch (WSOVODRPN_V2, find_top_rpn_proposals, meta-arch + ROI-heads glue) on one
+    training step: proposals, anchor labels and pseudo-GT exact, losses and every gradient norm."""
+    g = load("g12_rpn_train_step")
+    d = np.load(os.path.join(G, "shapes_rpn_r18.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    sd = gen.seeded_state(shapes, 41)
+    keys = [k[len("gradnorm/"):] for k in g if k.startswith("gradnorm/")]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
+    losses, inter = R.train_forward(sd, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD,
+                                    rpn=dict(cur_iter=1000, max_iter=4000, subsample=gen.first_k_subsample))
+    assert set(losses) == {"loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0", "loss_rpn_cls", "loss_rpn_loc"}
+    for k, v in losses.items():
+        torch.testing.assert_close(v.detach(), g["loss/" + k], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(inter["rpn_logits"].detach(), g["rpn_logits"], rtol=1e-4, atol=1e-5)
+    for i, (b, s) in enumerate(inter["rpn_proposals"]):
+        assert torch.equal(b, g[f"prop{i}/boxes"]) and torch.equal(s, g[f"prop{i}/logits"])
+        assert 0 < len(b) <= 1024
+    assert torch.equal(inter["rpn_labels"], g["anchor_labels"])
+    for i, t in enumerate(inter["rpn_targets"]):
+        assert torch.equal(t["gt_boxes"], g[f"target{i}/gt_boxes"])
+        assert torch.equal(t["gt_classes"], g[f"target{i}/gt_classes"])
+    grads = torch.autograd.grad(sum(losses.values()), [sd[k] for k in keys])
+    for k, gr in zip(keys, grads):
+        ref = float(g["gradnorm/" + k])
+        assert abs(float(gr.double().norm()) - ref) <= 2e-4 * ref + 1e-9, k
+
+
 def test_r50_bottleneck_backbone_matches_reference():
     g = load("g1_backbone_r50_small")
     d = np.load(os.path.join(G, "shapes_r50_backbone.npz"))

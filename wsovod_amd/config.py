@@ -104,9 +104,29 @@ def _d2_defaults():
     _C.MODEL.BACKBONE = C({"NAME": "build_resnet_backbone", "FREEZE_AT": 2})
     _C.MODEL.PROPOSAL_GENERATOR = C({"NAME": "RPN", "MIN_SIZE": 0})
     _C.MODEL.ANCHOR_GENERATOR = C()
+    _C.MODEL.ANCHOR_GENERATOR.NAME = "DefaultAnchorGenerator"
+    _C.MODEL.ANCHOR_GENERATOR.SIZES = [[32, 64, 128, 256, 512]]
+    _C.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS = [[0.5, 1.0, 2.0]]
+    _C.MODEL.ANCHOR_GENERATOR.OFFSET = 0.0
     _C.MODEL.RPN = C()
     _C.MODEL.RPN.HEAD_NAME = "StandardRPNHead"
     _C.MODEL.RPN.IN_FEATURES = ["res4"]
+    _C.MODEL.RPN.BOUNDARY_THRESH = -1
+    _C.MODEL.RPN.IOU_THRESHOLDS = [0.3, 0.7]
+    _C.MODEL.RPN.IOU_LABELS = [0, -1, 1]
+    _C.MODEL.RPN.BATCH_SIZE_PER_IMAGE = 256
+    _C.MODEL.RPN.POSITIVE_FRACTION = 0.5
+    _C.MODEL.RPN.BBOX_REG_LOSS_TYPE = "smooth_l1"
+    _C.MODEL.RPN.BBOX_REG_LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.BBOX_REG_WEIGHTS = (1.0, 1.0, 1.0, 1.0)
+    _C.MODEL.RPN.SMOOTH_L1_BETA = 0.0
+    _C.MODEL.RPN.LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.PRE_NMS_TOPK_TRAIN = 12000
+    _C.MODEL.RPN.PRE_NMS_TOPK_TEST = 6000
+    _C.MODEL.RPN.POST_NMS_TOPK_TRAIN = 2000
+    _C.MODEL.RPN.POST_NMS_TOPK_TEST = 1000
+    _C.MODEL.RPN.NMS_THRESH = 0.7
+    _C.MODEL.RPN.CONV_DIMS = [-1]
     _C.MODEL.ROI_HEADS = C()
     _C.MODEL.ROI_HEADS.NAME = "Res5ROIHeads"
     _C.MODEL.ROI_HEADS.NUM_CLASSES = 80

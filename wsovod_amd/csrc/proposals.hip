@@ -146,9 +146,61 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(const float4* __restric
   valid[t] = finite && __fsub_rn(x2, x1) > min_size && __fsub_rn(y2, y1) > min_size;
 }
 
+// Patch rows of the RPN's 3x3 conv for the weight gradient: only the <= BATCH_SIZE_PER_IMAGE sampled anchors of
+// an image carry a loss, so dW = dH_act^T . im2col(x)[act] needs the im2col rows of those pixels only
+// (rpn.py:296-375 -> label == -1 anchors contribute nothing).  One workgroup per selected output pixel, 16-byte
+// chunks; taps outside the map and rows with index < 0 are zero.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_rows_kernel(const T* __restrict__ x, const long long* __restrict__ rows,
+                                                          int H, int W, int Cin, int Ho, int Wo, int KH, int KW,
+                                                          int stride, int pad, int dil, T* __restrict__ out) {
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const long long r = rows[blockIdx.x];
+  const int cpc = Cin / EPC;               // chunks per tap
+  const int chunks = KH * KW * cpc;
+  uint4* dst = (uint4*)(out + (long long)blockIdx.x * KH * KW * Cin);
+  int img = 0, ho = 0, wo = 0;
+  if (r >= 0) {
+    img = (int)(r / ((long long)Ho * Wo));
+    const int rem = (int)(r - (long long)img * Ho * Wo);
+    ho = rem / Wo;
+    wo = rem - ho * Wo;
+  }
+  for (int c = threadIdx.x; c < chunks; c += 256) {
+    const int tap = c / cpc, cc = c - tap * cpc;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    const int hi = ho * stride - pad + kh * dil, wi = wo * stride - pad + kw * dil;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r >= 0 && hi >= 0 && hi < H && wi >= 0 && wi < W)
+      v = *(const uint4*)(x + (((long long)img * H + hi) * W + wi) * Cin + cc * EPC);
+    dst[c] = v;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int wsovod_im2col_rows(const void* x, int dtype, const long long* rows, int n_rows, int H, int W, int Cin, int Ho, int Wo,
+                       int KH, int KW, int stride, int pad, int dil, void* out, wsovod_stream_t stream) {
+  if (n_rows == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(x && rows && out, "wsovod_im2col_rows: null pointer");
+  const int esz = dtype == WSOVOD_BF16 ? 2 : 4;
+  WS_CHECK_ARG(dtype == WSOVOD_BF16 || dtype == WSOVOD_F32, "wsovod_im2col_rows: bad dtype");
+  WS_CHECK_ARG(Cin % (16 / esz) == 0, "wsovod_im2col_rows: Cin=%d must be a multiple of %d", Cin, 16 / esz);
+  WS_CHECK_ARG((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "wsovod_im2col_rows: x/out must be 16-byte aligned");
+  static int slot = wsovod::prof_slot("im2col_rows");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, 2.0 * n_rows * KH * KW * Cin * esz);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(im2col_rows_kernel<bf16_t>, dim3(n_rows), dim3(256), 0, s, (const bf16_t*)x, rows, H, W, Cin, Ho,
+                       Wo, KH, KW, stride, pad, dil, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(im2col_rows_kernel<float>, dim3(n_rows), dim3(256), 0, s, (const float*)x, rows, H, W, Cin, Ho,
+                       Wo, KH, KW, stride, pad, dil, (float*)out);
+  WS_CHECK_LAUNCH("wsovod_im2col_rows");
+  return WSOVOD_OK;
+}
 
 int wsovod_nms_segments(const float* boxes, const int* seg_offsets, const unsigned char* valid, int G, int N,
                         int max_seg_len, float iou_threshold, int max_keep, unsigned long long* workspace,

@@ -538,3 +538,19 @@ def rpn_decode(anchors, deltas, index, image_sizes, weights, scale_clamp, min_si
                                   C.c_float(scale_clamp), C.c_float(min_size), ptr(boxes), ptr(valid), stream()),
           "rpn_decode")
     return boxes, valid.bool()
+
+
+def im2col_rows(x_nhwc, rows, kernel_size, stride=1, padding=0, dilation=1):
+    """x (N,H,W,C) NHWC contiguous; rows (n) int64 flat output-pixel ids (negative -> zero row).
+    Returns (n, k*k*C) patch rows, tap-major then channel."""
+    require_gpu(x_nhwc, rows)
+    assert x_nhwc.is_contiguous() and rows.dtype == torch.int64
+    N, Hh, Ww, Cc = x_nhwc.shape
+    k = kernel_size
+    Ho = (Hh + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    Wo = (Ww + 2 * padding - dilation * (k - 1) - 1) // stride + 1
+    rows = rows.contiguous()
+    out = torch.empty((rows.numel(), k * k * Cc), dtype=x_nhwc.dtype, device=x_nhwc.device)
+    check(lib().wsovod_im2col_rows(ptr(x_nhwc), dtype_code(x_nhwc.dtype), ptr(rows), rows.numel(), Hh, Ww, Cc, Ho, Wo,
+                                   k, k, stride, padding, dilation, ptr(out), stream()), "im2col_rows")
+    return out

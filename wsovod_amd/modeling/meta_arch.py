@@ -19,6 +19,7 @@ from ..layers import hip_ops as H
 from ..structures import ImageList, Instances, ShapeSpec
 from .class_heads import DataAwareFeaturesHead
 from .fast_rcnn_open_vocabulary import segment_offsets
+from .proposal_generator import build_proposal_generator
 from .roi_heads import build_roi_heads
 
 __all__ = ["GeneralizedRCNN_WSOVOD", "GeneralizedRCNN_WSOVOD_MixedDatasets", "build_model", "build_backbone"]
@@ -54,12 +55,10 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
                  pixel_mean: Tuple[float], pixel_std: Tuple[float], input_format: Optional[str] = None,
                  vis_period: int = 0):
         super().__init__()
-        if proposal_generator is not None:
-            raise NotImplementedError("RPN branch (WSOVODRPN_V2) is a 'next' row; use PrecomputedProposals")
         self.cfg = cfg
         self.backbone = backbone
         self.data_aware_head = data_aware_head
-        self.proposal_generator = None
+        self.proposal_generator = proposal_generator
         self.roi_heads = roi_heads
         self.input_format = input_format
         self.vis_period = 0
@@ -72,15 +71,11 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
     @classmethod
     def from_config(cls, cfg):
         backbone = build_backbone(cfg)
-        if cfg.MODEL.PROPOSAL_GENERATOR.NAME != "PrecomputedProposals":
-            raise NotImplementedError(
-                f"MODEL.PROPOSAL_GENERATOR.NAME={cfg.MODEL.PROPOSAL_GENERATOR.NAME}: the RPN branch is a SURVEY 8f "
-                "'next' row; the hot path runs proposals-only (PrecomputedProposals)")
         return {
             "cfg": cfg, "backbone": backbone,
             "data_aware_head": DataAwareFeaturesHead(cfg, backbone.output_shape())
             if cfg.MODEL.ROI_BOX_HEAD.OPEN_VOCABULARY.DATA_AWARE else None,
-            "proposal_generator": None, "roi_heads": build_roi_heads(cfg, backbone.output_shape()),
+            "proposal_generator": build_proposal_generator(cfg, backbone.output_shape()), "roi_heads": build_roi_heads(cfg, backbone.output_shape()),
             "input_format": cfg.INPUT.FORMAT, "vis_period": cfg.VIS_PERIOD,
             "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
         }
@@ -113,8 +108,21 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
     def _proposals(self, batched_inputs):
         assert "proposals" in batched_inputs[0]
         proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+        if self.proposal_generator is None:  # rcnn_wsovod.py:198-203; with an RPN the loaded boxes stay as they are
+            for p in proposals:
+                p.level_ids = torch.zeros((len(p),), dtype=torch.int64, device=self.device)
+        return proposals
+
+    def _rpn_proposals(self, images, features, batched_inputs, loaded, gt_instances=None):
+        """rcnn_wsovod.py:177-197 / :267-283: RPN boxes (objectness = sigmoid, ramped by iter / MAX_ITER in
+        training) followed by the loaded SAM boxes of the image."""
+        proposals, _ = self.proposal_generator(images, features, gt_instances)
+        ramp = self.roi_heads.iter / self.cfg.SOLVER.MAX_ITER if self.training else 1.0
         for p in proposals:
-            p.level_ids = torch.zeros((len(p),), dtype=torch.int64, device=self.device)
+            p.objectness_logits = torch.sigmoid(p.objectness_logits) * ramp
+        self.rpn_proposals = proposals
+        if loaded is not None:
+            proposals = [Instances.cat([p1, p2]) for p1, p2 in zip(proposals, loaded)]
         return proposals
 
     def _image_level_gt(self, batched_inputs):
@@ -155,9 +163,11 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
                                   for x in batched_inputs]
         features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
         st["features"] = features
-        st["proposals"] = self._proposals(batched_inputs)
+        st["proposals"] = self._proposals(batched_inputs) if "proposals" in batched_inputs[0] else None
         st["gaps"] = self.data_aware_head.pooled_stats(features) if self.data_aware_head is not None else None
-        st["pooled"] = self.roi_heads.pool_features(features, st["proposals"])
+        # with an RPN the box set depends on trainable weights: pooling moves to the trainable part
+        st["pooled"] = self.roi_heads.pool_features(features, st["proposals"]) if self.proposal_generator is None \
+            else None
         return st
 
     def _heads_kwargs(self, st):
@@ -170,12 +180,17 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         """The trainable remainder: data-aware MLP, neck, object mining, refinement, losses."""
         self.roi_heads.image_level_gt = st["image_level_gt"]
         daf = self.data_aware_head.from_stats(st["gaps"]) if self.data_aware_head is not None else None
-        _, detector_losses = self.roi_heads(ImageList(st["canvas"], st["sizes"]), st["features"], st["proposals"],
-                                            daf, st["gt_instances"], append_background=True,
-                                            loaded_proposals=st["proposals"], pooled=st["pooled"],
-                                            **self._heads_kwargs(st))
+        images = ImageList(st["canvas"], st["sizes"])
+        proposals = st["proposals"]
+        if self.proposal_generator is not None:
+            proposals = self._rpn_proposals(images, st["features"], None, st["proposals"], st["gt_instances"])
+        _, detector_losses = self.roi_heads(images, st["features"], proposals, daf, st["gt_instances"],
+                                            append_background=True, loaded_proposals=st["proposals"],
+                                            pooled=st["pooled"], **self._heads_kwargs(st))
         losses = {}
         losses.update(detector_losses)
+        if self.proposal_generator is not None:  # rcnn_wsovod.py:222-223: trained from the heads' pseudo GT
+            losses.update(self.proposal_generator.get_losses(self.roi_heads.proposal_targets))
         return losses
 
     @torch.no_grad()
@@ -184,7 +199,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         assert detected_instances is None, "forward_with_given_boxes is not on the hot path"
         canvas, sizes_t, sizes = self._canvas(batched_inputs)
         features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
-        proposals = self._proposals(batched_inputs)
+        proposals = self._proposals(batched_inputs) if "proposals" in batched_inputs[0] else None
+        if self.proposal_generator is not None:
+            proposals = self._rpn_proposals(ImageList(canvas, sizes), features, batched_inputs, proposals)
         daf = self.data_aware_head.forward_per_image(features) if self.data_aware_head is not None else None
         if classifier is not None:
             self.classifier = classifier

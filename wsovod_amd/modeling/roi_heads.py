@@ -261,13 +261,30 @@ class WSOVODROIHeads(ROIHeads):
             predictions_k = self.box_refinery[k](box_features, classifier=classifier,
                                                  append_background=append_background)
             losses.update(self.box_refinery[k].losses(predictions_k, proposals_k, self.num_classes))
-            if k + 1 < self.refine_K:
+            if k + 1 < self.refine_K or self.rpn_on:
                 prev_pred_scores = torch.softmax(predictions_k[0].detach(), dim=-1)
                 prev_pred_boxes = torch.cat(self.box_refinery[k].predict_boxes(
                     (None, predictions_k[1].detach()), proposals_k), dim=0)
         if self.rpn_on:
-            self.proposal_targets = targets
+            self.proposal_targets = self.rpn_targets(prev_pred_scores, prev_pred_boxes, proposals, seg)
         return losses
+
+    @torch.no_grad()
+    def rpn_targets(self, prev_pred_scores, prev_pred_boxes, proposals, seg):
+        """roi_heads.py:862-881: the pseudo ground truth the RPN is trained on = get_pgt_top_k(top_k=1) of the LAST
+        refinement head's boxes and class probabilities.  Same mining kernel; one host read of the per-image counts
+        to cut the per-image Instances (the reference builds them on the host as well)."""
+        o = H.pgt_mine_and_label(prev_pred_scores.to(torch.float32), prev_pred_boxes, seg, self._gt_cat, self._gt_off,
+                                 self.pred_class_img_logits, self.num_classes, 0.5)
+        host = torch.cat([o["pgt_count"], self._gt_off]).tolist()
+        G = len(proposals)
+        counts, offs = host[:G], host[G:]
+        out = []
+        for g, p in enumerate(proposals):
+            sl = slice(offs[g], offs[g] + counts[g])
+            out.append(Instances(p.image_size, gt_boxes=Boxes(o["pgt_boxes"][sl]), gt_classes=o["pgt_classes"][sl],
+                                 gt_scores=o["pgt_scores"][sl], gt_weights=o["pgt_weights"][sl]))
+        return out
 
     @torch.no_grad()
     def mine_and_label(self, k, prev_pred_scores, prev_pred_boxes, proposals, seg, nums):

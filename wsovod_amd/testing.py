@@ -12,12 +12,15 @@ _CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs"
 
 
 def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", device="cuda", weight_path=None,
-                 emb_seed=7):
+                 emb_seed=7, rpn=False):
     """WSOVOD_WSR_{18,50}_DC5_1x in proposals-only mode: the keys below are the values of
     /root/reference/configs/PascalVOC-Detection/{Base-RCNN-DilatedC5,WSOVOD_WSR_18_DC5_1x}.yaml
     that the hot path reads, with PROPOSAL_GENERATOR=PrecomputedProposals, BBOX_REFINE off."""
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(_CONFIG_DIR, f"WSOVOD_WSR_{depth}_DC5_1x.yaml"))
+    if rpn:  # the shipped form: RPN boxes next to the loaded proposals (SURVEY 8f n1)
+        assert depth == 18
+        cfg.merge_from_file(os.path.join(_CONFIG_DIR, "WSOVOD_WSR_18_DC5_1x_rpn.yaml"))
     if weight_path is None:
         weight_path = os.path.join(tempfile.mkdtemp(prefix="wsovod_emb_"), f"emb_{K}x{D}.pkl")
         with open(weight_path, "wb") as f:
