@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--classes", type=int, default=20)
     ap.add_argument("--embed-dim", type=int, default=512)
     ap.add_argument("--pooler", default="ROIPool")
+    ap.add_argument("--rpn", action="store_true",
+                    help="the shipped form of the config: RPN branch on next to the loaded proposals (SURVEY 8f n1); "
+                         "not the north-star workload, so no CPU baseline is taken")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -149,7 +152,11 @@ def main():
     from wsovod_amd.testing import build_hot_path_model
 
     cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim,
-                                      precision=args.precision, pooler=args.pooler, device=f"cuda:{local_rank}")
+                                      precision=args.precision, pooler=args.pooler, device=f"cuda:{local_rank}",
+                                      rpn=args.rpn)
+    if args.rpn:
+        args.no_cpu_baseline = True
+        model.roi_heads.iter = cfg.SOLVER.MAX_ITER // 2  # mid-training objectness ramp (rcnn_wsovod.py:181-184)
     model.train()
     optimizer = build_optimizer(cfg, model)
     trainer = HotPathTrainer(model, optimizer)  # per-tensor async all-reduce overlapped with the frozen forward
@@ -230,7 +237,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"VOC07 WSOVOD_WSR_{args.depth}_DC5_1x, {args.proposals} proposals/img, "
                                    f"{args.classes}-class embeddings (D={args.embed_dim}), 800x600 images, "
-                                   f"proposals-only mode, {args.pooler}, full training step (fwd+bwd+SGD)",
+                                   f"{'RPN + loaded proposals' if args.rpn else 'proposals-only mode'}, {args.pooler}, "
+                                   f"full training step (fwd+bwd+SGD)",
                        "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "final_losses": final_losses},
         }

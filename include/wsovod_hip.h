@@ -273,6 +273,16 @@ int wsovod_rpn_decode(const float* anchors, const float* deltas, const long long
                       long long anchors_per_image, const float* image_sizes, const float* weights, float scale_clamp,
                       float min_size, float* boxes, unsigned char* valid, wsovod_stream_t stream);
 
+/* RPN anchor labelling: detectron2 pairwise_iou + Matcher(thresholds [lo, hi], labels [0, -1, 1],
+ * allow_low_quality_matches=True) (un-vendored) as used by
+ * WSOVODRPN_V2.label_and_sample_anchors (rpn.py:237-293) before the random sub-sampling.
+ *   anchors (A,4); gt_boxes (total_gt,4) pseudo-GT boxes, image b owns rows
+ *   [gt_start[b], gt_start[b] + gt_count[b]) (device arrays: no host round trip); outputs per (image, anchor): best_iou f32, best_gt int32 (row of gt_boxes
+ *   or -1), labels int8 in {1 positive, 0 negative, -1 ignore}; gt_best_ws: total_gt 32-bit words of scratch. */
+int wsovod_rpn_label_anchors(const float* anchors, int A, const float* gt_boxes, const int* gt_start,
+                             const int* gt_count, int num_images, int total_gt, float thr_lo, float thr_hi, float* best_iou, int* best_gt,
+                             unsigned int* gt_best_ws, signed char* labels, wsovod_stream_t stream);
+
 /* im2col rows of selected output pixels of an NHWC convolution input (weight gradient of the RPN's 3x3 conv,
  * detectron2 StandardRPNHead.conv, un-vendored; only the sampled anchors of rpn.py:217-233 carry a loss).
  *   x (n_img,H,W,Cin) NHWC in `dtype`; rows (n_rows) int64 flat output-pixel ids (img*Ho*Wo + ho*Wo + wo), a

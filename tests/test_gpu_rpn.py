@@ -36,6 +36,16 @@ def build_rpn_model(precision="fp32"):
     return cfg, model, sd, sampling
 
 
+def first_k_keys(model, monkeypatch):
+    """Sampling keys = anchor index: the batched sampler then picks the first-k anchors, the rule the golden step
+    and the oracle use (gen.first_k_subsample) in place of detectron2's random permutation."""
+    from wsovod_amd.modeling import sampling
+
+    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    monkeypatch.setattr(model.proposal_generator, "_sample_keys",
+                        lambda B, A, dev: torch.arange(A, device=dev, dtype=torch.float32).expand(B, A))
+
+
 def match_fraction(a, b, tol=0.05):
     """fraction of rows of a that have a row of b within tol (max abs coordinate difference)."""
     if len(a) == 0:
@@ -47,12 +57,15 @@ def match_fraction(a, b, tol=0.05):
 def test_rpn_step_matches_reference_golden(gpu, monkeypatch):
     g = load_golden("g12_rpn_train_step")
     cfg, model, sd, sampling = build_rpn_model("fp32")
-    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    first_k_keys(model, monkeypatch)
     batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
     losses = model(to_inputs(batch))
     sum(losses.values()).backward()
     torch.cuda.synchronize()
     pg = model.proposal_generator
+    # anchor labels after sampling: identical up to the few anchors whose IoU with a pseudo-GT box (decoded through
+    # expf on the device) sits within rounding of a threshold
+    assert (pg.sampled_labels.cpu() != g["anchor_labels"]).sum() <= 4
     torch.testing.assert_close(pg.pred_objectness_logits[0].detach().cpu(), g["rpn_logits"], rtol=1e-4, atol=2e-4)
     torch.testing.assert_close(gen.strided_sample(pg.pred_anchor_deltas[0].detach().cpu(), 8192), g["rpn_deltas_sample"],
                                rtol=1e-4, atol=2e-4)
@@ -81,7 +94,7 @@ def test_rpn_head_gradients_match_oracle(gpu, monkeypatch):
     """Given identical proposals (the oracle is fed the HIP path's own RPN boxes), every loss and the RPN-head
     gradients agree tightly -- isolates the sparse-row weight-gradient path (im2col rows + GEMMs)."""
     cfg, model, sd, sampling = build_rpn_model("fp32")
-    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    first_k_keys(model, monkeypatch)
     batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=47)
     losses = model(to_inputs(batch))
     sum(losses.values()).backward()
@@ -109,6 +122,23 @@ def test_rpn_head_gradients_match_oracle(gpu, monkeypatch):
         assert (got - gr).abs().max() <= 2e-3 * gr.abs().max() + 1e-7, kk
 
 
+def test_packed_and_list_label_paths_agree(gpu, monkeypatch):
+    """The batched sync-free labelling / loss path equals the reference-shaped per-image path (Matcher + first-k
+    sub-sampling + masked losses) on the same pseudo GT."""
+    cfg, model, sd, sampling = build_rpn_model("fp32")
+    first_k_keys(model, monkeypatch)
+    batch = gen.seeded_batch(3, 30, 20, 256, 352, seed=53)
+    losses = model(to_inputs(batch))
+    pg = model.proposal_generator
+    targets = model.roi_heads.proposal_targets
+    gt_labels, gt_boxes = pg.label_and_sample_anchors(pg.anchors, list(targets))
+    assert torch.equal(torch.stack(gt_labels), pg.sampled_labels)
+    ref = pg.losses(pg.anchors, pg.pred_objectness_logits, gt_labels, pg.pred_anchor_deltas, gt_boxes)
+    for k in ("loss_rpn_cls", "loss_rpn_loc"):
+        torch.testing.assert_close(losses[k], ref[k], rtol=1e-5, atol=1e-7)
+    assert int((pg.sampled_labels >= 0).sum(dim=1).max()) <= pg.batch_size_per_image
+
+
 def test_rpn_eval_inference_runs(gpu):
     cfg, model, sd, _ = build_rpn_model("fp32")
     model.eval()
@@ -122,7 +152,7 @@ def test_rpn_eval_inference_runs(gpu):
 def test_bf16_rpn_step_is_finite_and_close(gpu, monkeypatch):
     g = load_golden("g12_rpn_train_step")
     cfg, model, sd, sampling = build_rpn_model("bf16")
-    monkeypatch.setattr(sampling, "subsample_labels", gen.first_k_subsample)
+    first_k_keys(model, monkeypatch)
     batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
     losses = model(to_inputs(batch))
     sum(losses.values()).backward()

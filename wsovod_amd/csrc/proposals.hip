@@ -19,6 +19,10 @@
 //                           order (they stay sorted by score) and the scan stops at max_keep.
 #include "common.h"
 
+// Index results (bins, keep sets, labels) must match the reference bit for bit: no mul+add fusion anywhere in this
+// file (HIP's __fmul_rn & co. are plain operators and would still be contracted under the default fp-contract=fast).
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ __forceinline__ int find_segment(const int* __restrict__ seg, int G, int i) {
@@ -177,9 +181,94 @@ __global__ __launch_bounds__(256) void im2col_rows_kernel(const T* __restrict__ 
   }
 }
 
+// Anchor labelling of the RPN (rpn.py:237-293 with detectron2's Matcher(allow_low_quality_matches=True) and
+// pairwise_iou restated).  Pass 1: every (image, anchor) takes the best-overlapping pseudo-GT
+// box of its image and raises that box's best-IoU cell (IoUs are >= 0, so their bit patterns order like unsigned
+// ints).  Pass 2: thresholds -> {0, -1, 1}, then the low-quality rule: an anchor that attains some box's best IoU
+// is positive whatever its own maximum.  Both passes evaluate the same fp32 expression, so the equality is exact.
+// noinline: both passes must execute the very same instruction sequence for the equality test to be exact.
+__device__ __attribute__((noinline)) float box_iou_d2(const float4 g, const float area_g, const float4 a,
+                                                      const float area_a) {
+  const float w = fmaxf(__fsub_rn(fminf(g.z, a.z), fmaxf(g.x, a.x)), 0.f);
+  const float h = fmaxf(__fsub_rn(fminf(g.w, a.w), fmaxf(g.y, a.y)), 0.f);
+  const float inter = __fmul_rn(w, h);
+  return inter > 0.f ? __fdiv_rn(inter, __fsub_rn(__fadd_rn(area_g, area_a), inter)) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void rpn_match_kernel(const float4* __restrict__ anchors, int A,
+                                                        const float4* __restrict__ gt, const int* __restrict__ gt_start,
+                                                        const int* __restrict__ gt_count,
+                                                        float* __restrict__ best_val, int* __restrict__ best_gt,
+                                                        unsigned int* __restrict__ gt_best) {
+  const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (a >= A) return;
+  const float4 an = anchors[a];
+  const float area_a = __fmul_rn(__fsub_rn(an.z, an.x), __fsub_rn(an.w, an.y));
+  const int g0 = gt_start[b], g1 = g0 + gt_count[b];
+  float best = -1.f;
+  int arg = -1;
+  for (int g = g0; g < g1; ++g) {
+    const float4 q = gt[g];
+    const float iou = box_iou_d2(q, __fmul_rn(__fsub_rn(q.z, q.x), __fsub_rn(q.w, q.y)), an, area_a);
+    if (iou > best) { best = iou; arg = g; }
+    atomicMax(gt_best + g, __float_as_uint(iou));
+  }
+  best_val[(long long)b * A + a] = best;
+  best_gt[(long long)b * A + a] = arg;
+}
+
+__global__ __launch_bounds__(256) void rpn_label_kernel(const float4* __restrict__ anchors, int A,
+                                                        const float4* __restrict__ gt, const int* __restrict__ gt_start,
+                                                        const int* __restrict__ gt_count,
+                                                        const float* __restrict__ best_val,
+                                                        const unsigned int* __restrict__ gt_best, float lo, float hi,
+                                                        signed char* __restrict__ labels) {
+  const int a = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (a >= A) return;
+  const int g0 = gt_start[b], g1 = g0 + gt_count[b];
+  const float v = best_val[(long long)b * A + a];
+  signed char lab = 0;  // no box at all: background (Matcher's empty-matrix default)
+  if (g1 > g0) {
+    lab = v >= hi ? 1 : (v >= lo ? -1 : 0);
+    const float4 an = anchors[a];
+    const float area_a = __fmul_rn(__fsub_rn(an.z, an.x), __fsub_rn(an.w, an.y));
+    for (int g = g0; g < g1; ++g) {
+      const float4 q = gt[g];
+      const float iou = box_iou_d2(q, __fmul_rn(__fsub_rn(q.z, q.x), __fsub_rn(q.w, q.y)), an, area_a);
+      if (__float_as_uint(iou) == gt_best[g]) lab = 1;
+    }
+  }
+  labels[(long long)b * A + a] = lab;
+}
+
 }  // namespace
 
 extern "C" {
+
+int wsovod_rpn_label_anchors(const float* anchors, int A, const float* gt_boxes, const int* gt_start,
+                             const int* gt_count, int num_images, int total_gt, float thr_lo, float thr_hi, float* best_iou, int* best_gt,
+                             unsigned int* gt_best_ws, signed char* labels, wsovod_stream_t stream) {
+  if (num_images == 0 || A == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(anchors && gt_start && gt_count && best_iou && best_gt && labels,
+               "wsovod_rpn_label_anchors: null pointer");
+  WS_CHECK_ARG(total_gt == 0 || (gt_boxes && gt_best_ws), "wsovod_rpn_label_anchors: null pointer");
+  WS_CHECK_ARG((((uintptr_t)anchors | (uintptr_t)gt_boxes) & 15) == 0,
+               "wsovod_rpn_label_anchors: anchors/gt_boxes must be 16-byte aligned");
+  static int slot = wsovod::prof_slot("rpn_label_anchors");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)num_images * A * 25.0);
+  if (total_gt > 0 && hipMemsetAsync(gt_best_ws, 0, sizeof(unsigned int) * total_gt, s) != hipSuccess) {
+    wsovod::set_error("wsovod_rpn_label_anchors: memset failed");
+    return WSOVOD_ERR_HIP;
+  }
+  const dim3 grid(ceil_div(A, 256), num_images);
+  hipLaunchKernelGGL(rpn_match_kernel, grid, dim3(256), 0, s, (const float4*)anchors, A, (const float4*)gt_boxes,
+                     gt_start, gt_count, best_iou, best_gt, gt_best_ws);
+  hipLaunchKernelGGL(rpn_label_kernel, grid, dim3(256), 0, s, (const float4*)anchors, A, (const float4*)gt_boxes,
+                     gt_start, gt_count, best_iou, gt_best_ws, thr_lo, thr_hi, labels);
+  WS_CHECK_LAUNCH("wsovod_rpn_label_anchors");
+  return WSOVOD_OK;
+}
 
 int wsovod_im2col_rows(const void* x, int dtype, const long long* rows, int n_rows, int H, int W, int Cin, int Ho, int Wo,
                        int KH, int KW, int stride, int pad, int dil, void* out, wsovod_stream_t stream) {

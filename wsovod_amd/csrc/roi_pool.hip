@@ -17,6 +17,10 @@
 
 #include "common.h"
 
+// Index results (bins, keep sets, labels) must match the reference bit for bit: no mul+add fusion anywhere in this
+// file (HIP's __fmul_rn & co. are plain operators and would still be contracted under the default fp-contract=fast).
+#pragma clang fp contract(off)
+
 namespace {
 
 struct RoiBox {

@@ -554,3 +554,20 @@ def im2col_rows(x_nhwc, rows, kernel_size, stride=1, padding=0, dilation=1):
     check(lib().wsovod_im2col_rows(ptr(x_nhwc), dtype_code(x_nhwc.dtype), ptr(rows), rows.numel(), Hh, Ww, Cc, Ho, Wo,
                                    k, k, stride, padding, dilation, ptr(out), stream()), "im2col_rows")
     return out
+
+
+def rpn_label_anchors(anchors, gt_boxes, gt_start, gt_count, thr_lo, thr_hi):
+    """gt_start / gt_count: (B) int32 device arrays.
+    -> (labels (B,A) int8 {1,0,-1}, best_gt (B,A) int32 row of gt_boxes or -1, best_iou (B,A) f32)."""
+    require_gpu(anchors, gt_boxes, gt_start, gt_count)
+    num_images = gt_start.numel()
+    anchors, gt_boxes = anchors.contiguous(), gt_boxes.to(torch.float32).contiguous()
+    A, T, dev = anchors.shape[0], gt_boxes.shape[0], anchors.device
+    labels = torch.empty((num_images, A), dtype=torch.int8, device=dev)
+    best_gt = torch.empty((num_images, A), dtype=torch.int32, device=dev)
+    best_iou = torch.empty((num_images, A), dtype=torch.float32, device=dev)
+    ws = torch.empty((max(T, 1),), dtype=torch.int32, device=dev)
+    check(lib().wsovod_rpn_label_anchors(ptr(anchors), A, ptr(gt_boxes), ptr(gt_start), ptr(gt_count), num_images, T,
+                                         C.c_float(thr_lo), C.c_float(thr_hi), ptr(best_iou), ptr(best_gt), ptr(ws),
+                                         ptr(labels), stream()), "rpn_label_anchors")
+    return labels, best_gt, best_iou

@@ -268,11 +268,12 @@ class WSOVODRPN_V2(nn.Module):
 
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances: List[Instances]):
-        """rpn.py:237-293: IoU-match every anchor to the pseudo-GT boxes, then sample a fixed-size batch."""
+        """rpn.py:237-293, the reference's per-image form on list[Instances] (host loop; kept for API parity and as
+        the cross-check of the batched path below)."""
         anchors = Boxes.cat(anchors)
         gt_labels, matched_gt_boxes = [], []
         for inst in gt_instances:
-            gt_boxes_i, image_size_i = inst.gt_boxes, inst.image_size
+            gt_boxes_i = inst.gt_boxes
             matched_idxs, gt_labels_i = self.anchor_matcher(pairwise_iou(gt_boxes_i, anchors))
             gt_labels_i = gt_labels_i.to(device=gt_boxes_i.device)
             if self.anchor_boundary_thresh >= 0:
@@ -286,9 +287,40 @@ class WSOVODRPN_V2(nn.Module):
             matched_gt_boxes.append(matched_gt_boxes_i)
         return gt_labels, matched_gt_boxes
 
+    def _sample_keys(self, num_images, num_anchors, device):
+        """Sort keys of the random sub-sampling: the k smallest keys among the positives / negatives of an image are
+        its sample (uniform without replacement, what subsample_labels' randperm does).  Tests replace this by the
+        anchor index (= the deterministic first-k rule the golden fixtures were generated with)."""
+        return torch.rand((num_images, num_anchors), device=device)
+
+    @torch.no_grad()
+    def label_and_sample_anchors_packed(self, anchors: List[Boxes], packed):
+        """Batched, sync-free form of label_and_sample_anchors on the device-resident pseudo GT: one labelling kernel
+        for the whole batch, then two batched top-k selections.  Returns fixed-size index sets
+        (pos_idx (B,P), pos_valid, neg_idx (B,S), neg_valid, matched boxes of the positives (B,P,4), labels (B,A))."""
+        gt_boxes, gt_start, gt_count = packed
+        anchors_t = Boxes.cat(anchors).tensor
+        m = self.anchor_matcher
+        assert m.labels == [0, -1, 1] and m.allow_low_quality_matches, "RPN anchor matcher: [0, -1, 1] + low-quality"
+        labels, best_gt, _ = H.rpn_label_anchors(anchors_t, gt_boxes, gt_start, gt_count, m.thresholds[1], m.thresholds[2])
+        B, A = labels.shape
+        S = min(self.batch_size_per_image, A)
+        P = min(int(self.batch_size_per_image * self.positive_fraction), A)
+        keys = self._sample_keys(B, A, labels.device).to(torch.float32)
+        inf = torch.full_like(keys, float("inf"))
+        pos_vals, pos_idx = torch.topk(torch.where(labels == 1, keys, inf), P, dim=1, largest=False, sorted=True)
+        pos_valid = torch.isfinite(pos_vals)
+        num_neg = S - pos_valid.sum(dim=1, keepdim=True)
+        neg_vals, neg_idx = torch.topk(torch.where(labels == 0, keys, inf), S, dim=1, largest=False, sorted=True)
+        neg_valid = torch.isfinite(neg_vals) & (torch.arange(S, device=keys.device)[None, :] < num_neg)
+        matched = gt_boxes[best_gt.gather(1, pos_idx).clamp(min=0).long()]  # (B,P,4)
+        sampled = torch.full_like(labels, -1)
+        sampled.scatter_(1, neg_idx, torch.where(neg_valid, 0, -1).to(torch.int8))
+        sampled.scatter_(1, pos_idx, torch.where(pos_valid, 1, sampled.gather(1, pos_idx).to(torch.int64)).to(torch.int8))
+        return pos_idx, pos_valid, neg_idx, neg_valid, matched, sampled
+
     def losses(self, anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes):
-        """rpn.py:296-375: sum-reduced BCE-with-logits over the sampled anchors and smooth-L1 over the positive
-        ones, both divided by batch_size_per_image * num_images.  A few thousand elements: torch on the device."""
+        """rpn.py:296-375 on the reference's list interface (see losses_packed for the hot form)."""
         num_images = len(gt_labels)
         gt_labels = torch.stack(gt_labels)
         pos_mask = gt_labels == 1
@@ -299,18 +331,42 @@ class WSOVODRPN_V2(nn.Module):
         if not bool(torch.isfinite(pos_targets).all()):
             localization_loss = pred_deltas[pos_mask].sum() * 0.0
         else:
-            diff = (pred_deltas[pos_mask] - pos_targets).abs()
-            if self.smooth_l1_beta < 1e-5:
-                localization_loss = diff.sum()
-            else:
-                b = self.smooth_l1_beta
-                localization_loss = torch.where(diff < b, 0.5 * diff * diff / b, diff - 0.5 * b).sum()
+            localization_loss = self._smooth_l1(pred_deltas[pos_mask] - pos_targets).sum()
         valid_mask = gt_labels >= 0
         objectness_loss = F.binary_cross_entropy_with_logits(
             torch.cat(pred_objectness_logits, dim=1)[valid_mask], gt_labels[valid_mask].to(torch.float32),
             reduction="sum")
         normalizer = self.batch_size_per_image * num_images
         losses = {"loss_rpn_cls": objectness_loss / normalizer, "loss_rpn_loc": localization_loss / normalizer}
+        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+
+    def _smooth_l1(self, diff):
+        diff = diff.abs()
+        if self.smooth_l1_beta < 1e-5:
+            return diff
+        b = self.smooth_l1_beta
+        return torch.where(diff < b, 0.5 * diff * diff / b, diff - 0.5 * b)
+
+    def losses_packed(self, anchors, pred_objectness_logits, pred_anchor_deltas, sample):
+        """The same two sums over the fixed-size sample (invalid slots weigh zero): no boolean-mask indexing, so no
+        host synchronisation.  A few thousand elements -- torch on the device."""
+        pos_idx, pos_valid, neg_idx, neg_valid, matched, _ = sample
+        logits = torch.cat(pred_objectness_logits, dim=1)
+        deltas = torch.cat(pred_anchor_deltas, dim=1)
+        B = logits.shape[0]
+        anchors_t = Boxes.cat(anchors).tensor
+        a_pos = anchors_t[pos_idx]  # (B,P,4)
+        target = self.box2box_transform.get_deltas(a_pos.reshape(-1, 4), matched.reshape(-1, 4), check=False).view_as(a_pos)
+        pv = pos_valid.unsqueeze(-1)
+        finite = torch.isfinite(torch.where(pv, target, torch.zeros_like(target))).all()
+        pred = deltas.gather(1, pos_idx.unsqueeze(-1).expand(-1, -1, 4))
+        loc = (self._smooth_l1(pred - torch.where(pv, target, pred.detach())) * pv).sum()
+        loc = torch.where(finite, loc, loc * 0.0)  # rpn.py:337-343: non-finite targets drop the term
+        lp, ln = logits.gather(1, pos_idx), logits.gather(1, neg_idx)
+        obj = (F.binary_cross_entropy_with_logits(lp, torch.ones_like(lp), reduction="none") * pos_valid).sum() + \
+              (F.binary_cross_entropy_with_logits(ln, torch.zeros_like(ln), reduction="none") * neg_valid).sum()
+        normalizer = self.batch_size_per_image * B
+        losses = {"loss_rpn_cls": obj / normalizer, "loss_rpn_loc": loc / normalizer}
         return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
 
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor],
@@ -331,6 +387,11 @@ class WSOVODRPN_V2(nn.Module):
 
     def get_losses(self, gt_instances):
         assert gt_instances is not None, "RPN requires gt_instances in training!"
+        packed = getattr(gt_instances, "packed", None)
+        if packed is not None:  # pseudo GT still on the device: batched, sync-free path
+            sample = self.label_and_sample_anchors_packed(self.anchors, packed)
+            self.sampled_labels = sample[-1]
+            return self.losses_packed(self.anchors, self.pred_objectness_logits, self.pred_anchor_deltas, sample)
         gt_labels, gt_boxes = self.label_and_sample_anchors(self.anchors, gt_instances)
         return self.losses(self.anchors, self.pred_objectness_logits, gt_labels, self.pred_anchor_deltas, gt_boxes)
 

@@ -76,6 +76,37 @@ class ROIHeads(nn.Module):
         }
 
 
+class PseudoTargets:
+    """list[Instances] view of the mining kernel's output.  `packed` = (boxes (T,4), start (G) int32, count (G)
+    int32) on the device: image g owns rows [start[g], start[g] + count[g])."""
+
+    def __init__(self, mined, gt_off, image_sizes):
+        self._o, self._off, self._sizes, self._items = mined, gt_off, image_sizes, None
+        self.packed = (mined["pgt_boxes"], gt_off[:-1].contiguous(), mined["pgt_count"])
+
+    def _materialise(self):
+        if self._items is None:
+            G = len(self._sizes)
+            host = torch.cat([self._o["pgt_count"], self._off]).tolist()
+            counts, offs = host[:G], host[G:]
+            self._items = []
+            for g, size in enumerate(self._sizes):
+                sl = slice(offs[g], offs[g] + counts[g])
+                self._items.append(Instances(size, gt_boxes=Boxes(self._o["pgt_boxes"][sl]),
+                                             gt_classes=self._o["pgt_classes"][sl], gt_scores=self._o["pgt_scores"][sl],
+                                             gt_weights=self._o["pgt_weights"][sl]))
+        return self._items
+
+    def __len__(self):
+        return len(self._sizes)
+
+    def __getitem__(self, i):
+        return self._materialise()[i]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+
 @ROI_HEADS_REGISTRY.register()
 class WSOVODROIHeads(ROIHeads):
     @configurable
@@ -272,19 +303,12 @@ class WSOVODROIHeads(ROIHeads):
     @torch.no_grad()
     def rpn_targets(self, prev_pred_scores, prev_pred_boxes, proposals, seg):
         """roi_heads.py:862-881: the pseudo ground truth the RPN is trained on = get_pgt_top_k(top_k=1) of the LAST
-        refinement head's boxes and class probabilities.  Same mining kernel; one host read of the per-image counts
-        to cut the per-image Instances (the reference builds them on the host as well)."""
+        refinement head's boxes and class probabilities.  Same mining kernel.  The result stays on the device
+        (`.packed`); the per-image Instances of the reference's interface are cut only if somebody indexes the
+        list (one host read of the counts)."""
         o = H.pgt_mine_and_label(prev_pred_scores.to(torch.float32), prev_pred_boxes, seg, self._gt_cat, self._gt_off,
                                  self.pred_class_img_logits, self.num_classes, 0.5)
-        host = torch.cat([o["pgt_count"], self._gt_off]).tolist()
-        G = len(proposals)
-        counts, offs = host[:G], host[G:]
-        out = []
-        for g, p in enumerate(proposals):
-            sl = slice(offs[g], offs[g] + counts[g])
-            out.append(Instances(p.image_size, gt_boxes=Boxes(o["pgt_boxes"][sl]), gt_classes=o["pgt_classes"][sl],
-                                 gt_scores=o["pgt_scores"][sl], gt_weights=o["pgt_weights"][sl]))
-        return out
+        return PseudoTargets(o, self._gt_off, [p.image_size for p in proposals])
 
     @torch.no_grad()
     def mine_and_label(self, k, prev_pred_scores, prev_pred_boxes, proposals, seg, nums):
