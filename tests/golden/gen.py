@@ -94,6 +94,31 @@ def first_k_subsample(labels, num_samples, positive_fraction, bg_label):
     return positive[:num_pos], negative[:num_neg]
 
 
+def proposal_pickle(n_images=4, seed=5):
+    """A D1-style proposal file ({indexes, scores, boxes}) + dataset records that reference a shuffled subset of
+    it; boxes include exact duplicates, near-duplicates that collide after rounding, and boxes below the size cut."""
+    import numpy as np
+
+    rng = np.random.RandomState(seed)
+    ids = [str(2007000 + i) for i in range(n_images + 2)]
+    boxes, scores = [], []
+    for i in range(len(ids)):
+        n = 120 + 7 * i
+        h, w = 200 + 10 * i, 300 + 20 * i
+        xy = rng.rand(n, 2) * [w - 40, h - 40]
+        wh = 2 + rng.rand(n, 2) * [w / 2, h / 2]
+        b = np.concatenate([xy, np.minimum(xy + wh, [w, h])], axis=1).astype(np.float32)
+        b[10:20] = b[0:10]                      # exact duplicates
+        b[20:25] = b[0:5] + 0.2                 # collide after rounding
+        b[25:30, 2:] = b[25:30, :2] + 3.0       # tiny
+        boxes.append(b)
+        scores.append(rng.rand(n).astype(np.float32))
+    pk = {"indexes": ids, "boxes": boxes, "scores": scores}
+    order = [3, 0, 4, 1][:n_images]
+    recs = [{"image_id": int(ids[j]) if j % 2 else ids[j], "height": 200 + 10 * j, "width": 300 + 20 * j} for j in order]
+    return pk, recs
+
+
 def seeded_batch(n_images, R, K, H, W, seed=0, edge_cases=True):
     """Plain-tensor batch (oracle.wsovod_ref.train_forward format)."""
     batch = []

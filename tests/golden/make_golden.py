@@ -489,6 +489,72 @@ def golden_rpn(r):
     save("g12_rpn_train_step", **arrays)
 
 
+def golden_formats():
+    """G13: the REFERENCE's load_proposals_into_dataset (data/build.py:112-173) and unique_boxes /
+    transform_proposals (data/detection_utils.py:206-265) on a synthetic D1-style proposal pickle (`indexes` /
+    `scores` aliases, shuffled ids, duplicates, tiny boxes).  detectron2's BoxMode / TransformList are the
+    restated stand-ins (XYXY proposals: identity conversion)."""
+    import enum
+    import pickle
+    import tempfile
+    from wsovod_amd.data import proposals as P
+
+    class BoxMode(enum.IntEnum):
+        XYXY_ABS = 0
+        XYWH_ABS = 1
+
+        @staticmethod
+        def convert(box, from_mode, to_mode):
+            assert int(from_mode) == int(to_mode) == 0
+            return box
+
+    class _Any:
+        def __getattr__(self, k):
+            return None
+
+    for name in ("detectron2", "detectron2.data", "detectron2.utils", "wsovod", "wsovod.data"):
+        if name not in sys.modules:
+            _mod(name)
+    _mod("pycocotools")
+    _mod("pycocotools.mask")
+    _mod("termcolor", colored=lambda s, *a, **k: s)
+    _mod("detectron2.config", CfgNode=C.CfgNode,
+         configurable=lambda *a, **k: a[0] if a and callable(a[0]) else (lambda f: f))
+    _mod("detectron2.data.transforms")
+    _mod("detectron2.data.catalog", MetadataCatalog=None, DatasetCatalog=None)
+    _mod("detectron2.data.common", AspectRatioGroupedDataset=None, DatasetFromList=None, MapDataset=None,
+         ToIterableDataset=None)
+    _mod("detectron2.data.detection_utils", check_metadata_consistency=None)
+    _mod("detectron2.data.samplers", InferenceSampler=None, RepeatFactorTrainingSampler=None, TrainingSampler=None)
+    _mod("detectron2.structures", Boxes=S.Boxes, Instances=S.Instances, BoxMode=BoxMode, BitMasks=None, Keypoints=None,
+         PolygonMasks=None, RotatedBoxes=None, polygons_to_bitmask=None)
+    _mod("detectron2.utils.comm", get_world_size=lambda: 1)
+    _mod("detectron2.utils.env", seed_all_rng=None)
+    _mod("detectron2.utils.file_io", PathManager=types.SimpleNamespace(open=open))
+    _mod("detectron2.utils.logger", _log_api_usage=None, log_first_n=None)
+    _mod("wsovod.data.common", ClassAspectRatioGroupedDataset=None)
+    _mod("wsovod.data.dataset_mapper", DatasetMapper=None)
+    du = load_ref("wsovod.data.detection_utils", "wsovod/data/detection_utils.py")
+    bd = load_ref("wsovod.data.build", "wsovod/data/build.py")
+
+    pk, recs = gen.proposal_pickle()
+    path = os.path.join(tempfile.mkdtemp(prefix="golden_"), "props.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(pk, f)
+    recs = bd.load_proposals_into_dataset(recs, path)
+    arrays = {}
+    for i, rec in enumerate(recs):
+        arrays[f"rec{i}/boxes"], arrays[f"rec{i}/logits"] = rec["proposal_boxes"], rec["proposal_objectness_logits"]
+        d = dict(rec)
+        h, w = rec["height"], rec["width"]
+        tl = P.TransformList([P.ResizeTransform(h, w, h * 2, w * 2)] + ([P.HFlipTransform(w * 2)] if i % 2 else []))
+        du.transform_proposals(d, (h * 2, w * 2), tl, proposal_topk=50, min_box_size=8)
+        arrays[f"rec{i}/out_boxes"] = d["proposals"].proposal_boxes.tensor
+        arrays[f"rec{i}/out_logits"] = d["proposals"].objectness_logits
+        arrays[f"rec{i}/unique"] = du.unique_boxes(S.Boxes(torch.as_tensor(rec["proposal_boxes"])))
+    save("g13_proposal_formats", **arrays)
+
+
 def golden_sampler():
     """G11: the REFERENCE's MultiDatasetTrainingSampler (repeat factors with class-aware sampling on one dataset,
     and the per-rank index streams of a 2-rank job)."""
@@ -523,6 +589,8 @@ def golden_sampler():
 def main():
     if "--only-sampler" in sys.argv:
         return golden_sampler()
+    if "--only-formats" in sys.argv:
+        return golden_formats()
     torch.manual_seed(0)
     torch.set_num_threads(8)
     r = load_reference()
@@ -631,6 +699,7 @@ def main():
     golden_mixed(r)
     golden_sampler()
     golden_rpn(r)
+    golden_formats()
 
 
 if __name__ == "__main__":

@@ -194,3 +194,65 @@ def test_repeat_factor_and_batcher_semantics():
         seen += [d["i"] for d in b]
     assert len(seen) == len(set(seen))
     assert seen[:2] == [d["i"] for d in batches[0]]
+
+
+def test_proposal_file_format_matches_reference_golden(tmp_path):
+    """n4 input formats: D1-style proposal pickle -> records -> transformed / de-duplicated / top-k Instances, against
+    the reference's own load_proposals_into_dataset / unique_boxes / transform_proposals (fixture g13).  Index work:
+    exact."""
+    import pickle
+
+    import numpy as np
+    from tests.golden import gen
+    from wsovod_amd.data import proposals as P
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g13_proposal_formats.npz"))
+    pk, recs = gen.proposal_pickle()
+    path = tmp_path / "props.pkl"
+    with open(path, "wb") as f:
+        pickle.dump(pk, f)
+    recs = P.load_proposals_into_dataset(recs, str(path))
+    for i, rec in enumerate(recs):
+        assert np.array_equal(rec["proposal_boxes"], g[f"rec{i}/boxes"])
+        assert np.array_equal(rec["proposal_objectness_logits"], g[f"rec{i}/logits"])
+        assert np.all(np.diff(rec["proposal_objectness_logits"]) <= 0)
+        assert np.array_equal(P.unique_boxes(rec["proposal_boxes"]), g[f"rec{i}/unique"])
+        h, w = rec["height"], rec["width"]
+        tl = P.TransformList([P.ResizeTransform(h, w, h * 2, w * 2)] + ([P.HFlipTransform(w * 2)] if i % 2 else []))
+        d = dict(rec)
+        P.transform_proposals(d, (h * 2, w * 2), tl, proposal_topk=50, min_box_size=8)
+        assert "proposal_boxes" not in d and len(d["proposals"]) <= 50
+        assert np.array_equal(d["proposals"].proposal_boxes.tensor.numpy(), g[f"rec{i}/out_boxes"])
+        assert np.array_equal(d["proposals"].objectness_logits.numpy(), g[f"rec{i}/out_logits"])
+    # directory form: one pickle per image, resolved lazily
+    recs2 = P.load_proposals_into_dataset([{"image_id": 7}], str(tmp_path))
+    assert recs2[0]["proposal_file"].endswith("/7.pkl")
+
+
+def test_embedding_and_backbone_pickles(tmp_path):
+    import pickle
+
+    import numpy as np
+    from wsovod_amd.data import load_class_embeddings, load_d2_pickle_into, make_class_embeddings
+    from wsovod_amd.modeling.meta_arch import build_backbone
+    from wsovod_amd.testing import hot_path_cfg
+
+    emb = make_class_embeddings(20, 512, seed=3)
+    p = tmp_path / "emb.pkl"
+    with open(p, "wb") as f:
+        pickle.dump(emb, f)
+    w = load_class_embeddings(str(p))
+    assert w.dtype == torch.float32 and w.shape == (20, 512) and torch.equal(w, emb)
+    # detectron2-format backbone pickle: names without the model prefix, numpy arrays, plus a key the model lacks
+    bb = build_backbone(hot_path_cfg(device="cpu"))
+    sd = bb.state_dict()
+    rng = np.random.RandomState(0)
+    ckpt = {k: rng.randn(*v.shape).astype(np.float32) for k, v in sd.items()}
+    ckpt["fc1000.weight"] = np.zeros((10, 4), dtype=np.float32)
+    q = tmp_path / "r18_d2.pkl"
+    with open(q, "wb") as f:
+        pickle.dump({"model": ckpt, "__author__": "test", "matching_heuristics": True}, f)
+    loaded, unused = load_d2_pickle_into(bb, str(q))
+    assert unused == ["fc1000.weight"] and set(loaded) == set(sd)
+    for k, v in bb.state_dict().items():
+        assert np.array_equal(v.numpy(), ckpt[k]), k
