@@ -61,6 +61,64 @@ def test_gemm_epilogue(gpu, dtype):
     torch.testing.assert_close(out3.cpu().float(), _ref_mm(A, B), rtol=1e-2, atol=1e-1)
 
 
+@pytest.mark.parametrize("shape", [(512, 4096, 1024), (100, 40, 256), (333, 129, 192), (700, 300, 64), (256, 512, 8192)])
+def test_gemm_8phase_tile(gpu, shape):
+    """The 8-wavefront staggered 256x256 tile (bf16 only): plain, ragged edges, short and long K."""
+    from wsovod_amd.layers import hip_ops
+
+    M, N, K = shape
+    torch.manual_seed(0)
+    A = torch.randn(M, K).to(torch.bfloat16)
+    B = torch.randn(N, K).to(torch.bfloat16)
+    ref = _ref_mm(A, B)
+    out = hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, tile_hint=8256256)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-6 * K ** 0.5 * 40)
+    # same summation order as the 16-wavefront tile: bit-identical
+    out16 = hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, tile_hint=256256)
+    assert torch.equal(out, out16)
+    with pytest.raises(RuntimeError, match="bf16 only"):
+        hip_ops.gemm_nt(A.float().to(gpu), B.float().to(gpu), tile_hint=8256256)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("variant", ["fast", "fast_dropout", "generic"])
+def test_gemm_8phase_epilogues(gpu, out_dtype, variant):
+    """Vectorised fast epilogue (bias / residual / ReLU / dropout) and the generic one (row scale, group add, mask,
+    transposed copy, accumulate) of the 8-phase tile against the 16-wavefront tile's results."""
+    from wsovod_amd.layers import hip_ops
+
+    M, N, K = 600, 512, 320
+    torch.manual_seed(3)
+    A = torch.randn(M, K, device=gpu).to(torch.bfloat16)
+    B = torch.randn(N, K, device=gpu).to(torch.bfloat16)
+    bias = torch.randn(N, device=gpu)
+    res = torch.randn(M, N, device=gpu).to(out_dtype)
+    kw = dict(alpha=0.5, bias=bias, residual=res, relu=True, out_dtype=out_dtype)
+    if variant == "fast_dropout":
+        kw.update(dropout_p=0.5, dropout_seed=77)
+    if variant == "generic":
+        kw.update(row_scale=torch.rand(M, device=gpu) + 0.5, row_group=torch.randint(0, 3, (M,), dtype=torch.int32, device=gpu),
+                  group_add=torch.randn(3, N, device=gpu), mask_src=torch.randn(M, N, device=gpu), mask_scale=2.0)
+    outs = {}
+    for tile in (256256, 8256256):
+        out_t = torch.zeros(N, 640, device=gpu) if variant == "generic" else None
+        outs[tile] = (hip_ops.gemm_nt(A, B, tile_hint=tile, out_t=out_t, **kw), out_t)
+    assert torch.equal(outs[256256][0], outs[8256256][0])
+    if variant == "generic":
+        assert torch.equal(outs[256256][1], outs[8256256][1])
+    ref = torch.relu(_ref_mm(A.cpu(), B.cpu()) * 0.5 + bias.cpu()[None] + res.cpu().float())
+    if variant == "fast":
+        torch.testing.assert_close(outs[8256256][0].cpu().float(), ref, rtol=2e-2 if out_dtype == torch.bfloat16 else 1e-4,
+                                   atol=0.2 if out_dtype == torch.bfloat16 else 1e-3)
+    if variant == "generic" and out_dtype == torch.float32:
+        acc0 = torch.randn(M, N, device=gpu)
+        o = {}
+        for tile in (256256, 8256256):
+            o[tile] = acc0.clone()
+            hip_ops.gemm_nt(A, B, out=o[tile], accumulate=True, tile_hint=tile)
+        assert torch.equal(o[256256], o[8256256])
+
+
 def test_gemm_dropout_statistics(gpu):
     from wsovod_amd.layers import hip_ops
 
@@ -85,9 +143,12 @@ def test_gemm_dropout_statistics(gpu):
     dict(Cin=64, Cout=96, H=20, W=26, k=3, stride=2, pad=1, dil=1),
     dict(Cin=64, Cout=64, H=37, W=71, k=3, stride=1, pad=1, dil=1),  # halo-tile kernel with ragged tiles
 ])
-@pytest.mark.parametrize("tile", [0, 256256, 256128, 1128128, 1128064, 1256064, 3256128, 4128128])
+@pytest.mark.parametrize("tile", [0, 256256, 8256256, 256128, 1128128, 1128064, 1256064, 3256128, 4128128])
 def test_conv_implicit_gemm(gpu, dtype, cfg, tile):
     from wsovod_amd.layers import hip_ops
+
+    if tile == 8256256 and dtype != torch.bfloat16:
+        pytest.skip("the 8-phase tile is bf16 only")
 
     torch.manual_seed(2)
     n = 2

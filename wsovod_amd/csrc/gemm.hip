@@ -19,80 +19,9 @@
 // one K-step ahead with LDS double buffering (one barrier per K-step).
 // Workgroup ids are remapped so that the 8 XCDs each get a contiguous run of tiles that
 // share the B (weight) slab in their private L2.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace wsovod_gemm {
-
-struct GemmArgs {
-  const char* A;
-  const char* B;
-  long long lda, ldb;  // elements
-  int M, N, K;
-  void* C;
-  long long ldc;
-  int dtype_c;
-  void* Ct;
-  long long ldct;
-  int dtype_ct;
-  float alpha;
-  const float* row_scale;
-  const float* bias;
-  const void* residual;
-  long long ldr;
-  int dtype_r;
-  int relu;
-  float dropout_p;
-  unsigned long long seed;
-  const int* row_group;
-  const float* group_add;
-  long long ld_ga;
-  const void* mask_src;
-  long long ldm;
-  int dtype_m;
-  float mask_scale;
-  int accumulate;
-  // implicit-GEMM convolution geometry
-  int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
-  long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
-  int tiles_m, tiles_n;
-  int group_m;  // tile-order group height (see the XCD remap in the kernel)
-};
-
-template <typename T>
-struct Traits;
-template <>
-struct Traits<float> {
-  static constexpr int EPC = 4;   // elements per 16-byte chunk
-  static constexpr int BKE = 32;  // elements per K-step (128 B)
-};
-template <>
-struct Traits<bf16_t> {
-  static constexpr int EPC = 8;
-  static constexpr int BKE = 64;
-};
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
-}
-
-__device__ __forceinline__ float load_as_f32(const void* p, long long idx, int dtype) {
-  return dtype == WSOVOD_BF16 ? (float)((const bf16_t*)p)[idx] : ((const float*)p)[idx];
-}
-__device__ __forceinline__ void store_from_f32(void* p, long long idx, int dtype, float v) {
-  if (dtype == WSOVOD_BF16)
-    ((bf16_t*)p)[idx] = (bf16_t)v;
-  else
-    ((float*)p)[idx] = v;
-}
-
-// splitmix64 finaliser: counter-based, stateless dropout mask on (seed, m, n)
-__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
-  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 
 template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p) {
@@ -313,8 +242,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  // operands swapped: see the epilogue
+                __builtin_bit_cast(bf16x8, bfr[j]), __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -323,7 +252,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                  __builtin_bit_cast(f32x4, af[i])[e], __builtin_bit_cast(f32x4, bfr[j])[e], acc[i][j], 0, 0, 0);
+                  __builtin_bit_cast(f32x4, bfr[j])[e], __builtin_bit_cast(f32x4, af[i])[e], acc[i][j], 0, 0, 0);
       }
     }
   };
@@ -384,24 +313,70 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   }
   }
 
-  // ---- epilogue (fp32): D[row=(lane>>4)*4+reg][col=lane&15]
+  // ---- epilogue (fp32).  The MFMAs take the B fragment as their first operand, so a lane's four accumulator
+  // registers are four CONSECUTIVE COLUMNS of one output row: acc[i][j][r] = C[m = .. + (lane & 15)]
+  // [n = .. + (lane >> 4) * 4 + r] -- row-major outputs move as one 16-byte (fp32) / 8-byte (bf16) store per tile.
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const bool vec_c = p.C && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const bool vec_r = !p.residual || ((p.ldr & 3) == 0 && ((uintptr_t)p.residual & 15) == 0);
+  const int mrow = m0 + wm * (BM / WM) + frow;
+  const int ncol = n0 + wn * (BN / WN) + fq * 4;
+  // Fast path (bias / residual / ReLU / dropout, aligned row-major output, all tile columns in range): feature tests
+  // hoisted out of the element loops, bias fetched once per column tile, residual and output as vector accesses.
+  if (vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add && !p.mask_src &&
+      !p.accumulate && n0 + BN <= p.N) {
+    f32x4 b4[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + ncol + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const bool drop = p.dropout_p > 0.f, has_res = p.residual != nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long long mm = mrow + i * 16;
+      if (mm >= p.M) continue;
+      const long long base = mm * p.ldc + ncol;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        f32x4 x = acc[i][j] * p.alpha + b4[j];
+        if (has_res) {
+          if (p.dtype_r == WSOVOD_BF16) {
+            const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + ncol + j * 16);
+            x += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+          } else {
+            x += *(const f32x4*)((const float*)p.residual + mm * p.ldr + ncol + j * 16);
+          }
+        }
+        x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};
+        if (drop) {
+          const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + j * 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) x[r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[r] * keep_scale : 0.f;
+        }
+        if (p.dtype_c == WSOVOD_BF16)
+          *(bf16x4*)((bf16_t*)p.C + base + j * 16) = bf16x4{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
+        else
+          *(f32x4*)((float*)p.C + base + j * 16) = x;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    const int m = mrow + i * 16;
+    if (m >= p.M) continue;
+    const float rs = p.row_scale ? p.row_scale[m] : 1.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / WN) + j * 16 + frow;
-      const int mb = m0 + wm * (BM / WM) + i * 16 + fq * 4;
-      if (n >= p.N) continue;
-      const float bias = p.bias ? p.bias[n] : 0.f;
+      const int nb = ncol + j * 16;
+      if (nb >= p.N) continue;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = mb + r;
+        const int n = nb + r;
         float x = acc[i][j][r] * p.alpha;
-        if (m < p.M) {
-          if (p.row_scale) x *= p.row_scale[m];
-          x += bias;
+        if (n < p.N) {
+          if (p.row_scale) x *= rs;
+          if (p.bias) x += p.bias[n];
           if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
           if (p.relu) x = fmaxf(x, 0.f);
           if (p.dropout_p > 0.f) {
@@ -411,17 +386,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
           if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
           if (p.mask_src)
             x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
-          if (p.C) {
-            if (p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
-            store_from_f32(p.C, (long long)m * p.ldc + n, p.dtype_c, x);
-          }
+          if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
         }
         v[r] = x;
+      }
+      if (p.C) {
+        if (vec_c && nb + 3 < p.N) {
+          if (p.dtype_c == WSOVOD_BF16)
+            *(bf16x4*)((bf16_t*)p.C + (long long)m * p.ldc + nb) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          else
+            *(f32x4*)((float*)p.C + (long long)m * p.ldc + nb) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nb + r < p.N) store_from_f32(p.C, (long long)m * p.ldc + nb + r, p.dtype_c, v[r]);
+        }
       }
       if (p.Ct) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (mb + r < p.M) store_from_f32(p.Ct, (long long)n * p.ldct + mb + r, p.dtype_ct, v[r]);
+          if (nb + r < p.N) store_from_f32(p.Ct, (long long)(nb + r) * p.ldct + m, p.dtype_ct, v[r]);
       }
     }
   }
@@ -575,6 +559,10 @@ template <typename T, bool CONV>
 int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, double bytes) {
   constexpr bool bf = sizeof(T) == 2;
   switch (tile) {
+    case 8256256:  // 8 wavefronts in two staggered groups, four phases per K-step (gemm8.hip); bf16 only
+      if constexpr (bf) return launch_gemm256_8ph(a, CONV, s, flops, bytes);
+      wsovod::set_error("wsovod_gemm_nt: tile 8256256 is bf16 only");
+      return WSOVOD_ERR_UNSUPPORTED;
     case 256256:  // 16 wavefronts (4x4), 128 KiB LDS, one workgroup per CU: 128 FLOP per staged byte
       return launch<T, 256, 256, CONV, 4, 4, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x256" : "conv_igemm_f32_256x256")
                                                        : (bf ? "gemm_nt_bf16_256x256" : "gemm_nt_f32_256x256"),
@@ -740,7 +728,10 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64)");
     return WSOVOD_OK;
   }
-  const int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
+  int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
+  // plain bf16 contractions take the staggered 8-wavefront form of the 256x256 tile (measured +11-13 % on the FC
+  // shapes, tools/gemm_ab.py); the implicit-GEMM conv stays on the 16-wavefront form (tools/conv_ab.py)
+  if (!d->tile_hint && tile == 256256 && d->dtype_in == WSOVOD_BF16 && !d->conv) tile = 8256256;
   if (d->dtype_in == WSOVOD_BF16)
     return d->conv ? dispatch_tile<bf16_t, true>(a, tile, s, flops, bytes) : dispatch_tile<bf16_t, false>(a, tile, s, flops, bytes);
   return d->conv ? dispatch_tile<float, true>(a, tile, s, flops, bytes) : dispatch_tile<float, false>(a, tile, s, flops, bytes);

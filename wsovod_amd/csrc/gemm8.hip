@@ -1,0 +1,417 @@
+// bf16 256x256x64 GEMM / implicit-GEMM tile in the "8-phase" shape (cdna_hip_programming.md section 5, "The 256^2
+// 8-phase template"), written for this library's operand layout and epilogue.
+//
+//   * 512 threads = 8 wavefronts as 2 (M) x 4 (N); a wavefront owns 128 x 64 of the tile = 8 x 4 MFMA tiles
+//     (128 accumulator VGPRs), so a K-step reads (128 + 64) rows x 128 B of fragments per wavefront: 192 KiB per
+//     workgroup against 256 KiB for 16 wavefronts of 64 x 64 -- the LDS array is no longer half as busy as the MFMA.
+//   * A K-step is four PHASES, one 64 x 32 quadrant of the wavefront's output each (16 MFMAs):
+//         phase 1: A rows 0-63, B cols 0-31  (12 ds_read_b128)   quadrant (lo, lo)
+//         phase 2:              B cols 32-63 ( 4)                 quadrant (lo, hi)
+//         phase 3: A rows 64-127             ( 8, reuse A regs)   quadrant (hi, hi)
+//         phase 4: nothing to read                                quadrant (hi, lo)
+//     every phase is  [fragment reads, LDS-DMA issue]  s_barrier  [16 MFMA at raised priority]  s_barrier.
+//   * The two M-halves of the workgroup (wavefronts 0-3 / 4-7, one of each per SIMD) run STAGGERED by one barrier:
+//     while one group is in its MFMA section the other is in its read/stage section, so the matrix pipe and the
+//     LDS array are both busy all the time instead of alternating.
+//   * Staging is LDS-direct (buffer_load ... lds), two K-step buffers (128 KiB), two DMA instructions per phase,
+//     issued as early as the LDS rows they overwrite are free (>= 2 phases after their last read) and retired by
+//     COUNTED s_waitcnt vmcnt(N) that leave the younger ones in flight -- the prefetch runs 2-5 phases ahead of its
+//     use and crosses the barriers.  Every wait sits before a barrier that each reader passes before it reads
+//     those rows, also the staggered group (the "one barrier more" rule of the guide).
+//   * Fragment reads are inline asm: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read it can
+//     see while an LDS-DMA is outstanding and drain the prefetch at once.
+// Same XOR swizzle (chunk ^ ((row >> 1) & 7), applied to the DMA source address and to the read address), XCD-aware
+// grouped tile order and epilogue as gemm.hip.
+#include "gemm_common.h"
+
+namespace wsovod_gemm {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <bool CONV>
+__global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
+  constexpr int BM = 256, BN = 256, BKE = 64, EPC = 8, esz = 2;
+  constexpr int LR = 64;  // rows staged per DMA pass (512 threads x 16 B = 64 rows x 128 B)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                  // 2 x [256][128 B]
+  char* sB = smem + 2 * BM * 128;   // 2 x [256][128 B]
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int group_size = p.group_m * p.tiles_n;
+  const int group_id = wg / group_size;
+  const int first_m = group_id * p.group_m;
+  const int gm = min(p.tiles_m - first_m, p.group_m);
+  const int in_group = wg - group_id * group_size;
+  const int tile_m = first_m + in_group % gm;
+  const int tile_n = in_group / gm;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int lrow = tid >> 3;
+  const int lchunk = (tid & 7) ^ ((lrow >> 1) & 7);  // swizzle on the DMA source
+
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  int a_off[4], hi0[4], wi0[4], b_off[4];
+  if (CONV) {
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  } else {
+    const long long rows = min(BM, p.M - m0);
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * esz), 0, (int)(rows * p.lda * esz),
+                                              0x00020000);
+  }
+  {
+    const long long rows = min(BN, p.N - n0);
+    rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n0 * p.ldb * esz), 0, (int)(rows * p.ldb * esz),
+                                              0x00020000);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + lrow + LR * i;
+    const bool ok = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int mm = ok ? m : 0;
+      const int img = mm / hw;
+      const int rem = mm - img * hw;
+      const int ho = rem / p.Wo;
+      const int wo = rem - ho * p.Wo;
+      hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);
+      wi0[i] = wo * p.stride - p.pad;
+      a_off[i] = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
+    } else {
+      hi0[i] = wi0[i] = 0;
+      a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
+    }
+    const int n = n0 + lrow + LR * i;
+    b_off[i] = n < p.N ? (int)(((long long)(lrow + LR * i) * p.ldb + lchunk * EPC) * esz) : -1;
+  }
+  const int nk = (p.K + BKE - 1) / BKE;
+
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // one DMA pass = 64 tile rows x 128 B (8 rows per wavefront instruction).  A passes 0 / 2 hold the rows the two
+  // wavefront groups read in phase 1 ("A_lo"), passes 1 / 3 the rows they read in phase 3 ("A_hi"); B pass i holds
+  // the 64 columns of the wavefronts with wc == i.
+  // conv: (filter row, filter column, first channel) of a K-step, advanced incrementally (scalar adds instead of the
+  // two integer divisions per staged K-step)
+  struct Tap { int r, q, c0; };
+  auto tap_next = [&](Tap t) {
+    t.c0 += BKE;
+    if (t.c0 >= p.Cin) { t.c0 = 0; if (++t.q >= p.KW) { t.q = 0; ++t.r; } }
+    return t;
+  };
+  auto stage_A = [&](int kt, int buf, int i, const Tap t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int kbase = kt * BKE;
+    char* dA = sA + buf * BM * 128 + wave_u * 1024 + LR * i * 128;
+    if (CONV) {
+      const int hi = hi0[i] + t.r * p.dil;
+      const int wi = wi0[i] + t.q * p.dil;
+      const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + t.c0) * esz;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, ok ? off : -1, 0, 0, 0);
+    } else {
+      const bool k_ok = kbase + lchunk * EPC < p.K;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
+                                               (k_ok && a_off[i] >= 0) ? a_off[i] + kbase * esz : -1, 0, 0, 0);
+    }
+#endif
+  };
+  auto stage_B = [&](int kt, int buf, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int kbase = kt * BKE;
+    const bool k_ok = kbase + lchunk * EPC < p.K;
+    char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16,
+                                             (k_ok && b_off[i] >= 0) ? b_off[i] + kbase * esz : -1, 0, 0, 0);
+#endif
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  // per-lane LDS byte offsets of its fragment rows (row bases are multiples of 16: the swizzle term is per lane)
+  const int sw = (frow >> 1) & 7;
+  [[maybe_unused]] const unsigned offA = (unsigned)((wr * 128 + frow) * 128);
+  [[maybe_unused]] const unsigned offB = (unsigned)((wc * 64 + frow) * 128);
+  [[maybe_unused]] const unsigned c0 = (unsigned)(((fq) ^ sw) << 4), c1 = (unsigned)(((fq + 4) ^ sw) << 4);
+
+  u32x4 af[4][2], bl[2][2], bh[2][2];
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const unsigned ldsA = (unsigned)(size_t)(lds_cchar*)sA, ldsB = (unsigned)(size_t)(lds_cchar*)sB;
+#define WS_DS_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define WS_LGKM0_12() \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), \
+               "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]))
+#define WS_LGKM0_A() \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), \
+               "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]))
+#define WS_LGKM0_BH() \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]))
+#else
+#define WS_DS_READ(dst, addr) (void)0
+#define WS_LGKM0_12() (void)0
+#define WS_LGKM0_A() (void)0
+#define WS_LGKM0_BH() (void)0
+  const unsigned ldsA = 0, ldsB = 0;
+#endif
+
+#define WS_MFMA_QUAD(I0, BREG, J0)                                                                                   \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
+          __builtin_bit_cast(bf16x8, BREG[j][ks]), __builtin_bit_cast(bf16x8, af[i][ks]), acc[(I0) + i][(J0) + j], 0, 0, 0)
+
+  // ---- DMA schedule (two instructions per phase; the LDS rows a pass overwrites were last read >= 2 phases ago):
+  //   phase 1 (kt): B passes 0,1 of kt+1      phase 2 (kt): B passes 2,3 of kt+1, then vmcnt -> A_hi(kt) landed
+  //   phase 3 (kt): A_hi of kt+1              phase 4 (kt): A_lo of kt+2,          then vmcnt -> A_lo, B of kt+1 landed
+  // Each wait sits in the read section of its phase, i.e. before a barrier that every reader (also the staggered
+  // group) passes before the phase in which it reads those rows.  Counts = DMA instructions issued after the ones
+  // waited for; at the tail, where fewer are issued, the waits fall back to vmcnt(0).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WS_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#else
+#define WS_VMCNT(N) (void)0
+#endif
+  Tap t0{0, 0, 0};
+  Tap t1 = tap_next(t0);   // K-step kt + 1
+  Tap t2 = tap_next(t1);   // K-step kt + 2
+  stage_A(0, 0, 0, t0); stage_A(0, 0, 2, t0);
+  stage_B(0, 0, 0); stage_B(0, 0, 1); stage_B(0, 0, 2); stage_B(0, 0, 3);
+  stage_A(0, 0, 1, t0); stage_A(0, 0, 3, t0);
+  if (nk > 1) { stage_A(1, 1, 0, t1); stage_A(1, 1, 2, t1); }
+  WS_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second M-half runs one barrier behind
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
+    const unsigned bA = ldsA + cur * (BM * 128) + offA, bB = ldsB + cur * (BN * 128) + offB;
+    // ---- phase 1: A rows 0-63 + B cols 0-31 of this wavefront
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      WS_DS_READ(bl[j][0], bB + j * 2048 + c0);
+      WS_DS_READ(bl[j][1], bB + j * 2048 + c1);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      WS_DS_READ(af[i][0], bA + i * 2048 + c0);
+      WS_DS_READ(af[i][1], bA + i * 2048 + c1);
+    }
+    if (more) { stage_B(kt + 1, cur ^ 1, 0); stage_B(kt + 1, cur ^ 1, 1); }
+    __builtin_amdgcn_s_barrier();
+    WS_LGKM0_12();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    WS_MFMA_QUAD(0, bl, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: B cols 32-63
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      WS_DS_READ(bh[j][0], bB + (2 + j) * 2048 + c0);
+      WS_DS_READ(bh[j][1], bB + (2 + j) * 2048 + c1);
+    }
+    if (more) {
+      stage_B(kt + 1, cur ^ 1, 2); stage_B(kt + 1, cur ^ 1, 3);
+      WS_VMCNT(6);  // younger: A_lo(kt+1), B(kt+1) -> A_hi(kt) has landed
+    } else {
+      WS_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    WS_LGKM0_BH();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    WS_MFMA_QUAD(0, bh, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: A rows 64-127 (into the same registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      WS_DS_READ(af[i][0], bA + (4 + i) * 2048 + c0);
+      WS_DS_READ(af[i][1], bA + (4 + i) * 2048 + c1);
+    }
+    if (more) { stage_A(kt + 1, cur ^ 1, 1, t1); stage_A(kt + 1, cur ^ 1, 3, t1); }
+    __builtin_amdgcn_s_barrier();
+    WS_LGKM0_A();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+    WS_MFMA_QUAD(4, bh, 2);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 4: no fragment reads
+    if (more2) {
+      stage_A(kt + 2, cur, 0, t2); stage_A(kt + 2, cur, 2, t2);
+      WS_VMCNT(4);  // younger: A_hi(kt+1), A_lo(kt+2) -> A_lo(kt+1) and B(kt+1) have landed
+    } else {
+      WS_VMCNT(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+    WS_MFMA_QUAD(4, bl, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    if (CONV) { t1 = t2; t2 = tap_next(t2); }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
+#undef WS_VMCNT
+
+  // ---- epilogue (fp32).  The MFMAs were issued with the operands swapped (B fragment first), so a lane's four
+  // accumulator registers are four CONSECUTIVE COLUMNS of one output row: acc[i][j][r] = C[m = .. + (lane & 15)]
+  // [n = .. + (lane >> 4) * 4 + r] -- one 16-byte (fp32) / 8-byte (bf16) store per tile instead of four 4-byte ones.
+  // Tile indices are compile-time constants (a runtime index into acc would put the accumulators in scratch).
+  const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const bool vec_c = p.C && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+  auto emit = [&](const f32x4 a4, const int i, const int j) {
+    const int m = m0 + wr * 128 + i * 16 + frow;
+    const int nb = n0 + wc * 64 + j * 16 + fq * 4;
+    if (m >= p.M || nb >= p.N) return;
+    const float rs = p.row_scale ? p.row_scale[m] : 1.f;
+    const bool full = nb + 3 < p.N;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nb + r;
+      float x = a4[r] * p.alpha;
+      if (n < p.N) {
+        if (p.row_scale) x *= rs;
+        if (p.bias) x += p.bias[n];
+        if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+        if (p.relu) x = fmaxf(x, 0.f);
+        if (p.dropout_p > 0.f) {
+          const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+          x = u >= p.dropout_p ? x * keep_scale : 0.f;
+        }
+        if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
+        if (p.mask_src)
+          x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+        if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
+      }
+      v[r] = x;
+    }
+    if (p.C) {
+      if (vec_c && full) {
+        if (p.dtype_c == WSOVOD_BF16) {
+          bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          *(bf16x4*)((bf16_t*)p.C + (long long)m * p.ldc + nb) = o;
+        } else {
+          *(f32x4*)((float*)p.C + (long long)m * p.ldc + nb) = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nb + r < p.N) store_from_f32(p.C, (long long)m * p.ldc + nb + r, p.dtype_c, v[r]);
+      }
+    }
+    if (p.Ct) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.N) store_from_f32(p.Ct, (long long)(nb + r) * p.ldct + m, p.dtype_ct, v[r]);
+    }
+  };
+  // Fast path (bias / residual / ReLU / dropout, row-major output with 16-byte aligned rows, whole tile columns in
+  // range): the feature tests are hoisted out of the element loops, bias is fetched once per column tile, residual
+  // and output move as one 8- or 16-byte access per MFMA tile.
+  const bool vec_r = !p.residual || ((p.ldr & 3) == 0 && ((uintptr_t)p.residual & 15) == 0);
+  const bool plain = vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add && !p.mask_src && !p.accumulate &&
+                     n0 + BN <= p.N;
+  if (plain) {
+    f32x4 b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      b4[j] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * 64 + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    const int mrow = m0 + wr * 128 + frow;
+    const long long col = n0 + wc * 64 + fq * 4;
+    const bool drop = p.dropout_p > 0.f;
+    const bool has_res = p.residual != nullptr;
+#define WS_FAST_ROW(I)                                                                                        \
+  if (mrow + (I) * 16 < p.M) {                                                                                \
+    const long long mm = mrow + (I) * 16;                                                                     \
+    const long long base = mm * p.ldc + col;                                                                  \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+      f32x4 x = acc[I][j] * p.alpha + b4[j];                                                                  \
+      if (has_res) {                                                                                          \
+        if (p.dtype_r == WSOVOD_BF16) {                                                                       \
+          const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + col + j * 16);          \
+          x += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};                                 \
+        } else {                                                                                              \
+          x += *(const f32x4*)((const float*)p.residual + mm * p.ldr + col + j * 16);                         \
+        }                                                                                                     \
+      }                                                                                                       \
+      x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};                          \
+      if (drop) {                                                                                             \
+        const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (col + j * 16);     \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
+            x[r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[r] * keep_scale : 0.f;                       \
+      }                                                                                                       \
+      if (p.dtype_c == WSOVOD_BF16)                                                                           \
+        *(bf16x4*)((bf16_t*)p.C + base + j * 16) = bf16x4{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]}; \
+      else                                                                                                    \
+        *(f32x4*)((float*)p.C + base + j * 16) = x;                                                           \
+    }                                                                                                         \
+  }
+    WS_FAST_ROW(0) WS_FAST_ROW(1) WS_FAST_ROW(2) WS_FAST_ROW(3) WS_FAST_ROW(4) WS_FAST_ROW(5) WS_FAST_ROW(6) WS_FAST_ROW(7)
+#undef WS_FAST_ROW
+    return;
+  }
+#define WS_EMIT_ROW(I) emit(acc[I][0], I, 0); emit(acc[I][1], I, 1); emit(acc[I][2], I, 2); emit(acc[I][3], I, 3)
+  WS_EMIT_ROW(0); WS_EMIT_ROW(1); WS_EMIT_ROW(2); WS_EMIT_ROW(3);
+  WS_EMIT_ROW(4); WS_EMIT_ROW(5); WS_EMIT_ROW(6); WS_EMIT_ROW(7);
+#undef WS_EMIT_ROW
+#undef WS_DS_READ
+#undef WS_LGKM0_12
+#undef WS_LGKM0_A
+#undef WS_LGKM0_BH
+#undef WS_MFMA_QUAD
+}
+
+}  // namespace
+
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes) {
+  static int slot_g = wsovod::prof_slot("gemm_nt_bf16_256x256_8ph");
+  static int slot_c = wsovod::prof_slot("conv_igemm_bf16_256x256_8ph");
+  static bool attr_set = false;
+  constexpr int lds_bytes = 2 * (256 + 256) * 128;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  GemmArgs args = a;
+  args.tiles_m = ceil_div(a.M, 256);
+  args.tiles_n = ceil_div(a.N, 256);
+  {
+    const int run = std::max(1, args.tiles_m * args.tiles_n / 8);
+    int g = 1;
+    while ((g + 1) * (g + 1) <= run) ++g;
+    args.group_m = std::max(1, std::min(g, args.tiles_m));
+  }
+  wsovod::ProfScope prof(conv ? slot_c : slot_g, s, flops, bytes);
+  if (conv)
+    hipLaunchKernelGGL(gemm256_8ph_kernel<true>, dim3(args.tiles_m * args.tiles_n), dim3(512), lds_bytes, s, args);
+  else
+    hipLaunchKernelGGL(gemm256_8ph_kernel<false>, dim3(args.tiles_m * args.tiles_n), dim3(512), lds_bytes, s, args);
+  WS_CHECK_LAUNCH("wsovod_gemm_nt(256x256 8-phase)");
+  return WSOVOD_OK;
+}
+
+}  // namespace wsovod_gemm

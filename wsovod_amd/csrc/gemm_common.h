@@ -1,0 +1,82 @@
+// Pieces shared by the GEMM / implicit-GEMM kernels (gemm.hip: generic tiles; gemm8.hip: the 8-phase 256x256 tile).
+#pragma once
+#include "common.h"
+
+namespace wsovod_gemm {
+
+struct GemmArgs {
+  const char* A;
+  const char* B;
+  long long lda, ldb;  // elements
+  int M, N, K;
+  void* C;
+  long long ldc;
+  int dtype_c;
+  void* Ct;
+  long long ldct;
+  int dtype_ct;
+  float alpha;
+  const float* row_scale;
+  const float* bias;
+  const void* residual;
+  long long ldr;
+  int dtype_r;
+  int relu;
+  float dropout_p;
+  unsigned long long seed;
+  const int* row_group;
+  const float* group_add;
+  long long ld_ga;
+  const void* mask_src;
+  long long ldm;
+  int dtype_m;
+  float mask_scale;
+  int accumulate;
+  // implicit-GEMM convolution geometry
+  int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
+  long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
+  int tiles_m, tiles_n;
+  int group_m;  // tile-order group height (see the XCD remap in the kernel)
+};
+
+template <typename T>
+struct Traits;
+template <>
+struct Traits<float> {
+  static constexpr int EPC = 4;   // elements per 16-byte chunk
+  static constexpr int BKE = 32;  // elements per K-step (128 B)
+};
+template <>
+struct Traits<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int BKE = 64;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ float load_as_f32(const void* p, long long idx, int dtype) {
+  return dtype == WSOVOD_BF16 ? (float)((const bf16_t*)p)[idx] : ((const float*)p)[idx];
+}
+__device__ __forceinline__ void store_from_f32(void* p, long long idx, int dtype, float v) {
+  if (dtype == WSOVOD_BF16)
+    ((bf16_t*)p)[idx] = (bf16_t)v;
+  else
+    ((float*)p)[idx] = v;
+}
+
+// splitmix64 finaliser: counter-based, stateless dropout mask on (seed, m, n)
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+
+// gemm8.hip: bf16 256x256 tile, 8 wavefronts in two staggered groups (see the file header).
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes);
+
+}  // namespace wsovod_gemm
