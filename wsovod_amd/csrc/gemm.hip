@@ -502,28 +502,48 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[i]),
-                                                              __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),  // swapped: a lane
+                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);  // holds 4 channels
     }
     __syncthreads();
   }
-  // epilogue: bias + residual + ReLU; D[row=(lane>>4)*4+reg][col=lane&15]
+  // epilogue: bias + residual + ReLU.  Operands were swapped in the MFMA, so lane (frow, fq) holds, for pixel
+  // group i and channel tile j, the 4 consecutive output channels j*16 + fq*4 + r of pixel frow: one 8-byte (bf16)
+  // or 16-byte (fp32) store and one vector residual load per tile.
+  const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.bias & 15) == 0 &&
+                   (!p.residual || ((p.ldr & 3) == 0 && ((uintptr_t)p.residual & 15) == 0));
+  const float lo = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int y = y0 + wave * 2 + (i >> 1);
+    const int x = x0 + (i & 1) * 16 + frow;
+    if (y >= p.H || x >= p.W) continue;
+    const long long m = ((long long)img * p.H + y) * p.W + x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = j * 16 + frow;
-      const float bias = p.bias ? p.bias[n] : 0.f;
+      const int n = j * 16 + fq * 4;
+      f32x4 v = acc[i][j] * p.alpha;
+      if (vec) {
+        if (p.bias) v += *(const f32x4*)(p.bias + n);
+        if (p.residual) {
+          if (p.dtype_r == WSOVOD_BF16) {
+            const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + m * p.ldr + n);
+            v += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+          } else {
+            v += *(const f32x4*)((const float*)p.residual + m * p.ldr + n);
+          }
+        }
+        v = f32x4{fmaxf(v[0], lo), fmaxf(v[1], lo), fmaxf(v[2], lo), fmaxf(v[3], lo)};
+        if (p.dtype_c == WSOVOD_BF16)
+          *(bf16x4*)((bf16_t*)p.C + m * p.ldc + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        else
+          *(f32x4*)((float*)p.C + m * p.ldc + n) = v;
+      } else {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int x = x0 + (i & 1) * 16 + fq * 4 + rr;
-        if (y < p.H && x < p.W) {
-          const long long m = ((long long)img * p.H + y) * p.W + x;
-          float v = acc[i][j][rr] * p.alpha + bias;
-          if (p.residual) v += load_as_f32(p.residual, m * p.ldr + n, p.dtype_r);
-          if (p.relu) v = fmaxf(v, 0.f);
-          store_from_f32(p.C, m * p.ldc + n, p.dtype_c, v);
+        for (int rr = 0; rr < 4; ++rr) {
+          float u = v[rr] + (p.bias ? p.bias[n + rr] : 0.f);
+          if (p.residual) u += load_as_f32(p.residual, m * p.ldr + n + rr, p.dtype_r);
+          store_from_f32(p.C, m * p.ldc + n + rr, p.dtype_c, fmaxf(u, lo));
         }
       }
     }
