@@ -60,11 +60,16 @@ def pmc_traffic(kernel_name, args):
     path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}_bf16.json")
     if not (os.path.exists(path) and args.precision == "bf16" and args.depth == 18 and args.proposals == 512):
         return None
-    m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma)?$", kernel_name)
+    if getattr(args, "rpn", False):
+        return None
+    m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
     if not m:
         return None
-    tag = "gemm_nt_kernelI%sLi%sELi%sELb%d" % ("DF16b" if m.group(2) == "bf16" else "f", m.group(3), m.group(4),
-                                             1 if m.group(1) == "conv_igemm" else 0)
+    if m.group(5) == "_8ph":
+        tag = "gemm256_8ph_kernelILb%d" % (1 if m.group(1) == "conv_igemm" else 0)
+    else:
+        tag = "gemm_nt_kernelI%sLi%sELi%sELb%d" % ("DF16b" if m.group(2) == "bf16" else "f", m.group(3), m.group(4),
+                                                 1 if m.group(1) == "conv_igemm" else 0)
     with open(path) as f:
         table = json.load(f)["kernels"]
     hits = [v for k, v in table.items() if tag in k]
