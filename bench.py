@@ -65,14 +65,15 @@ def pmc_traffic(kernel_name, args):
     m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
     if not m:
         return None
-    if m.group(5) == "_8ph":
-        tag = "gemm256_8ph_kernelILb%d" % (1 if m.group(1) == "conv_igemm" else 0)
+    conv = m.group(1) == "conv_igemm"
+    if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled
+        tags = ("gemm256_8ph_kernelILb%d" % conv, "gemm256_8ph_kernel<%s>" % ("true" if conv else "false"))
     else:
-        tag = "gemm_nt_kernelI%sLi%sELi%sELb%d" % ("DF16b" if m.group(2) == "bf16" else "f", m.group(3), m.group(4),
-                                                 1 if m.group(1) == "conv_igemm" else 0)
+        tags = ("gemm_nt_kernelI%sLi%sELi%sELb%d" % ("DF16b" if m.group(2) == "bf16" else "f", m.group(3), m.group(4),
+                                                    conv),)
     with open(path) as f:
         table = json.load(f)["kernels"]
-    hits = [v for k, v in table.items() if tag in k]
+    hits = [v for k, v in table.items() if any(t in k for t in tags)]
     return hits[0]["traffic_bytes_per_launch"] if len(hits) == 1 else None
 
 
