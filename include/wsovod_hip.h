@@ -245,6 +245,13 @@ int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, cons
                                    float beta, int weighted, float* dpred, float* accum2, float* loss,
                                    wsovod_stream_t stream);
 
+/* Weight-gradient contraction over the SLOW index of two row-major bf16 operands (no transposed copies):
+ *   C[i][j] (+)= alpha * sum_m P[m][i] * Q[m][j],   P (Mred, NI) row stride ldp, Q (Mred, NJ) row stride ldq, C fp32.
+ * nn.Linear backward dW = dY^T X (box_head.py:60-75, open_vocabulary_classifier.py:60-66 under autograd) with
+ * P = dY, Q = X as the forward pass left them.  ldp, ldq, NI, NJ multiples of 8; operands < 2 GiB. */
+int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, int Mred, int NI, int NJ, float* C,
+                   long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
+
 /* Greedy non-maximum suppression over G independent segments of boxes that are already sorted by
  * descending score inside each segment.  Replaces torchvision.ops.nms / batched_nms (un-vendored; SURVEY
  * Appendix A) at the reference's call sites: find_top_rpn_proposals (proposal_utils.py:123; one segment per

@@ -119,6 +119,30 @@ def test_gemm_8phase_epilogues(gpu, out_dtype, variant):
         assert torch.equal(o[256256], o[8256256])
 
 
+@pytest.mark.parametrize("shape", [(8192, 512, 768), (249, 256, 512), (1000, 136, 264), (64, 8, 8), (5000, 1024, 256)])
+def test_gemm_tn_transposed_reads(gpu, shape):
+    """dW-style contraction over the slow index of two row-major bf16 operands (ds_read_b64_tr_b16 fragments):
+    ragged reduction length, ragged tile edges, strided operands, accumulate; and bit-identity with the NT tile fed
+    with explicit transposes (same products, same order)."""
+    from wsovod_amd.layers import hip_ops
+
+    Mred, NI, NJ = shape
+    torch.manual_seed(4)
+    P = torch.randn(Mred, NI + 8).to(torch.bfloat16)[:, :NI]  # row stride > NI
+    Q = torch.randn(Mred, NJ).to(torch.bfloat16)
+    ref = (P.double().t() @ Q.double()).float()
+    Pg, Qg = P.to(gpu), Q.to(gpu)
+    out = hip_ops.gemm_tn(Pg, Qg)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=2e-6 * Mred ** 0.5 * 40)
+    Mp = (Mred + 63) // 64 * 64
+    nt = hip_ops.gemm_nt(hip_ops.transpose_cast(Pg.contiguous(), torch.bfloat16, ld_dst=Mp),
+                         hip_ops.transpose_cast(Qg, torch.bfloat16, ld_dst=Mp), out_dtype=torch.float32, tile_hint=8256256)
+    assert torch.equal(out, nt)
+    acc = torch.randn(NI, NJ, device=gpu)
+    out2 = hip_ops.gemm_tn(Pg, Qg, out=acc.clone(), alpha=0.5, accumulate=True)
+    torch.testing.assert_close(out2.cpu(), acc.cpu() + 0.5 * ref, rtol=1e-4, atol=2e-6 * Mred ** 0.5 * 40)
+
+
 def test_gemm_dropout_statistics(gpu):
     from wsovod_amd.layers import hip_ops
 

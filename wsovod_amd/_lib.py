@@ -85,6 +85,7 @@ SIGNATURES = {
     "wsovod_data_aware_forward": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
+    "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_nms_segments": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     "wsovod_rpn_label_anchors": [_P, _I, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "wsovod_im2col_rows": [_P, _I, _P, _I] + [_I] * 10 + [_P, _P],

@@ -1,0 +1,267 @@
+// Weight-gradient contraction without operand transposes:  C[i][j] = alpha * sum_m P[m][i] * Q[m][j]   (bf16 in, fp32 out)
+//
+//   nn.Linear dW = dY^T X   (P = dY (rows = proposals, cols = out features), Q = X (rows = proposals, cols = in features);
+//   both ROW-MAJOR as the forward pass left them -- the reduction runs over the SLOW index of both operands).
+//
+// An MFMA fragment wants 8 consecutive reduction elements per lane, which here are 8 different ROWS of the operand.
+// gfx950's ds_read_b64_tr_b16 does that transpose in the LDS read path (cdna_hip_programming.md T10): per 16-lane
+// group it reads a 4-row x 16-column block and hands lane i column i of the 4 rows.  So the operand tiles are staged
+// row-major exactly as they lie in HBM (LDS-direct DMA, 256-byte sub-rows, the guide's conflict-free image (b):
+// off = 256*row + 16*(chunk ^ (((row&3)<<2) | ((row>>2)&3))), applied to the DMA SOURCE address and to the read
+// address) and every fragment is two transposed 8-byte reads.  Replaces the x^T / dY^T copies (transpose_cast,
+// mask_transpose's second output) that the NT kernel needed: 0.5 ms of an 9.6 ms step.
+//
+// Shape of the kernel = gemm8.hip: 256x256 output tile, 8 wavefronts as 2 (i) x 4 (j), 128x64 per wavefront, two groups
+// staggered by one barrier, MFMAs at raised priority, counted vmcnt.  A K-step is 64 reduction rows = two PHASES of
+// 32 rows; a phase reads its 8 + 4 fragments (24 transposed reads), issues the DMA of the same 32-row half of the NEXT
+// K-step (4 instructions: P/Q x two 128-column sub-images) and waits vmcnt(4), i.e. for the half issued one phase
+// earlier, which is read one phase later.  A row half is overwritten two phases after its last read.
+#include "gemm_common.h"
+
+namespace wsovod_gemm {
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+struct TnArgs {
+  const char* P;
+  const char* Q;
+  long long ldp, ldq;  // elements
+  int Mred, NI, NJ;
+  float* C;
+  long long ldc;
+  float alpha;
+  int accumulate;
+  int tiles_i, tiles_j, group_m;
+};
+
+__global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
+  constexpr int BI = 256, BJ = 256, BK = 64;
+  constexpr int OP_BYTES = 2 * BK * 256;        // one operand of one K-step: 2 sub-images x 64 rows x 256 B
+  constexpr int STEP_BYTES = 2 * OP_BYTES;      // P + Q
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int nwg = p.tiles_i * p.tiles_j;
+  int wg;
+  {
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int group_size = p.group_m * p.tiles_j;
+  const int group_id = wg / group_size;
+  const int first_i = group_id * p.group_m;
+  const int gm = min(p.tiles_i - first_i, p.group_m);
+  const int in_group = wg - group_id * group_size;
+  const int tile_i = first_i + in_group % gm;
+  const int tile_j = in_group / gm;
+  const int i0 = tile_i * BI, j0 = tile_j * BJ;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // ---- DMA lane geometry: a pass = 32 rows x 256 B of one sub-image; lane -> (row tid>>4, 16-byte slot tid&15)
+  const int lrow = tid >> 4, lslot = tid & 15;
+  const int lchunk = lslot ^ (((lrow & 3) << 2) | ((lrow >> 2) & 3));  // inverse swizzle on the source (rows r, r+32 agree)
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.P, 0, (int)min((long long)p.Mred * p.ldp * 2, (long long)0x7fffffff), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcQ = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.Q, 0, (int)min((long long)p.Mred * p.ldq * 2, (long long)0x7fffffff), 0x00020000);
+  // column offsets (bytes) of this lane's chunk in the two sub-images; <0 = beyond the matrix (zero fill)
+  int pcol[2], qcol[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int ci = i0 + s * 128 + lchunk * 8, cj = j0 + s * 128 + lchunk * 8;
+    pcol[s] = ci < p.NI ? ci * 2 : -1;
+    qcol[s] = cj < p.NJ ? cj * 2 : -1;
+  }
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nk = (p.Mred + BK - 1) / BK;
+  // stage rows [32*half, 32*half+32) of K-step kt into buffer buf: 4 DMA instructions
+  auto stage_half = [&](int kt, int buf, int half) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int m = kt * BK + half * 32 + lrow;
+    const bool ok = m < p.Mred;
+    const long long rp = (long long)m * p.ldp * 2, rq = (long long)m * p.ldq * 2;
+    char* d = smem + buf * STEP_BYTES + half * 32 * 256 + wave_u * 1024;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void*)(d + s * (BK * 256)), 16,
+                                               (ok && pcol[s] >= 0) ? (int)(rp + pcol[s]) : -1, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_void*)(d + OP_BYTES + s * (BK * 256)), 16,
+                                               (ok && qcol[s] >= 0) ? (int)(rq + qcol[s]) : -1, 0, 0, 0);
+    }
+#endif
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- transposed-read lane geometry (T10): within its 16-lane group, lane 4q+pp supplies the address of block row q,
+  // columns 4pp..4pp+3; the group g = lane>>4 covers reduction rows 8g..8g+7 of a 32-row phase as two 4-row blocks.
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, pp = lane & 3;
+  [[maybe_unused]] unsigned offA[2][8], offB[2][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * g + 4 * h + q4;  // row inside the 32-row half
+    const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+      offA[h][t] = (unsigned)(wr * (BK * 256) + row * 256 + (((2 * t + (pp >> 1)) ^ swz) << 4) + 8 * (pp & 1));
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      offB[h][t] = (unsigned)(OP_BYTES + (wc >> 1) * (BK * 256) + row * 256 +
+                              (((2 * ((wc & 1) * 4 + t) + (pp >> 1)) ^ swz) << 4) + 8 * (pp & 1));
+  }
+
+  u32x2 al[8], ah[8], bl[4], bh[4];  // low / high 4 reduction elements of every fragment
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const unsigned lds0 = (unsigned)(size_t)(lds_cchar*)smem;
+#define WS_TR_READ(dst, addr) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr))
+#define WS_LGKM0_ALL()                                                                                               \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                                \
+               : "+v"(al[0]), "+v"(al[1]), "+v"(al[2]), "+v"(al[3]), "+v"(al[4]), "+v"(al[5]), "+v"(al[6]), "+v"(al[7]), \
+                 "+v"(ah[0]), "+v"(ah[1]), "+v"(ah[2]), "+v"(ah[3]), "+v"(ah[4]), "+v"(ah[5]), "+v"(ah[6]), "+v"(ah[7]), \
+                 "+v"(bl[0]), "+v"(bl[1]), "+v"(bl[2]), "+v"(bl[3]), "+v"(bh[0]), "+v"(bh[1]), "+v"(bh[2]), "+v"(bh[3]))
+#define WS_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+#else
+  const unsigned lds0 = 0;
+#define WS_TR_READ(dst, addr) (void)0
+#define WS_LGKM0_ALL() (void)0
+#define WS_VMCNT(N) (void)0
+#endif
+
+  // ---- prologue: K-step 0 completely, then the stagger barrier
+  stage_half(0, 0, 0);
+  stage_half(0, 0, 1);
+  WS_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second i-half runs one barrier behind
+
+  // A phase stages the SAME 32-row half of the next K-step (that half of the other buffer was last read two phases
+  // ago) and waits vmcnt(4): the half issued one phase earlier has landed before the barrier its readers pass first;
+  // it is read one phase later.  (A three-phase-deep ring with the reads retired before the barrier was measured
+  // 18 % slower: the loop no longer unrolls over the two halves and the LDS latency moves in front of the barrier.)
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const unsigned base = lds0 + cur * STEP_BYTES + half * (32 * 256);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        WS_TR_READ(bl[t], base + offB[0][t]);
+        WS_TR_READ(bh[t], base + offB[1][t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        WS_TR_READ(al[t], base + offA[0][t]);
+        WS_TR_READ(ah[t], base + offA[1][t]);
+      }
+      if (more) {
+        stage_half(kt + 1, cur ^ 1, half);
+        WS_VMCNT(4);
+      } else {
+        WS_VMCNT(0);
+      }
+      __builtin_amdgcn_s_barrier();
+      WS_LGKM0_ALL();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  // Q fragment first: a lane holds 4 consecutive j
+              __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3)),
+              __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3)), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: acc[i][j][r] = C[i0 + wr*128 + i*16 + (lane&15)][j0 + wc*64 + j*16 + (lane>>4)*4 + r]
+  const int frow = lane & 15, fq = lane >> 4;
+  const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && j0 + BJ <= p.NJ;
+#define WS_TN_ROW(I)                                                                                      \
+  {                                                                                                       \
+    const int ii = i0 + wr * 128 + (I) * 16 + frow;                                                       \
+    if (ii < p.NI) {                                                                                      \
+      float* crow = p.C + (long long)ii * p.ldc + j0 + wc * 64 + fq * 4;                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+        f32x4 x = acc[I][j] * p.alpha;                                                                    \
+        if (vec) {                                                                                        \
+          if (p.accumulate) x += *(const f32x4*)(crow + j * 16);                                          \
+          *(f32x4*)(crow + j * 16) = x;                                                                   \
+        } else {                                                                                          \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) if (j0 + wc * 64 + fq * 4 + j * 16 + r < p.NJ)    \
+              crow[j * 16 + r] = p.accumulate ? crow[j * 16 + r] + x[r] : x[r];                           \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+  WS_TN_ROW(0) WS_TN_ROW(1) WS_TN_ROW(2) WS_TN_ROW(3) WS_TN_ROW(4) WS_TN_ROW(5) WS_TN_ROW(6) WS_TN_ROW(7)
+#undef WS_TN_ROW
+#undef WS_TR_READ
+#undef WS_LGKM0_ALL
+#undef WS_VMCNT
+}
+
+}  // namespace
+}  // namespace wsovod_gemm
+
+extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, int Mred, int NI, int NJ,
+                              float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream) {
+  using namespace wsovod_gemm;
+  WS_CHECK_ARG(Mred >= 0 && NI >= 0 && NJ >= 0, "wsovod_gemm_tn: negative dimension");
+  if (NI == 0 || NJ == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(P && Q && C, "wsovod_gemm_tn: null pointer");
+  WS_CHECK_ARG((((uintptr_t)P | (uintptr_t)Q) & 15) == 0, "wsovod_gemm_tn: P/Q must be 16-byte aligned");
+  WS_CHECK_ARG(ldp % 8 == 0 && ldq % 8 == 0 && NI % 8 == 0 && NJ % 8 == 0,
+               "wsovod_gemm_tn: row strides and column counts must be multiples of 8 bf16 elements");
+  WS_CHECK_ARG((long long)Mred * ldp * 2 < (1ll << 31) && (long long)Mred * ldq * 2 < (1ll << 31),
+               "wsovod_gemm_tn: operand exceeds the 2 GiB buffer-addressing limit");
+  TnArgs a;
+  a.P = (const char*)P;
+  a.Q = (const char*)Q;
+  a.ldp = ldp;
+  a.ldq = ldq;
+  a.Mred = Mred;
+  a.NI = NI;
+  a.NJ = NJ;
+  a.C = C;
+  a.ldc = ldc;
+  a.alpha = alpha;
+  a.accumulate = accumulate;
+  a.tiles_i = ceil_div(NI, 256);
+  a.tiles_j = ceil_div(NJ, 256);
+  {
+    const int run = std::max(1, a.tiles_i * a.tiles_j / 8);
+    int g = 1;
+    while ((g + 1) * (g + 1) <= run) ++g;
+    a.group_m = std::max(1, std::min(g, a.tiles_i));
+  }
+  static int slot = wsovod::prof_slot("gemm_tn_bf16_256x256_tr");
+  static bool attr_set = false;
+  constexpr int lds_bytes = 2 * 2 * 2 * 64 * 256;  // 2 K-steps x (P, Q) x 2 sub-images x 64 rows x 256 B = 128 KiB
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * Mred * NI * NJ;
+  const double bytes = 2.0 * Mred * ((double)NI + NJ) + 4.0 * NI * NJ;
+  wsovod::ProfScope prof(slot, s, flops, bytes);
+  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(a.tiles_i * a.tiles_j), dim3(512), lds_bytes, s, a);
+  WS_CHECK_LAUNCH("wsovod_gemm_tn");
+  return WSOVOD_OK;
+}

@@ -3,11 +3,16 @@
 `once_differentiable`) extended to every op on the hot path.  Forward AND backward run on the
 C-ABI kernels; torch only carries tensors, streams and the autograd graph.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import hip_ops as H
+
+
+_USE_TN = os.environ.get("WSOVOD_DISABLE_TN", "0") != "1"  # A/B switch for the transposed-read dW kernel
 
 
 def _pad(n, m):
@@ -59,10 +64,18 @@ class _Linear(Function):
         dy = _contig2d(dy)
         scale = 1.0 / (1.0 - ctx.dropout_p) if ctx.dropout_p > 0 else 1.0
         Mp, Np = _pad(M, 64), _pad(N, 8)
-        dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or need_db, want_t=need_dw, ld_t=Mp,
-                                   ld_plain=Np)
+        # dW = dA^T X contracts over the slow (proposal) index of both row-major operands.  Large bf16 layers use the
+        # transposed-read kernel on them as they are; the rest goes through explicit transposes + the NT kernel.
+        tn = (_USE_TN and need_dw and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0
+              and ((Np + 255) // 256) * ((K + 255) // 256) >= 128)
+        dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or need_db or tn, want_t=need_dw and not tn,
+                                   ld_t=Mp, ld_plain=Np)
         dx = dw = db = None
-        if need_dw:
+        if tn:
+            dw = H.gemm_tn(dA, x)  # (Np, K)
+            if Np != N:
+                dw = dw[:N]
+        elif need_dw:
             xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
             dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
         if need_db:
