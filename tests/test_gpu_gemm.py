@@ -143,6 +143,39 @@ def test_gemm_tn_transposed_reads(gpu, shape):
     torch.testing.assert_close(out2.cpu(), acc.cpu() + 0.5 * ref, rtol=1e-4, atol=2e-6 * Mred ** 0.5 * 40)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_linear_group_equals_separate_linears(gpu, dtype):
+    """Heads sharing one input: grouped autograd node (one dX GEMM, one dW contraction) vs one Linear per head."""
+    from wsovod_amd.layers import functions as Fn
+
+    torch.manual_seed(5)
+    M, K = 1000, 512
+    x0 = torch.randn(M, K, device=gpu).to(dtype)
+    specs = [(40, False, torch.float32), (1024, True, None), (4, False, torch.float32)]
+    params = [(torch.randn(n, K, device=gpu) * 0.05, torch.randn(n, device=gpu) * 0.1) for n, _, _ in specs]
+    gys = None
+    res = {}
+    for mode in ("separate", "group"):
+        x = x0.clone().requires_grad_(True)
+        ws = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in params]
+        if mode == "separate":
+            ys = [Fn.linear(x, w, b, relu=r, out_dtype=od) for (w, b), (_, r, od) in zip(ws, specs)]
+        else:
+            ys = Fn.linear_group(x, [(w, b, r, od) for (w, b), (_, r, od) in zip(ws, specs)])
+        if gys is None:
+            gys = [torch.randn_like(y) for y in ys]
+        torch.autograd.backward(list(ys), gys)
+        res[mode] = ([y.detach() for y in ys], x.grad, [(w.grad, b.grad) for w, b in ws])
+    for a, b in zip(res["separate"][0], res["group"][0]):
+        assert torch.equal(a, b)  # same forward GEMMs
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
+    # dx: one K = sum N_h contraction vs a bf16-rounded sum of per-head products
+    torch.testing.assert_close(res["group"][1].float(), res["separate"][1].float(), **tol)
+    for (wa, ba), (wb, bb) in zip(res["separate"][2], res["group"][2]):
+        torch.testing.assert_close(wb, wa, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(bb, ba, rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_dropout_statistics(gpu):
     from wsovod_amd.layers import hip_ops
 

@@ -91,6 +91,83 @@ def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=No
     return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype)
 
 
+class _LinearGroup(Function):
+    """Several Linear(+ReLU) heads on ONE input (object mining, box regression and the classifier projection all
+    read the same box features).  Forward: one GEMM per head (own output dtype / activation).  Backward: the heads'
+    masked output gradients are written side by side into one (M, sum N_h) matrix, so that the input gradient is ONE
+    GEMM against the stacked weights (instead of one skinny GEMM per head plus adds), the weight gradients ONE
+    contraction (one pass over x, no per-head x^T), the bias gradients one column sum."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *wb):
+        cd = x.dtype
+        heads = len(meta)
+        ws, bs = wb[0::2], wb[1::2]
+        ys = []
+        for h in range(heads):
+            relu, out_dtype = meta[h]
+            ys.append(H.gemm_nt(x, weight_shadow(ws[h], cd), bias=bs[h], relu=relu, out_dtype=out_dtype or cd))
+        ctx.meta = meta
+        ctx.save_for_backward(x, *ws, *[y if meta[h][0] else None for h, y in enumerate(ys)])
+        ctx.has_bias = [b is not None for b in bs]
+        return tuple(ys)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *dys):
+        heads = len(ctx.meta)
+        saved = ctx.saved_tensors
+        x, ws, ys = saved[0], saved[1:1 + heads], saved[1 + heads:]
+        cd = x.dtype
+        M, K = x.shape
+        Ns = [w.size(0) for w in ws]
+        offs = [0]
+        for n in Ns:
+            offs.append(offs[-1] + _pad(n, 8))
+        Nt = offs[-1]
+        dA = torch.zeros((M, Nt), dtype=cd, device=x.device)
+        for h in range(heads):
+            if dys[h] is not None:
+                H.mask_transpose(_contig2d(dys[h]), ys[h], 1.0, cd, want_t=False,
+                                 out_plain=dA[:, offs[h]:offs[h] + Ns[h]])
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = any(ctx.needs_input_grad[2 + 2 * h] for h in range(heads))
+        wcat = torch.zeros((Nt, K), dtype=cd, device=x.device)
+        for h in range(heads):
+            wcat[offs[h]:offs[h] + Ns[h]] = ws[h]
+        dx = None
+        if need_dx:
+            dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=cd)  # (M,K) = dA_cat @ W_cat
+        grads = [None] * (2 * heads)
+        if need_dw:
+            if _USE_TN and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 \
+                    and ((Nt + 255) // 256) * ((K + 255) // 256) >= 64:
+                dwcat = H.gemm_tn(dA, x)
+            else:
+                Mp = _pad(M, 64)
+                dwcat = H.gemm_nt(H.transpose_cast(dA, cd, ld_dst=Mp), H.transpose_cast(x, cd, ld_dst=Mp),
+                                  out_dtype=torch.float32)
+            for h in range(heads):
+                if ctx.needs_input_grad[2 + 2 * h]:
+                    grads[2 * h] = dwcat[offs[h]:offs[h] + Ns[h]]
+        if any(ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h] for h in range(heads)):
+            seg = H.const_tensor((0, M), torch.int32, x.device)
+            dbcat = H.segment_colsum(dA, seg).view(Nt)
+            for h in range(heads):
+                if ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h]:
+                    grads[2 * h + 1] = dbcat[offs[h]:offs[h] + Ns[h]]
+        return (dx, None, *grads)
+
+
+def linear_group(x, heads):
+    """heads: list of (weight (N_h,K) fp32 master, bias or None, relu, out_dtype or None) -> tuple of outputs."""
+    meta = tuple((bool(h[2]), h[3]) for h in heads)
+    wb = []
+    for h in heads:
+        wb += [h[0], h[1]]
+    return _LinearGroup.apply(x, meta, *wb)
+
+
 class _RoIPool(Function):
     @staticmethod
     def forward(ctx, feat, rois, output_size, spatial_scale, roi_scale, out_dtype):

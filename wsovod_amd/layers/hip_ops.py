@@ -434,13 +434,17 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
     return o
 
 
-def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None):
-    """dA = dy * [y>0] * scale -> (dA (M, ld_plain>=N) or None, dAt (N, ld_t>=M) or None), zero padded."""
+def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None, out_plain=None):
+    """dA = dy * [y>0] * scale -> (dA (M, ld_plain>=N) or None, dAt (N, ld_t>=M) or None), zero padded.
+    out_plain: optional (M, N) view (contiguous last dim) of a wider buffer that receives dA in place."""
     require_gpu(dy, y)
     M, N = dy.shape
     ldp = ld_plain or N
     dA = None
-    if want_plain:
+    if out_plain is not None:
+        assert out_plain.shape == (M, N) and out_plain.stride(1) == 1 and out_plain.dtype == out_dtype
+        dA, ldp, want_plain = out_plain, out_plain.stride(0), True
+    elif want_plain:
         dA = (torch.zeros if ldp != N else torch.empty)((M, ldp), dtype=out_dtype, device=dy.device)
     dAt = None
     if want_t:

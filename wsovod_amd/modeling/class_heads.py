@@ -90,10 +90,11 @@ class OpenVocabularyClassifier(nn.Module):
         self._cache[key] = (wn, wnT)
         return wn, wnT
 
-    def forward(self, x, classifier=None, append_background=False):
-        """x: (B, D_in) in the compute dtype; classifier: optional (C', D) raw embeddings."""
+    def forward(self, x, classifier=None, append_background=False, hidden=None):
+        """x: (B, D_in) in the compute dtype; classifier: optional (C', D) raw embeddings; hidden: optional
+        precomputed relu(projection[0](x)) (the ROI heads batch that layer with the other heads on x)."""
         l1, l2 = self.projection[0], self.projection[2]
-        x = Fn.linear(x, l1.weight, l1.bias, relu=True)
+        x = hidden if hidden is not None else Fn.linear(x, l1.weight, l1.bias, relu=True)
         x = Fn.linear(x, l2.weight, l2.bias, relu=True)
         wn, wnT = self._class_matrix(classifier, append_background, x.dtype)
         bias_vec = self.cls_bias.expand(wn.size(0)).contiguous() if self.use_bias else None

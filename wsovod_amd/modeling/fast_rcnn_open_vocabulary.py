@@ -139,17 +139,21 @@ class ObjectMiningOutputLayers(nn.Module):
             "mean_loss": cfg.WSOVOD.OBJECT_MINING.MEAN_LOSS,
         }
 
-    def forward(self, x, proposals=None, context=False):
-        """-> (scores (R,K) = softmax_classes(C) * softmax_proposals(D) per image, zero deltas)."""
+    def stacked_params(self):
+        """rows [cls | det] of one (2K, F) weight: both heads are one contraction."""
+        return (torch.cat([self.cls.weight, self.det.weight], dim=0), torch.cat([self.cls.bias, self.det.bias], dim=0))
+
+    def forward(self, x, proposals=None, context=False, logits=None):
+        """-> (scores (R,K) = softmax_classes(C) * softmax_proposals(D) per image, zero deltas).
+        logits: optional precomputed (R, 2K) = [C | D] (batched with the other heads on x by the ROI heads)."""
         if context:
             raise NotImplementedError("contextlocnet needs POOLER_TYPE ROILoopPool (out of hot-path scope)")
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
         K = self.num_classes
-        # one contraction for both heads: rows [cls | det] of a (2K, F) weight
-        w = torch.cat([self.cls.weight, self.det.weight], dim=0)
-        b = torch.cat([self.cls.bias, self.det.bias], dim=0)
-        logits = Fn.linear(x, w, b, out_dtype=torch.float32)  # (R, 2K) = [C | D]
+        if logits is None:
+            w, b = self.stacked_params()
+            logits = Fn.linear(x, w, b, out_dtype=torch.float32)  # (R, 2K) = [C | D]
         if K == 1:  # fast_rcnn_open_vocabulary.py:338-340
             z = torch.zeros_like(logits[:, :1])
             logits = torch.cat((logits[:, :1], z, logits[:, 1:], z), dim=1)
@@ -245,13 +249,16 @@ class InstanceRefinementOutputLayers(nn.Module):
             "cross_entropy_weighted": cfg.WSOVOD.INSTANCE_REFINEMENT.CROSS_ENTROPY_WEIGHTED,
         }
 
-    def forward(self, x, classifier=None, append_background=True):
-        """-> (logits (R,K+1) with background logit == 0, class-agnostic deltas (R,4))."""
+    def forward(self, x, classifier=None, append_background=True, pre=None):
+        """-> (logits (R,K+1) with background logit == 0, class-agnostic deltas (R,4)).
+        pre: optional (hidden, deltas) precomputed by the ROI heads' grouped contraction on x."""
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
-        scores = self.cls(x, classifier, append_background=append_background)
+        hidden, deltas = pre if pre is not None else (None, None)
+        scores = self.cls(x, classifier, append_background=append_background, hidden=hidden)
         if self.refine_reg[self.refine_k]:
-            proposal_deltas = Fn.linear(x, self.bbox_pred.weight, self.bbox_pred.bias, out_dtype=torch.float32)
+            proposal_deltas = deltas if deltas is not None else \
+                Fn.linear(x, self.bbox_pred.weight, self.bbox_pred.bias, out_dtype=torch.float32)
         else:
             proposal_deltas = torch.zeros(scores.shape[0], self.num_bbox_reg_classes * self.box_dim,
                                           dtype=scores.dtype, device=scores.device, requires_grad=False)

@@ -14,6 +14,7 @@ instance-refinement branch.  Out of scope (raise): MRRP, ROILoopPool/contextlocn
 refinement, in-loop SAM box refinement, `_vis_*` debug dumps.
 """
 import inspect
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -272,7 +273,8 @@ class WSOVODROIHeads(ROIHeads):
     def _forward_box(self, features, proposals, data_aware_features=None, classifier=None, append_background=True,
                      pooled=None):
         box_features = self.get_features(features, proposals, data_aware_features, pooled=pooled)
-        predictions = self.object_miner(box_features, proposals)
+        pre = self._grouped_heads(box_features) if self.training else None
+        predictions = self.object_miner(box_features, proposals, logits=pre[0] if pre else None)
         if not self.training:
             if self.refine_K <= 0:
                 raise NotImplementedError("REFINE_NUM=0 inference is not used by any WSOVOD config")
@@ -290,7 +292,7 @@ class WSOVODROIHeads(ROIHeads):
         for k in range(self.refine_K):
             targets, proposals_k = self.mine_and_label(k, prev_pred_scores, prev_pred_boxes, proposals, seg, nums)
             predictions_k = self.box_refinery[k](box_features, classifier=classifier,
-                                                 append_background=append_background)
+                                                 append_background=append_background, pre=pre[1 + k] if pre else None)
             losses.update(self.box_refinery[k].losses(predictions_k, proposals_k, self.num_classes))
             if k + 1 < self.refine_K or self.rpn_on:
                 prev_pred_scores = torch.softmax(predictions_k[0].detach(), dim=-1)
@@ -299,6 +301,29 @@ class WSOVODROIHeads(ROIHeads):
         if self.rpn_on:
             self.proposal_targets = self.rpn_targets(prev_pred_scores, prev_pred_boxes, proposals, seg)
         return losses
+
+    def _grouped_heads(self, box_features):
+        """Every Linear that reads the box features directly -- object mining [cls | det], each refinement head's
+        box regression and first classifier projection -- as ONE autograd node (layers/functions.py:_LinearGroup):
+        separate forward GEMMs, but a single input-gradient GEMM and a single weight-gradient contraction.
+        Returns (mining logits, [(hidden_k, deltas_k)])."""
+        if self.object_miner.num_classes == 1 or os.environ.get("WSOVOD_DISABLE_GROUP", "0") == "1":
+            return None  # the K == 1 padding path keeps the per-module form (env switch: A/B measurements)
+        w, b = self.object_miner.stacked_params()
+        heads = [(w, b, False, torch.float32)]
+        slots = []
+        for k in range(self.refine_K):
+            r = self.box_refinery[k]
+            l1 = r.cls.projection[0]
+            heads.append((l1.weight, l1.bias, True, None))
+            hid = len(heads) - 1
+            reg = None
+            if r.refine_reg[r.refine_k]:
+                heads.append((r.bbox_pred.weight, r.bbox_pred.bias, False, torch.float32))
+                reg = len(heads) - 1
+            slots.append((hid, reg))
+        outs = Fn.linear_group(box_features, heads)
+        return [outs[0]] + [(outs[hid], outs[reg] if reg is not None else None) for hid, reg in slots]
 
     @torch.no_grad()
     def rpn_targets(self, prev_pred_scores, prev_pred_boxes, proposals, seg):
