@@ -1,0 +1,120 @@
+"""-m gpu: BASELINE.json's full sizes (800x600 images, 512 proposals, 20 classes, fc1 = 25088 -> 4096) through
+size-independent properties -- the oracle cannot run these sizes in seconds, the properties can be checked exactly or
+against O(size) fp64 checksums."""
+import pytest
+import torch
+
+from oracle import roi_ops
+from tests.conftest import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fc1_sized_contractions_checksum(gpu):
+    """Checksum of checksums at the fc1 shapes: (A B^T) 1 = A (B^T 1) and 1^T (P^T Q) = (P 1)^T Q, evaluated in fp64
+    from O(size) vectors, for the 8-phase NT tile (forward) and the transposed-read TN kernel (weight gradient)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, N, K = 8192, 4096, 25088
+    A = (torch.rand(M, K, device=gpu, generator=g) - 0.5).to(torch.bfloat16)
+    B = (torch.rand(N, K, device=gpu, generator=g) - 0.5).to(torch.bfloat16)
+    C = H.gemm_nt(A, B, out_dtype=torch.float32)
+    rows = C.double().sum(dim=1)
+    ref = A.double() @ B.double().sum(dim=0)
+    scale = (A.double().abs() @ B.double().abs().sum(dim=0))  # sum of |terms|: the natural error scale
+    assert float(((rows - ref).abs() / scale).max()) < 2e-6
+    dA = (torch.rand(M, N, device=gpu, generator=g) - 0.5).to(torch.bfloat16)
+    dW = H.gemm_tn(dA, A)  # (N, K) = dA^T A
+    cols = dW.double().sum(dim=0)
+    ref = dA.double().sum(dim=1) @ A.double()
+    scale = dA.double().abs().sum(dim=1) @ A.double().abs()
+    assert float(((cols - ref).abs() / scale).max()) < 2e-6
+    # linearity in the first operand (exact products, fp32 accumulation)
+    A2 = (torch.rand(256, K, device=gpu, generator=g) - 0.5).to(torch.bfloat16)
+    lhs = H.gemm_nt((A[:256].float() + A2.float()).to(torch.bfloat16), B, out_dtype=torch.float32)
+    both = H.gemm_nt(A[:256], B, out_dtype=torch.float32) + H.gemm_nt(A2, B, out_dtype=torch.float32)
+    inexact = (A[:256].float() + A2.float()).to(torch.bfloat16).float() - (A[:256].float() + A2.float())
+    slack = float(inexact.abs().max()) * K * 0.5 + 1e-2  # the bf16 rounding of A1 + A2 itself
+    assert float((lhs - both).abs().max()) <= slack
+
+
+def test_roi_pool_full_size_properties(gpu):
+    """512-channel 75x100 map, 512 boxes per image, 16 images: (i) a sample of boxes against the C oracle bit for bit,
+    (ii) shift equivariance pool(f + c) = pool(f) + c where every bin is non-empty, (iii) idempotence on a constant map,
+    (iv) every pooled value is a value of the map (max, not a blend)."""
+    from tests.util import random_rois
+    from wsovod_amd.layers import hip_ops as H
+
+    n, Cc, Hh, Ww = 16, 512, 75, 100
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(n, Hh, Ww, Cc, generator=g).to(torch.bfloat16)  # NHWC storage
+    rois = random_rois(n * 512, n, 600, 800, seed=2)
+    f_dev = feat.to(gpu).permute(0, 3, 1, 2)  # NCHW view of channels_last memory
+    out = H.roi_pool_forward(f_dev, rois.to(gpu), 0.125, (7, 7), need_argmax=False)[0]
+    assert out.shape == (n * 512, Cc, 7, 7)
+    pick = torch.arange(0, n * 512, 257)
+    ref = roi_ops.roi_pool_forward(feat[:, :, :, :64].permute(0, 3, 1, 2).float().contiguous(), rois[pick], 0.125, (7, 7))[0]
+    assert torch.equal(out[pick][:, :64].float().cpu(), ref)
+    shifted = H.roi_pool_forward((f_dev.float() + 2.0).to(torch.bfloat16), rois.to(gpu), 0.125, (7, 7),
+                                 need_argmax=False)[0]
+    ref_shift = roi_ops.roi_pool_forward((feat[:, :, :, :64].float() + 2.0).to(torch.bfloat16).permute(0, 3, 1, 2).float()
+                                         .contiguous(), rois[pick], 0.125, (7, 7))[0]
+    assert torch.equal(shifted[pick][:, :64].float().cpu(), ref_shift)
+    const = torch.full((2, Hh, Ww, Cc), 3.0, dtype=torch.bfloat16, device=gpu).permute(0, 3, 1, 2)
+    oc = H.roi_pool_forward(const, rois[:1024].to(gpu) * torch.tensor([0, 1, 1, 1, 1.0], device=gpu), 0.125, (7, 7),
+                            need_argmax=False)[0]
+    assert bool(((oc == 3.0) | (oc == 0.0)).all())
+    vals = torch.unique(feat[:, :, :, 5].float())
+    got = torch.unique(out[:, 5].float().cpu())
+    assert bool(torch.isin(got[got != 0], vals).all())
+
+
+def test_full_size_training_step_properties(gpu):
+    """One bf16 training step at the benchmark size (4 images of 800x600, 512 proposals, K = 20)."""
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, precision="bf16", device="cuda:0")
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    host = make_batch(4, 512, 20, seed=77)
+    batch = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
+              "height": x["height"], "width": x["width"]} for x in host]
+    cap = {}
+    rh = model.roi_heads
+    om, rf = rh.object_miner.forward, rh.box_refinery[0].forward
+    rh.object_miner.forward = lambda *a, **k: cap.setdefault("miner", om(*a, **k))
+    rh.box_refinery[0].forward = lambda *a, **k: cap.setdefault("refine", rf(*a, **k))
+    losses = model(batch)
+    rh.object_miner.forward, rh.box_refinery[0].forward = om, rf
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    scores = cap["miner"][0].float()
+    assert scores.shape == (4 * 512, 20) and bool((scores >= 0).all())
+    per_img = scores.view(4, 512, 20).sum(dim=1)
+    assert bool((per_img <= 1.0 + 1e-4).all()) and bool((per_img > 0).all())  # sum_r softmax_r(D) * softmax_k(C) <= 1
+    img = rh.pred_class_img_logits
+    assert bool((img >= 1e-6).all()) and bool((img <= 1 - 1e-6).all())
+    logits = cap["refine"][0].float()
+    assert logits.shape == (4 * 512, 21) and bool((logits[:, -1] == 0).all())
+    assert float(logits.detach().abs().max()) <= 50.0 * 1.001  # temperature * cosine
+    pgt = rh._last_pgt
+    gt_cls = [set(torch.unique(x["instances"].gt_classes).tolist()) for x in host]
+    labels = pgt["gt_classes"].view(4, 512).cpu()
+    for i in range(4):
+        assert set(labels[i].tolist()) <= gt_cls[i] | {20}
+        assert (labels[i] != 20).any()  # the mined box labels itself (IoU 1)
+    assert bool((pgt["gt_weights"] >= 0).all()) and bool((pgt["gt_weights"] <= 1).all())
+    for k, v in losses.items():
+        assert torch.isfinite(v) and float(v) >= 0, k
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    # image order does not matter: the same losses for the batch in reverse (per-image MIL softmax, per-image mining)
+    model.zero_grad(set_to_none=True)
+    losses_r = model(batch[::-1])
+    for k in losses:
+        torch.testing.assert_close(losses_r[k], losses[k], rtol=2e-3, atol=1e-5)
