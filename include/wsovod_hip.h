@@ -173,6 +173,12 @@ int wsovod_stem_im2col(const unsigned char* img, const int* sizes, const float* 
                        const float* std_host, int N, int Hp, int Wp, void* out, int out_dtype,
                        wsovod_stream_t stream);
 
+/* The same layer fused end to end for bf16: uint8 images -> normalise -> 3x3/s2 conv (w32: the folded [64][32] bf16
+ * weight in wsovod_stem_im2col's k order, bias: folded FrozenBN shift) -> ReLU -> (N, Ho, Wo, 64) bf16 NHWC.  The
+ * im2col operand is never materialised; results are bit-identical to wsovod_stem_im2col + wsovod_gemm_nt. */
+int wsovod_stem_conv1(const unsigned char* img, const int* sizes, const float* mean_host, const float* std_host, int N,
+                      int Hp, int Wp, const void* w32, const float* bias, void* out, wsovod_stream_t stream);
+
 /* 2x2 max pool over NHWC, stride 1 or 2; zero_pad_br=1 first pads one zero row/column at the
  * bottom/right (nn.ZeroPad2d((0,1,0,1)) + MaxPool2d(2, 1)).  Replaces the pools of
  * resnet_wsl.py:85-92,408. */

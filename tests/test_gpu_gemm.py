@@ -176,6 +176,25 @@ def test_linear_group_equals_separate_linears(gpu, dtype):
         torch.testing.assert_close(bb, ba, rtol=1e-4, atol=1e-4)
 
 
+def test_fused_stem_conv1_is_bit_identical_to_im2col_gemm(gpu):
+    """uint8 images -> normalise -> 3x3/s2 conv -> ReLU in one kernel vs the im2col operand + GEMM (ragged sizes)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(9)
+    N, Hp, Wp = 3, 77, 130
+    img = torch.randint(0, 256, (N, 3, Hp, Wp), dtype=torch.uint8, generator=g).to(gpu)
+    sizes = torch.tensor([[77, 130], [64, 101], [33, 130]], dtype=torch.int32, device=gpu)
+    mean, std = (102.98, 115.95, 122.77), (57.4, 57.1, 58.4)
+    w32 = torch.zeros(64, 32)
+    w32[:, :27] = torch.randn(64, 27, generator=g) * 0.1
+    w32 = w32.to(torch.bfloat16).to(gpu)
+    bias = torch.randn(64, generator=g).to(gpu)
+    a, ho, wo = H.stem_im2col(img, sizes, mean, std, torch.bfloat16)
+    ref = H.gemm_nt(a, w32, bias=bias, relu=True, out_dtype=torch.bfloat16).view(N, ho, wo, 64)
+    out = H.stem_conv1(img, sizes, mean, std, w32, bias)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+
+
 def test_gemm_dropout_statistics(gpu):
     from wsovod_amd.layers import hip_ops
 

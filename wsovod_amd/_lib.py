@@ -64,6 +64,7 @@ SIGNATURES = {
     "wsovod_gemm_nt": [C.POINTER(GemmDesc), _P],
     "wsovod_preprocess_image": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
     "wsovod_stem_im2col": [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
+    "wsovod_stem_conv1": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "wsovod_maxpool2x2_nhwc": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "wsovod_global_avgpool_nhwc": [_P, _I, _I, _I, _I, _P, _P],
     "wsovod_transpose_cast": [_P, _I, _L, _I, _I, _P, _I, _L, _P],

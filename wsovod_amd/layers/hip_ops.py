@@ -240,6 +240,18 @@ def stem_im2col(images_u8, sizes, mean, std, dtype):
     return out, Ho, Wo
 
 
+def stem_conv1(images_u8, sizes, mean, std, w32, bias):
+    """uint8 (N,3,Hp,Wp) images -> relu(conv1 3x3/s2 (folded BN)) as (N,Ho,Wo,64) bf16 NHWC, no im2col operand."""
+    require_gpu(images_u8, sizes, w32, bias)
+    assert w32.dtype == torch.bfloat16 and tuple(w32.shape) == (64, 32) and w32.is_contiguous()
+    N, _, Hp, Wp = images_u8.shape
+    Ho, Wo = (Hp - 1) // 2 + 1, (Wp - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, 64), dtype=torch.bfloat16, device=images_u8.device)
+    check(lib().wsovod_stem_conv1(ptr(images_u8), ptr(sizes), _f3(mean), _f3(std), N, Hp, Wp, ptr(w32), ptr(bias),
+                                  ptr(out), stream()), "stem_conv1")
+    return out
+
+
 def maxpool2x2_nhwc(x, stride, zero_pad_br=False):
     """x: (N,H,W,C) contiguous -> (N,Ho,Wo,C)."""
     require_gpu(x)

@@ -205,6 +205,19 @@ class BasicStem(CNNBlockBase):
         """x: NHWC with Cin zero-padded to the kernel's K-step (generic float entry)."""
         return self._tail(hip_conv(x, self.conv1, relu=True))
 
+    def _im2col_weight(self, dtype):
+        wq, b = self.conv1.folded(dtype)  # [Cout][27]
+        wpad = getattr(self, "_w_im2col", None)
+        if wpad is None or wpad[0] is not wq:
+            w32 = torch.zeros((wq.size(0), 32), dtype=wq.dtype, device=wq.device)
+            w32[:, :27] = wq
+            self._w_im2col = wpad = (wq, w32)
+        return wpad[1], b
+
+    def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
+        w32, b = self._im2col_weight(torch.bfloat16)
+        return self._tail(H.stem_conv1(images_u8, sizes, pixel_mean, pixel_std, w32, b))
+
     def forward_im2col(self, a, n, ho, wo):
         """a: (n*ho*wo, 32) fused normalise+im2col operand of conv1 (K = 27 padded to 32)."""
         assert self.in_channels == 3
@@ -294,6 +307,9 @@ class ResNet(nn.Module):
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
         self._check_frozen()
+        if self.compute_dtype == torch.bfloat16 and self.stem.out_channels == 64 and self.stem.in_channels == 3:
+            # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)
+            return self._run(self.stem.forward_uint8(images_u8, sizes, pixel_mean, pixel_std))
         a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
         return self._run(self.stem.forward_im2col(a, images_u8.size(0), ho, wo))
 
