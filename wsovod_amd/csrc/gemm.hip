@@ -447,9 +447,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = (tid >> 3) + 32 * i;                 // cout
+      const int row = (tid >> 3) + 32 * i;                 // LDS row = MFMA tile j = row >> 4, tile row f = row & 15
       const int chunk = (tid & 7) ^ ((row >> 1) & 7);      // swizzle on the source
-      const int off = (int)((row * p.ldb + tap * 64 + chunk * 8) * 2);
+      // LDS row (j, f) holds output channel 16*(f>>2) + 4*j + (f&3): after the MFMA a lane owns 16 CONSECUTIVE
+      // channels of its pixel (see the epilogue) while the fragment reads keep their conflict-free row pattern
+      const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);
+      const int off = (int)((cout * p.ldb + tap * 64 + chunk * 8) * 2);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + buf * 8192 + i * 4096 + wave_u * 1024), 16,
                                                off, 0, 0, 0);
     }
@@ -507,44 +510,57 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
     }
     __syncthreads();
   }
-  // epilogue: bias + residual + ReLU.  Operands were swapped in the MFMA, so lane (frow, fq) holds, for pixel
-  // group i and channel tile j, the 4 consecutive output channels j*16 + fq*4 + r of pixel frow: one 8-byte (bf16)
-  // or 16-byte (fp32) store and one vector residual load per tile.
-  const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.bias & 15) == 0 &&
-                   (!p.residual || ((p.ldr & 3) == 0 && ((uintptr_t)p.residual & 15) == 0));
+  // epilogue: bias + residual + ReLU.  Operands were swapped in the MFMA and the weight rows permuted at staging, so
+  // lane (frow, fq) holds, for pixel group i, the 16 consecutive output channels 16*fq + 4*j + r of pixel frow: its
+  // 32 bytes (bf16) go out as two 16-byte stores and the four lanes of a pixel cover its whole 128-byte row.
+  const bool vec = (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.bias & 15) == 0 &&
+                   (!p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0));
   const float lo = p.relu ? 0.f : -__builtin_inff();
+  const int n0c = 16 * fq;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int y = y0 + wave * 2 + (i >> 1);
     const int x = x0 + (i & 1) * 16 + frow;
     if (y >= p.H || x >= p.W) continue;
     const long long m = ((long long)img * p.H + y) * p.W + x;
+    float v[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = j * 16 + fq * 4;
-      f32x4 v = acc[i][j] * p.alpha;
-      if (vec) {
-        if (p.bias) v += *(const f32x4*)(p.bias + n);
-        if (p.residual) {
-          if (p.dtype_r == WSOVOD_BF16) {
-            const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + m * p.ldr + n);
-            v += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
-          } else {
-            v += *(const f32x4*)((const float*)p.residual + m * p.ldr + n);
-          }
-        }
-        v = f32x4{fmaxf(v[0], lo), fmaxf(v[1], lo), fmaxf(v[2], lo), fmaxf(v[3], lo)};
-        if (p.dtype_c == WSOVOD_BF16)
-          *(bf16x4*)((bf16_t*)p.C + m * p.ldc + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        else
-          *(f32x4*)((float*)p.C + m * p.ldc + n) = v;
-      } else {
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          float u = v[rr] + (p.bias ? p.bias[n + rr] : 0.f);
-          if (p.residual) u += load_as_f32(p.residual, m * p.ldr + n + rr, p.dtype_r);
-          store_from_f32(p.C, m * p.ldc + n + rr, p.dtype_c, fmaxf(u, lo));
+      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha;
+    if (vec && p.dtype_c == WSOVOD_BF16 && (!p.residual || p.dtype_r == WSOVOD_BF16)) {
+      if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b4 = *(const f32x4*)(p.bias + n0c + 4 * j);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * j + r] += b4[r];
         }
+      }
+      if (p.residual) {
+        const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
+        const bf16x8 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] += (float)r0[e];
+          v[8 + e] += (float)r1[e];
+        }
+      }
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o0[e] = (bf16_t)fmaxf(v[e], lo);
+        o1[e] = (bf16_t)fmaxf(v[8 + e], lo);
+      }
+      bf16x8* dst = (bf16x8*)((bf16_t*)p.C + m * p.ldc + n0c);
+      dst[0] = o0;
+      dst[1] = o1;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float u = v[e] + (p.bias ? p.bias[n0c + e] : 0.f);
+        if (p.residual) u += load_as_f32(p.residual, m * p.ldr + n0c + e, p.dtype_r);
+        store_from_f32(p.C, m * p.ldc + n0c + e, p.dtype_c, fmaxf(u, lo));
       }
     }
   }
