@@ -109,8 +109,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   int b_off[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
-    const int n = n0 + lrow + LR * i;
-    b_off[i] = n < p.N ? (int)(((long long)(lrow + LR * i) * p.ldb + lchunk * EPC) * esz) : -1;
+    // LDS row (tile j = rho >> 4, tile row f = rho & 15 inside a wavefront's BN/WN columns) is fed from B row
+    // 4*TN*(f>>2) + 4*j + (f&3): after the (operand-swapped) MFMAs a lane owns 4*TN CONSECUTIVE output columns, so a
+    // wavefront writes 16*TN contiguous elements per output row; the LDS image and its reads are unchanged.
+    constexpr int WCOLS = BN / WN;
+    const int r_lds = lrow + LR * i;
+    const int rho = r_lds % WCOLS;
+    const int src = r_lds - rho + 4 * TN * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+    b_off[i] = n0 + src < p.N ? (int)(((long long)src * p.ldb + lchunk * EPC) * esz) : -1;
   }
 
   const int nk = (p.K + BKE - 1) / BKE;
@@ -313,21 +319,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   }
   }
 
-  // ---- epilogue (fp32).  The MFMAs take the B fragment as their first operand, so a lane's four accumulator
-  // registers are four CONSECUTIVE COLUMNS of one output row: acc[i][j][r] = C[m = .. + (lane & 15)]
-  // [n = .. + (lane >> 4) * 4 + r] -- row-major outputs move as one 16-byte (fp32) / 8-byte (bf16) store per tile.
+  // ---- epilogue (fp32).  The MFMAs take the B fragment as their first operand and the B rows were permuted at
+  // staging, so lane (frow, fq) holds, for row tile i, output row m = .. + frow and the 4*TN consecutive columns
+  // n = ncol + 4*j + r: row-major outputs move as 16-byte stores, 16*TN contiguous elements per row and wavefront.
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const bool vec_c = p.C && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
-  const bool vec_r = !p.residual || ((p.ldr & 3) == 0 && ((uintptr_t)p.residual & 15) == 0);
+  const bool vec_c = p.C && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const bool vec_r = !p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0);
   const int mrow = m0 + wm * (BM / WM) + frow;
-  const int ncol = n0 + wn * (BN / WN) + fq * 4;
+  const int ncol = n0 + wn * (BN / WN) + 4 * TN * fq;
   // Fast path (bias / residual / ReLU / dropout, aligned row-major output, all tile columns in range): feature tests
   // hoisted out of the element loops, bias fetched once per column tile, residual and output as vector accesses.
   if (vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add && !p.mask_src &&
-      !p.accumulate && n0 + BN <= p.N) {
+      !p.accumulate && n0 + BN <= p.N && (TN % 2 == 0 || p.dtype_c == WSOVOD_F32)) {
     f32x4 b4[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + ncol + j * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + ncol + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float lo = p.relu ? 0.f : -__builtin_inff();
     const bool drop = p.dropout_p > 0.f, has_res = p.residual != nullptr;
 #pragma unroll
@@ -335,27 +341,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       const long long mm = mrow + i * 16;
       if (mm >= p.M) continue;
       const long long base = mm * p.ldc + ncol;
+      f32x4 x[TN];
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        f32x4 x = acc[i][j] * p.alpha + b4[j];
+        x[j] = acc[i][j] * p.alpha + b4[j];
         if (has_res) {
           if (p.dtype_r == WSOVOD_BF16) {
-            const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + ncol + j * 16);
-            x += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
+            const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + ncol + 4 * j);
+            x[j] += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
           } else {
-            x += *(const f32x4*)((const float*)p.residual + mm * p.ldr + ncol + j * 16);
+            x[j] += *(const f32x4*)((const float*)p.residual + mm * p.ldr + ncol + 4 * j);
           }
         }
-        x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};
+        x[j] = f32x4{fmaxf(x[j][0], lo), fmaxf(x[j][1], lo), fmaxf(x[j][2], lo), fmaxf(x[j][3], lo)};
         if (drop) {
-          const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + j * 16);
+          const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[r] * keep_scale : 0.f;
+          for (int r = 0; r < 4; ++r) x[j][r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;
         }
-        if (p.dtype_c == WSOVOD_BF16)
-          *(bf16x4*)((bf16_t*)p.C + base + j * 16) = bf16x4{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
-        else
-          *(f32x4*)((float*)p.C + base + j * 16) = x;
+      }
+      if (p.dtype_c == WSOVOD_BF16) {
+#pragma unroll
+        for (int j = 0; j + 1 < TN; j += 2)
+          *(bf16x8*)((bf16_t*)p.C + base + 4 * j) =
+              bf16x8{(bf16_t)x[j][0],     (bf16_t)x[j][1],     (bf16_t)x[j][2],     (bf16_t)x[j][3],
+                     (bf16_t)x[j + 1][0], (bf16_t)x[j + 1][1], (bf16_t)x[j + 1][2], (bf16_t)x[j + 1][3]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *(f32x4*)((float*)p.C + base + 4 * j) = x[j];
       }
     }
     return;
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     const float rs = p.row_scale ? p.row_scale[m] : 1.f;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int nb = ncol + j * 16;
+      const int nb = ncol + 4 * j;
       if (nb >= p.N) continue;
       float v[4];
 #pragma unroll

@@ -91,8 +91,10 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       hi0[i] = wi0[i] = 0;
       a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
     }
-    const int n = n0 + lrow + LR * i;
-    b_off[i] = n < p.N ? (int)(((long long)(lrow + LR * i) * p.ldb + lchunk * EPC) * esz) : -1;
+    // B pass i = the 64 columns of the wavefronts with wc == i; LDS row (tile j = lrow >> 4, tile row f = lrow & 15) is
+    // fed from B row 16*(f>>2) + 4*j + (f&3), so that after the MFMAs a lane owns 16 CONSECUTIVE output columns
+    const int src = LR * i + 16 * ((lrow & 15) >> 2) + 4 * (lrow >> 4) + (lrow & 3);
+    b_off[i] = n0 + src < p.N ? (int)(((long long)src * p.ldb + lchunk * EPC) * esz) : -1;
   }
   const int nk = (p.K + BKE - 1) / BKE;
 
@@ -274,15 +276,16 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
 #undef WS_VMCNT
 
-  // ---- epilogue (fp32).  The MFMAs were issued with the operands swapped (B fragment first), so a lane's four
-  // accumulator registers are four CONSECUTIVE COLUMNS of one output row: acc[i][j][r] = C[m = .. + (lane & 15)]
-  // [n = .. + (lane >> 4) * 4 + r] -- one 16-byte (fp32) / 8-byte (bf16) store per tile instead of four 4-byte ones.
+  // ---- epilogue (fp32).  The MFMAs were issued with the operands swapped (B fragment first) and the B rows permuted
+  // at staging, so lane (frow, fq) holds output row m = .. + frow and the 16 consecutive columns ncol + 4*j + r:
+  // per output row a wavefront writes 64 contiguous elements as 16-byte stores.
   // Tile indices are compile-time constants (a runtime index into acc would put the accumulators in scratch).
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const bool vec_c = p.C && (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const bool vec_c = p.C && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const int ncol = n0 + wc * 64 + 16 * fq;
   auto emit = [&](const f32x4 a4, const int i, const int j) {
     const int m = m0 + wr * 128 + i * 16 + frow;
-    const int nb = n0 + wc * 64 + j * 16 + fq * 4;
+    const int nb = ncol + 4 * j;
     if (m >= p.M || nb >= p.N) return;
     const float rs = p.row_scale ? p.row_scale[m] : 1.f;
     const bool full = nb + 3 < p.N;
@@ -329,44 +332,47 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   };
   // Fast path (bias / residual / ReLU / dropout, row-major output with 16-byte aligned rows, whole tile columns in
   // range): the feature tests are hoisted out of the element loops, bias is fetched once per column tile, residual
-  // and output move as one 8- or 16-byte access per MFMA tile.
-  const bool vec_r = !p.residual || ((p.ldr & 3) == 0 && ((uintptr_t)p.residual & 15) == 0);
-  const bool plain = vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add && !p.mask_src && !p.accumulate &&
-                     n0 + BN <= p.N;
+  // and output move as 16-byte accesses.
+  const bool vec_r = !p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0);
+  const bool plain = vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add &&
+                     !p.mask_src && !p.accumulate && n0 + BN <= p.N;
   if (plain) {
     f32x4 b4[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      b4[j] = p.bias ? *(const f32x4*)(p.bias + n0 + wc * 64 + j * 16 + fq * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + ncol + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
     const float lo = p.relu ? 0.f : -__builtin_inff();
     const int mrow = m0 + wr * 128 + frow;
-    const long long col = n0 + wc * 64 + fq * 4;
     const bool drop = p.dropout_p > 0.f;
     const bool has_res = p.residual != nullptr;
 #define WS_FAST_ROW(I)                                                                                        \
   if (mrow + (I) * 16 < p.M) {                                                                                \
     const long long mm = mrow + (I) * 16;                                                                     \
-    const long long base = mm * p.ldc + col;                                                                  \
+    const long long base = mm * p.ldc + ncol;                                                                 \
+    f32x4 x[4];                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
-      f32x4 x = acc[I][j] * p.alpha + b4[j];                                                                  \
+      x[j] = acc[I][j] * p.alpha + b4[j];                                                                     \
       if (has_res) {                                                                                          \
         if (p.dtype_r == WSOVOD_BF16) {                                                                       \
-          const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + col + j * 16);          \
-          x += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};                                 \
+          const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + ncol + 4 * j);          \
+          x[j] += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};                              \
         } else {                                                                                              \
-          x += *(const f32x4*)((const float*)p.residual + mm * p.ldr + col + j * 16);                         \
+          x[j] += *(const f32x4*)((const float*)p.residual + mm * p.ldr + ncol + 4 * j);                      \
         }                                                                                                     \
       }                                                                                                       \
-      x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};                          \
+      x[j] = f32x4{fmaxf(x[j][0], lo), fmaxf(x[j][1], lo), fmaxf(x[j][2], lo), fmaxf(x[j][3], lo)};           \
       if (drop) {                                                                                             \
-        const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (col + j * 16);     \
+        const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);     \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
-            x[r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[r] * keep_scale : 0.f;                       \
+            x[j][r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;                 \
       }                                                                                                       \
-      if (p.dtype_c == WSOVOD_BF16)                                                                           \
-        *(bf16x4*)((bf16_t*)p.C + base + j * 16) = bf16x4{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]}; \
-      else                                                                                                    \
-        *(f32x4*)((float*)p.C + base + j * 16) = x;                                                           \
+    }                                                                                                         \
+    if (p.dtype_c == WSOVOD_BF16) {                                                                           \
+      _Pragma("unroll") for (int j = 0; j < 4; j += 2)                                                        \
+          *(bf16x8*)((bf16_t*)p.C + base + 4 * j) =                                                           \
+              bf16x8{(bf16_t)x[j][0],     (bf16_t)x[j][1],     (bf16_t)x[j][2],     (bf16_t)x[j][3],          \
+                     (bf16_t)x[j + 1][0], (bf16_t)x[j + 1][1], (bf16_t)x[j + 1][2], (bf16_t)x[j + 1][3]};     \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) *(f32x4*)((float*)p.C + base + 4 * j) = x[j];             \
     }                                                                                                         \
   }
     WS_FAST_ROW(0) WS_FAST_ROW(1) WS_FAST_ROW(2) WS_FAST_ROW(3) WS_FAST_ROW(4) WS_FAST_ROW(5) WS_FAST_ROW(6) WS_FAST_ROW(7)
