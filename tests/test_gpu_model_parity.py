@@ -164,6 +164,47 @@ def test_eval_tail_matches_oracle(gpu):
     assert checked > 0
 
 
+def test_tta_wrappers(gpu):
+    """Test-time augmentation (n2): (i) a single identity view reproduces plain inference; (ii) the AVG merge equals
+    the oracle tail applied to the hand-averaged per-view scores / back-mapped boxes; (iii) UNION returns boxes from
+    the pooled per-view detections."""
+    from wsovod_amd.modeling import GeneralizedRCNNWithTTAAVG, GeneralizedRCNNWithTTAUNION
+    from wsovod_amd.modeling.test_time_augmentation import DatasetMapperTTAAVG
+
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    model.eval()
+    model.classifier = torch.randn(20, 512, device=gpu)
+    batch = to_inputs(gen.seeded_batch(1, 60, 20, 256, 352, seed=21))
+    pred = model.roi_heads.box_refinery[-1]
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST, cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = pred.test_score_thresh, pred.test_nms_thresh
+    cfg.TEST.DETECTIONS_PER_IMAGE = pred.test_topk_per_image
+    plain = model.inference(batch, do_postprocess=False)[0][0]
+    ident = GeneralizedRCNNWithTTAAVG(cfg, model, DatasetMapperTTAAVG([256], 4000, False, 0))(batch)[0]["instances"]
+    assert torch.equal(ident.pred_boxes.tensor, plain.pred_boxes.tensor) and torch.equal(ident.scores, plain.scores)
+    mapper = DatasetMapperTTAAVG([192, 256], 4000, True, 0)
+    tta = GeneralizedRCNNWithTTAAVG(cfg, model, mapper)
+    out = tta(batch)[0]["instances"]
+    views = mapper(dict(batch[0]))
+    assert len(views) == 4 and views[1]["image"].shape[-1] == views[0]["image"].shape[-1]
+    boxes, scores = [], []
+    for v in views:
+        tf = v.pop("transforms")
+        _, sc, bx = model.inference([v], do_postprocess=False)
+        b = tf.inverse().apply_box(bx[0][0].cpu().numpy())
+        boxes.append(torch.from_numpy(b).float())
+        scores.append(sc[0][0].cpu())
+    rb, rs, rc, _ = R.fast_rcnn_inference_single_image(torch.stack(boxes).mean(0), torch.stack(scores).mean(0), (256, 352),
+                                                       pred.test_score_thresh, pred.test_nms_thresh, pred.test_topk_per_image)
+    assert torch.equal(out.pred_classes.cpu(), rc)
+    torch.testing.assert_close(out.pred_boxes.tensor.cpu(), rb, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(out.scores.cpu(), rs, rtol=1e-5, atol=1e-7)
+    # a flipped view maps back onto the original frame: same x-extent as the unflipped view of that size
+    torch.testing.assert_close(boxes[0][:, [1, 3]], boxes[1][:, [1, 3]], rtol=0, atol=64.0)
+    uni = GeneralizedRCNNWithTTAUNION(cfg, model, mapper)(batch)[0]["instances"]
+    assert len(uni) > 0 and len(uni) <= pred.test_topk_per_image and bool(torch.isfinite(uni.pred_boxes.tensor).all())
+    assert bool((uni.scores[:-1] >= uni.scores[1:]).all())
+
+
 def test_product_path_fails_loudly_without_gpu_tensors(gpu):
     from wsovod_amd.layers import hip_ops
 

@@ -183,7 +183,8 @@ def _d2_defaults():
     _C.TEST = C()
     _C.TEST.DETECTIONS_PER_IMAGE = 100
     _C.TEST.EVAL_PERIOD = 0
-    _C.TEST.AUG = C({"ENABLED": False})
+    _C.TEST.AUG = C({"ENABLED": False, "MIN_SIZES": (400, 500, 600, 700, 800, 900, 1000, 1100, 1200), "MAX_SIZE": 4000,
+                     "FLIP": True})
     _C.OUTPUT_DIR = "./output"
     _C.VIS_PERIOD = 0
     return _C
