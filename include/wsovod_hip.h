@@ -78,6 +78,14 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
                             const float* roi_scale, int R, int N, int C, int H, int W, int ph,
                             int pw, float spatial_scale, void* out, int out_dtype, int* argmax,
                             wsovod_stream_t stream);
+/* ROILoopPool in the 3-output form of the reference's CUDA op (wsovod/layers/ROILoopPool/ROILoopPool_cuda.cu:9-204,
+ * bound as `_C.roi_loop_pool_forward`, wsovod/layers/roi_loop_pool.py:9-22; context_ratio is 1.8 there): out and
+ * argmax are (3R, C, ph, pw) = [region | frame | context] fp32 / int32 (NCHW order).  The matching backward is
+ * wsovod_roi_pool_backward over the 3R outputs with the rois repeated three times (ROILoopPool_cuda.cu:207-243). */
+int wsovod_roi_loop_pool_forward(const void* feat, int dtype, int layout, const float* rois, int R, int N, int C, int H,
+                                 int W, int ph, int pw, float spatial_scale, float context_ratio, float* out,
+                                 int* argmax, wsovod_stream_t stream);
+
 /* grad_in (N,C,H,W) in `layout`, fp32, must be zero-filled by the caller; scatter-add
  * through argmax (ROILoopPool_cpu.cpp:82-123).  grad_out is (R,C,ph,pw) contiguous fp32. */
 int wsovod_roi_pool_backward(const float* grad_out, const float* rois, const float* roi_scale,

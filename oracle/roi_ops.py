@@ -136,3 +136,17 @@ def nms_segments(boxes, seg_offsets, iou_threshold, max_keep=0, valid=None):
         _clib().nms_segments(_p(boxes), _p(seg), _p(v) if v is not None else None, G, C.c_float(iou_threshold),
                              int(max_keep), _p(keep), _p(count))
     return [keep[int(seg[g]):int(seg[g]) + int(count[g])].to(torch.int64) for g in range(G)]
+
+
+def roi_loop_pool_forward(feat, rois, spatial_scale, output_size, context_ratio=1.8):
+    """The reference's 3-output ROILoopPool (restated from its CUDA kernel) -> (out (3R,C,ph,pw), argmax int32)."""
+    feat, rois = _prep(feat, rois)
+    ph, pw = output_size
+    N, Cc, H, W = feat.shape
+    R = rois.shape[0]
+    out = torch.zeros(3 * R, Cc, ph, pw, dtype=torch.float32)
+    arg = torch.full((3 * R, Cc, ph, pw), -1, dtype=torch.int32)
+    if R:
+        _clib().roi_loop_pool_forward(_p(feat), C.c_float(spatial_scale), Cc, H, W, ph, pw, _p(rois), R,
+                                      C.c_float(context_ratio), _p(out), _p(arg))
+    return out, arg

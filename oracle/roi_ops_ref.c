@@ -198,3 +198,86 @@ void roi_align_backward(const float* grad_output, float spatial_scale, int chann
     }
   }
 }
+
+/* ROILoopPool, 3-output form: restated from the reference's CUDA kernel
+ * (wsovod/layers/ROILoopPool/ROILoopPool_cuda.cu:9-204; launched with context_ratio 1.8 at :311) -- the reference's
+ * CPU source implements the first output only, so this part of the oracle is pinned by source reading, not by a
+ * compiled reference ("parity unpinned" for frame / context; the region output equals roi_pool_forward on
+ * non-negative inputs, which IS pinned against oracle/_ref).
+ * out, argmax: (3R, C, PH, PW) = [region | frame | context]. */
+void roi_loop_pool_forward(const float* input, float spatial_scale, int channels, int height, int width,
+                           int pooled_height, int pooled_width, const float* rois, int num_rois, float context_ratio,
+                           float* output, int* argmax_data) {
+  const long part = (long)num_rois * channels * pooled_height * pooled_width;
+  for (int n = 0; n < num_rois; ++n) {
+    const float* roi = rois + n * 5;
+    const int b = (int)roi[0];
+    const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+    const float rois_w = x2 - x1, rois_h = y2 - y1;
+    const float rois_inner_w = rois_w / context_ratio, rois_inner_h = rois_h / context_ratio;
+    const float rois_outer_w = rois_w * context_ratio, rois_outer_h = rois_h * context_ratio;
+    const float inner_residual_w = rois_w - rois_inner_w, inner_residual_h = rois_h - rois_inner_h;
+    const float outer_residual_w = rois_outer_w - rois_w, outer_residual_h = rois_outer_h - rois_h;
+    const float xmax = (float)(1.0 * width / spatial_scale), ymax = (float)(1.0 * height / spatial_scale);
+#define CLAMPF(v, hi) fminf(fmaxf((v), 0.f), (hi))
+    const float x1_inner = CLAMPF(x1 + inner_residual_w / 2, xmax), y1_inner = CLAMPF(y1 + inner_residual_h / 2, ymax);
+    const float x2_inner = CLAMPF(x2 - inner_residual_w / 2, xmax), y2_inner = CLAMPF(y2 - inner_residual_h / 2, ymax);
+    const float x1_outer = CLAMPF(x1 - outer_residual_w / 2, xmax), y1_outer = CLAMPF(y1 - outer_residual_h / 2, ymax);
+    const float x2_outer = CLAMPF(x2 + outer_residual_w / 2, xmax), y2_outer = CLAMPF(y2 + outer_residual_h / 2, ymax);
+#undef CLAMPF
+    const int sw = (int)roundf(x1 * spatial_scale), sh = (int)roundf(y1 * spatial_scale);
+    const int ew = (int)roundf(x2 * spatial_scale), eh = (int)roundf(y2 * spatial_scale);
+    const int sw_in = (int)roundf(x1_inner * spatial_scale), sh_in = (int)roundf(y1_inner * spatial_scale);
+    const int ew_in = (int)roundf(x2_inner * spatial_scale), eh_in = (int)roundf(y2_inner * spatial_scale);
+    const int sw_out = (int)roundf(x1_outer * spatial_scale), sh_out = (int)roundf(y1_outer * spatial_scale);
+    const int ew_out = (int)roundf(x2_outer * spatial_scale), eh_out = (int)roundf(y2_outer * spatial_scale);
+    for (int c = 0; c < channels; ++c) {
+      const float* plane = input + ((long)b * channels + c) * height * width;
+      for (int ph = 0; ph < pooled_height; ++ph)
+        for (int pw = 0; pw < pooled_width; ++pw) {
+          const long index = (((long)n * channels + c) * pooled_height + ph) * pooled_width + pw;
+          {
+            const int roi_width = imax(ew - sw + 1, 1), roi_height = imax(eh - sh + 1, 1);
+            const float bin_h = (float)roi_height / (float)pooled_height, bin_w = (float)roi_width / (float)pooled_width;
+            const int hstart = imin(imax((int)floorf((float)ph * bin_h) + sh, 0), height);
+            const int hend = imin(imax((int)ceilf((float)(ph + 1) * bin_h) + sh, 0), height);
+            const int wstart = imin(imax((int)floorf((float)pw * bin_w) + sw, 0), width);
+            const int wend = imin(imax((int)ceilf((float)(pw + 1) * bin_w) + sw, 0), width);
+            float maxval = 0, maxval_F = 0;
+            int maxidx = -1, maxidx_F = -1;
+            for (int h = hstart; h < hend; ++h)
+              for (int w = wstart; w < wend; ++w) {
+                const int ii = h * width + w;
+                if (plane[ii] > maxval) { maxval = plane[ii]; maxidx = ii; }
+                if (h > sh_in && h < eh_in && w > sw_in && w < ew_in) continue;
+                if (plane[ii] > maxval_F) { maxval_F = plane[ii]; maxidx_F = ii; }
+              }
+            output[index] = maxval;
+            argmax_data[index] = maxidx;
+            output[index + part] = maxval_F;
+            argmax_data[index + part] = maxidx_F;
+          }
+          {
+            const int roi_width = imax(ew_out - sw_out + 1, 1), roi_height = imax(eh_out - sh_out + 1, 1);
+            const float bin_h = (float)roi_height / (float)pooled_height, bin_w = (float)roi_width / (float)pooled_width;
+            const int hstart = imin(imax((int)floorf((float)ph * bin_h) + sh_out, 0), height);
+            const int hend = imin(imax((int)ceilf((float)(ph + 1) * bin_h) + sh_out, 0), height);
+            const int wstart = imin(imax((int)floorf((float)pw * bin_w) + sw_out, 0), width);
+            const int wend = imin(imax((int)ceilf((float)(pw + 1) * bin_w) + sw_out, 0), width);
+            float maxval = 0;
+            int maxidx = -1;
+            for (int h = hstart; h < hend; ++h) {
+              const int in_h = h > sh && h < eh;
+              for (int w = wstart; w < wend; ++w) {
+                if (in_h && w > sw && w < ew) continue;
+                const int ii = h * width + w;
+                if (plane[ii] > maxval) { maxval = plane[ii]; maxidx = ii; }
+              }
+            }
+            output[index + 2 * part] = maxval;
+            argmax_data[index + 2 * part] = maxidx;
+          }
+        }
+    }
+  }
+}

@@ -107,6 +107,8 @@ def roi_pooler(feat, boxes_list, pooler_type="ROIPool", output_size=7, scale=0.1
     size = (output_size, output_size)
     if pooler_type == "ROIPool":
         return roi_ops.roi_pool_forward(feat, rois, scale, size)[0]
+    if pooler_type == "ROILoopPool":  # (3R, C, ph, pw) = [region | frame | context]
+        return roi_ops.roi_loop_pool_forward(feat, rois, scale, size)[0]
     if pooler_type == "ROIAlignV2":
         return roi_ops.roi_align_forward(feat, rois, scale, size, sampling_ratio, True)
     if pooler_type == "ROIAlign":
@@ -148,6 +150,14 @@ def mining_forward(sd, x, nums, prefix="roi_heads.object_miner."):
     if K == 1:
         scores, _ = torch.split(scores, 1, dim=1)
     return scores
+
+
+def mining_forward_contextlocnet(sd, x, fx, cx, nums, prefix="roi_heads.object_miner."):
+    """fast_rcnn_open_vocabulary.py:369-390 (forward_contextlocnet) + :345-357: C = cls(x), D = det(Fx) - det(Cx)."""
+    C = F.linear(x, sd[prefix + "cls.weight"], sd[prefix + "cls.bias"])
+    D = F.linear(fx, sd[prefix + "det.weight"], sd[prefix + "det.bias"]) - \
+        F.linear(cx, sd[prefix + "det.weight"], sd[prefix + "det.bias"])
+    return torch.cat([F.softmax(c, dim=1) * F.softmax(d, dim=0) for c, d in zip(C.split(nums), D.split(nums))], dim=0)
 
 
 def predict_probs_img(scores, nums):
@@ -483,15 +493,26 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
     nums = [len(b) for b in boxes_list]
     pooled = roi_pooler(res5.detach(), boxes_list, pooler_type, 7, 0.125, sampling_ratio)
     objectness = torch.cat([o + 1 for o in obj_list], dim=0)
+    loop = pooler_type == "ROILoopPool"
+    if loop:
+        objectness = objectness.repeat(3)
     pooled = pooled * objectness.view(-1, 1, 1, 1)  # roi_heads.py:733-739
     inter["pooled"] = pooled
     feat = neck_forward(sd, pooled, dropout_masks=dropout_masks)
+    if loop:
+        feat, feat_f, feat_c = torch.chunk(feat, 3, dim=0)  # roi_heads.py:748-760
     if data_aware:
         daf = data_aware_forward(sd, res5)
         inter["daf"] = daf
-        feat = feat + torch.cat([daf[i].repeat(n, 1) for i, n in enumerate(nums)])  # roi_heads.py:762-763
+        rep = torch.cat([daf[i].repeat(n, 1) for i, n in enumerate(nums)])
+        feat = feat + rep  # roi_heads.py:762-763
+        if loop:
+            feat_f, feat_c = feat_f + rep, feat_c + rep
     inter["box_features"] = feat
-    scores = mining_forward(sd, feat, nums, prefix=miner_prefix)
+    if loop:
+        scores = mining_forward_contextlocnet(sd, feat, feat_f, feat_c, nums, prefix=miner_prefix)
+    else:
+        scores = mining_forward(sd, feat, nums, prefix=miner_prefix)
     inter["mining_scores"] = scores
     gt_int, gt_oh = get_image_level_gt([b["gt_classes"] for b in batch], num_classes)
     losses = {"loss_cls_object_mining": mining_loss(scores, nums, gt_oh, mean_loss)}

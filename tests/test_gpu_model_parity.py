@@ -164,6 +164,26 @@ def test_eval_tail_matches_oracle(gpu):
     assert checked > 0
 
 
+def test_roi_loop_pool_contextlocnet_step_matches_oracle(gpu):
+    """POOLER_TYPE ROILoopPool (the reference's native 3-output op) + the contextlocnet mining head: whole fp32
+    training step against the oracle on identical seeded parameters."""
+    cfg, model, sd = build_seeded_hip_model("fp32", pooler="ROILoopPool")
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=61)
+    sdc = {k: v.clone() for k, v in sd.items()}
+    ref_losses, inter = R.train_forward(sdc, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD,
+                                        pooler_type="ROILoopPool")
+    losses, cap, pgt = _run(model, batch)
+    assert (cap["miner"][0].detach().cpu() - inter["mining_scores"]).abs().max() < 1e-3
+    assert (cap["refine"][0].detach().cpu() - inter["refine_logits"]).abs().max() < 1e-3
+    for name, v in ref_losses.items():
+        torch.testing.assert_close(losses[name].detach().cpu(), v.detach(), rtol=2e-3, atol=1e-5)
+    lab = inter["labelled"]
+    assert torch.equal(pgt["gt_classes"].cpu(), torch.cat([l["gt_classes"] for l in lab]))
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
 def test_tta_wrappers(gpu):
     """Test-time augmentation (n2): (i) a single identity view reproduces plain inference; (ii) the AVG merge equals
     the oracle tail applied to the hand-averaged per-view scores / back-mapped boxes; (iii) UNION returns boxes from

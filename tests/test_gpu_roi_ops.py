@@ -108,3 +108,30 @@ def test_roi_pool_empty_and_errors(gpu):
         hip_ops.roi_pool_forward(feat, torch.zeros(3, 4, device=gpu), 0.125, (7, 7))
     with pytest.raises(RuntimeError):
         hip_ops.roi_pool_forward(feat.cpu(), torch.zeros(3, 5), 0.125, (7, 7))
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_roi_loop_pool_three_outputs_bit_exact(gpu, channels_last, dtype):
+    """The reference's native op in its CUDA form (region / frame / context) against the C restatement: values and
+    argmax bit for bit; region == plain RoIPool on the non-negative map; frame <= region; the backward through the
+    3R outputs is the RoIPool scatter with the rois repeated."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(11)
+    feat = torch.relu(torch.randn(2, 16, 38, 50, generator=g)).to(dtype)
+    rois = random_rois(96, 2, 300, 400, seed=12)
+    ref, ref_arg = O.roi_loop_pool_forward(feat.float(), rois, 0.125, (7, 7))
+    f = feat.to(gpu)
+    if channels_last:
+        f = f.contiguous(memory_format=torch.channels_last)
+    out, arg = H.roi_loop_pool_forward(f, rois.to(gpu), 0.125, (7, 7))
+    assert out.shape == (3 * 96, 16, 7, 7)
+    assert torch.equal(out.cpu(), ref) and torch.equal(arg.cpu(), ref_arg)
+    plain = O.roi_pool_forward(feat.float(), rois, 0.125, (7, 7))[0]
+    assert torch.equal(ref[:96], plain) and bool((ref[96:192] <= ref[:96]).all())
+    assert bool((ref[192:] != ref[:96]).any())  # the context ring is a different window
+    grad = torch.randn(3 * 96, 16, 7, 7, generator=g)
+    gi = H.roi_pool_backward(grad.to(gpu), rois.repeat(3, 1).to(gpu), arg, (2, 16, 38, 50))
+    ref_gi = O.roi_pool_backward(grad, rois.repeat(3, 1), ref_arg, (2, 16, 38, 50))
+    torch.testing.assert_close(gi.cpu(), ref_gi, rtol=1e-5, atol=1e-5)

@@ -277,6 +277,91 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nchw(const T* __restrict__ f
   }
 }
 
+// ---------------------------------------------------------------------------------
+// ROILoopPool, the reference's own native op in its 3-output CUDA form (ROILoopPool_cuda.cu:9-204; the CPU source
+// implements only the first output): per roi and bin
+//   region : max over the bin (as RoIPool, but with the accumulator starting at 0: inputs are post-ReLU)
+//   frame  : the same bin without the cells STRICTLY inside the roi shrunk by context_ratio about its centre
+//   context: the bin of the roi GROWN by context_ratio, without the cells strictly inside the roi itself
+// out / argmax: (3R, C, PH, PW) = [region | frame | context].  One thread per (roi, channel, bin), as the reference;
+// this op is selected by the MRRP / contextlocnet configs only, not by the WSR hot path.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void roi_loop_pool_fwd(const T* __restrict__ feat, const float* __restrict__ rois,
+                                                         long long total, int R, int C, int H, int W, int PH, int PW,
+                                                         float spatial_scale, float context_ratio, int nhwc,
+                                                         float* __restrict__ out, int* __restrict__ argmax) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % PW);
+    const int ph = (int)((idx / PW) % PH);
+    const int c = (int)((idx / ((long long)PW * PH)) % C);
+    const int r = (int)(idx / ((long long)PW * PH * C));
+    const float* roi = rois + (long long)r * 5;
+    const int batch = (int)roi[0];
+    const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float in_rw = rw - rw / context_ratio, in_rh = rh - rh / context_ratio;    // inner residuals
+    const float out_rw = rw * context_ratio - rw, out_rh = rh * context_ratio - rh;  // outer residuals
+    const float xmax = (float)(1.0 * W / spatial_scale), ymax = (float)(1.0 * H / spatial_scale);
+    const float x1i = fminf(fmaxf(x1 + in_rw / 2, 0.f), xmax), y1i = fminf(fmaxf(y1 + in_rh / 2, 0.f), ymax);
+    const float x2i = fminf(fmaxf(x2 - in_rw / 2, 0.f), xmax), y2i = fminf(fmaxf(y2 - in_rh / 2, 0.f), ymax);
+    const float x1o = fminf(fmaxf(x1 - out_rw / 2, 0.f), xmax), y1o = fminf(fmaxf(y1 - out_rh / 2, 0.f), ymax);
+    const float x2o = fminf(fmaxf(x2 + out_rw / 2, 0.f), xmax), y2o = fminf(fmaxf(y2 + out_rh / 2, 0.f), ymax);
+    const T* plane = nhwc ? feat + (long long)batch * H * W * C + c : feat + ((long long)batch * C + c) * H * W;
+    const long long es = nhwc ? C : 1;
+    const long long part = (long long)R * C * PH * PW;
+    // the roi's own rounded rectangle: bins of region/frame, hole of context
+    const int sw = (int)roundf(x1 * spatial_scale), sh = (int)roundf(y1 * spatial_scale);
+    const int ew = (int)roundf(x2 * spatial_scale), eh = (int)roundf(y2 * spatial_scale);
+    {
+      const int swi = (int)roundf(x1i * spatial_scale), shi = (int)roundf(y1i * spatial_scale);
+      const int ewi = (int)roundf(x2i * spatial_scale), ehi = (int)roundf(y2i * spatial_scale);
+      const int roi_w = max(ew - sw + 1, 1), roi_h = max(eh - sh + 1, 1);
+      const float bin_h = (float)roi_h / (float)PH, bin_w = (float)roi_w / (float)PW;
+      const int hs = min(max((int)floorf((float)ph * bin_h) + sh, 0), H);
+      const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + sh, 0), H);
+      const int ws = min(max((int)floorf((float)pw * bin_w) + sw, 0), W);
+      const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + sw, 0), W);
+      float mv = 0.f, mvf = 0.f;
+      int mi = -1, mif = -1;
+      for (int h = hs; h < he; ++h)
+        for (int w = ws; w < we; ++w) {
+          const float v = to_f32(plane[(long long)(h * W + w) * es]);
+          if (v > mv) { mv = v; mi = h * W + w; }
+          if (h > shi && h < ehi && w > swi && w < ewi) continue;  // strictly inside the inner rectangle
+          if (v > mvf) { mvf = v; mif = h * W + w; }
+        }
+      out[idx] = mv;
+      argmax[idx] = mi;
+      out[idx + part] = mvf;
+      argmax[idx + part] = mif;
+    }
+    {
+      const int swo = (int)roundf(x1o * spatial_scale), sho = (int)roundf(y1o * spatial_scale);
+      const int ewo = (int)roundf(x2o * spatial_scale), eho = (int)roundf(y2o * spatial_scale);
+      const int roi_w = max(ewo - swo + 1, 1), roi_h = max(eho - sho + 1, 1);
+      const float bin_h = (float)roi_h / (float)PH, bin_w = (float)roi_w / (float)PW;
+      const int hs = min(max((int)floorf((float)ph * bin_h) + sho, 0), H);
+      const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + sho, 0), H);
+      const int ws = min(max((int)floorf((float)pw * bin_w) + swo, 0), W);
+      const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + swo, 0), W);
+      float mv = 0.f;
+      int mi = -1;
+      for (int h = hs; h < he; ++h) {
+        const bool in_h = h > sh && h < eh;
+        for (int w = ws; w < we; ++w) {
+          if (in_h && w > sw && w < ew) continue;
+          const float v = to_f32(plane[(long long)(h * W + w) * es]);
+          if (v > mv) { mv = v; mi = h * W + w; }
+        }
+      }
+      out[idx + 2 * part] = mv;
+      argmax[idx + 2 * part] = mi;
+    }
+  }
+}
+
 // RoIPool backward: scatter-add through argmax (ROILoopPool_cpu.cpp:82-123).
 __global__ __launch_bounds__(256) void roi_pool_bwd(const float* __restrict__ grad_out, const float* __restrict__ rois,
                                                     const float* __restrict__ roi_scale,
@@ -566,6 +651,30 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
                          total, C, H, W, ph, pw, spatial_scale, out, out_dtype, argmax, 0);
   }
   WS_CHECK_LAUNCH("wsovod_roi_pool_forward");
+  return WSOVOD_OK;
+}
+
+int wsovod_roi_loop_pool_forward(const void* feat, int dtype, int layout, const float* rois, int R, int N, int C, int H,
+                                 int W, int ph, int pw, float spatial_scale, float context_ratio, float* out,
+                                 int* argmax, wsovod_stream_t stream) {
+  WS_CHECK_ARG(layout == WSOVOD_NCHW || layout == WSOVOD_NHWC, "wsovod_roi_loop_pool_forward: bad layout");
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_roi_loop_pool_forward: bad dtype");
+  WS_CHECK_ARG(R >= 0 && N >= 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && context_ratio > 0.f,
+               "wsovod_roi_loop_pool_forward: bad shape");
+  if (R == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(feat && rois && out && argmax, "wsovod_roi_loop_pool_forward: null pointer");
+  static int slot = wsovod::prof_slot("roi_loop_pool_fwd");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)R * C * ph * pw;
+  const int grid = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)total * 24.0);
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL(roi_loop_pool_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois, total, R, C, H,
+                       W, ph, pw, spatial_scale, context_ratio, layout == WSOVOD_NHWC ? 1 : 0, out, argmax);
+  else
+    hipLaunchKernelGGL(roi_loop_pool_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, total, R, C, H, W,
+                       ph, pw, spatial_scale, context_ratio, layout == WSOVOD_NHWC ? 1 : 0, out, argmax);
+  WS_CHECK_LAUNCH("wsovod_roi_loop_pool_forward");
   return WSOVOD_OK;
 }
 

@@ -190,6 +190,30 @@ class _RoIPool(Function):
         return g.to(ctx.in_dtype), None, None, None, None, None
 
 
+class _RoILoopPool(Function):
+    """The reference's own autograd front (wsovod/layers/roi_loop_pool.py:9-35) on the HIP op: (3R, C, ph, pw)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, output_size, spatial_scale):
+        out, argmax = H.roi_loop_pool_forward(feat, rois, spatial_scale, output_size)
+        ctx.shape = tuple(feat.shape)
+        ctx.cl = not feat.is_contiguous()
+        ctx.in_dtype = feat.dtype
+        ctx.save_for_backward(rois, argmax)
+        return out.to(feat.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        rois, argmax = ctx.saved_tensors
+        g = H.roi_pool_backward(grad_output, rois.repeat(3, 1), argmax, ctx.shape, channels_last=ctx.cl)
+        return g.to(ctx.in_dtype), None, None, None
+
+
+def roi_loop_pool(feat, rois, output_size, spatial_scale):
+    return _RoILoopPool.apply(feat, rois, tuple(output_size), float(spatial_scale))
+
+
 def roi_pool(feat, rois, output_size, spatial_scale, roi_scale=None, out_dtype=None):
     return _RoIPool.apply(feat, rois, tuple(output_size), float(spatial_scale), roi_scale, out_dtype or feat.dtype)
 

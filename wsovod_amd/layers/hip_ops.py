@@ -103,6 +103,21 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     return out, argmax
 
 
+def roi_loop_pool_forward(feat, rois, spatial_scale, output_size, context_ratio=1.8):
+    """The reference's 3-output ROILoopPool: -> (out (3R,C,ph,pw) fp32 = [region | frame | context], argmax int32)."""
+    require_gpu(feat, rois)
+    layout, N, Cc, Hh, Ww = feature_layout(feat)
+    rois = _rois_f32(rois)
+    ph, pw = output_size
+    R = rois.shape[0]
+    out = torch.zeros((3 * R, Cc, ph, pw), dtype=torch.float32, device=feat.device)
+    arg = torch.full((3 * R, Cc, ph, pw), -1, dtype=torch.int32, device=feat.device)
+    check(lib().wsovod_roi_loop_pool_forward(ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), R, N, Cc, Hh, Ww, ph,
+                                             pw, C.c_float(spatial_scale), C.c_float(context_ratio), ptr(out), ptr(arg),
+                                             stream()), "roi_loop_pool_forward")
+    return out, arg
+
+
 def roi_pool_backward(grad_out, rois, argmax, input_shape, channels_last=False, roi_scale=None):
     require_gpu(grad_out, rois, argmax)
     N, Cc, H, W = input_shape

@@ -146,11 +146,15 @@ class ObjectMiningOutputLayers(nn.Module):
     def forward(self, x, proposals=None, context=False, logits=None):
         """-> (scores (R,K) = softmax_classes(C) * softmax_proposals(D) per image, zero deltas).
         logits: optional precomputed (R, 2K) = [C | D] (batched with the other heads on x by the ROI heads)."""
-        if context:
-            raise NotImplementedError("contextlocnet needs POOLER_TYPE ROILoopPool (out of hot-path scope)")
+        K = self.num_classes
+        if context:  # forward_contextlocnet (fast_rcnn_open_vocabulary.py:369-390): C = cls(x), D = det(Fx) - det(Cx)
+            x, fx, cx = [t.flatten(start_dim=1) if t.dim() > 2 else t for t in x]
+            c = Fn.linear(x, self.cls.weight, self.cls.bias, out_dtype=torch.float32)
+            d = Fn.linear(fx, self.det.weight, self.det.bias, out_dtype=torch.float32) - \
+                Fn.linear(cx, self.det.weight, self.det.bias, out_dtype=torch.float32)
+            logits = torch.cat([c, d], dim=1)
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
-        K = self.num_classes
         if logits is None:
             w, b = self.stacked_params()
             logits = Fn.linear(x, w, b, out_dtype=torch.float32)  # (R, 2K) = [C | D]

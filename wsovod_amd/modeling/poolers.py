@@ -15,7 +15,7 @@ from torch import nn
 from ..layers import functions as Fn
 from ..structures import Boxes
 
-__all__ = ["ROIPooler", "RoIPool", "ROIAlign", "convert_boxes_to_pooler_format", "assign_boxes_to_levels"]
+__all__ = ["ROIPooler", "RoIPool", "ROILoopPool", "ROIAlign", "convert_boxes_to_pooler_format", "assign_boxes_to_levels"]
 
 
 class RoIPool(nn.Module):
@@ -29,6 +29,21 @@ class RoIPool(nn.Module):
     def forward(self, input, rois, roi_scale=None, out_dtype=None):
         assert rois.dim() == 2 and rois.size(1) == 5
         return Fn.roi_pool(input, rois, self.output_size, self.spatial_scale, roi_scale, out_dtype)
+
+
+class ROILoopPool(nn.Module):
+    """wsovod.layers.ROILoopPool(output_size, spatial_scale): (3R, C, ph, pw) = [region | frame | context]."""
+
+    def __init__(self, output_size, spatial_scale):
+        super().__init__()
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.spatial_scale = spatial_scale
+
+    def forward(self, input, rois, roi_scale=None, out_dtype=None):
+        assert rois.dim() == 2 and rois.size(1) == 5
+        assert roi_scale is None, "the objectness scale is applied by the caller for ROILoopPool"
+        out = Fn.roi_loop_pool(input, rois, self.output_size, self.spatial_scale)
+        return out if out_dtype is None else out.to(out_dtype)
 
 
 class ROIAlign(nn.Module):
@@ -81,9 +96,10 @@ class ROIPooler(nn.Module):
                 for scale in scales)
         elif pooler_type == "ROIPool":
             self.level_poolers = nn.ModuleList(RoIPool(output_size, spatial_scale=scale) for scale in scales)
-        elif pooler_type in ("ROILoopPool", "ROIAlignRotated"):
-            raise NotImplementedError(
-                f"pooler type {pooler_type} is outside the hot path (no shipped WSR config selects it; SURVEY 8f n4)")
+        elif pooler_type == "ROILoopPool":  # poolers.py:183-186 of the reference (single level)
+            self.level_poolers = nn.ModuleList(ROILoopPool(output_size, spatial_scale=scale) for scale in scales)
+        elif pooler_type == "ROIAlignRotated":
+            raise NotImplementedError(f"pooler type {pooler_type} is outside the hot path (no WSOVOD config selects it)")
         else:
             raise ValueError("Unknown pooler type: {}".format(pooler_type))
         min_level = -(math.log2(scales[0]))

@@ -10,7 +10,7 @@ append_background=True, file_names=None, loaded_proposals=None)` and return valu
 What is on the HIP path: RoI pooling with the fused objectness scale, the neck, object mining,
 pseudo-GT mining + proposal labelling (one kernel, no host syncs, replacing the python list
 comprehensions of get_pgt_top_k :1043-1343 and label_and_sample_proposals_wsl :1722-1825) and the
-instance-refinement branch.  Out of scope (raise): MRRP, ROILoopPool/contextlocnet, MIST
+instance-refinement branch.  Out of scope (raise): MRRP, MIST
 refinement, in-loop SAM box refinement, `_vis_*` debug dumps.
 """
 import inspect
@@ -251,6 +251,9 @@ class WSOVODROIHeads(ROIHeads):
         (roi_heads.py:727-739)."""
         feats = [features[f] for f in self.box_in_features]
         roi_scale = torch.cat([x.objectness_logits + 1 for x in proposals], dim=0).to(torch.float32)
+        if self.pooler_type == "ROILoopPool":  # (3R, C, 7, 7) = [region | frame | context], roi_heads.py:727-739
+            out = self.box_pooler(feats, [x.proposal_boxes for x in proposals], out_dtype=torch.float32)
+            return (out * roi_scale.repeat(3).view(-1, 1, 1, 1)).to(self.compute_dtype)
         return self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
                                out_dtype=self.compute_dtype)
 
@@ -258,6 +261,15 @@ class WSOVODROIHeads(ROIHeads):
         """roi_heads.py:1827-1857: pooled -> objectness scale -> neck -> (+ data-aware features)."""
         box_features = pooled if pooled is not None else self.pool_features(features, proposals)
         box_features = self.box_head(box_features)
+        if self.pooler_type == "ROILoopPool":  # contextlocnet: the neck ran on region, frame and context rows
+            parts = list(torch.chunk(box_features, 3, dim=0))
+            if data_aware_features is not None:
+                nums = [len(p) for p in proposals]
+                daf = data_aware_features.to(torch.float32)
+                if daf.size(0) == len(proposals) and daf.size(0) != sum(nums):
+                    daf = torch.cat([daf[i:i + 1].expand(n, -1) for i, n in enumerate(nums)])
+                parts = [(q.float() + daf).to(q.dtype) for q in parts]
+            return parts
         if data_aware_features is not None:
             nums = [len(p) for p in proposals]
             dev = box_features.device
@@ -273,8 +285,13 @@ class WSOVODROIHeads(ROIHeads):
     def _forward_box(self, features, proposals, data_aware_features=None, classifier=None, append_background=True,
                      pooled=None):
         box_features = self.get_features(features, proposals, data_aware_features, pooled=pooled)
-        pre = self._grouped_heads(box_features) if self.training else None
-        predictions = self.object_miner(box_features, proposals, logits=pre[0] if pre else None)
+        if self.pooler_type == "ROILoopPool":  # roi_heads.py:748-760: mining sees [region, frame, context]
+            pre = None
+            predictions = self.object_miner(box_features, proposals, context=True)
+            box_features = box_features[0]
+        else:
+            pre = self._grouped_heads(box_features) if self.training else None
+            predictions = self.object_miner(box_features, proposals, logits=pre[0] if pre else None)
         if not self.training:
             if self.refine_K <= 0:
                 raise NotImplementedError("REFINE_NUM=0 inference is not used by any WSOVOD config")
