@@ -224,6 +224,19 @@ int wsovod_sgd_momentum(float* param, const float* grad, float* momentum_buf, lo
                         float momentum, float weight_decay, float grad_scale, void* bf16_shadow,
                         wsovod_stream_t stream);
 
+/* The same update for up to 32 tensors in ONE launch (every trainable tensor of the path is its own parameter group,
+ * engine/defaults.py:274-318: 19 launches per step otherwise).  `tensors` is a HOST array. */
+typedef struct wsovod_sgd_tensor {
+  float* param;
+  const float* grad;
+  float* momentum_buf;
+  void* bf16_shadow; /* optional bf16 copy of param refreshed in the same pass */
+  long long numel;
+  float lr, weight_decay;
+} wsovod_sgd_tensor;
+int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
+                              wsovod_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Proposal-concept MIL head.  Per-image segments: proposals of image g are rows
  * [seg_offsets[g], seg_offsets[g+1]).

@@ -134,6 +134,37 @@ def test_sgd_step_matches_torch_sgd(gpu):
     torch.testing.assert_close(hip.detach().cpu(), ref.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_multi_tensor_sgd_matches_torch_sgd(gpu):
+    """One launch for many tensors (odd sizes, misaligned tails, per-tensor lr / weight decay, bf16 shadows, >32
+    tensors -> two launches) against torch.optim.SGD with the same groups."""
+    from wsovod_amd.engine import HipSGD
+
+    torch.manual_seed(1)
+    sizes = [1, 3, 4, 5, 4095, 4096, 4097, 100003, 20, 512 * 1024] + [7 + i for i in range(30)]
+    refs = [torch.nn.Parameter(torch.randn(n)) for n in sizes]
+    hips = [torch.nn.Parameter(r.detach().clone().to(gpu)) for r in refs]
+    groups = lambda ps: [{"params": [p], "lr": 0.01 * (1 + i % 3), "weight_decay": 1e-4 * (i % 2)} for i, p in enumerate(ps)]
+    opt_ref = torch.optim.SGD(groups(refs), lr=0.01, momentum=0.9)
+    opt = HipSGD(groups(hips), lr=0.01, momentum=0.9)
+    shadows = {}
+    for i in (5, 7, 9):  # bf16 shadows as the MFMA layers keep them
+        shadows[i] = torch.empty(sizes[i], dtype=torch.bfloat16, device=gpu)
+        hips[i]._hip_shadow = (shadows[i], hips[i]._version)
+    for step in range(3):
+        for r, h in zip(refs, hips):
+            g = torch.randn_like(r)
+            r.grad, h.grad = g, g.to(gpu)
+        v0 = hips[0]._version
+        opt_ref.step()
+        opt.step()
+        assert hips[0]._version > v0  # caches keyed on the version counter see the update
+    for i, (r, h) in enumerate(zip(refs, hips)):
+        torch.testing.assert_close(h.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7, msg=lambda m: f"tensor {i}: {m}")
+    for i, sh in shadows.items():
+        assert torch.equal(sh.cpu(), hips[i].detach().to(torch.bfloat16).cpu())
+        assert hips[i]._hip_shadow[1] == hips[i]._version  # still valid: no re-cast on the next forward
+
+
 def test_eval_inference_runs(gpu):
     cfg, model, sd = build_seeded_hip_model("fp32")
     model.eval()

@@ -139,6 +139,33 @@ def test_packed_and_list_label_paths_agree(gpu, monkeypatch):
     assert int((pg.sampled_labels >= 0).sum(dim=1).max()) <= pg.batch_size_per_image
 
 
+def test_rpn_weights_are_live_across_optimizer_steps(gpu, monkeypatch):
+    """The RPN conv runs on a folded / re-laid-out copy of its weight that is cached on the parameter's version: after an
+    optimizer step (raw-pointer update) the next forward must see the NEW weights."""
+    from wsovod_amd.engine import build_optimizer
+
+    cfg, model, sd, sampling = build_rpn_model("fp32")
+    first_k_keys(model, monkeypatch)
+    cfg.SOLVER.BASE_LR = 0.05
+    opt = build_optimizer(cfg, model)
+    batch = to_inputs(gen.seeded_batch(2, 30, 20, 256, 352, seed=71))
+    pg = model.proposal_generator
+    logits = []
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        losses = model(batch)
+        logits.append(pg.pred_objectness_logits[0].detach().clone())
+        sum(losses.values()).backward()
+        opt.step()
+    conv = pg.rpn_head.conv
+    x = torch.randn(1, 8, 8, 512, device=gpu)
+    from wsovod_amd.modeling.backbone import hip_conv
+    got = hip_conv(x, conv, relu=False).permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2), conv.weight.detach(), conv.bias.detach(), padding=1)
+    torch.testing.assert_close(got, ref, rtol=1e-3, atol=1e-3)  # folded copy == current parameter
+    assert not torch.equal(logits[0], logits[1])
+
+
 def test_rpn_eval_inference_runs(gpu):
     cfg, model, sd, _ = build_rpn_model("fp32")
     model.eval()

@@ -87,12 +87,19 @@ SIGNATURES = {
     "wsovod_data_aware_forward": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
+    "wsovod_sgd_momentum_multi": [_P, _I, _F, _F, _P],
     "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_nms_segments": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     "wsovod_rpn_label_anchors": [_P, _I, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "wsovod_im2col_rows": [_P, _I, _P, _I] + [_I] * 10 + [_P, _P],
     "wsovod_rpn_decode": [_P, _P, _P, _I, _I, _L, _P, C.POINTER(C.c_float), _F, _F, _P, _P, _P],
 }
+
+class SgdTensor(C.Structure):
+    """wsovod_sgd_tensor (include/wsovod_hip.h)."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
+                ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float)]
+
 
 _lib = None
 
@@ -138,8 +145,9 @@ def ptr(t):
 
 
 def stream():
-    """The current torch HIP stream as a raw hipStream_t."""
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current torch HIP stream as a raw hipStream_t (the raw C getters: torch.cuda.current_stream() costs ~9 us
+    per call in Python, which is 0.6 ms of a 3 ms host-bound step)."""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_gpu(*tensors):

@@ -369,6 +369,55 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
   }
 }
 
+// Multi-tensor form: one launch updates up to kSgdMax tensors; block b works on a 4096-element chunk of the tensor
+// whose block range contains b (the table travels as a kernel argument).
+constexpr int kSgdMax = 32, kSgdChunk = 4096;
+struct SgdTable {
+  float* p[kSgdMax];
+  const float* g[kSgdMax];
+  float* buf[kSgdMax];
+  bf16_t* shadow[kSgdMax];
+  long long n[kSgdMax];
+  float lr[kSgdMax], wd[kSgdMax];
+  int first_block[kSgdMax + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable t, float mu, float gscale) {
+  int k = 0;
+  while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+  const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * kSgdChunk;
+  float* __restrict__ p = t.p[k];
+  const float* __restrict__ g = t.g[k];
+  float* __restrict__ buf = t.buf[k];
+  bf16_t* __restrict__ shadow = t.shadow[k];
+  const long long n = t.n[k];
+  const float lr = t.lr[k], wd = t.wd[k];
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0) && (((uintptr_t)shadow & 7) == 0);
+  for (int e = threadIdx.x * 4; e < kSgdChunk; e += 256 * 4) {
+    const long long i = base + e;
+    if (i >= n) break;
+    if (vec && i + 3 < n) {
+      f32x4 pv = __builtin_nontemporal_load((const f32x4*)(p + i));
+      const f32x4 gv = __builtin_nontemporal_load((const f32x4*)(g + i));
+      f32x4 bv = __builtin_nontemporal_load((const f32x4*)(buf + i));
+      bv = mu * bv + (gv * gscale + wd * pv);
+      pv -= lr * bv;
+      __builtin_nontemporal_store(bv, (f32x4*)(buf + i));
+      __builtin_nontemporal_store(pv, (f32x4*)(p + i));
+      if (shadow) *(bf16x4*)(shadow + i) = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+    } else {
+      for (long long q = i; q < min(i + 4, n); ++q) {
+        const float b = mu * buf[q] + (g[q] * gscale + wd * p[q]);
+        buf[q] = b;
+        const float pv = p[q] - lr * b;
+        p[q] = pv;
+        if (shadow) shadow[q] = (bf16_t)pv;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // Backward prologue of Linear+ReLU(+Dropout): dA = dy * [y > 0] * scale, written both as
 // [M][N] (operand of the dX contraction) and transposed [N][ldt] (operand of the dW
@@ -709,6 +758,41 @@ int wsovod_sgd_momentum(float* param, const float* grad, float* momentum_buf, lo
   hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, s, param, grad, momentum_buf,
                      n, lr, momentum, weight_decay, grad_scale, (bf16_t*)bf16_shadow);
   WS_CHECK_LAUNCH("wsovod_sgd_momentum");
+  return WSOVOD_OK;
+}
+
+int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
+                              wsovod_stream_t stream) {
+  WS_CHECK_ARG(count >= 0 && (count == 0 || tensors), "wsovod_sgd_momentum_multi: bad table");
+  static int slot = wsovod::prof_slot("sgd_momentum_multi");
+  hipStream_t s = (hipStream_t)stream;
+  for (int start = 0; start < count; start += kSgdMax) {
+    SgdTable t;
+    memset(&t, 0, sizeof(t));
+    long long total = 0;
+    int blocks = 0;
+    for (int k = 0; k < kSgdMax && start + k < count; ++k) {
+      const wsovod_sgd_tensor& d = tensors[start + k];
+      WS_CHECK_ARG(d.numel >= 0 && (d.numel == 0 || (d.param && d.grad && d.momentum_buf)),
+                   "wsovod_sgd_momentum_multi: null pointer in entry %d", start + k);
+      t.p[k] = d.param;
+      t.g[k] = d.grad;
+      t.buf[k] = d.momentum_buf;
+      t.shadow[k] = (bf16_t*)d.bf16_shadow;
+      t.n[k] = d.numel;
+      t.lr[k] = d.lr;
+      t.wd[k] = d.weight_decay;
+      t.first_block[k] = blocks;
+      blocks += (int)ceil_div_ll(d.numel, kSgdChunk);
+      total += d.numel;
+      t.count = k + 1;
+    }
+    t.first_block[t.count] = blocks;
+    if (blocks == 0) continue;
+    wsovod::ProfScope prof(slot, s, 3.0 * total, (double)total * 22.0);
+    hipLaunchKernelGGL(sgd_momentum_multi_kernel, dim3(blocks), dim3(256), 0, s, t, momentum, grad_scale);
+    WS_CHECK_LAUNCH("wsovod_sgd_momentum_multi");
+  }
   return WSOVOD_OK;
 }
 

@@ -22,6 +22,7 @@ class HipSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         assert closure is None
+        by_momentum = {}
         for group in self.param_groups:
             for p in group["params"]:
                 if p.grad is None:
@@ -32,8 +33,17 @@ class HipSGD(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 sh = getattr(p, "_hip_shadow", None)  # bf16 copy used by the MFMA kernels: refreshed in the same pass
                 shadow = sh[0] if (sh is not None and sh[1] == p._version and sh[0].dtype == torch.bfloat16) else None
-                H.sgd_momentum(p.data, g, state["momentum_buffer"], group["lr"], group["momentum"],
-                               group["weight_decay"], grad_scale=self.grad_scale, bf16_shadow=shadow)
+                by_momentum.setdefault(group["momentum"], []).append(
+                    (p.data, g, state["momentum_buffer"], shadow, group["lr"], group["weight_decay"], p))
+        for mu, entries in by_momentum.items():  # every tensor of the model in one launch
+            H.sgd_momentum_multi([e[:6] for e in entries], mu, grad_scale=self.grad_scale)
+            for e in entries:
+                # the kernel wrote through raw pointers: advance the version counter so that caches keyed on it (folded
+                # conv weights, class matrices) are rebuilt, and re-stamp the bf16 shadow the kernel refreshed itself
+                p, shadow = e[6], e[3]
+                torch.autograd.graph.increment_version(p)
+                if shadow is not None:
+                    p._hip_shadow = (shadow, p._version)
 
 
 def build_optimizer(cfg, model):

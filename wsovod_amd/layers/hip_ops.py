@@ -615,3 +615,19 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False):
     check(lib().wsovod_gemm_tn(ptr(P), _ld(P), ptr(Q), _ld(Q), Mred, NI, NJ, ptr(out), _ld(out), C.c_float(alpha),
                                int(bool(accumulate)), stream()), "gemm_tn")
     return out
+
+
+def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
+    """entries: list of (param, grad, momentum_buf, bf16_shadow or None, lr, weight_decay); one launch per 32."""
+    from .._lib import SgdTensor
+
+    if not entries:
+        return
+    arr = (SgdTensor * len(entries))()
+    for d, (p, g, b, sh, lr, wd) in zip(arr, entries):
+        require_gpu(p, g, b, sh)
+        d.param, d.grad, d.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
+        d.bf16_shadow = sh.data_ptr() if sh is not None else None
+        d.numel, d.lr, d.weight_decay = p.numel(), lr, wd
+    check(lib().wsovod_sgd_momentum_multi(arr, len(entries), C.c_float(momentum), C.c_float(grad_scale), stream()),
+          "sgd_momentum_multi")
