@@ -277,10 +277,16 @@ class ResNet(nn.Module):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32
 
     def _check_frozen(self):
-        if any(p.requires_grad for p in self.parameters()):
+        if any(p.requires_grad for p in self._param_list()):
             raise NotImplementedError(
                 "wsovod_amd: the HIP backbone is forward-only; all shipped WSR configs use "
                 "MODEL.BACKBONE.FREEZE_AT=5 (conv backward is outside the hot path, SURVEY F3)")
+
+    def _param_list(self):
+        cached = getattr(self, "_params_cache", None)
+        if cached is None:  # the module tree is fixed after construction: walk it once, not every step
+            cached = self._params_cache = list(self.parameters())
+        return cached
 
     def _run(self, x):
         outputs = {}
