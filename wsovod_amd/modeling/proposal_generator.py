@@ -22,12 +22,11 @@ from torch.autograd import Function
 
 from ..config import Registry, configurable
 from ..layers import hip_ops as H
-from ..structures import Boxes, ImageList, Instances, ShapeSpec, pairwise_iou
+from ..structures import Boxes, ImageList, Instances, ShapeSpec
 from .anchor_generator import build_anchor_generator
 from .backbone import Conv2d, hip_conv
 from .box_regression import Box2BoxTransform
 from .matcher import Matcher
-from . import sampling
 
 PROPOSAL_GENERATOR_REGISTRY = Registry("PROPOSAL_GENERATOR")
 RPN_HEAD_REGISTRY = Registry("RPN_HEAD")
@@ -259,33 +258,26 @@ class WSOVODRPN_V2(nn.Module):
             "head": build_rpn_head(cfg, shapes),
         }
 
-    def _subsample_labels(self, label):
-        pos_idx, neg_idx = sampling.subsample_labels(label, self.batch_size_per_image, self.positive_fraction, 0)
-        label.fill_(-1)
-        label.scatter_(0, pos_idx, 1)
-        label.scatter_(0, neg_idx, 0)
-        return label
+    @staticmethod
+    def _pack_targets(gt_instances):
+        """list[Instances] -> (boxes (T,4), start (G) int32, count (G) int32) on the device."""
+        boxes = [x.gt_boxes.tensor.to(torch.float32) for x in gt_instances]
+        dev = boxes[0].device
+        counts = [len(b) for b in boxes]
+        starts = [sum(counts[:i]) for i in range(len(counts))]
+        cat = torch.cat(boxes) if sum(counts) else torch.zeros((0, 4), device=dev)
+        return cat, H.const_tensor(starts, torch.int32, dev), H.const_tensor(counts, torch.int32, dev)
 
     @torch.no_grad()
     def label_and_sample_anchors(self, anchors: List[Boxes], gt_instances: List[Instances]):
-        """rpn.py:237-293, the reference's per-image form on list[Instances] (host loop; kept for API parity and as
-        the cross-check of the batched path below)."""
-        anchors = Boxes.cat(anchors)
-        gt_labels, matched_gt_boxes = [], []
-        for inst in gt_instances:
-            gt_boxes_i = inst.gt_boxes
-            matched_idxs, gt_labels_i = self.anchor_matcher(pairwise_iou(gt_boxes_i, anchors))
-            gt_labels_i = gt_labels_i.to(device=gt_boxes_i.device)
-            if self.anchor_boundary_thresh >= 0:
-                raise NotImplementedError("RPN.BOUNDARY_THRESH >= 0 is a legacy option no WSOVOD config sets")
-            gt_labels_i = self._subsample_labels(gt_labels_i)
-            if len(gt_boxes_i) == 0:
-                matched_gt_boxes_i = torch.zeros_like(anchors.tensor)
-            else:
-                matched_gt_boxes_i = gt_boxes_i[matched_idxs].tensor
-            gt_labels.append(gt_labels_i)
-            matched_gt_boxes.append(matched_gt_boxes_i)
-        return gt_labels, matched_gt_boxes
+        """The reference's interface (rpn.py:237-293): per image a label vector in {-1, 0, 1} over all anchors and the
+        matched ground-truth box of every anchor.  Thin view of the batched kernel path."""
+        packed = getattr(gt_instances, "packed", None) or self._pack_targets(list(gt_instances))
+        sample = self.label_and_sample_anchors_packed(anchors, packed)
+        sampled, best_gt = sample[5], sample[6]
+        matched = packed[0][best_gt.clamp(min=0).long()]  # (B, A, 4)
+        matched = matched * (best_gt >= 0).unsqueeze(-1)  # no box in the image: zeros, as the reference returns
+        return list(sampled.unbind(0)), list(matched.unbind(0))
 
     def _sample_keys(self, num_images, num_anchors, device):
         """Sort keys of the random sub-sampling: the k smallest keys among the positives / negatives of an image are
@@ -297,7 +289,8 @@ class WSOVODRPN_V2(nn.Module):
     def label_and_sample_anchors_packed(self, anchors: List[Boxes], packed):
         """Batched, sync-free form of label_and_sample_anchors on the device-resident pseudo GT: one labelling kernel
         for the whole batch, then two batched top-k selections.  Returns fixed-size index sets
-        (pos_idx (B,P), pos_valid, neg_idx (B,S), neg_valid, matched boxes of the positives (B,P,4), labels (B,A))."""
+        (pos_idx (B,P), pos_valid, neg_idx (B,S), neg_valid, matched boxes of the positives (B,P,4), labels (B,A),
+        best-box index per anchor (B,A))."""
         gt_boxes, gt_start, gt_count = packed
         anchors_t = Boxes.cat(anchors).tensor
         m = self.anchor_matcher
@@ -317,28 +310,23 @@ class WSOVODRPN_V2(nn.Module):
         sampled = torch.full_like(labels, -1)
         sampled.scatter_(1, neg_idx, torch.where(neg_valid, 0, -1).to(torch.int8))
         sampled.scatter_(1, pos_idx, torch.where(pos_valid, 1, sampled.gather(1, pos_idx).to(torch.int64)).to(torch.int8))
-        return pos_idx, pos_valid, neg_idx, neg_valid, matched, sampled
+        return pos_idx, pos_valid, neg_idx, neg_valid, matched, sampled, best_gt
 
     def losses(self, anchors, pred_objectness_logits, gt_labels, pred_anchor_deltas, gt_boxes):
-        """rpn.py:296-375 on the reference's list interface (see losses_packed for the hot form)."""
-        num_images = len(gt_labels)
-        gt_labels = torch.stack(gt_labels)
-        pos_mask = gt_labels == 1
-        anchors = Boxes.cat(anchors).tensor
-        gt_anchor_deltas = torch.stack([self.box2box_transform.get_deltas(anchors, k) for k in gt_boxes])
-        pred_deltas = torch.cat(pred_anchor_deltas, dim=1)
-        pos_targets = gt_anchor_deltas[pos_mask]
-        if not bool(torch.isfinite(pos_targets).all()):
-            localization_loss = pred_deltas[pos_mask].sum() * 0.0
-        else:
-            localization_loss = self._smooth_l1(pred_deltas[pos_mask] - pos_targets).sum()
-        valid_mask = gt_labels >= 0
-        objectness_loss = F.binary_cross_entropy_with_logits(
-            torch.cat(pred_objectness_logits, dim=1)[valid_mask], gt_labels[valid_mask].to(torch.float32),
-            reduction="sum")
-        normalizer = self.batch_size_per_image * num_images
-        losses = {"loss_rpn_cls": objectness_loss / normalizer, "loss_rpn_loc": localization_loss / normalizer}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+        """The reference's list interface (rpn.py:296-375): labels / matched boxes as label_and_sample_anchors returns
+        them.  Re-expressed as the fixed-size index sets of losses_packed (one code path for the arithmetic)."""
+        labels = torch.stack(gt_labels)
+        matched_all = torch.stack(gt_boxes)
+        B, A = labels.shape
+        P = min(int(self.batch_size_per_image * self.positive_fraction), A)
+        S = min(self.batch_size_per_image, A)
+        order = torch.arange(A, device=labels.device, dtype=torch.float32).expand(B, A)
+        inf = torch.full_like(order, float("inf"))
+        pv, pos_idx = torch.topk(torch.where(labels == 1, order, inf), P, dim=1, largest=False)
+        nv, neg_idx = torch.topk(torch.where(labels == 0, order, inf), S, dim=1, largest=False)
+        matched = matched_all.gather(1, pos_idx.unsqueeze(-1).expand(-1, -1, 4))
+        sample = (pos_idx, torch.isfinite(pv), neg_idx, torch.isfinite(nv), matched, labels)
+        return self.losses_packed(anchors, pred_objectness_logits, pred_anchor_deltas, sample)
 
     def _smooth_l1(self, diff):
         diff = diff.abs()
@@ -350,7 +338,7 @@ class WSOVODRPN_V2(nn.Module):
     def losses_packed(self, anchors, pred_objectness_logits, pred_anchor_deltas, sample):
         """The same two sums over the fixed-size sample (invalid slots weigh zero): no boolean-mask indexing, so no
         host synchronisation.  A few thousand elements -- torch on the device."""
-        pos_idx, pos_valid, neg_idx, neg_valid, matched, _ = sample
+        pos_idx, pos_valid, neg_idx, neg_valid, matched = sample[:5]
         logits = torch.cat(pred_objectness_logits, dim=1)
         deltas = torch.cat(pred_anchor_deltas, dim=1)
         B = logits.shape[0]
@@ -390,7 +378,7 @@ class WSOVODRPN_V2(nn.Module):
         packed = getattr(gt_instances, "packed", None)
         if packed is not None:  # pseudo GT still on the device: batched, sync-free path
             sample = self.label_and_sample_anchors_packed(self.anchors, packed)
-            self.sampled_labels = sample[-1]
+            self.sampled_labels = sample[5]
             return self.losses_packed(self.anchors, self.pred_objectness_logits, self.pred_anchor_deltas, sample)
         gt_labels, gt_boxes = self.label_and_sample_anchors(self.anchors, gt_instances)
         return self.losses(self.anchors, self.pred_objectness_logits, gt_labels, self.pred_anchor_deltas, gt_boxes)
