@@ -17,10 +17,10 @@ def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", devi
     /root/reference/configs/PascalVOC-Detection/{Base-RCNN-DilatedC5,WSOVOD_WSR_18_DC5_1x}.yaml
     that the hot path reads, with PROPOSAL_GENERATOR=PrecomputedProposals, BBOX_REFINE off."""
     cfg = get_cfg()
-    cfg.merge_from_file(os.path.join(_CONFIG_DIR, f"WSOVOD_WSR_{depth}_DC5_1x.yaml"))
+    cfg.merge_from_file(os.path.join(_CONFIG_DIR, f"hot_path_wsr{depth}.yaml"))
     if rpn:  # the shipped form: RPN boxes next to the loaded proposals (SURVEY 8f n1)
         assert depth == 18
-        cfg.merge_from_file(os.path.join(_CONFIG_DIR, "WSOVOD_WSR_18_DC5_1x_rpn.yaml"))
+        cfg.merge_from_file(os.path.join(_CONFIG_DIR, "hot_path_wsr18_rpn.yaml"))
     if weight_path is None:
         weight_path = os.path.join(tempfile.mkdtemp(prefix="wsovod_emb_"), f"emb_{K}x{D}.pkl")
         with open(weight_path, "wb") as f:
@@ -41,7 +41,7 @@ def mixed_datasets_cfg(names=("voc_2007_train", "voc_2007_val", "coco_2017_train
     """The mixed-dataset variant (BASELINE config 5): one text-embedding file per dataset,
     object miners shared per dataset family."""
     cfg = hot_path_cfg(K=max(Ks), D=D, **kw)
-    cfg.merge_from_file(os.path.join(_CONFIG_DIR, "MixedDatasets_WSOVOD_WSR_18_DC5_1x.yaml"))
+    cfg.merge_from_file(os.path.join(_CONFIG_DIR, "hot_path_wsr18_mixed.yaml"))
     tmp = tempfile.mkdtemp(prefix="wsovod_emb_")
     paths = []
     for i, K in enumerate(Ks):
