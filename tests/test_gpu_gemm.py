@@ -195,6 +195,35 @@ def test_fused_stem_conv1_is_bit_identical_to_im2col_gemm(gpu):
     assert out.shape == ref.shape and torch.equal(out, ref)
 
 
+def test_staggered_tiles_race_screen(gpu):
+    """The 8-phase NT tile and the transposed-read TN kernel order their LDS-DMA prefetch by counted waits and raw
+    barriers only.  Screen for races: many shapes (short / long / ragged K, ragged edges), repeated launches, with a
+    second stream hammering HBM to perturb DMA timing; every result must be bit-identical to the 16-wavefront tile
+    (whose LDS hand-off is a plain __syncthreads) fed with the same operands."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator(device="cuda").manual_seed(123)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 * 1024 * 1024, device=gpu)
+    shapes = [(256, 256, 64), (512, 768, 128), (300, 520, 192), (1024, 1024, 1000), (2048, 512, 4096), (777, 1333, 2048),
+              (4096, 4096, 512), (256, 4096, 8192), (1536, 256, 320)]
+    for (M, N, K) in shapes:
+        K8 = (K + 7) // 8 * 8
+        A = (torch.rand(M, K8, device=gpu, generator=g) - 0.5).to(torch.bfloat16)
+        B = (torch.rand(N, K8, device=gpu, generator=g) - 0.5).to(torch.bfloat16)
+        ref = H.gemm_nt(A, B, out_dtype=torch.float32, tile_hint=256256)
+        At, Bt = A.t().contiguous(), B.t().contiguous()  # (K, M), (K, N): operands of the TN form
+        for rep in range(6):
+            with torch.cuda.stream(side):
+                junk.mul_(1.0001)
+            out = H.gemm_nt(A, B, out_dtype=torch.float32, tile_hint=8256256)
+            assert torch.equal(out, ref), (M, N, K, rep, "8-phase")
+            if M % 8 == 0 and N % 8 == 0:
+                tn = H.gemm_tn(At, Bt)
+                assert torch.equal(tn, ref), (M, N, K, rep, "tn")
+    torch.cuda.synchronize()
+
+
 def test_gemm_dropout_statistics(gpu):
     from wsovod_amd.layers import hip_ops
 
