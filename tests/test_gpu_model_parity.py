@@ -215,6 +215,27 @@ def test_roi_loop_pool_contextlocnet_step_matches_oracle(gpu):
             assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+def test_maximum_proposal_count_matches_oracle(gpu):
+    """DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TRAIN = 4000 of the shipped configs: one image with 4000 proposals next to
+    one with 7 (ragged extremes) through the whole fp32 step against the oracle -- the per-image softmax over 4000
+    rows, the mining arg-max and the labelling at the largest R the configs allow."""
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    big = gen.seeded_batch(1, 4007, 20, 256, 352, seed=81, edge_cases=False)[0]
+    small = gen.seeded_batch(1, 14, 20, 192, 256, seed=82, edge_cases=False)[0]  # a 1-image batch has R - 7 boxes
+    batch = [big, small]
+    sdc = {k: v.clone() for k, v in sd.items()}
+    ref_losses, inter = R.train_forward(sdc, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD)
+    losses, cap, pgt = _run(model, batch)
+    assert cap["miner"][0].shape[0] == len(big["boxes"]) + len(small["boxes"])
+    assert (cap["miner"][0].detach().cpu() - inter["mining_scores"]).abs().max() < 1e-3
+    assert (cap["refine"][0].detach().cpu() - inter["refine_logits"]).abs().max() < 1e-3
+    for name, v in ref_losses.items():
+        torch.testing.assert_close(losses[name].detach().cpu(), v.detach(), rtol=2e-3, atol=1e-5)
+    lab = inter["labelled"]
+    assert torch.equal(pgt["gt_classes"].cpu(), torch.cat([l["gt_classes"] for l in lab]))
+    assert torch.equal(pgt["gt_boxes"].cpu(), torch.cat([l["gt_boxes"] for l in lab]))
+
+
 def test_tta_wrappers(gpu):
     """Test-time augmentation (n2): (i) a single identity view reproduces plain inference; (ii) the AVG merge equals
     the oracle tail applied to the hand-averaged per-view scores / back-mapped boxes; (iii) UNION returns boxes from
