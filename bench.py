@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--rpn", action="store_true",
                     help="the shipped form of the config: RPN branch on next to the loaded proposals (SURVEY 8f n1); "
                          "not the north-star workload, so no CPU baseline is taken")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="gradient all-reduce format at N>1: auto = the compute precision (bf16 run -> bf16 wire, the "
+                         "counterpart of the reference's fp16 compression hook; master weights/momentum stay fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -165,7 +168,9 @@ def main():
         model.roi_heads.iter = cfg.SOLVER.MAX_ITER // 2  # mid-training objectness ramp (rcnn_wsovod.py:181-184)
     model.train()
     optimizer = build_optimizer(cfg, model)
-    trainer = HotPathTrainer(model, optimizer)  # per-tensor async all-reduce overlapped with the frozen forward
+    wire = args.precision if args.grad_wire == "auto" else args.grad_wire
+    # async gradient all-reduce overlapped with the next step's frozen forward
+    trainer = HotPathTrainer(model, optimizer, grad_wire=wire)
     trainer.broadcast_parameters()
 
     def run_step(_m, _o, data):
@@ -246,7 +251,8 @@ def main():
                                    f"{'RPN + loaded proposals' if args.rpn else 'proposals-only mode'}, {args.pooler}, "
                                    f"full training step (fwd+bwd+SGD)",
                        "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "final_losses": final_losses},
+                       "parallelism": f"dp{world}", "grad_allreduce": f"{wire} over RCCL" if world > 1 else "none (1 GPU)",
+                       "final_losses": final_losses},
         }
         if roofline is not None:
             out["roofline"] = roofline

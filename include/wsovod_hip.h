@@ -233,9 +233,21 @@ typedef struct wsovod_sgd_tensor {
   void* bf16_shadow; /* optional bf16 copy of param refreshed in the same pass */
   long long numel;
   float lr, weight_decay;
+  int grad_is_bf16; /* `grad` points at bf16 values (gradients that crossed the wire in bf16, see below) */
+  int reserved_;
 } wsovod_sgd_tensor;
 int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
                               wsovod_stream_t stream);
+
+/* bf16 gradient wire format (the reference's counterpart is DDP's fp16 compression hook, engine/defaults.py:149-152):
+ * every tensor's fp32 gradient is rounded to bf16 into its slice of one flat buffer, the operand of ONE RCCL
+ * all-reduce; wsovod_sgd_momentum_multi then reads the reduced slices (grad_is_bf16).  `tensors` is a HOST array. */
+typedef struct wsovod_pack_tensor {
+  const float* src;
+  void* dst; /* bf16, 8-byte aligned for the vector path */
+  long long numel;
+} wsovod_pack_tensor;
+int wsovod_pack_bf16_multi(const wsovod_pack_tensor* tensors, int count, wsovod_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Proposal-concept MIL head.  Per-image segments: proposals of image g are rows

@@ -187,3 +187,77 @@ def test_mixed_dataset_ranks_with_different_sources_stay_in_lockstep():
         opt.step()
     for h, w in zip(model.heads, res[0][1]):
         torch.testing.assert_close(h.weight.detach(), torch.tensor(w), rtol=1e-5, atol=1e-6)
+
+
+def _worker_bf16_wire(rank, world, port, q):
+    """grad_wire="bf16" on CPU/gloo: the two HIP kernels of that path (gradient pack, SGD on bf16 slices) are replaced
+    by torch stand-ins with the same contract, so that the trainer's own logic -- flat buffer slices, one collective,
+    zero contribution for untouched tensors, 1/world scaling, release of the fp32 gradients -- runs under 2 ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import HotPathTrainer
+    from wsovod_amd.engine.trainer import HipSGD
+    from wsovod_amd.layers import hip_ops as H
+
+    def pack(pairs):
+        for src, dst in pairs:
+            assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and dst.data_ptr() % 16 == 0
+            dst.copy_(src.reshape(-1))
+
+    def sgd(entries, momentum, grad_scale=1.0):
+        for p, g, buf, shadow, lr, wd in entries:
+            assert g.dtype == torch.bfloat16
+            d = g.float().view_as(p) * grad_scale + wd * p
+            buf.mul_(momentum).add_(d)
+            p.sub_(lr * buf)
+
+    H.pack_bf16_multi, H.sgd_momentum_multi = pack, sgd
+    model = _TwoPhaseModel()
+    model.unused = nn.Linear(3, 3)  # never touched by the loss: takes part with zeros (reduce_unused)
+    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.0} for p in model.parameters()], 0.1, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True, reduce_unused=True, grad_wire="bf16")
+    tr.broadcast_parameters()
+    g = torch.Generator().manual_seed(1234 + rank)
+    batch = [{"x": torch.randn(8, generator=g)} for _ in range(3)]
+    for it in range(3):
+        tr.run_step(batch)
+        assert all(p.grad is None for p in tr.params)
+    tr.flush()
+    q.put((rank, model.fc.weight.detach().tolist(), model.unused.weight.detach().tolist(),
+           [b["x"].tolist() for b in batch]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bf16_gradient_wire():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_bf16_wire, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    w0, w1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(w0, w1), "replicas diverged"
+    # reference: the same three steps in one process, gradients averaged in fp32 and rounded to bf16 per rank first
+    model = _TwoPhaseModel()
+    buf = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    batches = [[{"x": torch.tensor(x)} for x in r[3]] for r in res]
+    for it in range(3):
+        grads = []
+        for b in batches:
+            model.zero_grad()
+            sum(model(b).values()).backward()
+            grads.append({n: p.grad.to(torch.bfloat16) for n, p in model.named_parameters()})
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                gsum = (grads[0][n].float() + grads[1][n].float()).to(torch.bfloat16)  # gloo sums in bf16
+                buf[n].mul_(0.9).add_(gsum.float() * 0.5)
+                p.sub_(0.1 * buf[n])
+    torch.testing.assert_close(w0, model.fc.weight.detach(), rtol=0, atol=2e-3)
+    assert (w0 - model.fc.weight.detach()).abs().max() < 2e-3
+    # the untouched tensor saw zero gradients on both ranks: unchanged (no weight decay here), identical on both
+    assert res[0][2] == res[1][2]

@@ -321,6 +321,54 @@ def test_overlapped_trainer_equals_plain_run_step(gpu):
             torch.testing.assert_close(outs[0][k], other[k], rtol=1e-5, atol=1e-7, msg=lambda m: f"{k}: {m}")
 
 
+def test_bf16_gradient_wire_matches_fp32_exchange(gpu):
+    """grad_wire="bf16": pack kernel -> one flat RCCL all-reduce -> SGD on the bf16 slices.  Against the fp32 exchange
+    the only difference is one bf16 rounding of each gradient element: after 3 steps at lr 1e-4 the parameters agree to
+    lr * 2^-8 * |g| (far inside 1e-6 absolute), and the pack kernel itself is bit-exact against torch's cast."""
+    import os
+    import torch.distributed as dist
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.layers import hip_ops as H
+
+    src = [torch.randn(n, device="cuda") for n in (5, 4096, 4099, 100003)]
+    flat = torch.zeros(sum((t.numel() + 7) // 8 * 8 for t in src), dtype=torch.bfloat16, device="cuda")
+    dst, o = [], 0
+    for t in src:
+        dst.append(flat[o:o + t.numel()])
+        o += (t.numel() + 7) // 8 * 8
+    H.pack_bf16_multi(list(zip(src, dst)))
+    for t, d in zip(src, dst):
+        assert torch.equal(d, t.to(torch.bfloat16))
+
+    batch = to_inputs(gen.seeded_batch(2, 32, 20, 256, 352, seed=6))
+    outs = []
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for wire in ("fp32", "bf16"):
+            cfg, model, sd = build_seeded_hip_model("fp32")
+            cfg.SOLVER.BASE_LR = 1e-4
+            tr = HotPathTrainer(model, build_optimizer(cfg, model), grad_wire=wire)
+            tr.broadcast_parameters()
+            for it in range(3):
+                losses = tr.run_step(batch)
+            tr.flush()
+            torch.cuda.synchronize()
+            assert all(p.grad is None and p._wire_grad is None for p in tr.params)
+            outs.append(({k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad},
+                         {k: float(v) for k, v in losses.items()}))
+    finally:
+        dist.destroy_process_group()
+    moved = 0
+    for k in outs[0][0]:
+        a, b = outs[0][0][k], outs[1][0][k]
+        torch.testing.assert_close(a, b, rtol=0, atol=2e-6, msg=lambda m: f"{k}: {m}")
+        moved += int(not torch.equal(a, sd[k].to(a)))
+    assert moved > 0
+    for k in outs[0][1]:
+        assert abs(outs[0][1][k] - outs[1][1][k]) <= 1e-4 * max(1.0, abs(outs[0][1][k])), k
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])
 def test_r50_backbone_matches_reference_golden(gpu, precision, tol):
     """WSR_50 (BottleneckBlock, 1x1 / dilated 3x3 / 1x1, 2048-channel res5) forward vs the reference."""

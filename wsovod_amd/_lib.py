@@ -88,6 +88,7 @@ SIGNATURES = {
     "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
     "wsovod_sgd_momentum_multi": [_P, _I, _F, _F, _P],
+    "wsovod_pack_bf16_multi": [_P, _I, _P],
     "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_nms_segments": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     "wsovod_rpn_label_anchors": [_P, _I, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
@@ -98,7 +99,13 @@ SIGNATURES = {
 class SgdTensor(C.Structure):
     """wsovod_sgd_tensor (include/wsovod_hip.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
-                ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float)]
+                ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
+                ("reserved_", C.c_int)]
+
+
+class PackTensor(C.Structure):
+    """wsovod_pack_tensor (include/wsovod_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("numel", C.c_longlong)]
 
 
 _lib = None

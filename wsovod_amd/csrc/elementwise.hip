@@ -381,6 +381,7 @@ struct SgdTable {
   float lr[kSgdMax], wd[kSgdMax];
   int first_block[kSgdMax + 1];
   int count;
+  unsigned g_bf16;  // bit k: g[k] points at bf16 values (gradients that travelled in the bf16 wire format)
 };
 
 __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable t, float mu, float gscale) {
@@ -393,13 +394,22 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
   bf16_t* __restrict__ shadow = t.shadow[k];
   const long long n = t.n[k];
   const float lr = t.lr[k], wd = t.wd[k];
-  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)buf) & 15) == 0) && (((uintptr_t)shadow & 7) == 0);
+  const bool gb = (t.g_bf16 >> k) & 1u;
+  const bf16_t* __restrict__ g16 = (const bf16_t*)t.g[k];
+  const bool vec = ((((uintptr_t)p | (uintptr_t)buf) & 15) == 0) && (((uintptr_t)shadow & 7) == 0) &&
+                   (((uintptr_t)g & (gb ? 7 : 15)) == 0);
   for (int e = threadIdx.x * 4; e < kSgdChunk; e += 256 * 4) {
     const long long i = base + e;
     if (i >= n) break;
     if (vec && i + 3 < n) {
       f32x4 pv = __builtin_nontemporal_load((const f32x4*)(p + i));
-      const f32x4 gv = __builtin_nontemporal_load((const f32x4*)(g + i));
+      f32x4 gv;
+      if (gb) {
+        const bf16x4 h = __builtin_nontemporal_load((const bf16x4*)(g16 + i));
+        gv = f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+      } else {
+        gv = __builtin_nontemporal_load((const f32x4*)(g + i));
+      }
       f32x4 bv = __builtin_nontemporal_load((const f32x4*)(buf + i));
       bv = mu * bv + (gv * gscale + wd * pv);
       pv -= lr * bv;
@@ -408,12 +418,42 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
       if (shadow) *(bf16x4*)(shadow + i) = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
     } else {
       for (long long q = i; q < min(i + 4, n); ++q) {
-        const float b = mu * buf[q] + (g[q] * gscale + wd * p[q]);
+        const float b = mu * buf[q] + ((gb ? (float)g16[q] : g[q]) * gscale + wd * p[q]);
         buf[q] = b;
         const float pv = p[q] - lr * b;
         p[q] = pv;
         if (shadow) shadow[q] = (bf16_t)pv;
       }
+    }
+  }
+}
+
+// Gradient wire format: every trainable tensor's fp32 gradient rounded to bf16 into its slice of ONE flat buffer (the
+// operand of a single RCCL all-reduce); same block->tensor table as the SGD kernel.
+struct PackTable {
+  const float* src[kSgdMax];
+  bf16_t* dst[kSgdMax];
+  long long n[kSgdMax];
+  int first_block[kSgdMax + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void pack_bf16_multi_kernel(const PackTable t) {
+  int k = 0;
+  while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+  const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * kSgdChunk;
+  const float* __restrict__ src = t.src[k];
+  bf16_t* __restrict__ dst = t.dst[k];
+  const long long n = t.n[k];
+  const bool vec = (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 7) == 0);
+  for (int e = threadIdx.x * 4; e < kSgdChunk; e += 256 * 4) {
+    const long long i = base + e;
+    if (i >= n) break;
+    if (vec && i + 3 < n) {
+      const f32x4 v = __builtin_nontemporal_load((const f32x4*)(src + i));
+      *(bf16x4*)(dst + i) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    } else {
+      for (long long q = i; q < min(i + 4, n); ++q) dst[q] = (bf16_t)src[q];
     }
   }
 }
@@ -779,6 +819,7 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
       t.g[k] = d.grad;
       t.buf[k] = d.momentum_buf;
       t.shadow[k] = (bf16_t*)d.bf16_shadow;
+      if (d.grad_is_bf16) t.g_bf16 |= 1u << k;
       t.n[k] = d.numel;
       t.lr[k] = d.lr;
       t.wd[k] = d.weight_decay;
@@ -792,6 +833,36 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
     wsovod::ProfScope prof(slot, s, 3.0 * total, (double)total * 22.0);
     hipLaunchKernelGGL(sgd_momentum_multi_kernel, dim3(blocks), dim3(256), 0, s, t, momentum, grad_scale);
     WS_CHECK_LAUNCH("wsovod_sgd_momentum_multi");
+  }
+  return WSOVOD_OK;
+}
+
+int wsovod_pack_bf16_multi(const wsovod_pack_tensor* tensors, int count, wsovod_stream_t stream) {
+  WS_CHECK_ARG(count >= 0 && (count == 0 || tensors), "wsovod_pack_bf16_multi: bad table");
+  static int slot = wsovod::prof_slot("pack_bf16_multi");
+  hipStream_t s = (hipStream_t)stream;
+  for (int start = 0; start < count; start += kSgdMax) {
+    PackTable t;
+    memset(&t, 0, sizeof(t));
+    long long total = 0;
+    int blocks = 0;
+    for (int k = 0; k < kSgdMax && start + k < count; ++k) {
+      const wsovod_pack_tensor& d = tensors[start + k];
+      WS_CHECK_ARG(d.numel >= 0 && (d.numel == 0 || (d.src && d.dst)), "wsovod_pack_bf16_multi: null pointer in entry %d",
+                   start + k);
+      t.src[k] = d.src;
+      t.dst[k] = (bf16_t*)d.dst;
+      t.n[k] = d.numel;
+      t.first_block[k] = blocks;
+      blocks += (int)ceil_div_ll(d.numel, kSgdChunk);
+      total += d.numel;
+      t.count = k + 1;
+    }
+    t.first_block[t.count] = blocks;
+    if (blocks == 0) continue;
+    wsovod::ProfScope prof(slot, s, 0.0, (double)total * 6.0);
+    hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
+    WS_CHECK_LAUNCH("wsovod_pack_bf16_multi");
   }
   return WSOVOD_OK;
 }

@@ -495,6 +495,117 @@ __global__ __launch_bounds__(256) void roi_align_fwd_nhwc(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------
+// ROIAlign forward, NHWC, pooled width PWT (7 on every shipped config): one WORKGROUP per (roi, 64*CPL channels),
+// one wavefront per pooled row ph, CPL adjacent channels per lane (one 8-byte load).  The PWT bins of the row advance
+// through their sample grids together: every inner iteration issues 4*PWT independent coalesced loads (the four
+// bilinear taps of one sample of each bin) before any arithmetic, instead of the dependent one-sample-at-a-time chain
+// of the generic kernel.  Per-sample arithmetic and the accumulation order (iy outer, ix inner) are those of the
+// generic kernel / torchvision's roi_align, so both produce the same bits.
+// ---------------------------------------------------------------------------------
+struct AlignAxis {
+  int lo, hi;
+  float l, h;
+  bool valid;
+};
+__device__ __forceinline__ AlignAxis align_axis(float v, int L) {
+  AlignAxis s;
+  s.valid = !(v < -1.0f || v > (float)L);
+  if (v <= 0.f) v = 0.f;
+  s.lo = (int)v;
+  if (s.lo >= L - 1) {
+    s.hi = s.lo = L - 1;
+    v = (float)s.lo;
+  } else {
+    s.hi = s.lo + 1;
+  }
+  s.l = v - (float)s.lo;
+  s.h = 1.f - s.l;
+  return s;
+}
+
+template <typename T, int PWT, int CPL>
+__global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
+                                        const float* __restrict__ roi_scale, int C, int H, int W, int PH,
+                                        float spatial_scale, int sampling_ratio, int aligned, void* out, int out_dtype,
+                                        int cgroups) {
+  typedef T vecc __attribute__((ext_vector_type(CPL)));
+  constexpr int CG = 64 * CPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int nbins = PH * PWT;
+  float* sval = (float*)smem;
+  const int r = blockIdx.x / cgroups;
+  const int c0 = (blockIdx.x - r * cgroups) * CG;
+  const int c = c0 + lane * CPL;
+  const AlignBox a = decode_align(rois + (long long)r * 5, spatial_scale, PH, PWT, sampling_ratio, aligned);
+  const float scale = roi_scale ? roi_scale[r] : 1.0f;
+  const T* base = feat + (long long)a.batch * H * W * C + (c < C ? c : 0);
+  float acc[PWT][CPL];
+#pragma unroll
+  for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc[pw][q] = 0.f;
+  for (int iy = 0; iy < a.grid_h; ++iy) {
+    const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
+    const AlignAxis ay = align_axis(y, H);
+    if (!ay.valid) continue;  // uniform over the wavefront (one roi, one pooled row)
+    const T* r0 = base + (long long)ay.lo * W * C;
+    const T* r1 = base + (long long)ay.hi * W * C;
+    for (int ix = 0; ix < a.grid_w; ++ix) {
+      AlignAxis ax[PWT];
+      vecc v1[PWT], v2[PWT], v3[PWT], v4[PWT];
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+        ax[pw] = align_axis(x, W);
+        v1[pw] = *(const vecc*)(r0 + (long long)ax[pw].lo * C);
+        v2[pw] = *(const vecc*)(r0 + (long long)ax[pw].hi * C);
+        v3[pw] = *(const vecc*)(r1 + (long long)ax[pw].lo * C);
+        v4[pw] = *(const vecc*)(r1 + (long long)ax[pw].hi * C);
+      }
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        if (!ax[pw].valid) continue;
+        const float w1 = ay.h * ax[pw].h, w2 = ay.h * ax[pw].l, w3 = ay.l * ax[pw].h, w4 = ay.l * ax[pw].l;
+#pragma unroll
+        for (int q = 0; q < CPL; ++q)
+          acc[pw][q] += w1 * to_f32(v1[pw][q]) + w2 * to_f32(v2[pw][q]) + w3 * to_f32(v3[pw][q]) +
+                        w4 * to_f32(v4[pw][q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      const float v = acc[pw][q] * a.inv_count;
+      sval[(lane * CPL + q) * nbins + ph * PWT + pw] = roi_scale ? v * scale : v;
+    }
+  __syncthreads();
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int nvalid = min(CG, C - c0) * nbins;
+  const long long obase = ((long long)r * C + c0) * nbins;
+  const bool vec = (nvalid & 3) == 0 && (obase & 3) == 0;
+  if (out_dtype == WSOVOD_F32) {
+    float* o = (float*)out + obase;
+    if (vec)
+      for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+  } else {
+    bf16_t* o = (bf16_t*)out + obase;
+    if (vec)
+      for (int i = tid * 4; i < nvalid; i += nthreads * 4) {
+        const float4 q = *(const float4*)(sval + i);
+        bf16x4 pk = {(bf16_t)q.x, (bf16_t)q.y, (bf16_t)q.z, (bf16_t)q.w};
+        *(bf16x4*)(o + i) = pk;
+      }
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = (bf16_t)sval[i];
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void roi_align_fwd_nchw(const T* __restrict__ feat, const float* __restrict__ rois,
                                                           const float* __restrict__ roi_scale, long long total, int C,
@@ -713,7 +824,23 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
     const int lds = 4 * 64 * ph * pw * 4;
     WS_CHECK_ARG(lds <= 160 * 1024, "wsovod_roi_align_forward: pooled size too large for LDS tile");
     wsovod::ProfScope prof(slot, s, 0.0, bytes);
-    if (dtype == WSOVOD_BF16) {
+    if (pw == 7 && ph <= 8 && ((uintptr_t)feat & 7) == 0 && C % (dtype == WSOVOD_BF16 ? 4 : 2) == 0) {
+      // fast path: workgroup per (roi, 64*CPL channels), wavefront per pooled row, 8-byte loads, 28 taps in flight
+      const int cg = dtype == WSOVOD_BF16 ? 256 : 128;
+      const int groups = ceil_div(C, cg);
+      const int lds7 = cg * ph * pw * 4;
+      if (dtype == WSOVOD_BF16) {
+        auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
+        if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
+                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups);
+      } else {
+        auto k = roi_align_fwd_nhwc_rows<float, 7, 2>;
+        if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const float*)feat, rois, roi_scale, C, H, W, ph,
+                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups);
+      }
+    } else if (dtype == WSOVOD_BF16) {
       auto k = roi_align_fwd_nhwc<bf16_t>;
       if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const bf16_t*)feat, rois, roi_scale, R, C, H, W, ph, pw,

@@ -618,7 +618,8 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False):
 
 
 def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
-    """entries: list of (param, grad, momentum_buf, bf16_shadow or None, lr, weight_decay); one launch per 32."""
+    """entries: list of (param, grad fp32 or bf16, momentum_buf, bf16_shadow or None, lr, weight_decay); one launch
+    per 32."""
     from .._lib import SgdTensor
 
     if not entries:
@@ -626,8 +627,28 @@ def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
     arr = (SgdTensor * len(entries))()
     for d, (p, g, b, sh, lr, wd) in zip(arr, entries):
         require_gpu(p, g, b, sh)
+        if g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != p.numel():
+            raise RuntimeError("sgd_momentum_multi: gradient must be fp32 or bf16 with the parameter's element count")
         d.param, d.grad, d.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
         d.bf16_shadow = sh.data_ptr() if sh is not None else None
         d.numel, d.lr, d.weight_decay = p.numel(), lr, wd
+        d.grad_is_bf16 = 1 if g.dtype == torch.bfloat16 else 0
     check(lib().wsovod_sgd_momentum_multi(arr, len(entries), C.c_float(momentum), C.c_float(grad_scale), stream()),
           "sgd_momentum_multi")
+
+
+def pack_bf16_multi(pairs):
+    """pairs: list of (src fp32 contiguous, dst bf16 contiguous view, same numel): the gradient wire format, one
+    launch per 32 tensors."""
+    from .._lib import PackTensor
+
+    if not pairs:
+        return
+    arr = (PackTensor * len(pairs))()
+    for d, (src, dst) in zip(arr, pairs):
+        require_gpu(src, dst)
+        if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or src.numel() != dst.numel() or not (
+                src.is_contiguous() and dst.is_contiguous()):
+            raise RuntimeError("pack_bf16_multi: (fp32, bf16) contiguous pairs of equal size expected")
+        d.src, d.dst, d.numel = src.data_ptr(), dst.data_ptr(), src.numel()
+    check(lib().wsovod_pack_bf16_multi(arr, len(pairs), stream()), "pack_bf16_multi")
