@@ -61,6 +61,13 @@ int wsovod_profile_reset(void);
 /* Synchronises pending events, then copies up to `cap` entries; returns the count. */
 int wsovod_profile_collect(wsovod_prof_entry* out_host, int cap);
 
+/* convert_boxes_to_pooler_format (wsovod/modeling/poolers.py:74-108) on the concatenated boxes of all images:
+ *   boxes (M,4) fp32, seg_offsets (G+1) int32 prefix offsets of the per-image counts
+ *   -> rois (M,5) fp32 [image index, x0, y0, x1, y1]
+ * and, when objectness (M) / roi_scale (M) are given, roi_scale = objectness + 1 (roi_heads.py:733-739). */
+int wsovod_format_rois(const float* boxes, const int* seg_offsets, int G, int M, const float* objectness,
+                       float* rois, float* roi_scale, wsovod_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * RoI max pooling.  Replaces torchvision.ops.RoIPool as used by
  * wsovod/modeling/poolers.py:183-186,284 and the reference's own native op

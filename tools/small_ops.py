@@ -1,8 +1,8 @@
-"""Where do the tiny ATen launches of one training step come from?  torch.profiler with python stacks; prints, per
-ATen device kernel family, launches per step and the nearest wsovod_amd / bench frame.  (python tools/small_ops.py [batch])"""
-import collections, os, sys, torch
+"""Where do the tiny ATen launches of one training step come from?  A TorchDispatchMode logs every ATen call of one
+step with the nearest wsovod_amd frame.  (python tools/small_ops.py [batch])"""
+import collections, os, sys, traceback, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from torch.profiler import ProfilerActivity, profile
+from torch.utils._python_dispatch import TorchDispatchMode
 from wsovod_amd.data import make_batch
 from wsovod_amd.engine import HotPathTrainer, build_optimizer
 from wsovod_amd.testing import build_hot_path_model
@@ -14,29 +14,31 @@ tr = HotPathTrainer(model, build_optimizer(cfg, model))
 host = make_batch(B, 512, 20, seed=1)
 batch = [{"image": x["image"].cuda(), "proposals": x["proposals"].to("cuda"), "instances": x["instances"],
           "height": x["height"], "width": x["width"]} for x in host]
-for _ in range(5):
+for _ in range(3):
     tr.run_step(batch)
 torch.cuda.synchronize()
-STEPS = 4
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    for _ in range(STEPS):
-        tr.run_step(batch)
-    torch.cuda.synchronize()
-agg = collections.Counter()
-dur = collections.Counter()
-for ev in prof.events():
-    if not ev.name.startswith("aten::") or ev.device_time_total <= 0 or ev.cpu_children and any(
-            c.name.startswith("aten::") and c.device_time_total > 0 for c in ev.cpu_children):
-        continue
-    where = "?"
-    for fr in ev.stack or []:
-        if "wsovod_amd" in fr or "bench.py" in fr:
-            where = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr[-90:]
-            break
-    agg[(ev.name, where)] += 1
-    dur[(ev.name, where)] += ev.device_time_total
-tot = 0.0
-for key, us in sorted(dur.items(), key=lambda kv: -kv[1])[:60]:
-    print(f"{us / STEPS:8.1f} us/step  {agg[key] / STEPS:6.1f} x  {key[0]:<28} {key[1]}")
-    tot += us / STEPS
-print(f"listed ATen device time: {tot:.1f} us/step")
+SKIP = ("view", "detach", "alias", "_unsafe_view", "slice", "select", "as_strided", "t.default", "transpose", "expand",
+        "unsqueeze", "squeeze", "split", "unbind", "permute", "reshape", "empty", "_local_scalar", "is_", "sym_",
+        "narrow", "chunk", "lift_fresh", "_to_copy")
+count = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not any(s in name for s in SKIP):
+            where = "?"
+            for fr in reversed(traceback.extract_stack()):
+                if "wsovod_amd" in fr.filename and "small_ops" not in fr.filename:
+                    where = f"{fr.filename.split('wsovod_amd/')[-1]}:{fr.lineno} {fr.line.strip()[:80]}"
+                    break
+            count[(name, where)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Log():
+    tr.run_step(batch)
+torch.cuda.synchronize()
+for (name, where), n in sorted(count.items(), key=lambda kv: -kv[1]):
+    print(f"{n:4d} x {name:<34} {where}")
+print("total:", sum(count.values()))

@@ -672,6 +672,29 @@ __global__ __launch_bounds__(256) void roi_align_bwd(const float* __restrict__ g
   }
 }
 
+// convert_boxes_to_pooler_format (poolers.py:74-108): (M,4) boxes of all images, concatenated, -> (M,5)
+// [image index as float, x0, y0, x1, y1]; the image of row r is found in the prefix offsets.  Optionally also the
+// objectness scale of roi_heads.py:733-739, objectness + 1.  One launch instead of a full_like + cat per image.
+__global__ __launch_bounds__(256) void format_rois_kernel(const float* __restrict__ boxes, const int* __restrict__ seg,
+                                                          int G, int M, const float* __restrict__ objectness,
+                                                          float* __restrict__ rois, float* __restrict__ scale) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  int lo = 0, hi = G;  // largest g in [0, G) with seg[g] <= r (empty images share an offset with their successor)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (seg[mid] <= r) lo = mid; else hi = mid;
+  }
+  const float4 b = ((const float4*)boxes)[r];
+  float* o = rois + (long long)r * 5;
+  o[0] = (float)lo;
+  o[1] = b.x;
+  o[2] = b.y;
+  o[3] = b.z;
+  o[4] = b.w;
+  if (scale) scale[r] = objectness[r] + 1.0f;
+}
+
 int check_common(const char* fn, const void* feat, int dtype, int layout, const float* rois, int R, int N, int C,
                  int H, int W, int ph, int pw, const void* out) {
   WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "%s: bad dtype %d", fn, dtype);
@@ -685,6 +708,22 @@ int check_common(const char* fn, const void* feat, int dtype, int layout, const 
 }  // namespace
 
 extern "C" {
+
+int wsovod_format_rois(const float* boxes, const int* seg_offsets, int G, int M, const float* objectness, float* rois,
+                       float* roi_scale, wsovod_stream_t stream) {
+  WS_CHECK_ARG(G >= 0 && M >= 0, "wsovod_format_rois: bad shape");
+  if (M == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(G > 0 && boxes && seg_offsets && rois, "wsovod_format_rois: null pointer");
+  WS_CHECK_ARG(((uintptr_t)boxes & 15) == 0, "wsovod_format_rois: boxes must be 16-byte aligned");
+  WS_CHECK_ARG(!roi_scale == !objectness, "wsovod_format_rois: objectness and roi_scale go together");
+  static int slot = wsovod::prof_slot("format_rois");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)M * (36.0 + (roi_scale ? 8.0 : 0.0)));
+  hipLaunchKernelGGL(format_rois_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, s, boxes, seg_offsets, G, M, objectness,
+                     rois, roi_scale);
+  WS_CHECK_LAUNCH("wsovod_format_rois");
+  return WSOVOD_OK;
+}
 
 int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
                             int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,

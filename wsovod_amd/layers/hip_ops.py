@@ -85,6 +85,44 @@ def _rois_f32(rois):
     return rois.to(torch.float32).contiguous()
 
 
+def cat_rows(tensors):
+    """torch.cat(tensors, 0) without the copy when the inputs already are consecutive row blocks of one buffer (the
+    per-image slices of a kernel's packed output): returns a view spanning them."""
+    tensors = list(tensors)
+    t0 = tensors[0]
+    if len(tensors) == 1:
+        return t0
+    if t0.is_contiguous() and not t0.requires_grad and t0.dim() >= 1:
+        base, inner, per_row = t0.untyped_storage().data_ptr(), t0.shape[1:], 1
+        for d in inner:
+            per_row *= d
+        off, rows, ok = t0.storage_offset(), 0, True
+        for t in tensors:
+            if (t.requires_grad or t.dtype != t0.dtype or t.shape[1:] != inner or not t.is_contiguous()
+                    or t.untyped_storage().data_ptr() != base or t.storage_offset() != off + rows * per_row):
+                ok = False
+                break
+            rows += t.shape[0]
+        if ok and per_row > 0:
+            return t0.as_strided((rows,) + tuple(inner), t0.stride(), off)
+    return torch.cat(tensors, dim=0)
+
+
+def format_rois(boxes, seg_offsets, objectness=None):
+    """(M,4) concatenated boxes + (G+1) int32 offsets -> ((M,5) pooler-format rois, objectness + 1 or None)."""
+    require_gpu(boxes, seg_offsets, objectness)
+    boxes = boxes.detach().to(torch.float32).contiguous()
+    M, G = boxes.size(0), seg_offsets.numel() - 1
+    rois = torch.empty((M, 5), dtype=torch.float32, device=boxes.device)
+    scale = None
+    if objectness is not None:
+        objectness = objectness.detach().to(torch.float32).contiguous()
+        scale = torch.empty((M,), dtype=torch.float32, device=boxes.device)
+    check(lib().wsovod_format_rois(ptr(boxes), ptr(seg_offsets), G, M, ptr(objectness), ptr(rois), ptr(scale), stream()),
+          "format_rois")
+    return rois, scale
+
+
 def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out_dtype=None, need_argmax=True):
     """RoI max pool -> (out (R,C,ph,pw), argmax int32 or None)."""
     require_gpu(feat, rois, roi_scale)
@@ -438,13 +476,14 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
     M = scores.size(0)
     G = seg_offsets.numel() - 1
     T = gt_classes_img.numel()
+    zero = torch.zeros((32 * T + 4 * G,), dtype=torch.uint8, device=dev)  # one fill for the five zero-initialised outputs
     o = dict(
-        pgt_boxes=torch.zeros((T, 4), dtype=torch.float32, device=dev),
-        pgt_classes=torch.zeros((T,), dtype=torch.int64, device=dev),
-        pgt_scores=torch.zeros((T,), dtype=torch.float32, device=dev),
-        pgt_weights=torch.zeros((T,), dtype=torch.float32, device=dev),
+        pgt_boxes=zero[:16 * T].view(torch.float32).view(T, 4),
+        pgt_classes=zero[16 * T:24 * T].view(torch.int64),
+        pgt_scores=zero[24 * T:28 * T].view(torch.float32),
+        pgt_weights=zero[28 * T:32 * T].view(torch.float32),
         pgt_index=torch.full((T,), -1, dtype=torch.int32, device=dev),
-        pgt_count=torch.zeros((G,), dtype=torch.int32, device=dev),
+        pgt_count=zero[32 * T:].view(torch.int32),
         gt_classes=torch.empty((M,), dtype=torch.int64, device=dev),
         gt_boxes=torch.empty((M, 4), dtype=torch.float32, device=dev),
         gt_scores=torch.empty((M,), dtype=torch.float32, device=dev),

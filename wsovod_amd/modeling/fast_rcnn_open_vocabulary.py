@@ -16,6 +16,7 @@ from torch.nn import functional as F
 
 from ..config import configurable
 from ..layers import functions as Fn
+from ..layers import hip_ops as H
 from ..structures import Boxes, Instances, ShapeSpec
 from .box_regression import Box2BoxTransform
 
@@ -268,22 +269,24 @@ class InstanceRefinementOutputLayers(nn.Module):
                                           dtype=scores.dtype, device=scores.device, requires_grad=False)
         return scores, proposal_deltas
 
-    def losses(self, predictions, proposals, num_classes=None):
+    def losses(self, predictions, proposals, num_classes=None, proposal_boxes=None):
+        """proposal_boxes: optional (sum R, 4) concatenation of the proposals' boxes the caller already holds.  The
+        per-proposal targets are slices of the labelling kernel's packed output, which `cat_rows` re-joins as views."""
         scores, proposal_deltas = predictions
         dev = scores.device
-        gt_classes = torch.cat([p.gt_classes for p in proposals], dim=0) if len(proposals) else \
+        gt_classes = H.cat_rows([p.gt_classes for p in proposals]) if len(proposals) else \
             torch.empty(0, dtype=torch.int64, device=dev)
         if len(proposals):
-            proposal_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            if proposal_boxes is None:
+                proposal_boxes = H.cat_rows([p.proposal_boxes.tensor for p in proposals])
             assert not proposal_boxes.requires_grad, "Proposals should not require gradients!"
-            gt_boxes = torch.cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals],
-                                 dim=0)
+            gt_boxes = H.cat_rows([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals])
         else:
             proposal_boxes = gt_boxes = torch.empty((0, 4), device=dev)
         weighted_box = self.box_reg_loss_type == "smooth_l1_weighted"
         weights = None
         if self.cross_entropy_weighted or weighted_box:
-            weights = torch.cat([p.gt_weights for p in proposals], dim=0)
+            weights = H.cat_rows([p.gt_weights for p in proposals])
         k = str(self.refine_k)
         losses = {"loss_cls_r" + k: Fn.weighted_cross_entropy(scores, gt_classes, weights,
                                                             weighted=self.cross_entropy_weighted)}

@@ -109,8 +109,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         assert "proposals" in batched_inputs[0]
         proposals = [x["proposals"].to(self.device) for x in batched_inputs]
         if self.proposal_generator is None:  # rcnn_wsovod.py:198-203; with an RPN the loaded boxes stay as they are
-            for p in proposals:
-                p.level_ids = torch.zeros((len(p),), dtype=torch.int64, device=self.device)
+            level_ids = torch.zeros((sum(len(p) for p in proposals),), dtype=torch.int64, device=self.device)
+            for p, ids in zip(proposals, level_ids.split([len(p) for p in proposals])):  # one fill, per-image views
+                p.level_ids = ids
         return proposals
 
     def _rpn_proposals(self, images, features, batched_inputs, loaded, gt_instances=None):

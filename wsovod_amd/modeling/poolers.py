@@ -74,7 +74,14 @@ def _fmt_box_list(box_tensor, batch_index: int):
 
 
 def convert_boxes_to_pooler_format(box_lists: List[Boxes]):
-    """(M,5) fp32 [batch index, x0, y0, x1, y1]  (poolers.py:81-108)."""
+    """(M,5) fp32 [batch index, x0, y0, x1, y1]  (poolers.py:81-108).  Device boxes: one concatenation + one
+    `wsovod_format_rois` launch instead of a full_like + cat per image."""
+    if box_lists and box_lists[0].tensor.is_cuda:
+        from ..layers import hip_ops as H
+        from .fast_rcnn_open_vocabulary import segment_offsets
+
+        boxes = H.cat_rows([b.tensor for b in box_lists])
+        return H.format_rois(boxes, segment_offsets([len(b) for b in box_lists], boxes.device))[0]
     return torch.cat([_fmt_box_list(box_list.tensor, i) for i, box_list in enumerate(box_lists)], dim=0)
 
 
@@ -112,7 +119,9 @@ class ROIPooler(nn.Module):
         assert canonical_box_size > 0
         self.canonical_box_size = canonical_box_size
 
-    def forward(self, x: List[torch.Tensor], box_lists: List[Boxes], level_ids=None, roi_scale=None, out_dtype=None):
+    def forward(self, x: List[torch.Tensor], box_lists: List[Boxes], level_ids=None, roi_scale=None, out_dtype=None,
+                rois=None):
+        """rois: optional precomputed pooler-format boxes of `box_lists` (single-level poolers only)."""
         num_level_assignments = len(self.level_poolers)
         assert isinstance(x, list) and isinstance(box_lists, list), "Arguments to pooler must be lists"
         assert len(x) == num_level_assignments, \
@@ -121,7 +130,8 @@ class ROIPooler(nn.Module):
             "unequal value, x[0] batch dim 0 is {}, but box_list has length {}".format(x[0].size(0), len(box_lists))
         if len(box_lists) == 0:
             return torch.zeros((0, x[0].shape[1]) + self.output_size, device=x[0].device, dtype=x[0].dtype)
-        pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
+        pooler_fmt_boxes = rois if (rois is not None and num_level_assignments == 1) else \
+            convert_boxes_to_pooler_format(box_lists)
         if num_level_assignments == 1:
             return self.level_poolers[0](x[0], pooler_fmt_boxes, roi_scale, out_dtype)
         level_assignments = assign_boxes_to_levels(box_lists, self.min_level, self.max_level,

@@ -250,12 +250,25 @@ class WSOVODROIHeads(ROIHeads):
         """Parameter-free part of the box branch: RoI pooling with the fused `* (objectness + 1)` scale
         (roi_heads.py:727-739)."""
         feats = [features[f] for f in self.box_in_features]
-        roi_scale = torch.cat([x.objectness_logits + 1 for x in proposals], dim=0).to(torch.float32)
+        # pooler-format rois and the scale `objectness + 1` in one launch on the concatenated boxes
+        boxes = self.boxes_cat(proposals)
+        rois, roi_scale = H.format_rois(boxes, segment_offsets([len(p) for p in proposals], boxes.device),
+                                        H.cat_rows([x.objectness_logits for x in proposals]))
         if self.pooler_type == "ROILoopPool":  # (3R, C, 7, 7) = [region | frame | context], roi_heads.py:727-739
-            out = self.box_pooler(feats, [x.proposal_boxes for x in proposals], out_dtype=torch.float32)
+            out = self.box_pooler(feats, [x.proposal_boxes for x in proposals], out_dtype=torch.float32, rois=rois)
             return (out * roi_scale.repeat(3).view(-1, 1, 1, 1)).to(self.compute_dtype)
         return self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
-                               out_dtype=self.compute_dtype)
+                               out_dtype=self.compute_dtype, rois=rois)
+
+    def boxes_cat(self, proposals):
+        """(sum R, 4) boxes of all images; concatenated once per step (pooling, mining and the box loss read it)."""
+        tensors = [p.proposal_boxes.tensor for p in proposals]
+        c = getattr(self, "_boxes_cat", None)
+        if c is not None and len(c[0]) == len(tensors) and all(a is b for a, b in zip(c[0], tensors)):
+            return c[1]
+        cat = H.cat_rows(tensors)
+        self._boxes_cat = (tensors, cat)
+        return cat
 
     def get_features(self, features, proposals, data_aware_features=None, pooled=None):
         """roi_heads.py:1827-1857: pooled -> objectness scale -> neck -> (+ data-aware features)."""
@@ -303,20 +316,22 @@ class WSOVODROIHeads(ROIHeads):
         losses = self.object_miner.losses(predictions, proposals, self.gt_classes_img_oh)
         self.pred_class_img_logits = self.object_miner.predict_probs_img(predictions, proposals).detach()
         prev_pred_scores = predictions[0].detach()  # (R,K); the appended zero bg column is never read
-        prev_pred_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        proposal_boxes = prev_pred_boxes = self.boxes_cat(proposals)
         nums = [len(p) for p in proposals]
         seg = segment_offsets(nums, box_features.device)
         for k in range(self.refine_K):
             targets, proposals_k = self.mine_and_label(k, prev_pred_scores, prev_pred_boxes, proposals, seg, nums)
             predictions_k = self.box_refinery[k](box_features, classifier=classifier,
                                                  append_background=append_background, pre=pre[1 + k] if pre else None)
-            losses.update(self.box_refinery[k].losses(predictions_k, proposals_k, self.num_classes))
+            losses.update(self.box_refinery[k].losses(predictions_k, proposals_k, self.num_classes,
+                                                      proposal_boxes=proposal_boxes))
             if k + 1 < self.refine_K or self.rpn_on:
                 prev_pred_scores = torch.softmax(predictions_k[0].detach(), dim=-1)
                 prev_pred_boxes = torch.cat(self.box_refinery[k].predict_boxes(
                     (None, predictions_k[1].detach()), proposals_k), dim=0)
         if self.rpn_on:
             self.proposal_targets = self.rpn_targets(prev_pred_scores, prev_pred_boxes, proposals, seg)
+        self._boxes_cat = None
         return losses
 
     def _grouped_heads(self, box_features):
