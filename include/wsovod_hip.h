@@ -365,6 +365,11 @@ int wsovod_pgt_mine_and_label(const float* scores, long long ld_scores, const fl
 int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype,
                           int M, int N, float scale, void* dA, long long ldda, void* dAt, long long ldt,
                           int out_dtype, wsovod_stream_t stream);
+/* The same pass, also ADDING the column sums of dA (fp32, before rounding to out_dtype) into colsum[N]: the bias
+ * gradient of the Linear layer (autograd's sum over rows) without a second read of dA.  The caller zero-fills colsum. */
+int wsovod_mask_transpose_colsum(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype,
+                                 int M, int N, float scale, void* dA, long long ldda, void* dAt, long long ldt,
+                                 int out_dtype, float* colsum, wsovod_stream_t stream);
 /* out[m][:] = x[m][:] + add[row_group[m]][:]  (box_features += data_aware_features,
  * roi_heads.py:762-763, without materialising the per-proposal repeat). */
 int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* row_group, const float* add,

@@ -1,0 +1,40 @@
+"""RoIPool / ROIAlign forward alone at the benchmark shape (16 images x 512 boxes, 512 channels, bf16 NHWC):
+time per launch and effective gather rate.  python tools/roi_probe.py [iters] [C] [R] [N]"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from wsovod_amd.data import make_batch
+from wsovod_amd.layers import hip_ops as H
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+N = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+dev = torch.device("cuda:0")
+host = make_batch(N, R, 20, seed=1)
+boxes = torch.cat([x["proposals"].proposal_boxes.tensor for x in host]).to(dev)
+obj = torch.cat([x["proposals"].objectness_logits for x in host]).to(dev)
+seg = torch.tensor([0] + [R * (i + 1) for i in range(N)], dtype=torch.int32, device=dev)
+rois, scale = H.format_rois(boxes, seg, obj)
+feat = torch.randn(N, 75, 100, Cc, device=dev).to(torch.bfloat16).permute(0, 3, 1, 2)  # NHWC storage
+cells = float(((boxes[:, 2] - boxes[:, 0]) / 8 + 1).mul((boxes[:, 3] - boxes[:, 1]) / 8 + 1).sum())
+
+
+def timeit(fn):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+ms = timeit(lambda: H.roi_pool_forward(feat, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=torch.bfloat16, need_argmax=False))
+print(f"roi_pool  values only : {ms:.3f} ms  window reads {cells * Cc * 2 / ms / 1e9:.2f} TB/s, out {N*R*Cc*49*2/ms/1e9:.2f} TB/s")
+ms = timeit(lambda: H.roi_pool_forward(feat, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=torch.bfloat16, need_argmax=True))
+print(f"roi_pool  + argmax    : {ms:.3f} ms")
+ms = timeit(lambda: H.roi_align_forward(feat, rois, 0.125, (7, 7), 0, True, roi_scale=scale, out_dtype=torch.bfloat16))
+print(f"roi_align aligned     : {ms:.3f} ms")

@@ -467,7 +467,8 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restrict__ dy, long long lddy,
                                                              const TI* __restrict__ y, long long ldy, int M, int N,
                                                              float scale, TO* __restrict__ dA, long long ldda,
-                                                             TO* __restrict__ dAt, long long ldt) {
+                                                             TO* __restrict__ dAt, long long ldt,
+                                                             float* __restrict__ colsum) {
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -500,6 +501,19 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restric
     for (int j = 0; j < 8; ++j) tile[row][cg + j] = v[j];
   }
   __syncthreads();
+  if (colsum) {  // bias gradient: column sums of the masked tile (rows past M hold zeros), one atomic per column and tile
+    __shared__ float part[4][64];
+    const int col = tid & 63, q = tid >> 6;
+    float sacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc += tile[q * 16 + r][col];
+    part[q][col] = sacc;
+    __syncthreads();
+    if (q == 0 && n0 + col < N) {
+      const float t = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
+      if (t != 0.f) atomicAdd(colsum + n0 + col, t);
+    }
+  }
   if (dAt) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -547,16 +561,16 @@ __global__ void scale_rows_kernel(const float* __restrict__ x, long long ldx, co
 
 extern "C" {
 
-int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype, int M, int N,
-                          float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
-                          wsovod_stream_t stream) {
+static int mask_transpose_impl(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype, int M, int N,
+                               float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
+                               float* colsum, wsovod_stream_t stream) {
   if (M == 0 || N == 0) return WSOVOD_OK;
-  WS_CHECK_ARG(dy && (dA || dAt), "wsovod_mask_transpose: null pointer");
+  WS_CHECK_ARG(dy && (dA || dAt || colsum), "wsovod_mask_transpose: null pointer");
   static int slot = wsovod::prof_slot("mask_transpose");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * 4.0 * 3);
-#define MT(TI, TO) hipLaunchKernelGGL((mask_transpose_kernel<TI, TO>), grid, dim3(256), 0, s, (const TI*)dy, lddy, (const TI*)y, ldy, M, N, scale, (TO*)dA, ldda, (TO*)dAt, ldt)
+#define MT(TI, TO) hipLaunchKernelGGL((mask_transpose_kernel<TI, TO>), grid, dim3(256), 0, s, (const TI*)dy, lddy, (const TI*)y, ldy, M, N, scale, (TO*)dA, ldda, (TO*)dAt, ldt, colsum)
   if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_F32) MT(float, float);
   else if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_BF16) MT(float, bf16_t);
   else if (in_dtype == WSOVOD_BF16 && out_dtype == WSOVOD_BF16) MT(bf16_t, bf16_t);
@@ -565,6 +579,19 @@ int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long lo
 #undef MT
   WS_CHECK_LAUNCH("wsovod_mask_transpose");
   return WSOVOD_OK;
+}
+
+int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype, int M, int N,
+                          float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
+                          wsovod_stream_t stream) {
+  return mask_transpose_impl(dy, lddy, y, ldy, in_dtype, M, N, scale, dA, ldda, dAt, ldt, out_dtype, nullptr, stream);
+}
+
+int wsovod_mask_transpose_colsum(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype, int M, int N,
+                                 float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
+                                 float* colsum, wsovod_stream_t stream) {
+  WS_CHECK_ARG(colsum, "wsovod_mask_transpose_colsum: null colsum");
+  return mask_transpose_impl(dy, lddy, y, ldy, in_dtype, M, N, scale, dA, ldda, dAt, ldt, out_dtype, colsum, stream);
 }
 
 int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* row_group, const float* add,

@@ -68,9 +68,10 @@ class _Linear(Function):
         # transposed-read kernel on them as they are; the rest goes through explicit transposes + the NT kernel.
         tn = (_USE_TN and need_dw and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0
               and ((Np + 255) // 256) * ((K + 255) // 256) >= 128)
-        dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or need_db or tn, want_t=need_dw and not tn,
-                                   ld_t=Mp, ld_plain=Np)
-        dx = dw = db = None
+        db = torch.zeros((N,), dtype=torch.float32, device=dy.device) if need_db else None  # summed in the same pass
+        dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or tn, want_t=need_dw and not tn,
+                                   ld_t=Mp, ld_plain=Np, colsum=db)
+        dx = dw = None
         if tn:
             dw = H.gemm_tn(dA, x)  # (Np, K)
             if Np != N:
@@ -78,9 +79,6 @@ class _Linear(Function):
         elif need_dw:
             xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
             dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
-        if need_db:
-            seg = H.const_tensor((0, M), torch.int32, x.device)
-            db = H.segment_colsum(dA[:, :N] if Np != N else dA, seg).view(N)
         if need_dx:
             wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
             dx = H.gemm_nt(dA, wt, out_dtype=cd)  # (M,K)
@@ -126,10 +124,13 @@ class _LinearGroup(Function):
             offs.append(offs[-1] + _pad(n, 8))
         Nt = offs[-1]
         dA = torch.zeros((M, Nt), dtype=cd, device=x.device)
+        want_db = any(ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h] for h in range(heads))
+        dbcat = torch.zeros((Nt,), dtype=torch.float32, device=x.device) if want_db else None
         for h in range(heads):
             if dys[h] is not None:
                 H.mask_transpose(_contig2d(dys[h]), ys[h], 1.0, cd, want_t=False,
-                                 out_plain=dA[:, offs[h]:offs[h] + Ns[h]])
+                                 out_plain=dA[:, offs[h]:offs[h] + Ns[h]],
+                                 colsum=dbcat[offs[h]:offs[h] + Ns[h]] if want_db else None)
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[2 + 2 * h] for h in range(heads))
         wcat = torch.zeros((Nt, K), dtype=cd, device=x.device)
@@ -150,9 +151,7 @@ class _LinearGroup(Function):
             for h in range(heads):
                 if ctx.needs_input_grad[2 + 2 * h]:
                     grads[2 * h] = dwcat[offs[h]:offs[h] + Ns[h]]
-        if any(ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h] for h in range(heads)):
-            seg = H.const_tensor((0, M), torch.int32, x.device)
-            dbcat = H.segment_colsum(dA, seg).view(Nt)
+        if want_db:
             for h in range(heads):
                 if ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h]:
                     grads[2 * h + 1] = dbcat[offs[h]:offs[h] + Ns[h]]

@@ -500,10 +500,12 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
     return o
 
 
-def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None, out_plain=None):
+def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None, out_plain=None,
+                   colsum=None):
     """dA = dy * [y>0] * scale -> (dA (M, ld_plain>=N) or None, dAt (N, ld_t>=M) or None), zero padded.
-    out_plain: optional (M, N) view (contiguous last dim) of a wider buffer that receives dA in place."""
-    require_gpu(dy, y)
+    out_plain: optional (M, N) view (contiguous last dim) of a wider buffer that receives dA in place.
+    colsum: optional zero-filled fp32 (N,) that receives the column sums of dA (the bias gradient) in the same pass."""
+    require_gpu(dy, y, colsum)
     M, N = dy.shape
     ldp = ld_plain or N
     dA = None
@@ -516,6 +518,13 @@ def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=N
     if want_t:
         ld = ld_t or M
         dAt = (torch.zeros if ld != M else torch.empty)((N, ld), dtype=out_dtype, device=dy.device)
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
+        check(lib().wsovod_mask_transpose_colsum(
+            ptr(dy), _ld(dy), ptr(y), _ld(y) if y is not None else 0, dtype_code(dy.dtype), M, N, C.c_float(scale),
+            ptr(dA), ldp, ptr(dAt), _ld(dAt) if want_t else 0, dtype_code(out_dtype), ptr(colsum), stream()),
+            "mask_transpose_colsum")
+        return dA, dAt
     check(lib().wsovod_mask_transpose(ptr(dy), _ld(dy), ptr(y), _ld(y) if y is not None else 0, dtype_code(dy.dtype),
                                       M, N, C.c_float(scale), ptr(dA), ldp, ptr(dAt), _ld(dAt) if want_t else 0,
                                       dtype_code(out_dtype), stream()), "mask_transpose")
