@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="gradient all-reduce format at N>1: auto = the compute precision (bf16 run -> bf16 wire, the "
                          "counterpart of the reference's fp16 compression hook; master weights/momentum stay fp32)")
+    ap.add_argument("--one-rank-group", action="store_true",
+                    help="debug/measurement: at N=1 still create a 1-rank RCCL group, so that the whole exchange path "
+                         "(gradient pack, split weight-gradient launch, collectives, SGD on the wire slices) runs and "
+                         "its cost without any wire time can be read off one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -139,6 +143,11 @@ def cpu_baseline(model, sd, batch, args):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner at
+    # communicator creation does) are sent to stderr for the duration of the run.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -148,8 +157,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.one_rank_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -251,15 +263,15 @@ def main():
                                    f"{'RPN + loaded proposals' if args.rpn else 'proposals-only mode'}, {args.pooler}, "
                                    f"full training step (fwd+bwd+SGD)",
                        "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "grad_allreduce": f"{wire} over RCCL" if world > 1 else "none (1 GPU)",
+                       "parallelism": f"dp{world}", "grad_allreduce": f"{wire} over RCCL" if dist.is_initialized() else "none (1 GPU)",
                        "final_losses": final_losses},
         }
         if roofline is not None:
             out["roofline"] = roofline
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cpu_state, host_batch, args)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -261,3 +261,119 @@ def test_two_rank_bf16_gradient_wire():
     assert (w0 - model.fc.weight.detach()).abs().max() < 2e-3
     # the untouched tensor saw zero gradients on both ranks: unchanged (no weight decay here), identical on both
     assert res[0][2] == res[1][2]
+
+
+class _SplitLinearFn(torch.autograd.Function):
+    """CPU stand-in with the protocol of layers/functions.py:_Linear: the weight gradient is produced in two row
+    blocks and `weight._dw_split = (rows, callback)` sees the first one before the second exists."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        ctx.dw_split = getattr(weight, "_dw_split", None)
+        return x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dw = torch.empty_like(weight)
+        ra = ctx.dw_split[0]
+        dw[:ra] = dy[:, :ra].t() @ x
+        ctx.dw_split[1](dw[:ra])
+        dw[ra:] = dy[:, ra:].t() @ x
+        return None, dw
+
+
+class _SplitModel(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.big = nn.Parameter(torch.randn(24, 16) * 0.1)
+        self.small = nn.Linear(24, 3)
+
+    def forward_frozen(self, batch):
+        return {"x": torch.stack([b["x"] for b in batch])}
+
+    def forward_trainable(self, st):
+        h = _SplitLinearFn.apply(st["x"], self.big)
+        return {"loss": self.small(torch.relu(h)).pow(2).mean()}
+
+
+def _worker_early_block(rank, world, port, q):
+    """The split-weight path of the bf16 wire: first row block packed and all-reduced from inside backward, the rest
+    (and every other tensor) after it; two collectives per step on every rank."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import HotPathTrainer
+    from wsovod_amd.engine.trainer import HipSGD
+    from wsovod_amd.layers import hip_ops as H
+
+    def pack(pairs):
+        for src, dst in pairs:
+            assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+            dst.copy_(src.reshape(-1))
+
+    def sgd(entries, momentum, grad_scale=1.0):
+        for p, g, buf, shadow, lr, wd in entries:
+            assert g.dtype == torch.bfloat16 and g.numel() == p.numel()
+            buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
+            p.sub_(lr * buf)
+
+    H.pack_bf16_multi, H.sgd_momentum_multi = pack, sgd
+    HotPathTrainer.split_on_cpu = True
+    HotPathTrainer.split_rows = staticmethod(lambda n_rows, n_cols, cus=256, tile=256: 8)
+    calls = []
+    real = dist.all_reduce
+
+    def counted(t, *a, **k):
+        calls.append(t.numel())
+        return real(t, *a, **k)
+
+    dist.all_reduce = counted
+    model = _SplitModel()
+    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.0} for p in model.parameters()], 0.1, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True, grad_wire="bf16")
+    assert tr._split is not None and tr._split[1] == 8 and model.big._dw_split[0] == 8
+    tr.broadcast_parameters()
+    calls.clear()
+    g = torch.Generator().manual_seed(99 + rank)
+    batch = [{"x": torch.randn(16, generator=g)} for _ in range(4)]
+    for it in range(3):
+        tr.run_step(batch)
+    tr.flush()
+    total = tr._wire_slices()[0].numel()
+    assert calls == [8 * 16, total - 8 * 16] * 3, calls  # early head, then the rest, every step
+    q.put((rank, model.big.detach().tolist(), model.small.weight.detach().tolist(), [b["x"].tolist() for b in batch]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_bf16_wire_early_block():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_early_block, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2], "replicas diverged"
+    model = _SplitModel()
+    model.big._dw_split = (8, lambda rows: None)
+    buf = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    batches = [[{"x": torch.tensor(x)} for x in r[3]] for r in res]
+    for it in range(3):
+        grads = []
+        for b in batches:
+            model.zero_grad()
+            sum(model.forward_trainable(model.forward_frozen(b)).values()).backward()
+            grads.append({n: p.grad.to(torch.bfloat16) for n, p in model.named_parameters()})
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                gsum = (grads[0][n].float() + grads[1][n].float()).to(torch.bfloat16)
+                buf[n].mul_(0.9).add_(gsum.float() * 0.5)
+                p.sub_(0.1 * buf[n])
+    torch.testing.assert_close(torch.tensor(res[0][1]), model.big.detach(), rtol=0, atol=2e-3)
+    torch.testing.assert_close(torch.tensor(res[0][2]), model.small.weight.detach(), rtol=0, atol=2e-3)

@@ -105,6 +105,8 @@ class HotPathTrainer:
     stalling the step.  Call `flush()` after the last step.
     """
 
+    split_on_cpu = False  # tests: let the early-exchange logic run on a CPU stand-in model
+
     def __init__(self, model, optimizer, overlap=True, reduce_unused=False, grad_wire="fp32"):
         """reduce_unused: parameters that received no gradient this step (mixed-dataset mode: the other
         datasets' object miners) still take part in the exchange with zeros, so that every rank issues the same
@@ -122,6 +124,8 @@ class HotPathTrainer:
             raise ValueError("grad_wire='bf16' needs the HIP optimizer (it reads the bf16 slices)")
         self.grad_wire = grad_wire
         self._wire = None
+        self._split = None  # (param, rows, elements) of the weight whose gradient is exchanged in two pieces
+        self._early = None
         self.reduce_unused = reduce_unused
         self.model = model
         self.optimizer = optimizer
@@ -132,6 +136,8 @@ class HotPathTrainer:
         self.params = [p for p in model.parameters() if p.requires_grad]
         for p in self.params:
             p._wire_grad = None
+        if self.exchange and grad_wire == "bf16" and self.params:
+            self._setup_early_exchange()
         if isinstance(optimizer, HipSGD):
             optimizer.grad_scale = 1.0 / self.world
 
@@ -156,33 +162,84 @@ class HotPathTrainer:
             p._wire_grad = None
         self._pending = None
 
+    @staticmethod
+    def split_rows(n_rows, n_cols, cus=256, tile=256):
+        """Rows of the first block when an (n_rows, n_cols) weight gradient is computed as two launches of 256x256
+        tiles on `cus` CUs: the split must not add a round of tiles (ceil(a*tj/cus) + ceil((ti-a)*tj/cus) equal to
+        the unsplit count) and the first block should carry ~30 % of the rows, so that its all-reduce has the second
+        block's contraction to hide behind.  0 = no admissible split."""
+        ti, tj = -(-n_rows // tile), -(-n_cols // tile)
+        whole = -(-ti * tj // cus)
+        ok = [a for a in range(1, ti) if -(-a * tj // cus) + -(-(ti - a) * tj // cus) == whole and a * tile < n_rows]
+        if not ok:
+            return 0
+        return min(ok, key=lambda a: abs(a - 0.3 * ti)) * tile
+
+    def _setup_early_exchange(self):
+        """The largest weight (fc1: 83 % of the gradient bytes) is the LAST gradient backward produces.  Its
+        contraction is cut into two row blocks (layers/functions.py:_Linear.backward); the first block's slice of
+        the wire buffer is packed and its all-reduce launched while the second block is still being computed."""
+        p = max(self.params, key=lambda q: q.numel())
+        if p.dim() != 2 or not (p.is_cuda or self.split_on_cpu):
+            return
+        cus = torch.cuda.get_device_properties(p.device).multi_processor_count if p.is_cuda else 256
+        ra = self.split_rows(p.shape[0], p.shape[1], cus)
+        if ra:
+            self._split = (p, ra, ra * p.shape[1])
+            p._dw_split = (ra, self._early_block)
+
+    def _early_block(self, dw_rows):
+        """Called from inside backward with the first row block of the split weight's gradient (fp32, contiguous)."""
+        flat, _ = self._wire_slices()
+        n = self._split[2]
+        assert dw_rows.numel() == n
+        H.pack_bf16_multi([(dw_rows.reshape(-1), flat[:n])])
+        self._early = dist.all_reduce(flat[:n], op=dist.ReduceOp.SUM, async_op=True)
+
     def _wire_slices(self):
-        """One flat bf16 buffer; tensor k owns [off_k, off_k + numel_k), offsets rounded up to 8 elements so that
-        every slice starts 16-byte aligned."""
+        """One flat bf16 buffer; every tensor owns a slice whose offset is rounded up to 8 elements (16-byte aligned).
+        The split weight comes first, so that its first row block is the head [0, rows * cols) of the buffer."""
         if self._wire is None:
-            offs, total = [], 0
-            for p in self.params:
-                offs.append(total)
+            order = list(self.params)
+            if self._split is not None:
+                order = [self._split[0]] + [p for p in order if p is not self._split[0]]
+            offs, total = {}, 0
+            for p in order:
+                offs[id(p)] = total
                 total += (p.numel() + 7) // 8 * 8
             flat = torch.zeros(total, dtype=torch.bfloat16, device=self.params[0].device)
-            self._wire = (flat, [flat[o:o + p.numel()] for o, p in zip(offs, self.params)])
+            self._wire = (flat, [flat[offs[id(p)]:offs[id(p)] + p.numel()] for p in self.params])
         return self._wire
 
     def _exchange_bf16(self):
         flat, slices = self._wire_slices()
         pairs = []
+        early, head = self._early, 0
+        self._early = None
+        if self._split is not None and early is None and self._split[0].grad is None and not self.reduce_unused:
+            raise RuntimeError("the split weight received no gradient: every rank must issue the same collectives")
         for p, sl in zip(self.params, slices):
             if p.grad is None:
                 if not self.reduce_unused:
                     continue
                 sl.zero_()  # this rank contributes nothing to a tensor another rank may have touched
             else:
-                pairs.append((p.grad if p.grad.is_contiguous() else p.grad.contiguous(), sl))
+                g = (p.grad if p.grad.is_contiguous() else p.grad.contiguous()).reshape(-1)
+                if early is not None and p is self._split[0]:  # its head is already packed and on the wire
+                    head = self._split[2]
+                    pairs.append((g[head:], sl[head:]))
+                else:
+                    pairs.append((g, sl))
             p._wire_grad = sl
         H.pack_bf16_multi(pairs)
         for p in self.params:  # the fp32 gradients are dead once packed (stream-ordered free): the update reads the slices
             p.grad = None
-        return [dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
+        if self._split is not None and early is None:
+            # the early block did not come (e.g. a non-TN contraction): keep the collective sequence of the other ranks
+            head = self._split[2]
+            early = dist.all_reduce(flat[:head], op=dist.ReduceOp.SUM, async_op=True)
+        return [early, dist.all_reduce(flat[head:], op=dist.ReduceOp.SUM, async_op=True)] if head else \
+            [dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
 
     def run_step(self, data):
         st = self.model.forward_frozen(data)

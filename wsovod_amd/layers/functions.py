@@ -50,6 +50,9 @@ class _Linear(Function):
         ctx.relu, ctx.dropout_p = relu, dropout_p
         ctx.save_for_backward(x, weight, y if (relu or dropout_p > 0) else None)
         ctx.has_bias = bias is not None
+        # (rows, callback) set by a data-parallel trainer on ONE large weight: its gradient is produced in two row
+        # blocks and the callback sees the first as soon as it is enqueued (engine/trainer.py: early exchange)
+        ctx.dw_split = getattr(weight, "_dw_split", None)
         return y
 
     @staticmethod
@@ -73,9 +76,17 @@ class _Linear(Function):
                                    ld_t=Mp, ld_plain=Np, colsum=db)
         dx = dw = None
         if tn:
-            dw = H.gemm_tn(dA, x)  # (Np, K)
-            if Np != N:
-                dw = dw[:N]
+            split = ctx.dw_split
+            if split is not None and Np == N and 0 < split[0] < N and split[0] % 8 == 0:
+                ra = split[0]  # two launches over row blocks of dW; the first block is handed over before the second runs
+                dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
+                H.gemm_tn(dA[:, :ra], x, out=dw[:ra])
+                split[1](dw[:ra])
+                H.gemm_tn(dA[:, ra:], x, out=dw[ra:])
+            else:
+                dw = H.gemm_tn(dA, x)  # (Np, K)
+                if Np != N:
+                    dw = dw[:N]
         elif need_dw:
             xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
             dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
