@@ -533,14 +533,33 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restric
 // roi_heads.py:762-763; the per-proposal repeat of data_aware_features_head.py:117-121 is
 // never materialised)
 template <typename T>
-__global__ void add_group_rows_kernel(const T* __restrict__ x, long long ldx, const int* __restrict__ row_group,
-                                      const float* __restrict__ add, long long lda, int M, int N,
-                                      T* __restrict__ out, long long ldo) {
-  const long long total = (long long)M * N;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / N), n = (int)(i - (long long)m * N);
-    out[(long long)m * ldo + n] = from_f32<T>(to_f32(x[(long long)m * ldx + n]) + add[(long long)row_group[m] * lda + n]);
+__global__ __launch_bounds__(256) void add_group_rows_kernel(const T* __restrict__ x, long long ldx,
+                                                             const int* __restrict__ row_group,
+                                                             const float* __restrict__ add, long long lda, int M, int N,
+                                                             T* __restrict__ out, long long ldo) {
+  // a workgroup owns RB consecutive rows; a lane owns 8 columns (16 B of bf16) of each: RB independent 16-byte loads
+  // in flight per lane, no per-element index division
+  constexpr int RB = 8;
+  const bool x_al = ((ldx * sizeof(T)) % 16 == 0) && (((uintptr_t)x & 15) == 0);
+  const bool o_al = ((ldo * sizeof(T)) % 16 == 0) && (((uintptr_t)out & 15) == 0);
+  const bool a_al = ((lda * sizeof(float)) % 16 == 0) && (((uintptr_t)add & 15) == 0);
+  for (int m0 = blockIdx.x * RB; m0 < M; m0 += gridDim.x * RB) {
+    for (int n = threadIdx.x * 8; n < N; n += 256 * 8) {
+      const bool full = n + 8 <= N;
+      float v[RB][8];
+#pragma unroll
+      for (int r = 0; r < RB; ++r)
+        if (m0 + r < M) load8(x + (long long)(m0 + r) * ldx + n, x_al && full, N - n, v[r]);
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        if (m0 + r >= M) continue;
+        float a[8];
+        load8(add + (long long)row_group[m0 + r] * lda + n, a_al && full, N - n, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[r][j] += a[j];
+        store8(out + (long long)(m0 + r) * ldo + n, o_al && full, N - n, v[r]);
+      }
+    }
   }
 }
 
@@ -601,7 +620,7 @@ int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* ro
   static int slot = wsovod::prof_slot("add_group_rows");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 4.0 : 8.0));
-  const int grid = grid_for((long long)M * N, 256);
+  const int grid = std::min(ceil_div(M, 8), 1 << 20);  // 8 rows per block step
   if (dtype == WSOVOD_BF16)
     hipLaunchKernelGGL(add_group_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, row_group, add, ld_add, M, N, (bf16_t*)out, ldo);
   else if (dtype == WSOVOD_F32)

@@ -54,12 +54,25 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const uint8_t* __restri
   }
   const bf16_t zero = (bf16_t)0.f;
   f32x4 acc[4][4];
+  // (n, ho, wo) of the wavefront's first pixel: one wave-uniform division (the launcher guarantees total < 2^31);
+  // the lanes' pixels follow by carries -- this kernel is VALU-bound and per-lane 64-bit divisions were 70 % of it.
+  const unsigned mb = (unsigned)__builtin_amdgcn_readfirstlane((int)m_base);
+  const unsigned row0 = mb / (unsigned)Wo;
+  const int wo0 = (int)(mb - row0 * (unsigned)Wo);
+  const int n0 = (int)(row0 / (unsigned)Ho);
+  const int ho0 = (int)(row0 - (unsigned)n0 * (unsigned)Ho);
+  const int last = (int)(total - 1 - m_base);  // >= 0
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long m = min(m_base + i * 16 + frow, total - 1);  // clamp: the tail lanes recompute the last pixel
-    const int wo = (int)(m % Wo);
-    const int ho = (int)((m / Wo) % Ho);
-    const int n = (int)(m / ((long long)Wo * Ho));
+    const int o = min(i * 16 + frow, last);  // clamp: the tail lanes recompute the last pixel
+    int wo = wo0 + o, ho = ho0, n = n0;
+    while (wo >= Wo) {  // at most ceil(64 / Wo) rounds
+      wo -= Wo;
+      if (++ho == Ho) {
+        ho = 0;
+        ++n;
+      }
+    }
     const int hi = sizes[2 * n], wi = sizes[2 * n + 1];
     const uint8_t* base = img + ((long long)n * 3 * Hp + 2 * ho) * Wp + 2 * wo;
     bf16x8 a;
@@ -107,6 +120,7 @@ extern "C" int wsovod_stem_conv1(const unsigned char* img, const int* sizes, con
                "wsovod_stem_conv1: weights / bias / output must be 16-byte aligned");
   const int Ho = (Hp - 1) / 2 + 1, Wo = (Wp - 1) / 2 + 1;
   const long long total = (long long)N * Ho * Wo;
+  WS_CHECK_ARG(total < (1ll << 31) - 64, "wsovod_stem_conv1: more than 2^31 output pixels in one launch");
   static int slot = wsovod::prof_slot("stem_conv1_fused");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 2.0 * total * 64 * 27, (double)N * 3 * Hp * Wp + (double)total * 128);
