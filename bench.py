@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
@@ -64,7 +64,7 @@ def pmc_traffic(kernel_name, args):
     profiled workload; otherwise null."""
     import re
 
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}_bf16.json")
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}_bf16.json")  # written by tools/collect_profiles.sh
     if not (os.path.exists(path) and args.precision == "bf16" and args.depth == 18 and args.proposals == 512):
         return None
     if getattr(args, "rpn", False):

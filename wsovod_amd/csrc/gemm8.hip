@@ -106,9 +106,11 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   // conv: (filter row, filter column, first channel) of a K-step, advanced incrementally (scalar adds instead of the
   // two integer divisions per staged K-step)
   struct Tap { int r, q, c0; };
-  auto tap_next = [&](Tap t) {
-    t.c0 += BKE;
-    if (t.c0 >= p.Cin) { t.c0 = 0; if (++t.q >= p.KW) { t.q = 0; ++t.r; } }
+  auto tap_next = [&](Tap t) {  // (channel chunk, tap) order with the tap innermost, as gemm.hip: the taps of a chunk
+    if (++t.q >= p.KW) {        // re-read the same input pixels while they are still in L2
+      t.q = 0;
+      if (++t.r >= p.KH) { t.r = 0; t.c0 += BKE; }
+    }
     return t;
   };
   auto stage_A = [&](int kt, int buf, int i, const Tap t) {
@@ -128,9 +130,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     }
 #endif
   };
-  auto stage_B = [&](int kt, int buf, int i) {
+  auto stage_B = [&](int kt, int buf, int i, const Tap t) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int kbase = kt * BKE;
+    const int kbase = CONV ? (t.r * p.KW + t.q) * p.Cin + t.c0 : kt * BKE;  // conv: weight rows are [kh][kw][Cin]
     const bool k_ok = kbase + lchunk * EPC < p.K;
     char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16,
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   Tap t1 = tap_next(t0);   // K-step kt + 1
   Tap t2 = tap_next(t1);   // K-step kt + 2
   stage_A(0, 0, 0, t0); stage_A(0, 0, 2, t0);
-  stage_B(0, 0, 0); stage_B(0, 0, 1); stage_B(0, 0, 2); stage_B(0, 0, 3);
+  stage_B(0, 0, 0, t0); stage_B(0, 0, 1, t0); stage_B(0, 0, 2, t0); stage_B(0, 0, 3, t0);
   stage_A(0, 0, 1, t0); stage_A(0, 0, 3, t0);
   if (nk > 1) { stage_A(1, 1, 0, t1); stage_A(1, 1, 2, t1); }
   WS_VMCNT(0);
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       WS_DS_READ(af[i][0], bA + i * 2048 + c0);
       WS_DS_READ(af[i][1], bA + i * 2048 + c1);
     }
-    if (more) { stage_B(kt + 1, cur ^ 1, 0); stage_B(kt + 1, cur ^ 1, 1); }
+    if (more) { stage_B(kt + 1, cur ^ 1, 0, t1); stage_B(kt + 1, cur ^ 1, 1, t1); }
     __builtin_amdgcn_s_barrier();
     WS_LGKM0_12();
     __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       WS_DS_READ(bh[j][1], bB + (2 + j) * 2048 + c1);
     }
     if (more) {
-      stage_B(kt + 1, cur ^ 1, 2); stage_B(kt + 1, cur ^ 1, 3);
+      stage_B(kt + 1, cur ^ 1, 2, t1); stage_B(kt + 1, cur ^ 1, 3, t1);
       WS_VMCNT(6);  // younger: A_lo(kt+1), B(kt+1) -> A_hi(kt) has landed
     } else {
       WS_VMCNT(0);
