@@ -408,10 +408,13 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   args.tiles_m = ceil_div(a.M, 256);
   args.tiles_n = ceil_div(a.N, 256);
   {
+    // Tile-order group height.  What has to share L2 is the set of workgroups an XCD runs AT THE SAME TIME (32 CUs x 1
+    // workgroup), not its whole run of tiles: group_m x (32 / group_m) of them should be near-square.  Measured on the fc1
+    // forward shape (16384 x 4096 x 25088): group 2/4/8/11/16/32 -> 1345/1350/1322/1298/1292/1260 TFLOP/s.
     const int run = std::max(1, args.tiles_m * args.tiles_n / 8);
     int g = 1;
     while ((g + 1) * (g + 1) <= run) ++g;
-    args.group_m = std::max(1, std::min(g, args.tiles_m));
+    args.group_m = std::max(1, std::min(std::min(g, 4), args.tiles_m));
   }
   wsovod::ProfScope prof(conv ? slot_c : slot_g, s, flops, bytes);
   if (conv)

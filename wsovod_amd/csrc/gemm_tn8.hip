@@ -248,7 +248,8 @@ extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long 
     const int run = std::max(1, a.tiles_i * a.tiles_j / 8);
     int g = 1;
     while ((g + 1) * (g + 1) <= run) ++g;
-    a.group_m = std::max(1, std::min(g, a.tiles_i));
+    // near-square CONCURRENT set per XCD (32 workgroups), see gemm8.hip; fc1 dW shape: group 4/8/14/16 -> 1197/1207/1154/1172
+    a.group_m = std::max(1, std::min(std::min(g, 8), a.tiles_i));
   }
   static int slot = wsovod::prof_slot("gemm_tn_bf16_256x256_tr");
   static bool attr_set = false;
