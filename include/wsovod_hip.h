@@ -131,6 +131,9 @@ typedef struct {
   int n_img, H, W, Cin; /* input NHWC */
   int Ho, Wo;           /* output spatial size */
   int KH, KW, stride, pad, dil;
+  int pool; /* 0, or 2: MaxPool2d(2, 2) of the conv output (stem tail resnet_wsl.py:418-420, BasicBlock tail :85-92)
+               applied in the epilogue; C is then the pooled (n_img, Ho/2, Wo/2, N) map and the full-resolution output is
+               never written.  Only the bf16 64 -> 64 channel 3x3 stride-1 kernel implements it (error otherwise). */
 } wsovod_conv_geom;
 
 typedef struct {

@@ -306,3 +306,31 @@ def test_conv3x3_c64_halo_kernel_with_residual(gpu):
     names = [e["name"] for e in _lib.profile_collect() if e["launches"] > 0]
     _lib.profile_enable(False)
     assert "conv3x3_c64_halo_bf16" in names  # the dedicated kernel is the one that ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 40, 64), (3, 41, 67), (1, 300, 400)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv3x3_c64_fused_maxpool_equals_conv_then_pool(gpu, shape, with_res):
+    """geom.pool = 2: the 64-channel kernel's epilogue applies MaxPool2d(2, 2) (stem tail / res2 block tail).  Same bits
+    as the unfused conv followed by the pool kernel (rounding to bf16 is monotonic), odd sizes drop the last row/column
+    as the pool does; any other conv shape with pool set is refused."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(11)
+    n, H, W = shape
+    x = torch.randn(n, H, W, 64, device=gpu).to(torch.bfloat16)
+    w = (torch.randn(64, 9 * 64, device=gpu) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(64, device=gpu)
+    res = torch.randn(n * H * W, 64, device=gpu).to(torch.bfloat16) if with_res else None
+    geom = dict(n_img=n, H=H, W=W, Cin=64, Ho=H, Wo=W, KH=3, KW=3, stride=1, pad=1, dil=1)
+    full = hip_ops.gemm_nt(x, w, conv=geom, bias=bias, relu=True, residual=res, out_dtype=torch.bfloat16)
+    want = hip_ops.maxpool2x2_nhwc(full.view(n, H, W, 64), 2)
+    got = hip_ops.gemm_nt(x, w, conv=dict(geom, pool=2), bias=bias, relu=True, residual=res, out_dtype=torch.bfloat16)
+    assert got.shape == (n * (H // 2) * (W // 2), 64)
+    assert torch.equal(got.view(n, H // 2, W // 2, 64), want)
+    x128 = torch.randn(1, 16, 16, 128, device=gpu).to(torch.bfloat16)
+    w128 = torch.randn(64, 9 * 128, device=gpu).to(torch.bfloat16)
+    with pytest.raises(RuntimeError, match="pool"):
+        hip_ops.gemm_nt(x128, w128, conv=dict(n_img=1, H=16, W=16, Cin=128, Ho=16, Wo=16, KH=3, KW=3, stride=1, pad=1,
+                                              dil=1, pool=2), out_dtype=torch.bfloat16)

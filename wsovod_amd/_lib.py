@@ -19,7 +19,7 @@ NCHW, NHWC = 0, 1
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, C.c_int) for n in
-                ("n_img", "H", "W", "Cin", "Ho", "Wo", "KH", "KW", "stride", "pad", "dil")]
+                ("n_img", "H", "W", "Cin", "Ho", "Wo", "KH", "KW", "stride", "pad", "dil", "pool")]
 
 
 class GemmDesc(C.Structure):

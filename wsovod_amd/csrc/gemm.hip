@@ -541,6 +541,58 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
                    (!p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0));
   const float lo = p.relu ? 0.f : -__builtin_inff();
   const int n0c = 16 * fq;
+  if (p.pool) {
+    // Fused MaxPool2d(2, 2) (stem tail resnet_wsl.py:418-420, block tail :85-92,107-108): the wavefront's two image rows
+    // are the two rows of one pooled row (y0 and wave*2 are even), the horizontal partner is the neighbouring lane
+    // (frow ^ 1, same channels).  Values are rounded to bf16 first, as the unfused conv output was, so the pooled map has
+    // the same bits as conv -> maxpool2x2_nhwc; the full-resolution map is never written.  (launcher: bf16, aligned)
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float best[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
+#pragma unroll
+      for (int iv = 0; iv < 2; ++iv) {
+        const int i = ih + 2 * iv;
+        const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
+        const long long m = ((long long)img * p.H + y) * p.W + x;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n0c + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + b4[r];
+        }
+        if (p.residual) {
+          const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
+          const bf16x8 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] += (float)r0[e];
+            v[8 + e] += (float)r1[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], (float)(bf16_t)fmaxf(v[e], lo));
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
+      const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
+      if ((frow & 1) == 0 && py < Hp && px < Wp) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o0[e] = (bf16_t)best[e];
+          o1[e] = (bf16_t)best[8 + e];
+        }
+        bf16x8* dst = (bf16x8*)((bf16_t*)p.C + (((long long)img * Hp + py) * Wp + px) * p.ldc + n0c);
+        dst[0] = o0;
+        dst[1] = o1;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int y = y0 + wave * 2 + (i >> 1);
@@ -765,6 +817,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     a.stride = g.stride;
     a.pad = g.pad;
     a.dil = g.dil;
+    a.pool = g.pool;
     a.a_bytes = (long long)g.n_img * g.H * g.W * g.Cin * esz;
     WS_CHECK_ARG(a.a_bytes < (1ll << 31), "wsovod_gemm_nt(conv): input of %lld bytes exceeds the 2 GiB buffer-addressing limit", a.a_bytes);
     bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K) * esz;
@@ -780,6 +833,12 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W && d->C && !d->Ct &&
       !d->row_scale && !d->group_add && !d->mask_src && !d->accumulate && d->dropout_p == 0.f) {
     static int slot = wsovod::prof_slot("conv3x3_c64_halo_bf16");
+    if (a.pool) {
+      WS_CHECK_ARG(a.pool == 2 && d->dtype_c == WSOVOD_BF16 && (d->ldc & 7) == 0 && ((uintptr_t)d->C & 15) == 0 &&
+                       (!d->bias || ((uintptr_t)d->bias & 15) == 0) &&
+                       (!d->residual || (d->dtype_r == WSOVOD_BF16 && (d->ldr & 7) == 0 && ((uintptr_t)d->residual & 15) == 0)),
+                   "wsovod_gemm_nt(conv, pool): the fused 2x2 max pool needs bf16, 16-byte aligned output / residual");
+    }
     const int lds_bytes = C64_PATCH_BYTES + 2 * 8192;
     const int tiles_x = ceil_div(a.W, C64_TW), tiles_y = ceil_div(a.H, C64_TH);
     wsovod::ProfScope prof(slot, s, flops, bytes);
@@ -788,6 +847,8 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64)");
     return WSOVOD_OK;
   }
+  WS_CHECK_ARG(!(d->conv && d->geom.pool), "wsovod_gemm_nt(conv): geom.pool is an epilogue of the bf16 64-channel 3x3 "
+               "kernel only (stride 1, pad 1, dilation 1, no tile_hint)");
   int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
   // plain bf16 contractions take the staggered 8-wavefront form of the 256x256 tile (measured +11-13 % on the FC
   // shapes, tools/gemm_ab.py); the implicit-GEMM conv stays on the 16-wavefront form (tools/conv_ab.py)

@@ -34,6 +34,7 @@ struct GemmArgs {
   int accumulate;
   // implicit-GEMM convolution geometry
   int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
+  int pool;  // conv3x3_c64 only: 2 = MaxPool2d(2, 2) fused into the epilogue, C is the pooled map
   long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
   int tiles_m, tiles_n;
   int group_m;  // tile-order group height (see the XCD remap in the kernel)

@@ -239,7 +239,8 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
         d.A, d.lda = A.data_ptr(), _ld(A)
     if want_c:
         if out is None:
-            out = torch.empty((d.M, d.N), dtype=out_dtype or A.dtype, device=B.device)
+            rows = d.M if not (conv is not None and d.geom.pool) else d.geom.n_img * (d.geom.Ho // 2) * (d.geom.Wo // 2)
+            out = torch.empty((rows, d.N), dtype=out_dtype or A.dtype, device=B.device)
         d.C, d.ldc, d.dtype_c = out.data_ptr(), _ld(out), dtype_code(out.dtype)
     if out_t is not None:
         d.Ct, d.ldct, d.dtype_ct = out_t.data_ptr(), _ld(out_t), dtype_code(out_t.dtype)

@@ -87,8 +87,10 @@ class Conv2d(nn.Module):
         return self._folded[1], self._folded[2]
 
 
-def hip_conv(x, conv, relu=False, residual=None):
-    """x: (N,H,W,Cin) NHWC contiguous in the compute dtype -> (N,Ho,Wo,Cout)."""
+def hip_conv(x, conv, relu=False, residual=None, pool2=False):
+    """x: (N,H,W,Cin) NHWC contiguous in the compute dtype -> (N,Ho,Wo,Cout); with pool2 the MaxPool2d(2, 2) that
+    follows the conv in the stem / block tail is applied too -> (N,Ho//2,Wo//2,Cout).  The 64-channel bf16 kernel pools
+    in its epilogue (the full-resolution map is never written); every other conv is followed by the pool kernel."""
     N, Hh, Ww, Cin = x.shape
     k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     Ho = (Hh + 2 * p - d * (k - 1) - 1) // s + 1
@@ -96,8 +98,15 @@ def hip_conv(x, conv, relu=False, residual=None):
     wq, b = conv.folded(x.dtype, cin_pad=Cin)
     geom = dict(n_img=N, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=s, pad=p, dil=d)
     res2d = residual.view(N * Ho * Wo, conv.out_channels) if residual is not None else None
+    fused = (pool2 and x.dtype == torch.bfloat16 and Cin == 64 and conv.out_channels == 64 and (k, s, p, d) == (3, 1, 1, 1)
+             and (residual is None or residual.dtype == torch.bfloat16))
+    if fused:
+        geom["pool"] = 2
+        out = H.gemm_nt(x, wq, conv=geom, bias=b, relu=relu, residual=res2d, out_dtype=x.dtype)
+        return out.view(N, Ho // 2, Wo // 2, conv.out_channels)
     out = H.gemm_nt(x, wq, conv=geom, bias=b, relu=relu, residual=res2d, out_dtype=x.dtype)
-    return out.view(N, Ho, Wo, conv.out_channels)
+    out = out.view(N, Ho, Wo, conv.out_channels)
+    return H.maxpool2x2_nhwc(out, 2) if pool2 else out
 
 
 class CNNBlockBase(nn.Module):
@@ -145,6 +154,8 @@ class BasicBlock(CNNBlockBase, _PoolMixin):
     def forward(self, x):
         out = hip_conv(x, self.conv1, relu=True)
         shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
+        if self.has_pool and self.pool_stride == 2:  # stride-2 tail pool (res2): fused where the kernel has it
+            return hip_conv(out, self.conv2, relu=True, residual=shortcut, pool2=True)
         out = hip_conv(out, self.conv2, relu=True, residual=shortcut)  # out += shortcut; relu
         return self._pool(out)
 
@@ -198,8 +209,7 @@ class BasicStem(CNNBlockBase):
 
     def _tail(self, x):
         x = hip_conv(x, self.conv2, relu=True)
-        x = hip_conv(x, self.conv3, relu=True)
-        return H.maxpool2x2_nhwc(x, 2)
+        return hip_conv(x, self.conv3, relu=True, pool2=True)
 
     def forward(self, x):
         """x: NHWC with Cin zero-padded to the kernel's K-step (generic float entry)."""
