@@ -106,6 +106,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
     }
   }
+  // conv: everything per-lane about a tap is hoisted out of the K loop -- the byte offset of the lane's pixel with the
+  // filter at its top-left position, and one validity bit per tap (image bounds / rows past M).  A K-step then costs one
+  // add of a wave-uniform tap offset and one bit test per staged chunk instead of two integer multiplies and four compares.
+  int pix_off[RA];
+  unsigned vmask[RA];
+  if (CONV) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      pix_off[i] = hi0[i] > -(1 << 27) ? a_off[i] + ((hi0[i] * p.W + wi0[i]) * p.Cin) * esz : 0;  // rows past M: unused
+      unsigned mk = 0;
+      for (int r = 0; r < p.KH; ++r)
+        for (int q = 0; q < p.KW; ++q) {
+          const int hi = hi0[i] + r * p.dil, wi = wi0[i] + q * p.dil;
+          if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) mk |= 1u << (r * p.KW + q);
+        }
+      vmask[i] = mk;
+    }
+  }
   int b_off[RB];
 #pragma unroll
   for (int i = 0; i < RB; ++i) {
@@ -134,14 +152,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       const int r = tap / p.KW;
       const int q = tap - r * p.KW;
       kbase = tap * p.Cin + c0;  // position of this K-step in the weight rows ([kh][kw][Cin])
+      const int delta = (((r * p.W + q) * p.dil) * p.Cin + c0) * esz;  // wave-uniform
 #pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const int hi = hi0[i] + r * p.dil;
-        const int wi = wi0[i] + q * p.dil;
-        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + c0) * esz;
-        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, ok ? off : -1, 0, 0);
-      }
+      for (int i = 0; i < RA; ++i)
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, ((vmask[i] >> tap) & 1u) ? pix_off[i] + delta : -1, 0, 0);
     }
     const bool k_ok = kbase + lchunk * EPC < p.K;
     if (!CONV) {
@@ -171,26 +185,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     int kbase = kt * BKE;
     char* dA = sA + buf * BM * 128 + wave_u * 1024;
     char* dB = sB + buf * BN * 128 + wave_u * 1024;
-    int r = 0, q = 0, c0 = 0;
+    int tap = 0, delta = 0;
     if (CONV) {  // (channel chunk, tap) order, tap innermost: see load_global
       const int taps = p.KH * p.KW;
       const int chunk = kt / taps;
-      const int tap = kt - chunk * taps;
-      c0 = chunk * BKE;
-      r = tap / p.KW;
-      q = tap - r * p.KW;
+      tap = kt - chunk * taps;
+      const int c0 = chunk * BKE;
+      const int r = tap / p.KW;
+      const int q = tap - r * p.KW;
       kbase = tap * p.Cin + c0;
+      delta = (((r * p.W + q) * p.dil) * p.Cin + c0) * esz;  // wave-uniform
     }
     const bool k_ok = kbase + lchunk * EPC < p.K;
     if (CONV) {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const int hi = hi0[i] + r * p.dil;
-        const int wi = wi0[i] + q * p.dil;
-        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + c0) * esz;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dA + LR * i * 128), 16, ok ? off : -1, 0, 0, 0);
-      }
+      for (int i = 0; i < RA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dA + LR * i * 128), 16,
+                                                 ((vmask[i] >> tap) & 1u) ? pix_off[i] + delta : -1, 0, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
@@ -805,6 +816,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     const int bke = d->dtype_in == WSOVOD_BF16 ? 64 : 32;
     WS_CHECK_ARG(g.Cin > 0 && g.Cin % bke == 0, "wsovod_gemm_nt(conv): Cin=%d must be a multiple of %d", g.Cin, bke);
     WS_CHECK_ARG(d->K == g.KH * g.KW * g.Cin, "wsovod_gemm_nt(conv): K=%d != KH*KW*Cin", d->K);
+    WS_CHECK_ARG(g.KH * g.KW <= 32, "wsovod_gemm_nt(conv): filters of more than 32 taps are not supported (per-tap validity mask)");
     WS_CHECK_ARG((long long)d->M == (long long)g.n_img * g.Ho * g.Wo, "wsovod_gemm_nt(conv): M=%d != n_img*Ho*Wo", d->M);
     WS_CHECK_ARG(g.stride >= 1 && g.dil >= 1 && g.pad >= 0, "wsovod_gemm_nt(conv): bad stride/dil/pad");
     a.H = g.H;
