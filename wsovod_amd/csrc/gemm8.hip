@@ -97,6 +97,23 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     b_off[i] = n0 + src < p.N ? (int)(((long long)src * p.ldb + lchunk * EPC) * esz) : -1;
   }
   const int nk = (p.K + BKE - 1) / BKE;
+  // conv: per-lane pixel offset (filter at its top-left tap) and one validity bit per tap, hoisted out of the K loop
+  // exactly as in gemm.hip
+  [[maybe_unused]] int pix_off[4];
+  [[maybe_unused]] unsigned vmask[4];
+  if (CONV) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pix_off[i] = hi0[i] > -(1 << 27) ? a_off[i] + ((hi0[i] * p.W + wi0[i]) * p.Cin) * esz : 0;
+      unsigned mk = 0;
+      for (int r = 0; r < p.KH; ++r)
+        for (int q = 0; q < p.KW; ++q) {
+          const int hi = hi0[i] + r * p.dil, wi = wi0[i] + q * p.dil;
+          if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) mk |= 1u << (r * p.KW + q);
+        }
+      vmask[i] = mk;
+    }
+  }
 
   typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -118,11 +135,10 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     const int kbase = kt * BKE;
     char* dA = sA + buf * BM * 128 + wave_u * 1024 + LR * i * 128;
     if (CONV) {
-      const int hi = hi0[i] + t.r * p.dil;
-      const int wi = wi0[i] + t.q * p.dil;
-      const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-      const int off = a_off[i] + ((hi * p.W + wi) * p.Cin + t.c0) * esz;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, ok ? off : -1, 0, 0, 0);
+      const int tap = t.r * p.KW + t.q;
+      const int delta = (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
+                                               ((vmask[i] >> tap) & 1u) ? pix_off[i] + delta : -1, 0, 0, 0);
     } else {
       const bool k_ok = kbase + lchunk * EPC < p.K;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
