@@ -3,97 +3,85 @@
 // gather and the contraction in one kernel -- the (pixels x 32) bf16 im2col operand (123 MB per 16 images) is never
 // written.  HBM-bound: 23 MB of uint8 in, 245 MB of bf16 NHWC out per 16 images.
 //
-// A wavefront owns 64 consecutive output pixels x 64 channels = 4 x 4 MFMA tiles of one K = 32 step (k = (r*3+q)*3+c,
-// 27 real taps + 5 zeros: the layout of wsovod_stem_im2col, so the folded weights are shared).  A fragments are built
-// in registers: lane (pixel = lane & 15 of the tile, k-group g = lane >> 4) gathers its 8 taps as byte loads --
-// consecutive lanes read every second byte of an image row -- normalises them with the same expression as the
-// im2col kernel (bit-identical operand) and packs them to bf16.  B fragments (the 64 x 32 weight) live in registers.
-// The MFMA takes the weight fragment first, so a lane ends up with 4 consecutive channels of its pixel: one 8-byte
-// store per tile.
+// A workgroup owns an 8 x 32 tile of output pixels.  Its 17 x 65 x 3 input patch is normalised ONCE into LDS as bf16
+// (zero outside the image: padding is zero AFTER normalisation, and the batch canvas is zero outside each image's own
+// size), every byte of the image is read and converted once instead of 2.25 times, and the gather that builds the MFMA
+// A fragments is 8 LDS reads per lane and 16-pixel group with no bounds test left in it (the first version gathered
+// from global memory with per-tap tests and was VALU-bound at 4x the HBM time).  K = 32 per MFMA: k = (r*3+q)*3+c,
+// 27 real taps + 5 zeros -- the layout of wsovod_stem_im2col, so the folded weights are shared and the operand is
+// bit-identical.  B fragments (the 64 x 32 weight) live in registers.  The MFMA takes the weight fragment first, so a
+// lane ends up with 16 consecutive channels of its pixel: a pixel's 128-byte row leaves as 4 lanes x 32 bytes.
 #include "common.h"
 
 namespace {
 
+constexpr int S_TH = 8, S_TW = 32;                    // output tile
+constexpr int S_PR = 2 * S_TH + 1, S_PC = 2 * S_TW + 1;  // input patch rows / columns
+constexpr int S_PCP = S_PC + 1;                       // padded row length (elements)
+
 __global__ __launch_bounds__(256) void stem_conv1_kernel(const uint8_t* __restrict__ img, const int* __restrict__ sizes,
                                                          float m0, float m1, float m2, float s0, float s1, float s2,
-                                                         int N, int Hp, int Wp, int Ho, int Wo,
+                                                         int N, int Hp, int Wp, int Ho, int Wo, int tiles_x, int tiles_y,
                                                          const bf16_t* __restrict__ w32, const float* __restrict__ bias,
                                                          bf16_t* __restrict__ out) {
-  // normalised value of every (channel, byte) as bf16: 768 table entries replace a float divide per gathered tap
-  __shared__ bf16_t lut[3 * 256];
-  for (int e = threadIdx.x; e < 768; e += 256) {
-    const int c = e >> 8;
-    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-    lut[e] = (bf16_t)(((float)(e & 255) - mean) / sd);
-  }
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ bf16_t patch[3 * S_PR * S_PCP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, g = lane >> 4;
-  const long long total = (long long)N * Ho * Wo;
-  const long long m_base = ((long long)blockIdx.x * 4 + wave) * 64;
-  if (m_base >= total) return;
+  const int tpi = tiles_x * tiles_y;
+  const int n = blockIdx.x / tpi;
+  const int t_in = blockIdx.x - n * tpi;
+  const int ty = t_in / tiles_x, tx = t_in - ty * tiles_x;
+  const int y0 = ty * S_TH, x0 = tx * S_TW;
+  const int hi = sizes[2 * n], wi = sizes[2 * n + 1];
+  // ---- stage the normalised patch: element (c, row, col) = image pixel (2*y0 - 1 + row, 2*x0 - 1 + col) of channel c
+  const uint8_t* plane = img + (long long)n * 3 * Hp * Wp;
+  for (int e = tid; e < 3 * S_PR * S_PC; e += 256) {
+    const int c = e / (S_PR * S_PC);
+    const int rem = e - c * (S_PR * S_PC);
+    const int row = rem / S_PC, col = rem - row * S_PC;
+    const int h = 2 * y0 - 1 + row, w = 2 * x0 - 1 + col;
+    const bool ok = h >= 0 && w >= 0 && h < hi && w < wi;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    const float v = ok ? ((float)plane[((long long)c * Hp + h) * Wp + w] - mean) / sd : 0.f;
+    patch[(c * S_PR + row) * S_PCP + col] = (bf16_t)v;  // same expression as wsovod_stem_im2col: bit-identical operand
+  }
   // weight fragments.  Row rho = lane & 15 of tile j is output channel 16*(rho>>2) + 4*j + (rho&3): after the MFMA
-  // (weights first) lane (pixel = lane&15, g) then owns channels 16g + 4j + r -- 16 CONSECUTIVE channels, so a pixel's
-  // 128-byte row is written as 4 lanes x 32 contiguous bytes.
+  // (weights first) lane (pixel = lane&15, g) then owns channels 16g + 4j + r -- 16 CONSECUTIVE channels.
   bf16x8 bw[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) bw[j] = *(const bf16x8*)(w32 + (16 * (frow >> 2) + 4 * j + (frow & 3)) * 32 + g * 8);
-  // this lane's 8 taps: k = 8g + t -> (r, q, c); image offset relative to (c = 0, h = 2*ho, w = 2*wo)
-  int dr[8], dq[8], ch[8];
-  long long doff[8];
+  // this lane's 8 taps: k = 8g + t -> (r, q, c) -> patch offset relative to the pixel's top-left patch element
+  int toff[8];
   bool real[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int k = 8 * g + t;
     const int tap = k / 3, c = k - 3 * tap, r = tap / 3, q = tap - 3 * r;
     real[t] = k < 27;
-    dr[t] = r - 1;
-    dq[t] = q - 1;
-    ch[t] = c << 8;
-    doff[t] = ((long long)c * Hp + (r - 1)) * Wp + (q - 1);
+    toff[t] = real[t] ? (c * S_PR + r) * S_PCP + q : 0;
   }
+  __syncthreads();
   const bf16_t zero = (bf16_t)0.f;
   f32x4 acc[4][4];
-  // (n, ho, wo) of the wavefront's first pixel: one wave-uniform division (the launcher guarantees total < 2^31);
-  // the lanes' pixels follow by carries -- this kernel is VALU-bound and per-lane 64-bit divisions were 70 % of it.
-  const unsigned mb = (unsigned)__builtin_amdgcn_readfirstlane((int)m_base);
-  const unsigned row0 = mb / (unsigned)Wo;
-  const int wo0 = (int)(mb - row0 * (unsigned)Wo);
-  const int n0 = (int)(row0 / (unsigned)Ho);
-  const int ho0 = (int)(row0 - (unsigned)n0 * (unsigned)Ho);
-  const int last = (int)(total - 1 - m_base);  // >= 0
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int o = min(i * 16 + frow, last);  // clamp: the tail lanes recompute the last pixel
-    int wo = wo0 + o, ho = ho0, n = n0;
-    while (wo >= Wo) {  // at most ceil(64 / Wo) rounds
-      wo -= Wo;
-      if (++ho == Ho) {
-        ho = 0;
-        ++n;
-      }
-    }
-    const int hi = sizes[2 * n], wi = sizes[2 * n + 1];
-    const uint8_t* base = img + ((long long)n * 3 * Hp + 2 * ho) * Wp + 2 * wo;
+    const int ly = wave * 2 + (i >> 1), lx = (i & 1) * 16 + frow;
+    const bf16_t* pb = patch + (2 * ly) * S_PCP + 2 * lx;
     bf16x8 a;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const int h = 2 * ho + dr[t], w = 2 * wo + dq[t];
-      const bool ok = real[t] && h >= 0 && w >= 0 && h < hi && w < wi;
-      a[t] = ok ? lut[ch[t] + base[doff[t]]] : zero;  // padding is zero AFTER normalisation
-    }
+    for (int t = 0; t < 8; ++t) a[t] = real[t] ? pb[toff[t]] : zero;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[j], a, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
-  // epilogue: acc[i][j][r] = pixel (i*16 + frow), channel 16g + 4j + r
+  // epilogue: acc[i][j][r] = pixel (row wave*2 + (i>>1), column (i&1)*16 + frow) of the tile, channel 16g + 4j + r
   f32x4 b4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) b4[j] = *(const f32x4*)(bias + 16 * g + 4 * j);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long m = m_base + i * 16 + frow;
-    if (m >= total) continue;
+    const int y = y0 + wave * 2 + (i >> 1), x = x0 + (i & 1) * 16 + frow;
+    if (y >= Ho || x >= Wo) continue;
     bf16x8 lo, hi8;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -102,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const uint8_t* __restri
       hi8[r] = (bf16_t)fmaxf(acc[i][2][r] + b4[2][r], 0.f);
       hi8[4 + r] = (bf16_t)fmaxf(acc[i][3][r] + b4[3][r], 0.f);
     }
-    bf16x8* dst = (bf16x8*)(out + m * 64 + 16 * g);
+    bf16x8* dst = (bf16x8*)(out + (((long long)n * Ho + y) * Wo + x) * 64 + 16 * g);
     dst[0] = lo;
     dst[1] = hi8;
   }
@@ -120,13 +108,14 @@ extern "C" int wsovod_stem_conv1(const unsigned char* img, const int* sizes, con
                "wsovod_stem_conv1: weights / bias / output must be 16-byte aligned");
   const int Ho = (Hp - 1) / 2 + 1, Wo = (Wp - 1) / 2 + 1;
   const long long total = (long long)N * Ho * Wo;
-  WS_CHECK_ARG(total < (1ll << 31) - 64, "wsovod_stem_conv1: more than 2^31 output pixels in one launch");
+  const int tiles_x = (Wo + S_TW - 1) / S_TW, tiles_y = (Ho + S_TH - 1) / S_TH;
+  WS_CHECK_ARG((long long)N * tiles_x * tiles_y < (1ll << 31), "wsovod_stem_conv1: too many tiles for one launch");
   static int slot = wsovod::prof_slot("stem_conv1_fused");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 2.0 * total * 64 * 27, (double)N * 3 * Hp * Wp + (double)total * 128);
-  hipLaunchKernelGGL(stem_conv1_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, img, sizes, mean_host[0],
-                     mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, Ho, Wo,
-                     (const bf16_t*)w32, bias, (bf16_t*)out);
+  hipLaunchKernelGGL(stem_conv1_kernel, dim3((unsigned)(N * tiles_x * tiles_y)), dim3(256), 0, s, img, sizes,
+                     mean_host[0], mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, Ho, Wo,
+                     tiles_x, tiles_y, (const bf16_t*)w32, bias, (bf16_t*)out);
   WS_CHECK_LAUNCH("wsovod_stem_conv1");
   return WSOVOD_OK;
 }
