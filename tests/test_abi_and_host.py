@@ -256,3 +256,40 @@ def test_embedding_and_backbone_pickles(tmp_path):
     assert unused == ["fc1000.weight"] and set(loaded) == set(sd)
     for k, v in bb.state_dict().items():
         assert np.array_equal(v.numpy(), ckpt[k]), k
+
+
+def test_cat_rows_returns_views_only_for_consecutive_blocks():
+    """hip_ops.cat_rows: a view when the inputs are consecutive row blocks of one buffer, torch.cat otherwise."""
+    from wsovod_amd.layers.hip_ops import cat_rows
+
+    base = torch.arange(60, dtype=torch.float32).view(15, 4)
+    parts = [base[0:4], base[4:4], base[4:9], base[9:15]]  # an empty block in the middle
+    v = cat_rows(parts)
+    assert v.data_ptr() == base.data_ptr() and torch.equal(v, base)
+    one_d = cat_rows([base.view(-1)[0:10], base.view(-1)[10:60]])
+    assert one_d.data_ptr() == base.data_ptr() and one_d.shape == (60,)
+    # not consecutive / different buffers / strided / requiring grad: a real concatenation with the right values
+    for bad in ([base[0:4], base[5:9]], [base[0:4], base[4:9].clone()], [base[0:4, :2], base[4:9, :2]]):
+        c = cat_rows(bad)
+        assert torch.equal(c, torch.cat(bad)) and c.data_ptr() != base.data_ptr()
+    g = base.clone().requires_grad_(True)
+    c = cat_rows([g[0:4], g[4:15]])
+    assert c.requires_grad and torch.equal(c, g)
+    assert cat_rows([base[2:7]]) is not None and cat_rows([base[2:7]]).data_ptr() == base[2:7].data_ptr()
+
+
+def test_split_rows_never_adds_a_tile_round():
+    """HotPathTrainer.split_rows: both launches together need exactly the tile rounds of the single launch."""
+    from wsovod_amd.engine import HotPathTrainer
+
+    def rounds(rows, cols, cus=256):
+        return -(-(-(-rows // 256) * -(-cols // 256)) // cus)
+
+    for rows, cols in ((4096, 25088), (4096, 100352), (4096, 4096), (1024, 4096), (300, 700), (8, 8)):
+        ra = HotPathTrainer.split_rows(rows, cols)
+        if ra == 0:
+            continue
+        assert 0 < ra < rows and ra % 256 == 0
+        assert rounds(ra, cols) + rounds(rows - ra, cols) == rounds(rows, cols), (rows, cols, ra)
+    assert HotPathTrainer.split_rows(4096, 25088) == 1280  # fc1 of WSR_18: 2 + 5 = 7 rounds
+    assert HotPathTrainer.split_rows(8, 8) == 0
