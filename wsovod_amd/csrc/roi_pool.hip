@@ -527,22 +527,39 @@ __device__ __forceinline__ AlignAxis align_axis(float v, int L) {
   return s;
 }
 
+constexpr int kAlignMaxGrid = 64;  // sample columns per bin the row kernel keeps in its LDS table (7 KB); wider rois recompute
+
 template <typename T, int PWT, int CPL>
 __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
-                                        const float* __restrict__ roi_scale, int C, int H, int W, int PH,
-                                        float spatial_scale, int sampling_ratio, int aligned, void* out, int out_dtype,
-                                        int cgroups) {
+                                                               const float* __restrict__ roi_scale, int C, int H, int W,
+                                                               int PH, float spatial_scale, int sampling_ratio,
+                                                               int aligned, void* out, int out_dtype, int cgroups) {
   typedef T vecc __attribute__((ext_vector_type(CPL)));
   constexpr int CG = 64 * CPL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int nbins = PH * PWT;
   float* sval = (float*)smem;
+  // The sample columns are the same for every lane (lane = channels), every pooled row and every sample row of the
+  // roi: their bilinear set-up (x position with its fp32 division, clamping, weights) is computed ONCE per workgroup
+  // by PWT*grid_w lanes into this table and read back as LDS broadcasts, instead of ~20 VALU instructions per bin and
+  // loop iteration on all 64 lanes (the kernel was VALU-bound on exactly that).  Record = {lo*C, hi*C, l, h}; lo < 0
+  // marks a sample outside the map.
+  int4* xtab = (int4*)(sval + CG * nbins);
   const int r = blockIdx.x / cgroups;
   const int c0 = (blockIdx.x - r * cgroups) * CG;
   const int c = c0 + lane * CPL;
   const AlignBox a = decode_align(rois + (long long)r * 5, spatial_scale, PH, PWT, sampling_ratio, aligned);
   const float scale = roi_scale ? roi_scale[r] : 1.0f;
+  auto x_record = [&](int pw, int ix) {
+    const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+    const AlignAxis ax = align_axis(x, W);
+    return int4{ax.valid ? ax.lo * C : -1, ax.hi * C, __float_as_int(ax.l), __float_as_int(ax.h)};
+  };
+  const bool tabled = a.grid_w <= kAlignMaxGrid;  // uniform over the workgroup
+  if (tabled)
+    for (int e = threadIdx.x; e < PWT * a.grid_w; e += blockDim.x) xtab[e] = x_record(e / a.grid_w, e % a.grid_w);
+  __syncthreads();
   const T* base = feat + (long long)a.batch * H * W * C + (c < C ? c : 0);
   float acc[PWT][CPL];
 #pragma unroll
@@ -556,21 +573,22 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
     const T* r0 = base + (long long)ay.lo * W * C;
     const T* r1 = base + (long long)ay.hi * W * C;
     for (int ix = 0; ix < a.grid_w; ++ix) {
-      AlignAxis ax[PWT];
+      int4 rec[PWT];
       vecc v1[PWT], v2[PWT], v3[PWT], v4[PWT];
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
-        const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
-        ax[pw] = align_axis(x, W);
-        v1[pw] = *(const vecc*)(r0 + (long long)ax[pw].lo * C);
-        v2[pw] = *(const vecc*)(r0 + (long long)ax[pw].hi * C);
-        v3[pw] = *(const vecc*)(r1 + (long long)ax[pw].lo * C);
-        v4[pw] = *(const vecc*)(r1 + (long long)ax[pw].hi * C);
+        rec[pw] = tabled ? xtab[pw * a.grid_w + ix] : x_record(pw, ix);
+        const int lo = max(rec[pw].x, 0);  // an invalid sample still loads a valid cell and is skipped below
+        v1[pw] = *(const vecc*)(r0 + lo);
+        v2[pw] = *(const vecc*)(r0 + rec[pw].y);
+        v3[pw] = *(const vecc*)(r1 + lo);
+        v4[pw] = *(const vecc*)(r1 + rec[pw].y);
       }
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
-        if (!ax[pw].valid) continue;
-        const float w1 = ay.h * ax[pw].h, w2 = ay.h * ax[pw].l, w3 = ay.l * ax[pw].h, w4 = ay.l * ax[pw].l;
+        if (rec[pw].x < 0) continue;
+        const float xl = __int_as_float(rec[pw].z), xh = __int_as_float(rec[pw].w);
+        const float w1 = ay.h * xh, w2 = ay.h * xl, w3 = ay.l * xh, w4 = ay.l * xl;
 #pragma unroll
         for (int q = 0; q < CPL; ++q)
           acc[pw][q] += w1 * to_f32(v1[pw][q]) + w2 * to_f32(v2[pw][q]) + w3 * to_f32(v3[pw][q]) +
@@ -876,7 +894,7 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
       // fast path: workgroup per (roi, 64*CPL channels), wavefront per pooled row, 8-byte loads, 28 taps in flight
       const int cg = dtype == WSOVOD_BF16 ? 256 : 128;
       const int groups = ceil_div(C, cg);
-      const int lds7 = cg * ph * pw * 4;
+      const int lds7 = cg * ph * pw * 4 + 7 * kAlignMaxGrid * 16;  // output transpose tile + sample-column table
       if (dtype == WSOVOD_BF16) {
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
