@@ -297,7 +297,10 @@ int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, cons
 /* Weight-gradient contraction over the SLOW index of two row-major bf16 operands (no transposed copies):
  *   C[i][j] (+)= alpha * sum_m P[m][i] * Q[m][j],   P (Mred, NI) row stride ldp, Q (Mred, NJ) row stride ldq, C fp32.
  * nn.Linear backward dW = dY^T X (box_head.py:60-75, open_vocabulary_classifier.py:60-66 under autograd) with
- * P = dY, Q = X as the forward pass left them.  ldp, ldq, NI, NJ multiples of 8; operands < 2 GiB. */
+ * P = dY, Q = X as the forward pass left them.  ldp, ldq, NI, NJ multiples of 8; operands < 2 GiB.
+ * accumulate: bit 0 = add to C; bit 1 = keep a partial last round of 256x256 tiles unsplit.  By default such a round
+ * (more than 256 tiles in all, at most 128 in the last round) is cut along the reduction into up to 8 slices per tile
+ * that meet by fp32 atomic adds, so that it fills the chip; the summation order of those tiles is then not fixed. */
 int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, int Mred, int NI, int NJ, float* C,
                    long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
 

@@ -334,3 +334,26 @@ def test_conv3x3_c64_fused_maxpool_equals_conv_then_pool(gpu, shape, with_res):
     with pytest.raises(RuntimeError, match="pool"):
         hip_ops.gemm_nt(x128, w128, conv=dict(n_img=1, H=16, W=16, Cin=128, Ho=16, Wo=16, KH=3, KW=3, stride=1, pad=1,
                                               dil=1, pool=2), out_dtype=torch.bfloat16)
+
+
+def test_gemm_tn_tail_split_matches_unsplit(gpu):
+    """More than one round of 256x256 tiles with a small last round: the tail tiles are reduced in K slices that meet
+    by atomic adds.  Same result as the unsplit launch up to fp32 summation order; accumulate keeps the old contents;
+    tiles of the full rounds are bit-identical."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(5)
+    Mred, NI, NJ = 1024, 2048 + 256, 256 * 33  # 9 x 33 = 297 tiles: one full round + 41 tail tiles
+    P = (torch.rand(Mred, NI, device=gpu) - 0.5).to(torch.bfloat16)
+    Q = (torch.rand(Mred, NJ, device=gpu) - 0.5).to(torch.bfloat16)
+    fixed = hip_ops.gemm_tn(P, Q, split_tail=False)
+    assert torch.equal(fixed, hip_ops.gemm_tn(P, Q, split_tail=False))
+    split = hip_ops.gemm_tn(P, Q)
+    torch.testing.assert_close(split, fixed, rtol=0, atol=1e-4)  # |terms| <= 0.25, 1024 of them
+    same = (split == fixed).view(9, 256, 33, 256).all(dim=3).all(dim=1)  # per tile
+    assert int(same.sum()) >= 256, int(same.sum())  # every tile of the full round
+    ref = (P.double().t() @ Q.double()).float()
+    torch.testing.assert_close(split, ref, rtol=1e-4, atol=1e-3)
+    acc = torch.randn(NI, NJ, device=gpu)
+    out = hip_ops.gemm_tn(P, Q, out=acc.clone(), alpha=0.5, accumulate=True)
+    torch.testing.assert_close(out, acc + 0.5 * ref, rtol=1e-4, atol=1e-3)

@@ -35,6 +35,9 @@ struct TnArgs {
   float alpha;
   int accumulate;
   int tiles_i, tiles_j, group_m;
+  // split-K of the LAST, partial round of tiles: blocks [0, full_tiles) own a whole tile; after them every remaining tile
+  // is cut into `ksplit` slices of `slice_steps` K-steps whose partial sums meet by fp32 atomic adds (0 = no split)
+  int full_tiles, ksplit, slice_steps;
 };
 
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
@@ -43,13 +46,20 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   constexpr int STEP_BYTES = 2 * OP_BYTES;      // P + Q
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int nwg = p.tiles_i * p.tiles_j;
-  int wg;
+  int wg, slice = 0;
   {
     const int bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int nwg = p.ksplit ? p.full_tiles : p.tiles_i * p.tiles_j;  // tiles that are remapped per XCD
+    if (bid < nwg) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+      wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    } else {  // a slice of a tail tile
+      const int t = bid - nwg;
+      wg = nwg + t / p.ksplit;
+      slice = t - (t / p.ksplit) * p.ksplit;
+    }
   }
+  const bool sliced = p.ksplit && (int)blockIdx.x >= p.full_tiles;
   const int group_size = p.group_m * p.tiles_j;
   const int group_id = wg / group_size;
   const int first_i = group_id * p.group_m;
@@ -79,7 +89,9 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   }
   typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int nk = (p.Mred + BK - 1) / BK;
+  const int nk_all = (p.Mred + BK - 1) / BK;
+  const int kt0 = sliced ? slice * p.slice_steps : 0;
+  const int nk = sliced ? min(nk_all, kt0 + p.slice_steps) : nk_all;  // this block reduces K-steps [kt0, nk)
   // stage rows [32*half, 32*half+32) of K-step kt into buffer buf: 4 DMA instructions
   auto stage_half = [&](int kt, int buf, int half) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -139,8 +151,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
 #endif
 
   // ---- prologue: K-step 0 completely, then the stagger barrier
-  stage_half(0, 0, 0);
-  stage_half(0, 0, 1);
+  stage_half(kt0, 0, 0);
+  stage_half(kt0, 0, 1);
   WS_VMCNT(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second i-half runs one barrier behind
@@ -149,8 +161,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   // ago) and waits vmcnt(4): the half issued one phase earlier has landed before the barrier its readers pass first;
   // it is read one phase later.  (A three-phase-deep ring with the reads retired before the barrier was measured
   // 18 % slower: the loop no longer unrolls over the two halves and the LDS latency moves in front of the barrier.)
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = (kt - kt0) & 1;
     const bool more = kt + 1 < nk;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -191,6 +203,35 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
 
   // ---- epilogue: acc[i][j][r] = C[i0 + wr*128 + i*16 + (lane&15)][j0 + wc*64 + j*16 + (lane>>4)*4 + r]
   const int frow = lane & 15, fq = lane >> 4;
+  if (sliced) {
+    // Partial sum of a K slice.  Float atomics run at full rate only on contiguous 256-byte wave accesses (one lane per
+    // (row, 4-column piece), as the accumulators lie, is ~6x slower): the wavefront's 128 x 64 block goes through its own
+    // 16-KB piece of the (now idle) staging buffers in two halves and is added row by row, 64 consecutive floats each.
+    // 8 wavefronts x 64 rows x 64 floats = exactly the 128 KiB of staging buffers; the 16-byte pieces of a row are
+    // XOR-swizzled with the row so that the 16 rows a store instruction touches fall into different banks
+    constexpr int SROW = 64;
+    float* stg = (float*)smem + wave * (64 * SROW);
+    const int cbase = j0 + wc * 64;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *(f32x4*)(stg + (i * 16 + frow) * SROW + (((j * 4 + fq) ^ frow) << 2)) = acc[half * 4 + i][j] * p.alpha;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int rbase = i0 + wr * 128 + half * 64;
+      for (int row = 0; row < 64; ++row) {
+        if (rbase + row >= p.NI) break;
+        const float v = stg[row * SROW + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
+        if (cbase + lane < p.NJ) unsafeAtomicAdd(p.C + (long long)(rbase + row) * p.ldc + cbase + lane, v);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && j0 + BJ <= p.NJ;
 #define WS_TN_ROW(I)                                                                                      \
   {                                                                                                       \
@@ -199,7 +240,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
       float* crow = p.C + (long long)ii * p.ldc + j0 + wc * 64 + fq * 4;                                  \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
         f32x4 x = acc[I][j] * p.alpha;                                                                    \
-        if (vec) {                                                                                        \
+        if (vec) {                                                                                 \
           if (p.accumulate) x += *(const f32x4*)(crow + j * 16);                                          \
           *(f32x4*)(crow + j * 16) = x;                                                                   \
         } else {                                                                                          \
@@ -214,6 +255,26 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
 #undef WS_TR_READ
 #undef WS_LGKM0_ALL
 #undef WS_VMCNT
+}
+
+// zero the output tiles [first_tile, tiles_i*tiles_j) (same tile id -> (i, j) map as the main kernel) before their
+// K slices are added into them
+__global__ __launch_bounds__(256) void tn_zero_tail_kernel(const TnArgs p) {
+  const int wg = p.full_tiles + blockIdx.x;
+  const int group_size = p.group_m * p.tiles_j;
+  const int group_id = wg / group_size;
+  const int first_i = group_id * p.group_m;
+  const int gm = min(p.tiles_i - first_i, p.group_m);
+  const int in_group = wg - group_id * group_size;
+  const int i0 = (first_i + in_group % gm) * 256, j0 = (in_group / gm) * 256;
+  for (int e = threadIdx.x; e < 256 * 64; e += 256) {
+    const int i = i0 + (e >> 6), j = j0 + (e & 63) * 4;
+    if (i >= p.NI) break;
+    float* c = p.C + (long long)i * p.ldc + j;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (j + r < p.NJ) c[r] = 0.f;
+  }
 }
 
 }  // namespace
@@ -241,7 +302,7 @@ extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long 
   a.C = C;
   a.ldc = ldc;
   a.alpha = alpha;
-  a.accumulate = accumulate;
+  a.accumulate = accumulate & 1;
   a.tiles_i = ceil_div(NI, 256);
   a.tiles_j = ceil_div(NJ, 256);
   {
@@ -262,7 +323,27 @@ extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long 
   const double flops = 2.0 * Mred * NI * NJ;
   const double bytes = 2.0 * Mred * ((double)NI + NJ) + 4.0 * NI * NJ;
   wsovod::ProfScope prof(slot, s, flops, bytes);
-  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(a.tiles_i * a.tiles_j), dim3(512), lds_bytes, s, a);
+  // Tail split: with more than one round of tiles on the 256 CUs, a last round that fills less than half of them is cut
+  // along K so that it fills the chip (fc1 dW: 1568 tiles = 6 rounds + 32 tiles -> 32 x 8 slices; one round of a 7-round
+  // launch becomes an eighth of a round plus the atomics).  The summation order of those tiles' slices is not fixed;
+  // `accumulate` bit 1 switches the split off for a bit-reproducible result.
+  const int ntiles = a.tiles_i * a.tiles_j, cus = 256;
+  const int tail = ntiles % cus, nk = ceil_div(Mred, 64);
+  a.full_tiles = ntiles;
+  a.ksplit = a.slice_steps = 0;
+  a.accumulate = accumulate & 1;
+  int grid = ntiles;
+  if (!(accumulate & 2) && ntiles > cus && tail > 0 && tail <= cus / 2) {
+    const int S = std::min(8, cus / tail);
+    if (nk >= 8 * S) {
+      a.full_tiles = ntiles - tail;
+      a.ksplit = S;
+      a.slice_steps = ceil_div(nk, S);
+      grid = a.full_tiles + tail * S;
+      if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(tail), dim3(256), 0, s, a);
+    }
+  }
+  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(grid), dim3(512), lds_bytes, s, a);
   WS_CHECK_LAUNCH("wsovod_gemm_tn");
   return WSOVOD_OK;
 }

@@ -653,16 +653,17 @@ def rpn_label_anchors(anchors, gt_boxes, gt_start, gt_count, thr_lo, thr_hi):
     return labels, best_gt, best_iou
 
 
-def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False):
+def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True):
     """out (NI, NJ) fp32 (+)= alpha * P^T @ Q for row-major bf16 P (Mred, NI) and Q (Mred, NJ): the weight-gradient
-    contraction over the operands' slow index, no transposed copies (transposed LDS reads)."""
+    contraction over the operands' slow index, no transposed copies (transposed LDS reads).
+    split_tail=False keeps a partial last round of tiles unsplit (fixed summation order, bit-reproducible)."""
     require_gpu(P, Q, out)
     assert P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and P.shape[0] == Q.shape[0]
     Mred, NI, NJ = P.shape[0], P.shape[1], Q.shape[1]
     if out is None:
         out = torch.empty((NI, NJ), dtype=torch.float32, device=P.device)
     check(lib().wsovod_gemm_tn(ptr(P), _ld(P), ptr(Q), _ld(Q), Mred, NI, NJ, ptr(out), _ld(out), C.c_float(alpha),
-                               int(bool(accumulate)), stream()), "gemm_tn")
+                               int(bool(accumulate)) | (0 if split_tail else 2), stream()), "gemm_tn")
     return out
 
 
