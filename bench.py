@@ -52,6 +52,9 @@ def parse():
                     help="debug/measurement: at N=1 still create a 1-rank RCCL group, so that the whole exchange path "
                          "(gradient pack, split weight-gradient launch, collectives, SGD on the wire slices) runs and "
                          "its cost without any wire time can be read off one GPU")
+    ap.add_argument("--eval", action="store_true",
+                    help="side measurement, not the headline metric: images/s of model.inference() (eval mode: frozen "
+                         "backbone, RoI pooling, heads, score threshold + per-class NMS tail) on the same synthetic batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -141,6 +144,39 @@ def cpu_baseline(model, sd, batch, args):
                       f"torch {torch.__version__} CPU, {ncores} of {host_cores} host threads = fastest of 16/32/64/all; RoIPool = single-thread C oracle)"}
 
 
+def eval_bench(args, cfg, model, dev, result_fd):
+    """Inference throughput (1 GPU): model.inference(batch) with the class text embeddings given per call."""
+    from wsovod_amd.data import make_batch
+
+    model.eval()
+    batch = to_device_batch(make_batch(args.batch, args.proposals, args.classes, seed=1234), dev)
+    g = torch.Generator().manual_seed(7)
+    classifier = torch.randn(args.classes, args.embed_dim, generator=g).to(dev)
+    for _ in range(args.warmup):
+        out = model.inference(batch, classifier=classifier)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.inference(batch, classifier=classifier)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        model.inference(batch, classifier=classifier, do_postprocess=False)
+    torch.cuda.synchronize()
+    elapsed_np = time.perf_counter() - t1
+    res = {"metric": "inference images/sec (side measurement)", "value": args.batch * args.steps / elapsed,
+           "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "dtype": args.precision,
+           "data": "synthetic",
+           "config": {"workload": f"WSR_{args.depth}_DC5 inference, {args.proposals} proposals/img, {args.classes} classes, "
+                                  f"{args.pooler}, score threshold + per-class NMS + top-100 tail", "images_per_step": args.batch,
+                      "ms_per_step_without_detector_postprocess": elapsed_np / args.steps * 1e3,
+                      "detections_first_image": int(len(out[0]["instances"]))}}
+    os.write(result_fd, (json.dumps(res) + "\n").encode())
+    return 0
+
+
 def main():
     args = parse()
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner at
@@ -178,6 +214,8 @@ def main():
     if args.rpn:
         args.no_cpu_baseline = True
         model.roi_heads.iter = cfg.SOLVER.MAX_ITER // 2  # mid-training objectness ramp (rcnn_wsovod.py:181-184)
+    if args.eval:
+        return eval_bench(args, cfg, model, dev, result_fd)
     model.train()
     optimizer = build_optimizer(cfg, model)
     wire = args.precision if args.grad_wire == "auto" else args.grad_wire

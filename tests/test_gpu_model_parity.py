@@ -196,6 +196,40 @@ def test_eval_tail_matches_oracle(gpu):
     assert checked > 0
 
 
+def test_batched_postprocess_equals_per_image(gpu):
+    """inference(do_postprocess=True) over the packed detections of the batched tail == detector_postprocess applied to
+    every image on its own (rescale to the requested output size, clip, drop empty boxes, order kept); ragged proposal
+    counts go through the padded form of the tail and still match the oracle."""
+    from wsovod_amd.modeling.meta_arch import detector_postprocess
+
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    model.eval()
+    batch = gen.seeded_batch(3, 120, 20, 256, 352, seed=21)
+    inputs = to_inputs(batch)
+    for i, x in enumerate(inputs):
+        x["height"], x["width"] = 300 + 40 * i, 500 - 30 * i
+    clf = torch.randn(20, 512, device=gpu)
+    raw, _, _ = model.inference(inputs, do_postprocess=False, classifier=clf)
+    assert getattr(raw, "packed", None) is not None  # the batched tail ran
+    full = model.inference(inputs, classifier=clf)
+    for x, r, f in zip(inputs, raw, full):
+        want = detector_postprocess(r, x["height"], x["width"])
+        got = f["instances"]
+        assert got.image_size == (x["height"], x["width"]) and len(got) == len(want) > 0
+        assert torch.equal(got.pred_boxes.tensor, want.pred_boxes.tensor) and torch.equal(got.scores, want.scores)
+        assert torch.equal(got.pred_classes, want.pred_classes) and torch.equal(got.pred_inds, want.pred_inds)
+    # ragged batch: drop proposals of the second image
+    inputs[1]["proposals"] = inputs[1]["proposals"][:70]
+    res, all_scores, all_boxes = model.inference(inputs, do_postprocess=False, classifier=clf)
+    pred = model.roi_heads.box_refinery[-1]
+    for x, r, sc, bx in zip(inputs, res, all_scores, all_boxes):
+        rb, rs, rc, ri = R.fast_rcnn_inference_single_image(bx[0].cpu(), sc[0].cpu(), tuple(x["image"].shape[-2:]),
+                                                            pred.test_score_thresh, pred.test_nms_thresh,
+                                                            pred.test_topk_per_image)
+        assert torch.equal(r.pred_classes.cpu(), rc) and torch.equal(r.pred_inds.cpu(), ri)
+        assert torch.equal(r.pred_boxes.tensor.cpu(), rb) and torch.equal(r.scores.cpu(), rs)
+
+
 def test_roi_loop_pool_contextlocnet_step_matches_oracle(gpu):
     """POOLER_TYPE ROILoopPool (the reference's native 3-output op) + the contextlocnet mining head: whole fp32
     training step against the oracle on identical seeded parameters."""

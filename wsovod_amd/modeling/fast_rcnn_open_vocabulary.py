@@ -20,7 +20,8 @@ from ..layers import hip_ops as H
 from ..structures import Boxes, Instances, ShapeSpec
 from .box_regression import Box2BoxTransform
 
-__all__ = ["fast_rcnn_inference", "ObjectMiningOutputLayers", "InstanceRefinementOutputLayers", "segment_offsets"]
+__all__ = ["fast_rcnn_inference", "BatchedDetections", "ObjectMiningOutputLayers", "InstanceRefinementOutputLayers",
+           "segment_offsets"]
 
 
 def segment_offsets(nums, device):
@@ -87,9 +88,85 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
 
 
 def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
+    if (len(scores) and scores[0].is_cuda and topk_per_image >= 0 and all(b.dim() == 2 and b.shape[1] == 4 for b in boxes)
+            and all(s.shape[0] > 0 for s in scores) and max(s.shape[0] for s in scores) <= 16384):
+        return _fast_rcnn_inference_batched(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image)
     r = [fast_rcnn_inference_single_image(b, s, shp, score_thresh, nms_thresh, topk_per_image)
          for s, b, shp in zip(scores, boxes, image_shapes)]
     return [x[0] for x in r], [x[1] for x in r], [x[2] for x in r], [x[3] for x in r]
+
+
+class BatchedDetections(list):
+    """list[Instances] of the batched tail; `packed` = (boxes (N,k,4), scores, classes, proposal ids (N,k), counts
+    list) are the batch-level tensors the per-image Instances are slices of, so that a caller that post-processes every
+    image the same way (detector_postprocess) can do it in one pass."""
+    packed = None
+
+
+def _fast_rcnn_inference_batched(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
+    """The tail of fast_rcnn_inference_single_image (fast_rcnn_open_vocabulary.py:149-217) for ALL images of the batch
+    at once, class-agnostic boxes: no per-image Python loop over index ops, ONE host read (the detection counts).
+
+    Every (image, class) pair is one fixed-length segment of the HIP segment-NMS kernel: the image's proposals sorted
+    by that class' score (stable), with a validity byte instead of a compaction for `score > thresh` / non-finite rows
+    (an invalid box is never kept and never suppresses -- the same keep set as filtering first).  The final per-image
+    ranking is a stable descending sort over the (class-major, rank) layout, i.e. the reference's tie order
+    (class, then proposal index).  Same detections in the same order as the per-image form (tests compare both with
+    the oracle)."""
+    from ..layers import hip_ops as H
+
+    dev = scores[0].device
+    N, K = len(scores), scores[0].shape[1] - 1
+    nums = [int(s.shape[0]) for s in scores]
+    Rm = max(nums)
+    all_scores = [s.unsqueeze(0) for s in scores]
+    all_boxes = [b.unsqueeze(0) for b in boxes]
+    if all(n == Rm for n in nums):
+        S = H.cat_rows(list(scores)).view(N, Rm, K + 1)
+        B = H.cat_rows(list(boxes)).view(N, Rm, 4)
+        pad = None
+    else:  # ragged batch: pad the short images with rows that can never pass the threshold
+        S = torch.full((N, Rm, K + 1), float("-inf"), dtype=scores[0].dtype, device=dev)
+        B = torch.zeros((N, Rm, 4), dtype=boxes[0].dtype, device=dev)
+        for i, (s, b) in enumerate(zip(scores, boxes)):
+            S[i, :nums[i]], B[i, :nums[i]] = s, b
+        pad = H.const_tensor([int(r < n) for n in nums for r in range(Rm)], torch.bool, dev).view(N, Rm)
+    S, B = S.float(), B.float()
+    row_ok = torch.isfinite(B).all(dim=2) & torch.isfinite(S).all(dim=2) if pad is None else \
+        torch.isfinite(B).all(dim=2) & torch.isfinite(torch.where(pad[..., None], S, torch.zeros_like(S))).all(dim=2) & pad
+    sc = torch.where(row_ok[..., None], S[..., :K], torch.full_like(S[..., :K], float("-inf")))
+    sorted_sc, order = torch.sort(sc.permute(0, 2, 1), dim=2, descending=True, stable=True)  # (N, K, Rm)
+    hw = H.const_tensor([float(v) for shp in image_shapes for v in (shp[1], shp[0], shp[1], shp[0])], torch.float32,
+                        dev).view(N, 1, 4)
+    Bc = torch.minimum(B.clamp(min=0), hw)  # Boxes.clip: x in [0, w], y in [0, h]
+    Bc = torch.where(row_ok[..., None], Bc, torch.zeros_like(Bc))
+    bs = torch.gather(Bc[:, None].expand(N, K, Rm, 4), 2, order[..., None].expand(N, K, Rm, 4)).contiguous()
+    valid = (sorted_sc > score_thresh).contiguous()
+    seg = torch.arange(N * K + 1, device=dev, dtype=torch.int32) * Rm
+    keep_rel, keep_count = H.nms_segments(bs.view(-1, 4), seg, Rm, float(nms_thresh), valid=valid.view(-1))
+    slot_used = torch.arange(Rm, device=dev, dtype=torch.int32)[None] < keep_count[:, None]  # (N*K, Rm)
+    kept = torch.zeros((N * K, Rm), dtype=torch.int32, device=dev)
+    kept.scatter_add_(1, keep_rel.view(N * K, Rm).clamp(0, Rm - 1).long(), slot_used.to(torch.int32))
+    final_sc = torch.where(kept > 0, sorted_sc.reshape(N * K, Rm), torch.full_like(sorted_sc.reshape(N * K, Rm),
+                                                                                  float("-inf"))).view(N, K * Rm)
+    top_sc, top_idx = torch.sort(final_sc, dim=1, descending=True, stable=True)
+    k = min(topk_per_image, K * Rm)
+    top_sc, top_idx = top_sc[:, :k], top_idx[:, :k]
+    counts = (top_sc > float("-inf")).sum(dim=1).tolist()  # the one host read of the tail
+    det_cls = torch.div(top_idx, Rm, rounding_mode="floor")
+    det_prop = order.reshape(N, K * Rm).gather(1, top_idx)
+    det_box = bs.view(N, K * Rm, 4).gather(1, top_idx[..., None].expand(N, k, 4))
+    results, kept_props = BatchedDetections(), []
+    results.packed = (det_box, top_sc, det_cls, det_prop, counts)  # (N,k,..) tensors behind the per-image slices
+    for i, n in enumerate(counts):
+        r = Instances(image_shapes[i])
+        r.pred_boxes = Boxes(det_box[i, :n])
+        r.scores = top_sc[i, :n]
+        r.pred_classes = det_cls[i, :n]
+        r.pred_inds = det_prop[i, :n]
+        results.append(r)
+        kept_props.append(det_prop[i, :n])
+    return results, kept_props, all_scores, all_boxes
 
 
 class ObjectMiningOutputLayers(nn.Module):

@@ -16,7 +16,7 @@ from torch import nn
 
 from ..config import BACKBONE_REGISTRY, META_ARCH_REGISTRY, configurable
 from ..layers import hip_ops as H
-from ..structures import ImageList, Instances, ShapeSpec
+from ..structures import Boxes, ImageList, Instances, ShapeSpec
 from .class_heads import DataAwareFeaturesHead
 from .fast_rcnn_open_vocabulary import segment_offsets
 from .proposal_generator import build_proposal_generator
@@ -218,12 +218,45 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
 
     @staticmethod
     def _postprocess(instances, batched_inputs, image_sizes):
+        packed = getattr(instances, "packed", None)
+        if packed is not None and len(instances):
+            return GeneralizedRCNN_WSOVOD._postprocess_packed(instances, packed, batched_inputs, image_sizes)
         processed_results = []
         for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
             height = input_per_image.get("height", image_size[0])
             width = input_per_image.get("width", image_size[1])
             processed_results.append({"instances": detector_postprocess(results_per_image, height, width)})
         return processed_results
+
+
+def _postprocess_packed(instances, packed, batched_inputs, image_sizes):
+    """detector_postprocess (postprocessing.py:8-82, boxes only) for every image of the batch in one pass over the packed
+    detections of the batched tail: rescale to the requested output size, clip, drop empty boxes (order kept) -- the
+    same arithmetic per box as the per-image form, one host read (the surviving counts) instead of two per image."""
+    det_box, det_sc, det_cls, det_prop, counts = packed
+    N, k = det_sc.shape
+    dev = det_box.device
+    out_hw = [(int(inp.get("height", sz[0])), int(inp.get("width", sz[1]))) for inp, sz in zip(batched_inputs, image_sizes)]
+    scale = H.const_tensor([v for (oh, ow), r in zip(out_hw, instances)
+                            for v in (ow / r.image_size[1], oh / r.image_size[0]) * 2], torch.float32, dev).view(N, 1, 4)
+    lim = H.const_tensor([float(v) for oh, ow in out_hw for v in (ow, oh, ow, oh)], torch.float32, dev).view(N, 1, 4)
+    bx = torch.minimum((det_box * scale).clamp(min=0), lim)
+    live = torch.arange(k, device=dev)[None] < H.const_tensor(counts, torch.int64, dev)[:, None]
+    keep = live & ((bx[..., 2] - bx[..., 0]) > 0) & ((bx[..., 3] - bx[..., 1]) > 0)
+    perm = torch.sort((~keep).to(torch.uint8), dim=1, stable=True).indices  # kept detections first, order preserved
+    n_keep = keep.sum(dim=1).tolist()
+    bx = bx.gather(1, perm[..., None].expand(N, k, 4))
+    sc, cl, pi = det_sc.gather(1, perm), det_cls.gather(1, perm), det_prop.gather(1, perm)
+    out = []
+    for i, n in enumerate(n_keep):
+        r = Instances(out_hw[i])
+        r.pred_boxes = Boxes(bx[i, :n])
+        r.scores, r.pred_classes, r.pred_inds = sc[i, :n], cl[i, :n], pi[i, :n]
+        out.append({"instances": r})
+    return out
+
+
+GeneralizedRCNN_WSOVOD._postprocess_packed = staticmethod(_postprocess_packed)
 
 
 @META_ARCH_REGISTRY.register()
