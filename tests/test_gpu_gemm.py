@@ -357,3 +357,29 @@ def test_gemm_tn_tail_split_matches_unsplit(gpu):
     acc = torch.randn(NI, NJ, device=gpu)
     out = hip_ops.gemm_tn(P, Q, out=acc.clone(), alpha=0.5, accumulate=True)
     torch.testing.assert_close(out, acc + 0.5 * ref, rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_split_k_matches_unsplit_tile(gpu):
+    """Few output tiles and a long K: the dispatcher takes the 256x256 8-phase tile with split-K (slices of K into a
+    workspace, then a finalize kernel with the whole epilogue).  Against the same tile named explicitly (never split):
+    equal up to fp32 summation order, dropout mask identical, accumulate / transposed copy / residual honoured."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(3)
+    M, N, K = 520, 1032, 8192 + 64  # ragged edges, 3 x 5 tiles
+    A = (torch.rand(M, K, device=gpu) - 0.5).to(torch.bfloat16)
+    B = (torch.rand(N, K, device=gpu) - 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=gpu)
+    res = torch.randn(M, N, device=gpu).to(torch.bfloat16)
+    kw = dict(bias=bias, relu=True, residual=res, alpha=0.5, dropout_p=0.5, dropout_seed=77)
+    want = hip_ops.gemm_nt(A, B, out_dtype=torch.float32, tile_hint=8256256, **kw)
+    got = hip_ops.gemm_nt(A, B, out_dtype=torch.float32, **kw)
+    assert torch.equal(got == 0, want == 0)  # same ReLU / dropout pattern
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-3)
+    acc = torch.randn(M, N, device=gpu)
+    ct = torch.zeros(N, M + 8, device=gpu)
+    o1 = hip_ops.gemm_nt(A, B, out=acc.clone(), accumulate=True, out_t=ct)
+    torch.testing.assert_close(o1, acc + A.float() @ B.float().t(), rtol=1e-4, atol=2e-2)
+    assert torch.equal(ct[:, :M], o1.t())  # the transposed copy carries the stored value (after the accumulate)
+    b16 = hip_ops.gemm_nt(A, B, bias=bias, relu=True, out_dtype=torch.bfloat16)
+    torch.testing.assert_close(b16.float(), torch.relu(A.float() @ B.float().t() + bias), rtol=2e-2, atol=0.2)

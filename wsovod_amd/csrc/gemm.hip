@@ -865,6 +865,12 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   // plain bf16 contractions take the staggered 8-wavefront form of the 256x256 tile (measured +11-13 % on the FC
   // shapes, tools/gemm_ab.py); the implicit-GEMM conv stays on the 16-wavefront form (tools/conv_ab.py)
   if (!d->tile_hint && tile == 256256 && d->dtype_in == WSOVOD_BF16 && !d->conv) tile = 8256256;
+  // few rows, long K (the FC layers at 1-4 images per step): the same tile with split-K instead of a small-tile grid
+  // (measured, M = 512: K = 25088 230 -> 143 us; at K = 4096 the workspace round trip costs more than it saves: 40 -> 53 us)
+  if (!d->tile_hint && d->dtype_in == WSOVOD_BF16 && !d->conv && d->M >= 256 && d->N >= 256 && d->K >= 8192 &&
+      (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
+    tile = 8256256;
+  a.ksplit = d->tile_hint == 0 ? -1 : 0;  // split-K may only change the summation order when the caller named no tile
   if (d->dtype_in == WSOVOD_BF16)
     return d->conv ? dispatch_tile<bf16_t, true>(a, tile, s, flops, bytes) : dispatch_tile<bf16_t, false>(a, tile, s, flops, bytes);
   return d->conv ? dispatch_tile<float, true>(a, tile, s, flops, bytes) : dispatch_tile<float, false>(a, tile, s, flops, bytes);

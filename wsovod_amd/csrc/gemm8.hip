@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const int nwg = p.tiles_m * p.tiles_n;
   int wg;
   {
-    const int bid = blockIdx.x;
+    const int bid = p.ksplit > 1 ? (int)(blockIdx.x % (unsigned)nwg) : (int)blockIdx.x;  // split-K: slice-major copies of the grid
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     const int src = LR * i + 16 * ((lrow & 15) >> 2) + 4 * (lrow >> 4) + (lrow & 3);
     b_off[i] = n0 + src < p.N ? (int)(((long long)src * p.ldb + lchunk * EPC) * esz) : -1;
   }
-  const int nk = (p.K + BKE - 1) / BKE;
+  const int kslice = p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;
+  const int kt_base = kslice * p.slice_steps;  // first K-step of this block (0 unless split-K)
+  const int nk = p.ksplit > 1 ? max(0, min((p.K + BKE - 1) / BKE - kt_base, p.slice_steps)) : (p.K + BKE - 1) / BKE;
   // conv: per-lane pixel offset (filter at its top-left tap) and one validity bit per tap, hoisted out of the K loop
   // exactly as in gemm.hip
   [[maybe_unused]] int pix_off[4];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   };
   auto stage_A = [&](int kt, int buf, int i, const Tap t) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int kbase = kt * BKE;
+    const int kbase = (kt + kt_base) * BKE;
     char* dA = sA + buf * BM * 128 + wave_u * 1024 + LR * i * 128;
     if (CONV) {
       const int tap = t.r * p.KW + t.q;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   };
   auto stage_B = [&](int kt, int buf, int i, const Tap t) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int kbase = CONV ? (t.r * p.KW + t.q) * p.Cin + t.c0 : kt * BKE;  // conv: weight rows are [kh][kw][Cin]
+    const int kbase = CONV ? (t.r * p.KW + t.q) * p.Cin + t.c0 : (kt + kt_base) * BKE;  // conv: weight rows are [kh][kw][Cin]
     const bool k_ok = kbase + lchunk * EPC < p.K;
     char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16,
@@ -298,6 +300,25 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   // at staging, so lane (frow, fq) holds output row m = .. + frow and the 16 consecutive columns ncol + 4*j + r:
   // per output row a wavefront writes 64 contiguous elements as 16-byte stores.
   // Tile indices are compile-time constants (a runtime index into acc would put the accumulators in scratch).
+  if (p.ksplit > 1) {  // split-K: raw partial sums of this K slice; the epilogue runs in splitk_finalize_kernel
+    float* part = p.partial + (long long)kslice * p.M * p.partial_ld;
+    const int ncol0 = n0 + wc * 64 + 16 * fq;
+#define WS_PART_ROW(I)                                                                                     \
+    {                                                                                                        \
+      const int m = m0 + wr * 128 + (I) * 16 + frow;                                                         \
+      if (m < p.M) {                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                      \
+          const int nb = ncol0 + 4 * j;                                                                      \
+          if (nb + 3 < p.N) *(f32x4*)(part + (long long)m * p.partial_ld + nb) = acc[I][j];                  \
+          else _Pragma("unroll") for (int r = 0; r < 4; ++r) if (nb + r < p.N)                               \
+              part[(long long)m * p.partial_ld + nb + r] = acc[I][j][r];                                     \
+        }                                                                                                    \
+      }                                                                                                      \
+    }
+    WS_PART_ROW(0) WS_PART_ROW(1) WS_PART_ROW(2) WS_PART_ROW(3) WS_PART_ROW(4) WS_PART_ROW(5) WS_PART_ROW(6) WS_PART_ROW(7)
+#undef WS_PART_ROW
+    return;
+  }
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
   const bool vec_c = p.C && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
   const int ncol = n0 + wc * 64 + 16 * fq;
@@ -408,9 +429,50 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #undef WS_MFMA_QUAD
 }
 
+// split-K finalize: C[m][n] = epilogue(sum over the K slices) -- the epilogue chain of the GEMM kernels, element-wise
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) {
+  const int n4 = (p.N + 3) >> 2;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long long)p.M * n4) return;
+  const int m = (int)(idx / n4), nb = (int)(idx - (long long)m * n4) * 4;
+  const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const float rs = p.row_scale ? p.row_scale[m] : 1.f;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.ksplit; ++z) {
+    const float* src = p.partial + ((long long)z * p.M + m) * p.partial_ld + nb;
+    if (nb + 3 < p.N) {
+      const f32x4 t = *(const f32x4*)src;
+      v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < p.N) v[r] += src[r];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = nb + r;
+    if (n >= p.N) continue;
+    float x = v[r] * p.alpha;
+    if (p.row_scale) x *= rs;
+    if (p.bias) x += p.bias[n];
+    if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+    if (p.relu) x = fmaxf(x, 0.f);
+    if (p.dropout_p > 0.f) {
+      const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+      x = u >= p.dropout_p ? x * keep_scale : 0.f;
+    }
+    if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
+    if (p.mask_src) x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+    if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
+    if (p.C) store_from_f32(p.C, (long long)m * p.ldc + n, p.dtype_c, x);
+    if (p.Ct) store_from_f32(p.Ct, (long long)n * p.ldct + m, p.dtype_ct, x);
+  }
+}
+
 }  // namespace
 
-int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes) {
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split) {
+  allow_split = allow_split || a.ksplit == -1;  // -1: the dispatcher chose this tile itself (no tile_hint)
   static int slot_g = wsovod::prof_slot("gemm_nt_bf16_256x256_8ph");
   static int slot_c = wsovod::prof_slot("conv_igemm_bf16_256x256_8ph");
   static bool attr_set = false;
@@ -432,11 +494,46 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
     while ((g + 1) * (g + 1) <= run) ++g;
     args.group_m = std::max(1, std::min(std::min(g, 4), args.tiles_m));
   }
+  // Split-K for contractions with few output tiles and a long K (the FC layers at 1-4 images per step: fc1 forward is
+  // 2 x 16 tiles of K = 25088): `ksplit` copies of the grid fill the chip, each reducing a slice of K into a workspace,
+  // and a finalize kernel adds the slices and applies the epilogue.  The 256x256 tile keeps the operand traffic through
+  // L2 low (a 64x64 tiling of the same GEMM re-reads the operands 8x / 64x and is L2-bound at ~1 TB/s of HBM).
+  args.ksplit = args.slice_steps = 0;
+  const int ntiles = args.tiles_m * args.tiles_n, nk = ceil_div(a.K, 64);
+  int grid = ntiles;
+  if (allow_split && !conv && ntiles <= 128 && nk >= 32) {
+    const int S = std::min(std::min(8, 256 / ntiles), nk / 16);
+    if (S >= 2) {
+      static float* ws = nullptr;
+      static size_t ws_bytes = 0;
+      const long long ldp = ((long long)a.N + 3) / 4 * 4;
+      const size_t need = (size_t)S * a.M * ldp * sizeof(float);
+      if (need > ws_bytes) {  // grow-only workspace of this process (single-stream use, as the rest of the library)
+        if (ws) (void)hipFree(ws);
+        ws = nullptr;
+        ws_bytes = 0;
+        if (hipMalloc((void**)&ws, need) != hipSuccess) {
+          wsovod::set_error("wsovod_gemm_nt: cannot allocate the split-K workspace");
+          return WSOVOD_ERR_HIP;
+        }
+        ws_bytes = need;
+      }
+      args.ksplit = S;
+      args.slice_steps = ceil_div(nk, S);
+      args.partial = ws;
+      args.partial_ld = ldp;
+      grid = ntiles * S;
+    }
+  }
   wsovod::ProfScope prof(conv ? slot_c : slot_g, s, flops, bytes);
   if (conv)
-    hipLaunchKernelGGL(gemm256_8ph_kernel<true>, dim3(args.tiles_m * args.tiles_n), dim3(512), lds_bytes, s, args);
+    hipLaunchKernelGGL(gemm256_8ph_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, args);
   else
-    hipLaunchKernelGGL(gemm256_8ph_kernel<false>, dim3(args.tiles_m * args.tiles_n), dim3(512), lds_bytes, s, args);
+    hipLaunchKernelGGL(gemm256_8ph_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, args);
+  if (args.ksplit > 1) {
+    const long long quads = (long long)a.M * ((a.N + 3) / 4);
+    hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, args);
+  }
   WS_CHECK_LAUNCH("wsovod_gemm_nt(256x256 8-phase)");
   return WSOVOD_OK;
 }

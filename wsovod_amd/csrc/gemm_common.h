@@ -35,6 +35,12 @@ struct GemmArgs {
   // implicit-GEMM convolution geometry
   int H, W, Cin, Ho, Wo, KH, KW, stride, pad, dil;
   int pool;  // conv3x3_c64 only: 2 = MaxPool2d(2, 2) fused into the epilogue, C is the pooled map
+  // split-K (gemm8.hip, plain GEMMs with few output tiles): the grid is ksplit copies of the tile grid, copy z reduces
+  // K-steps [z*slice_steps, (z+1)*slice_steps) and stores its raw fp32 sums to partial[z][M][partial_ld]; a finalize
+  // kernel adds the copies and applies the epilogue
+  int ksplit, slice_steps;
+  float* partial;
+  long long partial_ld;
   long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
   int tiles_m, tiles_n;
   int group_m;  // tile-order group height (see the XCD remap in the kernel)
@@ -78,6 +84,6 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
 
 
 // gemm8.hip: bf16 256x256 tile, 8 wavefronts in two staggered groups (see the file header).
-int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes);
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split = false);
 
 }  // namespace wsovod_gemm
