@@ -102,3 +102,32 @@ def test_rpn_decode_matches_oracle(gpu, with_index):
         clear = fin & ((side - min_size).abs() > 1e-2)
         assert torch.equal(valid[b].cpu()[clear], ref_valid[clear])
         assert not bool(valid[b].cpu()[~fin].any())
+
+
+def test_batched_eval_tail_groups_of_images_equal_single_image_form(gpu):
+    """Large vocabularies: the batched tail bounds its (images, classes, proposals) candidate tensors by working
+    through the batch in groups of images.  Same detections as the per-image form, image by image."""
+    import torch
+    from wsovod_amd.modeling.fast_rcnn_open_vocabulary import (_fast_rcnn_inference_batched, fast_rcnn_inference,
+                                                               fast_rcnn_inference_single_image)
+
+    g = torch.Generator().manual_seed(12)
+    N, R, K = 3, 1500, 3000  # 4.5 M candidates per image -> groups of one image
+    shapes = [(600, 800), (480, 640), (600, 800)]
+    boxes, scores = [], []
+    for h, w in shapes:
+        xy = torch.rand(R, 2, generator=g) * torch.tensor([w - 40.0, h - 40.0])
+        wh = 16 + torch.rand(R, 2, generator=g) * torch.tensor([w / 3.0, h / 3.0])
+        boxes.append(torch.cat([xy, xy + wh], dim=1).to(gpu))
+        logits = torch.randn(R, K + 1, generator=g) * 4
+        scores.append(torch.softmax(logits, dim=1).to(gpu))
+    res, kept, all_s, all_b = fast_rcnn_inference(boxes, scores, shapes, 1e-3, 0.3, 100)
+    assert getattr(res, "packed", None) is None and len(res) == N  # went through in groups
+    for i in range(N):
+        one, k1, _, _ = fast_rcnn_inference_single_image(boxes[i], scores[i], shapes[i], 1e-3, 0.3, 100)
+        assert len(one) == len(res[i]) > 0
+        assert torch.equal(one.pred_classes, res[i].pred_classes) and torch.equal(one.pred_inds, res[i].pred_inds)
+        assert torch.equal(one.pred_boxes.tensor, res[i].pred_boxes.tensor) and torch.equal(one.scores, res[i].scores)
+        assert torch.equal(k1, kept[i])
+    two = _fast_rcnn_inference_batched(boxes[:2], scores[:2], shapes[:2], 1e-3, 0.3, 100)[0]
+    assert two.packed is not None and torch.equal(two[1].pred_inds, res[1].pred_inds)

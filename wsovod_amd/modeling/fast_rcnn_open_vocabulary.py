@@ -90,7 +90,18 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
 def fast_rcnn_inference(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image):
     if (len(scores) and scores[0].is_cuda and topk_per_image >= 0 and all(b.dim() == 2 and b.shape[1] == 4 for b in boxes)
             and all(s.shape[0] > 0 for s in scores) and max(s.shape[0] for s in scores) <= 16384):
-        return _fast_rcnn_inference_batched(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image)
+        # bound the (images, classes, proposals) candidate tensors: large vocabularies go through in groups of images
+        per_image = (scores[0].shape[1] - 1) * max(s.shape[0] for s in scores)
+        group = max(1, min(len(scores), (8 << 20) // max(per_image, 1)))
+        if group >= len(scores):
+            return _fast_rcnn_inference_batched(boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image)
+        out = ([], [], [], [])
+        for i in range(0, len(scores), group):
+            part = _fast_rcnn_inference_batched(boxes[i:i + group], scores[i:i + group], image_shapes[i:i + group],
+                                                score_thresh, nms_thresh, topk_per_image)
+            for acc, p in zip(out, part):
+                acc.extend(p)
+        return out  # (a plain list: the packed post-processing path applies to single-group batches only)
     r = [fast_rcnn_inference_single_image(b, s, shp, score_thresh, nms_thresh, topk_per_image)
          for s, b, shp in zip(scores, boxes, image_shapes)]
     return [x[0] for x in r], [x[1] for x in r], [x[2] for x in r], [x[3] for x in r]
