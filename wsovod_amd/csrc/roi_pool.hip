@@ -528,6 +528,8 @@ __device__ __forceinline__ AlignAxis align_axis(float v, int L) {
 }
 
 constexpr int kAlignMaxGrid = 64;  // sample columns per bin the row kernel keeps in its LDS table (7 KB); wider rois recompute
+constexpr int kSepMax = 24;        // cells per bin and axis of the separable form (rois up to ~150 cells wide / high)
+constexpr int kAlignTabBytes = 7 * kAlignMaxGrid * 16 + (7 + 16) * kSepMax * 4 + (2 * 7 + 2 * 16 + 1) * 4 + 12;
 
 template <typename T, int PWT, int CPL>
 __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
@@ -566,7 +568,101 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
   for (int pw = 0; pw < PWT; ++pw)
 #pragma unroll
     for (int q = 0; q < CPL; ++q) acc[pw][q] = 0.f;
-  for (int iy = 0; iy < a.grid_h; ++iy) {
+  // ---- separable form.  sum over the samples of a bin of (w1 v1 + w2 v2 + w3 v3 + w4 v4) = sum over the CELLS the bin
+  // touches of Wy[row] * Wx[col] * f[row][col], with Wy[row] = (sum of hy over sample rows whose low row it is) + (sum of
+  // ly over those whose high row it is), Wx likewise: every cell is loaded ONCE per bin instead of once per tap of every
+  // sample that touches it (4 taps x ~1 sample per cell: a quarter of the L2 requests, which bound this kernel).  Same
+  // value up to fp32 association.  Wx of the 7 bins is built by wavefront pw, Wy of pooled row ph by wavefront ph; rois
+  // whose bins span more than kSepMax cells per axis keep the per-sample loop below.
+  float* wx = (float*)(xtab + PWT * kAlignMaxGrid);  // [PWT][kSepMax] column weights
+  float* wy = wx + PWT * kSepMax;                    // [PH][kSepMax] row weights
+  int* meta = (int*)(wy + 16 * kSepMax);             // [0..PWT): first column, [PWT..2PWT): columns; then rows likewise
+  int* fits = meta + 2 * PWT + 2 * 16;
+  {
+    if (threadIdx.x == 0) *fits = 1;
+    __syncthreads();
+    if (lane == 0) {
+      // row weights of this wavefront's pooled row
+      int first = -1, last = -1;
+      for (int iy = 0; iy < a.grid_h; ++iy) {
+        const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
+        const AlignAxis ay = align_axis(y, H);
+        if (!ay.valid) continue;
+        first = first < 0 ? ay.lo : min(first, ay.lo);  // (a malformed roi, end < start, walks its samples backwards)
+        last = max(last, ay.hi);
+      }
+      const int n = first < 0 ? 0 : last - first + 1;
+      meta[2 * PWT + ph] = first;
+      meta[2 * PWT + 16 + ph] = n;
+      if (n > kSepMax) *fits = 0;
+      else {
+        for (int i = 0; i < n; ++i) wy[ph * kSepMax + i] = 0.f;
+        for (int iy = 0; iy < a.grid_h; ++iy) {
+          const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
+          const AlignAxis ay = align_axis(y, H);
+          if (!ay.valid) continue;
+          wy[ph * kSepMax + ay.lo - first] += ay.h;
+          wy[ph * kSepMax + ay.hi - first] += ay.l;
+        }
+      }
+      if (ph < PWT) {  // column weights of bin pw = ph (PH >= PWT wavefronts on every shipped config; checked by the host)
+        const int pw = ph;
+        int f2 = -1, l2 = -1;
+        for (int ix = 0; ix < a.grid_w; ++ix) {
+          const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+          const AlignAxis ax = align_axis(x, W);
+          if (!ax.valid) continue;
+          f2 = f2 < 0 ? ax.lo : min(f2, ax.lo);
+          l2 = max(l2, ax.hi);
+        }
+        const int n2 = f2 < 0 ? 0 : l2 - f2 + 1;
+        meta[pw] = f2;
+        meta[PWT + pw] = n2;
+        if (n2 > kSepMax) *fits = 0;
+        else {
+          for (int i = 0; i < n2; ++i) wx[pw * kSepMax + i] = 0.f;
+          for (int ix = 0; ix < a.grid_w; ++ix) {
+            const float x = a.start_w + (float)pw * a.bin_w + ((float)ix + .5f) * a.bin_w / (float)a.grid_w;
+            const AlignAxis ax = align_axis(x, W);
+            if (!ax.valid) continue;
+            wx[pw * kSepMax + ax.lo - f2] += ax.h;
+            wx[pw * kSepMax + ax.hi - f2] += ax.l;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (*fits) {
+      int x0[PWT], nc[PWT], ncmax = 0;
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        x0[pw] = max(meta[pw], 0);
+        nc[pw] = meta[PWT + pw];
+        ncmax = max(ncmax, nc[pw]);
+      }
+      const int y0 = meta[2 * PWT + ph], nr = meta[2 * PWT + 16 + ph];
+      for (int ri = 0; ri < nr; ++ri) {
+        const float wyv = wy[ph * kSepMax + ri];
+        const T* row = base + (long long)(y0 + ri) * W * C;
+        for (int ci = 0; ci < ncmax; ++ci) {
+          vecc v[PWT];
+          float w[PWT];
+#pragma unroll
+          for (int pw = 0; pw < PWT; ++pw) {
+            const bool in = ci < nc[pw];
+            v[pw] = *(const vecc*)(row + (long long)min(x0[pw] + ci, W - 1) * C);  // past the bin: a valid cell, weight 0
+            w[pw] = in ? wyv * wx[pw * kSepMax + ci] : 0.f;
+          }
+#pragma unroll
+          for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) acc[pw][q] += w[pw] * to_f32(v[pw][q]);
+        }
+      }
+    }
+  }
+  const bool separable_done = *fits != 0;  // uniform over the workgroup
+  for (int iy = 0; iy < (separable_done ? 0 : a.grid_h); ++iy) {
     const float y = a.start_h + (float)ph * a.bin_h + ((float)iy + .5f) * a.bin_h / (float)a.grid_h;
     const AlignAxis ay = align_axis(y, H);
     if (!ay.valid) continue;  // uniform over the wavefront (one roi, one pooled row)
@@ -890,11 +986,11 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
     const int lds = 4 * 64 * ph * pw * 4;
     WS_CHECK_ARG(lds <= 160 * 1024, "wsovod_roi_align_forward: pooled size too large for LDS tile");
     wsovod::ProfScope prof(slot, s, 0.0, bytes);
-    if (pw == 7 && ph <= 8 && ((uintptr_t)feat & 7) == 0 && C % (dtype == WSOVOD_BF16 ? 4 : 2) == 0) {
+    if (pw == 7 && ph >= 7 && ph <= 8 && ((uintptr_t)feat & 7) == 0 && C % (dtype == WSOVOD_BF16 ? 4 : 2) == 0) {
       // fast path: workgroup per (roi, 64*CPL channels), wavefront per pooled row, 8-byte loads, 28 taps in flight
       const int cg = dtype == WSOVOD_BF16 ? 256 : 128;
       const int groups = ceil_div(C, cg);
-      const int lds7 = cg * ph * pw * 4 + 7 * kAlignMaxGrid * 16;  // output transpose tile + sample-column table
+      const int lds7 = cg * ph * pw * 4 + kAlignTabBytes;  // output transpose tile + sample-column table + separable weights
       if (dtype == WSOVOD_BF16) {
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
