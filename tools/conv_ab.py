@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from wsovod_amd.layers import hip_ops
 tiles = [int(t) for t in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["256256", "8256256"])]
-n = 16
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 for (Cin, Cout, H, W, k, dil) in ((128, 128, 75, 100, 3, 1), (256, 256, 75, 100, 3, 2), (512, 512, 75, 100, 3, 2), (128, 256, 75, 100, 3, 2), (256, 512, 75, 100, 1, 1)):
     pad = dil * (k // 2)
     x = (torch.rand(n, H, W, Cin, device="cuda") * 2 - 1).to(torch.bfloat16)

@@ -435,8 +435,6 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) 
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long long)p.M * n4) return;
   const int m = (int)(idx / n4), nb = (int)(idx - (long long)m * n4) * 4;
-  const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const float rs = p.row_scale ? p.row_scale[m] : 1.f;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   for (int z = 0; z < p.ksplit; ++z) {
     const float* src = p.partial + ((long long)z * p.M + m) * p.partial_ld + nb;
@@ -448,25 +446,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) 
         if (nb + r < p.N) v[r] += src[r];
     }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = nb + r;
-    if (n >= p.N) continue;
-    float x = v[r] * p.alpha;
-    if (p.row_scale) x *= rs;
-    if (p.bias) x += p.bias[n];
-    if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
-    if (p.relu) x = fmaxf(x, 0.f);
-    if (p.dropout_p > 0.f) {
-      const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
-      x = u >= p.dropout_p ? x * keep_scale : 0.f;
-    }
-    if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
-    if (p.mask_src) x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
-    if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
-    if (p.C) store_from_f32(p.C, (long long)m * p.ldc + n, p.dtype_c, x);
-    if (p.Ct) store_from_f32(p.Ct, (long long)n * p.ldct + m, p.dtype_ct, x);
-  }
+  epilogue_store4(p, m, nb, v);
 }
 
 }  // namespace

@@ -83,6 +83,32 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned lon
 }
 
 
+// The epilogue chain of the GEMM kernels for 4 consecutive columns nb..nb+3 of row m (v = raw sums), stores included:
+// used by the split-K finalize kernels (the tile kernels carry vectorised copies of the same chain).
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int nb, const float (&v)[4]) {
+  const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  const float rs = p.row_scale ? p.row_scale[m] : 1.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = nb + r;
+    if (n >= p.N) continue;
+    float x = v[r] * p.alpha;
+    if (p.row_scale) x *= rs;
+    if (p.bias) x += p.bias[n];
+    if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+    if (p.relu) x = fmaxf(x, 0.f);
+    if (p.dropout_p > 0.f) {
+      const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+      x = u >= p.dropout_p ? x * keep_scale : 0.f;
+    }
+    if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
+    if (p.mask_src) x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+    if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
+    if (p.C) store_from_f32(p.C, (long long)m * p.ldc + n, p.dtype_c, x);
+    if (p.Ct) store_from_f32(p.Ct, (long long)n * p.ldct + m, p.dtype_ct, x);
+  }
+}
+
 // gemm8.hip: bf16 256x256 tile, 8 wavefronts in two staggered groups (see the file header).
 int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split = false);
 
