@@ -644,19 +644,23 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
       for (int ri = 0; ri < nr; ++ri) {
         const float wyv = wy[ph * kSepMax + ri];
         const T* row = base + (long long)(y0 + ri) * W * C;
-        for (int ci = 0; ci < ncmax; ++ci) {
-          vecc v[PWT];
-          float w[PWT];
+        for (int ci = 0; ci < ncmax; ci += 2) {  // two columns of every bin per iteration: 14 loads in flight
+          vecc v[2][PWT];
+          float w[2][PWT];
 #pragma unroll
-          for (int pw = 0; pw < PWT; ++pw) {
-            const bool in = ci < nc[pw];
-            v[pw] = *(const vecc*)(row + (long long)min(x0[pw] + ci, W - 1) * C);  // past the bin: a valid cell, weight 0
-            w[pw] = in ? wyv * wx[pw * kSepMax + ci] : 0.f;
-          }
+          for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int pw = 0; pw < PWT; ++pw)
+            for (int pw = 0; pw < PWT; ++pw) {
+              const bool in = ci + u < nc[pw];
+              v[u][pw] = *(const vecc*)(row + (long long)min(x0[pw] + ci + u, W - 1) * C);  // past the bin: weight 0
+              w[u][pw] = in ? wyv * wx[pw * kSepMax + min(ci + u, kSepMax - 1)] : 0.f;
+            }
 #pragma unroll
-            for (int q = 0; q < CPL; ++q) acc[pw][q] += w[pw] * to_f32(v[pw][q]);
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+              for (int q = 0; q < CPL; ++q) acc[pw][q] += w[u][pw] * to_f32(v[u][pw][q]);
         }
       }
     }
