@@ -14,6 +14,8 @@ Prints ONE JSON line on rank 0.  `value` = images/sec over all N GPUs (weak scal
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,6 +57,9 @@ def parse():
     ap.add_argument("--eval", action="store_true",
                     help="side measurement, not the headline metric: images/s of model.inference() (eval mode: frozen "
                          "backbone, RoI pooling, heads, score threshold + per-class NMS tail) on the same synthetic batch")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher self-test (no GPU work): every rank joins the group, all-reduces its rank and rank 0 "
+                         "prints {n_gpus, ranks_seen}; with --backend gloo it runs on a CPU-only host (tests/test_bench_launcher.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -177,8 +182,85 @@ def eval_bench(args, cfg, model, dev, result_fd):
     return 0
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks here, one process per GPU, as
+    the reference's `launch(main, num_gpus)` does (/root/reference/tools/train_net.py:80-90).  The parent never
+    touches the GPU (no HIP call, no exec after one): it only spawns children, relays rank 0's JSON line and
+    returns non-zero if any rank fails."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WSOVOD_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc, line = 0, b""
+    try:
+        pending = set(range(args.gpus))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if r == 0:
+                    line = procs[0].stdout.read()
+                if code != 0:
+                    rc = rc or code
+                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+            if rc:  # a dead rank leaves the others waiting in a collective: stop exactly the children started here
+                for r in pending:
+                    procs[r].terminate()
+                for r in pending:
+                    try:
+                        procs[r].wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        procs[r].kill()
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [x for x in line.decode().splitlines() if x.strip()]
+    if rc == 0 and (len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != args.gpus):
+        print(f"bench.py: expected one JSON line with n_gpus={args.gpus} from rank 0, got {lines!r}", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(lines[0] + "\n")
+        sys.stdout.flush()
+    return rc
+
+
+def launch_check(args, world, rank, result_fd):
+    """The launcher path without GPU work: group creation, one all-reduce, one JSON line."""
+    if os.environ.get("WSOVOD_BENCH_FAIL_RANK") == str(rank):  # tests: a rank that dies before joining the group
+        raise SystemExit(3)
+    dist.init_process_group(args.backend)
+    t = torch.tensor([1 << rank], dtype=torch.int64)
+    if args.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        t = t.cuda()
+    dist.all_reduce(t)
+    if rank == 0:
+        os.write(result_fd, (json.dumps({"metric": "launch-check", "n_gpus": dist.get_world_size(),
+                                         "ranks_seen": int(t.item()), "backend": args.backend}) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher and "
+                         f"the flag must agree (the reported n_gpus is the size of the process group)")
     # stdout carries exactly ONE line, the JSON result: libraries that print to fd 1 (RCCL's version banner at
     # communicator creation does) are sent to stderr for the duration of the run.
     sys.stdout.flush()
@@ -187,6 +269,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        return launch_check(args, world, rank, result_fd)
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X (no CPU fallback on the product path)")
     if args.share_device:
@@ -315,4 +399,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
