@@ -366,6 +366,19 @@ int wsovod_pgt_mine_and_label(const float* scores, long long ld_scores, const fl
                               long long* out_classes, float* out_boxes, float* out_scores,
                               float* out_weights, int* out_matched, wsovod_stream_t stream);
 
+/* Proposal sub-sampling for the refinement losses, no grad.  Replaces detectron2 `subsample_labels` as called by
+ * WSOVODROIHeads._sample_proposals_wsl (roi_heads.py:1566-1603) when an image has more proposals than
+ * WSOVOD.SAMPLING.BATCH_SIZE_PER_IMAGE or POSITIVE_FRACTION < 1 (the shipped RPN configs: up to 4000 loaded + 1024
+ * RPN boxes against 4096).  Per image g (rows [seg_offsets[g], seg_offsets[g+1]) of `labels`):
+ *   positives = labels not in {-1, bg_label}, negatives = labels == bg_label,
+ *   num_pos = min(#pos, pos_cap) with pos_cap = int(num_samples * positive_fraction), num_neg = min(#neg, num_samples - num_pos);
+ *   the num_pos / num_neg rows of each group with the smallest (keys[row], row) keep their label, all others get -1.
+ * keys ~ U[0,1) reproduces the reference's randperm sampling; keys = row index is the deterministic first-n rule.
+ * out_labels must not alias labels.  max_rows = the longest segment (launch geometry only). */
+int wsovod_subsample_labels(const long long* labels, const float* keys, const int* seg_offsets, int G, int max_rows,
+                            int num_samples, int pos_cap, long long bg_label, long long* out_labels,
+                            wsovod_stream_t stream);
+
 /* Backward prologue of Linear+ReLU(+Dropout) (box_head.py:60-66): dA = dy * [y > 0] * scale
  * written as [M][N] and/or transposed [N][ldt] (either output may be NULL; y NULL = no mask). */
 int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype,

@@ -282,6 +282,61 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
     return boxes[keep], scores[keep], filter_inds[keep, 1], pred_inds[filter_inds[keep, 0]]
 
 
+# ----------------------------------------------------------------------------------------
+# inference: rcnn_wsovod.py:236-319 -> roi_heads.py eval branch -> predict_probs_K / predict_boxes_K
+# (fast_rcnn_open_vocabulary.py:987-1058) -> fast_rcnn_inference_single_image -> detector_postprocess.
+# Pinned by tests/golden/g14_eval_tail.npz and g15_tta_avg.npz (outputs of the reference's own files).
+# ----------------------------------------------------------------------------------------
+@torch.no_grad()
+def eval_forward(sd, batch, *, depth=18, classifier=None, pooler_type="ROIPool", temperature=50.0,
+                 pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True, refine_K=1,
+                 sampling_ratio=0):
+    """Per image: (scores (R, K+1) = mean over the refinement heads of softmax(logits), boxes (R, 4) =
+    apply_deltas(mean deltas, proposals)) -- the `all_scores` / `all_boxes` the detection tail consumes."""
+    x = preprocess_image([b["image"] for b in batch], pixel_mean, pixel_std)
+    res5 = backbone_forward(sd, x, depth)["res5"]
+    boxes_list = [b["boxes"] for b in batch]
+    nums = [len(b) for b in boxes_list]
+    pooled = roi_pooler(res5, boxes_list, pooler_type, 7, 0.125, sampling_ratio)
+    pooled = pooled * torch.cat([b["objectness"] + 1 for b in batch]).view(-1, 1, 1, 1)
+    feat = neck_forward(sd, pooled)
+    if data_aware:
+        daf = data_aware_forward(sd, res5)
+        feat = feat + torch.cat([daf[i].repeat(n, 1) for i, n in enumerate(nums)])
+    probs, deltas = 0, 0
+    for k in range(refine_K):
+        prefix = f"roi_heads.box_refinery_{k}."
+        logits = ov_classifier_forward(sd, feat, prefix + "cls.", temperature, classifier=classifier)
+        probs = probs + torch.softmax(logits, dim=-1)
+        deltas = deltas + F.linear(feat, sd[prefix + "bbox_pred.weight"], sd[prefix + "bbox_pred.bias"])
+    boxes = box2box_apply_deltas(deltas / refine_K, torch.cat(boxes_list))
+    return list(zip((probs / refine_K).split(nums), boxes.split(nums)))
+
+
+def detector_postprocess(boxes, image_size, output_height, output_width):
+    """postprocessing.py:8-82 for box-only results: scale to the requested size, clip, keep non-empty boxes.
+    Returns (boxes, keep mask)."""
+    sx, sy = output_width / image_size[1], output_height / image_size[0]
+    b = boxes.clone()
+    b[:, 0::2] *= sx
+    b[:, 1::2] *= sy
+    b[:, 0::2] = b[:, 0::2].clamp(min=0, max=output_width)
+    b[:, 1::2] = b[:, 1::2].clamp(min=0, max=output_height)
+    keep = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+    return b[keep], keep
+
+
+def tta_avg_merge(view_boxes, view_scores, inverse_apply_box, shape_hw, score_thresh, nms_thresh, topk_per_image):
+    """test_time_augmentation_avg.py:279-318: every view's per-proposal boxes go back to the original frame through
+    the inverse of that view's transforms (`inverse_apply_box[i]`: (n,4) numpy -> (n,4) numpy), boxes and class
+    scores are averaged over the views, then ONE detection tail pass."""
+    back = [torch.from_numpy(inv(b.numpy())).to(b.dtype) for b, inv in zip(view_boxes, inverse_apply_box)]
+    boxes = torch.stack(back).mean(dim=0)
+    scores = torch.stack(list(view_scores)).mean(dim=0)
+    return (boxes, scores) + tuple(fast_rcnn_inference_single_image(boxes, scores, shape_hw, score_thresh, nms_thresh,
+                                                                     topk_per_image))
+
+
 def refinement_losses(logits, deltas, gt_classes, gt_weights, proposal_boxes, gt_boxes, num_classes,
                       bbox_weights=(10.0, 10.0, 5.0, 5.0), beta=0.0, cross_entropy_weighted=True,
                       box_loss_type="smooth_l1_weighted"):
@@ -354,17 +409,40 @@ def get_pgt_top_k(prev_pred_boxes, prev_pred_scores, gt_classes_img_int, pred_cl
     return out
 
 
+def subsample_labels_keyed(labels, num_samples, positive_fraction, bg_label, keys):
+    """detectron2 subsample_labels (un-vendored; call site roi_heads.py:1597-1602) with the
+    random permutations expressed as sort keys: `randperm(n)[:k]` of a group = its k rows with the smallest keys
+    (ties by row index).  Returns (pos_idx, neg_idx)."""
+    positive = ((labels != -1) & (labels != bg_label)).nonzero().flatten()
+    negative = (labels == bg_label).nonzero().flatten()
+    num_pos = min(positive.numel(), int(num_samples * positive_fraction))
+    num_neg = min(negative.numel(), num_samples - num_pos)
+    pos = positive[torch.argsort(keys[positive], stable=True)[:num_pos]]
+    neg = negative[torch.argsort(keys[negative], stable=True)[:num_neg]]
+    return pos, neg
+
+
 @torch.no_grad()
-def label_and_sample_proposals_wsl(proposal_boxes_list, targets, num_classes, iou_thr=0.5):
-    """roi_heads.py:1722-1825 + _sample_proposals_wsl :1566-1610 with Matcher([thr],[0,1]) and
-    subsample_labels(4096, 1.0) keeping every proposal (R <= 4096)."""
+def label_and_sample_proposals_wsl(proposal_boxes_list, targets, num_classes, iou_thr=0.5, batch_size_per_image=4096,
+                                   positive_fraction=1.0, keys=None):
+    """roi_heads.py:1722-1825 + _sample_proposals_wsl :1566-1610 with Matcher([thr],[0,1]).  subsample_labels keeps
+    every proposal when R <= batch_size_per_image and positive_fraction == 1; otherwise `keys` (one float tensor per
+    image) stand for the random permutations and rows outside the sample are labelled -1 (:1604-1607)."""
     res = []
-    for pb, t in zip(proposal_boxes_list, targets):
+    for i, (pb, t) in enumerate(zip(proposal_boxes_list, targets)):
         iou = pairwise_iou(t["gt_boxes"], pb)  # (G,R)
         matched_vals, matched_idxs = iou.max(dim=0)
         labels = (matched_vals >= iou_thr).to(torch.int8)
         gt_classes = t["gt_classes"][matched_idxs].clone()
         gt_classes[labels == 0] = num_classes
+        if keys is not None:
+            pos, neg = subsample_labels_keyed(gt_classes, batch_size_per_image, positive_fraction, num_classes, keys[i])
+            sampled = torch.full_like(gt_classes, -1)
+            idx = torch.cat([pos, neg])
+            sampled[idx] = gt_classes[idx]
+            gt_classes = sampled
+        else:
+            assert len(pb) <= batch_size_per_image and positive_fraction >= 1.0, "sub-sampling needs keys"
         res.append(dict(gt_classes=gt_classes, gt_boxes=t["gt_boxes"][matched_idxs],
                         gt_scores=t["gt_scores"][matched_idxs], gt_weights=t["gt_weights"][matched_idxs],
                         matched_idxs=matched_idxs))
@@ -468,9 +546,11 @@ def rpn_losses(anchors, logits, deltas, targets, subsample, batch_size_per_image
 def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool", temperature=50.0,
                   pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True,
                   mean_loss=True, sampling_ratio=0, dropout_masks=None, refine_prefix="roi_heads.box_refinery_0.",
-                  miner_prefix="roi_heads.object_miner.", classifier=None, rpn=None):
+                  miner_prefix="roi_heads.object_miner.", classifier=None, rpn=None, sampling=None):
     """batch: list of dicts {image uint8 (3,H,W), boxes (R,4), objectness (R), gt_classes (G)}.
-    Returns (losses dict, intermediates dict).  REFINE_NUM=1, REFINE_REG=[True], SAMPLING_ON."""
+    Returns (losses dict, intermediates dict).  REFINE_NUM=1, REFINE_REG=[True], SAMPLING_ON.
+    sampling: None (every proposal kept: R <= 4096, fraction 1) or dict(batch_size_per_image, positive_fraction,
+    keys = callable n -> (n,) float sort keys standing for subsample_labels' random permutation)."""
     inter = {}
     x = preprocess_image([b["image"] for b in batch], pixel_mean, pixel_std)
     feats = backbone_forward(sd, x, depth)
@@ -519,7 +599,13 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
     img_logits = predict_probs_img(scores, nums).detach()
     inter["pred_class_img_logits"] = img_logits
     targets = get_pgt_top_k(boxes_list, list(scores.detach().split(nums)), gt_int, img_logits, num_classes)
-    labelled = label_and_sample_proposals_wsl(boxes_list, targets, num_classes)
+    if sampling is None:
+        labelled = label_and_sample_proposals_wsl(boxes_list, targets, num_classes)
+    else:
+        labelled = label_and_sample_proposals_wsl(boxes_list, targets, num_classes,
+                                                  batch_size_per_image=sampling["batch_size_per_image"],
+                                                  positive_fraction=sampling["positive_fraction"],
+                                                  keys=[sampling["keys"](n) for n in nums])
     inter["targets"], inter["labelled"] = targets, labelled
     # mixed-dataset mode hands the dataset's raw text embeddings in per call (rcnn_wsovod_mixed_datasets.py:237)
     logits = ov_classifier_forward(sd, feat, refine_prefix + "cls.", temperature, classifier=classifier)

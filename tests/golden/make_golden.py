@@ -489,6 +489,211 @@ def golden_rpn(r):
     save("g12_rpn_train_step", **arrays)
 
 
+def brute_force_batched_nms(boxes, scores, idxs, iou_threshold):
+    """Stand-in for detectron2.layers.batched_nms (-> torchvision.ops.batched_nms, un-vendored) used ONLY to generate
+    g14/g15: a direct O(n^2) greedy per-class NMS in float32 numpy, written from the definition (visit boxes by
+    descending score, ties by index; drop a box whose IoU with an already kept box OF THE SAME CLASS exceeds the
+    threshold; return the kept indices in visiting order).  Independent of oracle/det_ops_ref.c and of the HIP kernel."""
+    b = boxes.detach().cpu().numpy().astype(np.float32)
+    sc = scores.detach().cpu().numpy()
+    cl = idxs.detach().cpu().numpy()
+    order = np.lexsort((np.arange(len(sc)), -sc.astype(np.float64)))
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    kept = []
+    for i in order:
+        if kept:
+            k = np.asarray(kept)
+            k = k[cl[k] == cl[i]]
+            if len(k):
+                iw = np.maximum(np.minimum(b[k, 2], b[i, 2]) - np.maximum(b[k, 0], b[i, 0]), np.float32(0))
+                ih = np.maximum(np.minimum(b[k, 3], b[i, 3]) - np.maximum(b[k, 1], b[i, 1]), np.float32(0))
+                inter = iw * ih
+                if np.any(inter / (area[k] + area[i] - inter) > np.float32(iou_threshold)):
+                    continue
+        kept.append(int(i))
+    return torch.as_tensor(kept, dtype=torch.int64)
+
+
+def _eval_reference_model(r, K=20, D=512, seed=1):
+    """The reference model in eval mode with the reference's own postprocessing.py and the brute-force NMS stand-in."""
+    sys.modules["detectron2.structures"].ROIMasks = _Unsupported
+    post = load_ref("wsovod.modeling.postprocessing", "wsovod/modeling/postprocessing.py")
+    r.meta.detector_postprocess = post.detector_postprocess
+    r.frcnn.batched_nms = brute_force_batched_nms
+    cfg, model, sd, shapes = build_ref_model(r, 18, K, D, seed=seed)
+    model.eval()
+    return cfg, model, post
+
+
+def golden_eval_tail(r):
+    """G14: the REFERENCE's inference path -- GeneralizedRCNN_WSOVOD.inference (rcnn_wsovod.py:236-319) ->
+    WSOVODROIHeads eval forward -> predict_probs_K / predict_boxes_K (fast_rcnn_open_vocabulary.py:987-1058) ->
+    fast_rcnn_inference_single_image (:149-217) -> detector_postprocess (postprocessing.py:8-82) on three images whose
+    requested output size differs from the network input.  Stored: the raw per-proposal scores / boxes the tail
+    consumes, the detections before and after post-processing."""
+    cfg, model, post = _eval_reference_model(r)
+    batch = gen.seeded_batch(3, 200, 20, 256, 352, seed=15)
+    # a few non-finite rows and exact score ties exercise the valid-mask and tie-order branches of the tail
+    inputs = to_inputs(batch)
+    for i, x in enumerate(inputs):
+        x["height"], x["width"] = 300 + 40 * i, 500 - 30 * i
+    clf = torch.randn(20, 512, generator=torch.Generator().manual_seed(77))
+    arrays = {"classifier": clf}
+    with torch.no_grad():
+        raw, all_scores, all_boxes = model.inference(inputs, do_postprocess=False, classifier=clf)
+        full = model.inference(inputs, do_postprocess=True, classifier=clf)
+    for i, (res, sc, bx, out) in enumerate(zip(raw, all_scores, all_boxes, full)):
+        arrays[f"img{i}/all_scores"], arrays[f"img{i}/all_boxes"] = sc[0], bx[0]
+        arrays[f"img{i}/raw_boxes"], arrays[f"img{i}/raw_scores"] = res.pred_boxes.tensor, res.scores
+        arrays[f"img{i}/raw_classes"], arrays[f"img{i}/raw_inds"] = res.pred_classes, res.pred_inds
+        o = out["instances"]
+        arrays[f"img{i}/out_size"] = np.array(o.image_size)
+        arrays[f"img{i}/out_boxes"], arrays[f"img{i}/out_scores"] = o.pred_boxes.tensor, o.scores
+        arrays[f"img{i}/out_classes"], arrays[f"img{i}/out_inds"] = o.pred_classes, o.pred_inds
+    # the tail on hand-made inputs: non-finite rows, exact score ties, class-specific (R, K*4) boxes, top-k cut
+    g = torch.Generator().manual_seed(78)
+    R_, K_ = 150, 6
+    xy = torch.rand(R_, 2, generator=g) * torch.tensor([300.0, 200.0])
+    wh = torch.rand(R_, 2, generator=g) * 120 + 4
+    base = torch.cat([xy, xy + wh], dim=1)
+    boxes_cs = (base[:, None, :] + torch.randn(R_, K_, 4, generator=g) * 3).reshape(R_, K_ * 4)
+    sc = torch.softmax(torch.randn(R_, K_ + 1, generator=g) * 2, dim=1)
+    sc[10] = sc[11]  # exact ties between two proposals
+    sc[20, 2] = float("nan")
+    boxes_cs[30, 5] = float("inf")
+    for name, bx, topk in (("agnostic", base, 40), ("specific", boxes_cs, -1)):
+        res, kept, _, _ = r.frcnn.fast_rcnn_inference_single_image(bx, sc, (210, 330), 0.05, 0.3, topk)
+        arrays[f"tail_{name}/boxes_in"], arrays[f"tail_{name}/scores_in"] = bx, sc
+        arrays[f"tail_{name}/boxes"], arrays[f"tail_{name}/scores"] = res.pred_boxes.tensor, res.scores
+        arrays[f"tail_{name}/classes"], arrays[f"tail_{name}/inds"] = res.pred_classes, res.pred_inds[:, 0] if res.pred_inds.dim() > 1 else res.pred_inds
+        arrays[f"tail_{name}/kept_rows"] = kept
+    save("g14_eval_tail", **arrays)
+
+
+def golden_tta(r):
+    """G15: the REFERENCE's DatasetMapperTTAAVG + GeneralizedRCNNWithTTAAVG (test_time_augmentation_avg.py:67-334)
+    around the reference model: 2 short-edge sizes x flip = 4 views of one image, per-view inference, boxes mapped back
+    through the inverse transforms, mean over views, one tail pass.  detectron2's ResizeShortestEdge / RandomFlip /
+    apply_augmentations / fvcore transforms are un-vendored: the stand-ins below wrap the restatements in
+    wsovod_amd/data/proposals.py (image resampling = PIL bilinear).  detectron2's own `fast_rcnn_inference_single_image`
+    (imported by the TTA file, un-vendored) is the reference's superset of it cut to its 2-tuple return."""
+    from wsovod_amd.data import proposals as P
+    from wsovod_amd.modeling import test_time_augmentation as T
+
+    class TL(T._InvertibleList):
+        def __add__(self, other):
+            return TL(list(self.transforms) + list(getattr(other, "transforms", [other])))
+
+        def __radd__(self, other):
+            return TL(list(getattr(other, "transforms", [other])) + list(self.transforms))
+
+    class NoOp(TL):
+        def __init__(self):
+            super().__init__([])
+
+    class ResizeShortestEdge:
+        def __init__(self, short, max_size):
+            self.short, self.max_size = short, max_size
+
+    class RandomFlip:
+        def __init__(self, prob=1.0):
+            assert prob == 1.0
+
+    def apply_augmentations(augs, image):
+        tf = []
+        for a in augs:
+            if isinstance(a, ResizeShortestEdge):
+                h, w = image.shape[:2]
+                nh, nw = T._shortest_edge_size(h, w, a.short, a.max_size)
+                image = T._resize_image(image, nh, nw)
+                tf.append(P.ResizeTransform(h, w, nh, nw))
+            else:
+                tf.append(P.HFlipTransform(image.shape[1]))
+                image = image[:, ::-1]
+        return image, TL(tf)
+
+    cfg, model, post = _eval_reference_model(r)
+    _mod("detectron2.data.detection_utils", read_image=None)
+    _mod("detectron2.data.transforms", RandomFlip=RandomFlip, ResizeShortestEdge=ResizeShortestEdge,
+         ResizeTransform=lambda h, w, nh, nw: TL([P.ResizeTransform(h, w, nh, nw)]),
+         apply_augmentations=apply_augmentations)
+    sys.modules["detectron2.modeling.meta_arch"].GeneralizedRCNN = type("GeneralizedRCNN", (), {})
+    _mod("detectron2.modeling.roi_heads.fast_rcnn",
+         fast_rcnn_inference_single_image=lambda *a: r.frcnn.fast_rcnn_inference_single_image(*a)[:2])
+    _mod("fvcore.transforms", HFlipTransform=P.HFlipTransform, NoOpTransform=NoOp)
+    tta_mod = load_ref("wsovod.modeling.test_time_augmentation_avg", "wsovod/modeling/test_time_augmentation_avg.py")
+    model.classifier = torch.randn(20, 512, generator=torch.Generator().manual_seed(77))
+    cfg.TEST.DETECTIONS_PER_IMAGE = 100
+    cfg.MODEL.KEYPOINT_ON = False
+    mapper = tta_mod.DatasetMapperTTAAVG([192, 256], 4000, True, 0)
+    tta = tta_mod.GeneralizedRCNNWithTTAAVG(cfg, model, mapper)
+    inp = to_inputs(gen.seeded_batch(1, 60, 20, 256, 352, seed=21))[0]
+    # the reference mapper leaves already-mapped `proposals` untouched when proposal_topk == 0; views of other sizes
+    # need their boxes moved with the image, so the harness hands each view its transformed boxes (what
+    # transform_proposals does for proposal_topk > 0, minus the top-k cut) through the mapper hook below
+    orig_call = mapper.__class__.__call__
+
+    def mapped(self, d):
+        views = orig_call(self, d)
+        for v in views:
+            p = v["proposals"]
+            q = S.Instances(tuple(v["image"].shape[1:]), **p.get_fields())
+            b = S.Boxes(torch.from_numpy(v["transforms"].apply_box(p.proposal_boxes.tensor.numpy())).float())
+            b.clip(q.image_size)
+            q.proposal_boxes = b
+            v["proposals"] = q
+        return views
+
+    mapper.__class__.__call__ = mapped
+    captured = {}
+    orig_get = tta._get_augmented_boxes
+
+    def cap(aug, tfms):
+        captured["views"] = [(a["image"].clone(), a["proposals"].proposal_boxes.tensor.clone()) for a in aug]
+        o = orig_get(aug, tfms)
+        captured["avg"] = o
+        return o
+
+    tta._get_augmented_boxes = cap
+    with torch.no_grad():
+        out = tta([inp])[0]["instances"]
+    arrays = {"classifier": model.classifier, "avg_boxes": captured["avg"][0], "avg_scores": captured["avg"][1],
+              "boxes": out.pred_boxes.tensor, "scores": out.scores, "classes": out.pred_classes}
+    for i, (img, bx) in enumerate(captured["views"]):
+        arrays[f"view{i}/shape"] = np.array(img.shape)
+        arrays[f"view{i}/image_checksum"] = img.double().sum()
+        arrays[f"view{i}/proposal_boxes"] = bx
+    save("g15_tta_avg", **arrays)
+
+
+def golden_subsample(r):
+    """G16: the REFERENCE's WSOVODROIHeads._sample_proposals_wsl (roi_heads.py:1566-1603) on label vectors longer
+    than BATCH_SIZE_PER_IMAGE (the shipped RPN form: 4000 loaded + 1024 RPN boxes against 4096) and with
+    POSITIVE_FRACTION < 1.  detectron2's random subsample_labels (un-vendored) is replaced by the deterministic
+    first-k rule of tests/golden/gen.py (randperm cannot be reproduced across implementations)."""
+    r.roi_heads.subsample_labels = gen.first_k_subsample
+    cfg, model, sd, shapes = build_ref_model(r, 18, 20, 512, seed=1)
+    rh = model.roi_heads
+    arrays = {}
+    g = torch.Generator().manual_seed(91)
+    cases = [(5024, 4096, 1.0, 0.02), (5024, 4096, 0.25, 0.4), (3000, 512, 0.25, 0.05), (300, 4096, 0.5, 0.9),
+             (4097, 4096, 1.0, 0.0)]
+    for i, (R_, num, frac, p_fg) in enumerate(cases):
+        rh.batch_size_per_images[0], rh.positive_sample_fractions[0] = num, frac
+        G_ = 3
+        matched_idxs = torch.randint(0, G_, (R_,), generator=g)
+        u = torch.rand(R_, generator=g)
+        matched_labels = (u < p_fg).to(torch.int8)  # Matcher([0.5],[0,1]): 1 = foreground, 0 = background
+        gt_classes = torch.tensor([3, 7, 11])
+        idx, lab = rh._sample_proposals_wsl(0, matched_idxs, matched_labels, gt_classes)
+        assert torch.equal(idx, torch.arange(R_))
+        full = gt_classes[matched_idxs].clone()
+        full[matched_labels == 0] = rh.num_classes
+        arrays[f"case{i}/params"] = np.array([R_, num, frac, rh.num_classes], dtype=np.float64)
+        arrays[f"case{i}/labels_in"], arrays[f"case{i}/labels_out"] = full, lab
+    save("g16_subsample", **arrays)
+
+
 def golden_formats():
     """G13: the REFERENCE's load_proposals_into_dataset (data/build.py:112-173) and unique_boxes /
     transform_proposals (data/detection_utils.py:206-265) on a synthetic D1-style proposal pickle (`indexes` /
@@ -598,6 +803,10 @@ def main():
         return golden_mixed(r)
     if "--only-rpn" in sys.argv:
         return golden_rpn(r)
+    if "--only-eval" in sys.argv:
+        golden_eval_tail(r)
+        golden_subsample(r)
+        return golden_tta(r)
 
     # ---------------- G2: RoIPool / ROIAlign (reference C++ op) ----------------
     from tests.util import random_rois
@@ -696,6 +905,9 @@ def main():
         daf = model.data_aware_head({"res5": fm}, props)
     save("g9_data_aware", res5=fm, daf=daf, nums=np.array([3, 1, 2]))
 
+    golden_eval_tail(r)
+    golden_subsample(r)
+    golden_tta(r)
     golden_mixed(r)
     golden_sampler()
     golden_rpn(r)

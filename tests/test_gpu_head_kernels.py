@@ -239,3 +239,63 @@ def test_elementwise_kernels(gpu):
                                             ("linear1.weight", "linear1.bias", "linear2.weight", "linear2.bias",
                                              "datasets_feat.weight")))
     torch.testing.assert_close(daf.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_subsample_labels_matches_reference_golden(gpu):
+    """G16 = the reference's _sample_proposals_wsl with the first-k stand-in for subsample_labels; the kernel with
+    keys = row index is that rule: labels bit-exact, incl. R = 5024 > 4096 (the shipped RPN form)."""
+    from tests.helpers import load_golden
+    from wsovod_amd.layers import hip_ops as H
+
+    g = load_golden("g16_subsample")
+    i = 0
+    while f"case{i}/params" in g:
+        R_, num, frac, K = g[f"case{i}/params"].tolist()
+        lab = g[f"case{i}/labels_in"].to(gpu)
+        seg = torch.tensor([0, int(R_)], dtype=torch.int32, device=gpu)
+        out = H.subsample_labels(lab, torch.arange(int(R_), dtype=torch.float32, device=gpu), seg, int(R_), int(num), frac,
+                                 int(K))
+        assert torch.equal(out.cpu(), g[f"case{i}/labels_out"]), i
+        i += 1
+    assert i == 5
+    # two of the cases (same quota) as ragged segments of one launch, an empty segment between them
+    a, b = g["case0/labels_in"], g["case4/labels_in"]
+    seg = torch.tensor([0, len(a), len(a), len(a) + len(b)], dtype=torch.int32, device=gpu)
+    keys = torch.cat([torch.arange(len(a)), torch.arange(len(b))]).float().to(gpu)
+    out = H.subsample_labels(torch.cat([a, b]).to(gpu), keys, seg, max(len(a), len(b)), 4096, 1.0, 20).cpu()
+    assert torch.equal(out, torch.cat([g["case0/labels_out"], g["case4/labels_out"]]))
+
+
+def test_subsample_labels_random_keys(gpu):
+    """Random keys: (i) the kernel equals the oracle's keyed subsample_labels on the same keys (ties broken by row);
+    (ii) quotas of detectron2's subsample_labels hold; (iii) every positive / negative is drawn with the same
+    frequency (uniform without replacement, what randperm does in the reference)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(5)
+    K, n, num, frac = 20, 300, 64, 0.25
+    lab = torch.full((n,), K, dtype=torch.int64)
+    lab[torch.randperm(n, generator=g)[:40]] = 3
+    lab[torch.randperm(n, generator=g)[:5]] = -1
+    pos, neg = (lab != K) & (lab != -1), lab == K
+    seg = torch.tensor([0, n], dtype=torch.int32, device=gpu)
+    hits = torch.zeros(n)
+    trials = 400
+    for t in range(trials):
+        keys = torch.rand(n, generator=g)
+        if t == 0:
+            keys[10:20] = keys[10]  # exact ties
+        out = H.subsample_labels(lab.to(gpu), keys.to(gpu), seg, n, num, frac, K).cpu()
+        p_idx, n_idx = R.subsample_labels_keyed(lab, num, frac, K, keys)
+        want = torch.full_like(lab, -1)
+        want[torch.cat([p_idx, n_idx])] = lab[torch.cat([p_idx, n_idx])]
+        assert torch.equal(out, want)
+        kept = out != -1
+        assert int((kept & pos).sum()) == min(int(pos.sum()), int(num * frac))
+        assert int((kept & neg).sum()) == min(int(neg.sum()), num - int((kept & pos).sum()))
+        hits += kept.float()
+    for grp in (pos, neg):
+        f = hits[grp] / trials
+        p = float(f.mean())
+        sigma = (p * (1 - p) / trials) ** 0.5
+        assert float((f - p).abs().max()) < 5 * sigma + 1e-9

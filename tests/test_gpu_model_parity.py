@@ -271,6 +271,123 @@ def test_maximum_proposal_count_matches_oracle(gpu):
     assert torch.equal(pgt["gt_boxes"].cpu(), torch.cat([l["gt_boxes"] for l in lab]))
 
 
+def test_proposals_beyond_sampling_batch_match_oracle(gpu):
+    """The shipped RPN form of the configs: up to 4000 loaded + 1024 RPN boxes per image against
+    SAMPLING.BATCH_SIZE_PER_IMAGE = 4096 (Base-RCNN-DilatedC5.yaml:12,58,84) -> _sample_proposals_wsl sub-samples
+    (roi_heads.py:1566-1610).  One image with 5031 boxes next to one with 7, deterministic first-k keys on both sides:
+    sampled labels exact, losses / logits as in the other fp32 tests; the ignored rows carry no loss."""
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    big = gen.seeded_batch(1, 5031, 20, 256, 352, seed=83, edge_cases=False)[0]
+    small = gen.seeded_batch(1, 14, 20, 192, 256, seed=84, edge_cases=False)[0]
+    batch = [big, small]
+    assert len(big["boxes"]) > 4096
+    model.roi_heads._sample_keys = lambda n, dev: torch.arange(n, dtype=torch.float32, device=dev)
+    sdc = {k: v.clone() for k, v in sd.items()}
+    ref_losses, inter = R.train_forward(sdc, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD,
+                                        sampling=dict(batch_size_per_image=4096, positive_fraction=1.0,
+                                                      keys=lambda n: torch.arange(n, dtype=torch.float32)))
+    losses, cap, pgt = _run(model, batch)
+    lab = torch.cat([l["gt_classes"] for l in inter["labelled"]])
+    assert torch.equal(pgt["gt_classes"].cpu(), lab)
+    n_big = len(big["boxes"])
+    assert int((lab[:n_big] != -1).sum()) == 4096 and int((lab[n_big:] == -1).sum()) == 0
+    assert (cap["refine"][0].detach().cpu() - inter["refine_logits"]).abs().max() < 1e-3
+    for name, v in ref_losses.items():
+        torch.testing.assert_close(losses[name].detach().cpu(), v.detach(), rtol=2e-3, atol=1e-5)
+    # POSITIVE_FRACTION < 1 (not shipped, but the same code path): quotas hold with random keys
+    model.roi_heads._sample_keys = lambda n, dev: torch.rand(n, device=dev)
+    model.roi_heads.positive_sample_fractions[0] = 0.25
+    model.roi_heads.batch_size_per_images[0] = 512
+    _, _, pgt = _run(model, batch)
+    out, full = pgt["gt_classes"].cpu(), pgt["gt_classes_all"].cpu()
+    fg = (full[:n_big] != 20)
+    assert int(((out[:n_big] != -1) & fg).sum()) == min(int(fg.sum()), 128)
+    assert int((out[:n_big] != -1).sum()) == 512
+
+
+def test_eval_tail_matches_reference_golden(gpu):
+    """G14 (the reference's own inference path).  (i) the HIP model's per-proposal class scores / decoded boxes match
+    the reference's (fp32 mode); (ii) fed the reference's tail inputs, the HIP tail (threshold, per-class segment NMS,
+    top-k) and the packed post-processing return the reference's detections EXACTLY, in its order -- single-image and
+    batched forms; (iii) hand-made tail inputs with non-finite rows, exact score ties, class-specific boxes."""
+    from wsovod_amd.modeling.fast_rcnn_open_vocabulary import fast_rcnn_inference, fast_rcnn_inference_single_image
+    from wsovod_amd.modeling.meta_arch import detector_postprocess
+
+    g = load_golden("g14_eval_tail")
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    model.eval()
+    batch = gen.seeded_batch(3, 200, 20, 256, 352, seed=15)
+    inputs = to_inputs(batch)
+    for i, x in enumerate(inputs):
+        x["height"], x["width"] = 300 + 40 * i, 500 - 30 * i
+    res, all_scores, all_boxes = model.inference(inputs, do_postprocess=False, classifier=g["classifier"].to(gpu))
+    for i in range(3):
+        assert (all_scores[i][0].cpu() - g[f"img{i}/all_scores"]).abs().max() < 1e-4
+        assert (all_boxes[i][0].cpu() - g[f"img{i}/all_boxes"]).abs().max() < 2e-2
+    sizes = [tuple(b["image"].shape[-2:]) for b in batch]
+    boxes_in = [g[f"img{i}/all_boxes"].to(gpu) for i in range(3)]
+    scores_in = [g[f"img{i}/all_scores"].to(gpu) for i in range(3)]
+    batched, _, _, _ = fast_rcnn_inference(boxes_in, scores_in, sizes, 1e-5, 0.3, 100)
+    assert getattr(batched, "packed", None) is not None
+    for i in range(3):
+        single = fast_rcnn_inference_single_image(boxes_in[i], scores_in[i], sizes[i], 1e-5, 0.3, 100)[0]
+        for r in (single, batched[i]):
+            assert torch.equal(r.pred_boxes.tensor.cpu(), g[f"img{i}/raw_boxes"])
+            assert torch.equal(r.scores.cpu(), g[f"img{i}/raw_scores"])
+            assert torch.equal(r.pred_classes.cpu(), g[f"img{i}/raw_classes"])
+            assert torch.equal(r.pred_inds.reshape(len(r), -1)[:, 0].cpu(), g[f"img{i}/raw_inds"].reshape(len(r), -1)[:, 0])
+        oh, ow = (int(v) for v in g[f"img{i}/out_size"])
+        o = detector_postprocess(single, oh, ow)
+        assert torch.equal(o.pred_boxes.tensor.cpu(), g[f"img{i}/out_boxes"])
+        assert torch.equal(o.scores.cpu(), g[f"img{i}/out_scores"])
+        assert torch.equal(o.pred_classes.cpu(), g[f"img{i}/out_classes"])
+    for name, topk in (("agnostic", 40), ("specific", -1)):
+        p = f"tail_{name}/"
+        r = fast_rcnn_inference_single_image(g[p + "boxes_in"].to(gpu), g[p + "scores_in"].to(gpu), (210, 330), 0.05,
+                                             0.3, topk)[0]
+        assert torch.equal(r.pred_boxes.tensor.cpu(), g[p + "boxes"]) and torch.equal(r.scores.cpu(), g[p + "scores"])
+        assert torch.equal(r.pred_classes.cpu(), g[p + "classes"])
+        assert torch.equal(r.pred_inds.reshape(len(r), -1)[:, 0].cpu(), g[p + "inds"])
+
+
+def test_tta_avg_matches_reference_golden(gpu):
+    """G15 (the reference's DatasetMapperTTAAVG + GeneralizedRCNNWithTTAAVG around the reference model, 4 views):
+    the HIP TTA wrapper's view set, averaged per-proposal scores / boxes and merged detections."""
+    from wsovod_amd.modeling import GeneralizedRCNNWithTTAAVG
+    from wsovod_amd.modeling.test_time_augmentation import DatasetMapperTTAAVG
+
+    g = load_golden("g15_tta_avg")
+    cfg, model, sd = build_seeded_hip_model("fp32")
+    model.eval()
+    model.classifier = g["classifier"].to(gpu)
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST, cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = 1e-5, 0.3
+    cfg.TEST.DETECTIONS_PER_IMAGE = 100
+    tta = GeneralizedRCNNWithTTAAVG(cfg, model, DatasetMapperTTAAVG([192, 256], 4000, True, 0))
+    inp = to_inputs(gen.seeded_batch(1, 60, 20, 256, 352, seed=21))[0]
+    captured = {}
+    orig = tta._get_augmented_boxes
+
+    def cap(aug, tfms):
+        for i, a in enumerate(aug):
+            assert torch.equal(a["proposals"].proposal_boxes.tensor.cpu(), g[f"view{i}/proposal_boxes"])
+            assert float(a["image"].double().sum()) == float(g[f"view{i}/image_checksum"])
+        o = orig(aug, tfms)
+        captured["avg"] = o
+        return o
+
+    tta._get_augmented_boxes = cap
+    out = tta([inp])[0]["instances"]
+    assert (captured["avg"][1].cpu() - g["avg_scores"]).abs().max() < 1e-4
+    assert (captured["avg"][0].cpu() - g["avg_boxes"]).abs().max() < 2e-2
+    # merged detections: the reference's averaged tensors through the HIP tail are exact
+    merged = tta._merge_detections(g["avg_boxes"].to(gpu), g["avg_scores"].to(gpu), None, (256, 352))
+    assert torch.equal(merged.pred_boxes.tensor.cpu(), g["boxes"]) and torch.equal(merged.scores.cpu(), g["scores"])
+    assert torch.equal(merged.pred_classes.cpu(), g["classes"])
+    # end to end: same number of detections, scores within the fp32 tolerance of the forward
+    assert len(out) == len(g["scores"])
+    torch.testing.assert_close(out.scores.cpu(), g["scores"], rtol=1e-3, atol=1e-4)
+
+
 def test_tta_wrappers(gpu):
     """Test-time augmentation (n2): (i) a single identity view reproduces plain inference; (ii) the AVG merge equals
     the oracle tail applied to the hand-averaged per-view scores / back-mapped boxes; (iii) UNION returns boxes from

@@ -88,6 +88,7 @@ SIGNATURES = {
     "wsovod_data_aware_forward": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
+    "wsovod_subsample_labels": [_P, _P, _P, _I, _I, _I, _I, _L, _P, _P],
     "wsovod_sgd_momentum_multi": [_P, _I, _F, _F, _P],
     "wsovod_pack_bf16_multi": [_P, _I, _P],
     "wsovod_format_rois": [_P, _P, _I, _I, _P, _P, _P, _P],

@@ -187,6 +187,7 @@ def _d2_defaults():
                      "FLIP": True})
     _C.OUTPUT_DIR = "./output"
     _C.VIS_PERIOD = 0
+    _C.SEED = -1  # detectron2 default: negative = not fixed
     return _C
 
 

@@ -536,6 +536,62 @@ __global__ void data_aware_bwd_stage2(const float* __restrict__ ddaf, int N, con
   }
 }
 
+
+// ---------------------------------------------------------------------------------
+// Proposal sub-sampling (no grad): _sample_proposals_wsl (roi_heads.py:1566-1603) ->
+// detectron2 subsample_labels(labels, num, positive_fraction, bg_label):
+//   positives = labels not in {-1, bg};  negatives = labels == bg
+//   num_pos = min(#pos, pos_cap)  (pos_cap = int(num * positive_fraction), computed by the host)
+//   num_neg = min(#neg, num - num_pos)
+//   a uniform sample without replacement of each group keeps its label; every other row becomes -1 (ignored).
+// The random permutation is expressed through per-row sort keys: a row is sampled when its rank among
+// the rows of its group, ordered by (key, row index), is below the group's quota -- uniform keys give the
+// reference's `randperm(...)[:n]`, keys = row index give a deterministic first-n rule (golden fixtures).
+// Workgroup per 256 rows of one image; the image's (key, group) pairs stream through LDS.  Index work only:
+// bit-exact against the oracle on the same keys.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void subsample_labels_kernel(const long long* __restrict__ labels,
+                                                               const float* __restrict__ keys,
+                                                               const int* __restrict__ seg, int num, int pos_cap,
+                                                               long long bg, long long* __restrict__ out) {
+  __shared__ float sh_key[256];
+  __shared__ int sh_grp[256];
+  const int g = blockIdx.y;
+  const int r0 = seg[g], n = seg[g + 1] - r0;
+  if ((int)blockIdx.x * 256 >= n) return;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  const bool live = r < n;
+  const long long lab = live ? labels[r0 + r] : -1;
+  const float key = live ? keys[r0 + r] : 0.f;
+  const int grp = lab == bg ? 1 : (lab == -1 ? 2 : 0);
+  int rank = 0, n_pos = 0, n_neg = 0;
+  for (int t0 = 0; t0 < n; t0 += 256) {
+    const int j = t0 + threadIdx.x;
+    __syncthreads();
+    if (j < n) {
+      const long long lj = labels[r0 + j];
+      sh_key[threadIdx.x] = keys[r0 + j];
+      sh_grp[threadIdx.x] = lj == bg ? 1 : (lj == -1 ? 2 : 0);
+    } else {
+      sh_grp[threadIdx.x] = 2;
+      sh_key[threadIdx.x] = 0.f;
+    }
+    __syncthreads();
+    const int lim = min(256, n - t0);
+    for (int q = 0; q < lim; ++q) {
+      const int gq = sh_grp[q];
+      const float kq = sh_key[q];
+      n_pos += gq == 0;
+      n_neg += gq == 1;
+      rank += (gq == grp) && (kq < key || (kq == key && t0 + q < r));
+    }
+  }
+  if (!live) return;
+  const int num_pos = min(n_pos, pos_cap);
+  const int num_neg = min(n_neg, num - num_pos);
+  const bool keep = (grp == 0 && rank < num_pos) || (grp == 1 && rank < num_neg);
+  out[r0 + r] = keep ? lab : -1;
+}
 }  // namespace
 
 extern "C" {
@@ -688,6 +744,21 @@ int wsovod_data_aware_backward(const float* ddaf, int N, const float* gap, int C
   hipLaunchKernelGGL(data_aware_bwd_stage2, dim3((int)std::min<long long>(ceil_div_ll(total, 256), 1024)), dim3(256),
                      0, s, ddaf, N, gap, C, F, h1, Hd, h2, P, dpre2, dh1, dW1, db1, dW2, db2, dE);
   WS_CHECK_LAUNCH("wsovod_data_aware_backward");
+  return WSOVOD_OK;
+}
+
+int wsovod_subsample_labels(const long long* labels, const float* keys, const int* seg_offsets, int G, int max_rows,
+                            int num_samples, int pos_cap, long long bg_label, long long* out_labels,
+                            wsovod_stream_t stream) {
+  if (G == 0 || max_rows == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(labels && keys && seg_offsets && out_labels && labels != out_labels && num_samples >= 0 && pos_cap >= 0,
+               "wsovod_subsample_labels: bad argument");
+  static int slot = wsovod::prof_slot("subsample_labels");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, 0.0);
+  hipLaunchKernelGGL(subsample_labels_kernel, dim3(ceil_div(max_rows, 256), G), dim3(256), 0, s, labels, keys,
+                     seg_offsets, num_samples, pos_cap, bg_label, out_labels);
+  WS_CHECK_LAUNCH("wsovod_subsample_labels");
   return WSOVOD_OK;
 }
 

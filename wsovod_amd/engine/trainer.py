@@ -107,7 +107,7 @@ class HotPathTrainer:
 
     split_on_cpu = False  # tests: let the early-exchange logic run on a CPU stand-in model
 
-    def __init__(self, model, optimizer, overlap=True, reduce_unused=False, grad_wire="fp32"):
+    def __init__(self, model, optimizer, overlap=True, reduce_unused=False, grad_wire="fp32", iter_size=1):
         """reduce_unused: parameters that received no gradient this step (mixed-dataset mode: the other
         datasets' object miners) still take part in the exchange with zeros, so that every rank issues the same
         collectives -- the job `find_unused_parameters=True` does in the reference (engine/defaults.py:146-148).
@@ -117,7 +117,17 @@ class HotPathTrainer:
         rounds every gradient into its slice of a flat bf16 buffer, ONE all-reduce moves half the bytes (249 MB
         instead of 498 MB on R18 -- what matters at 2 and 4 ranks, where a ring has one / three xGMI links per GPU
         to work with), and the SGD kernel reads the reduced bf16 slices; master weights, momentum and the update
-        stay fp32."""
+        stay fp32.
+
+        iter_size: WSOVOD.ITER_SIZE (engine/trainer.py:72-84 of the reference): losses are divided by iter_size,
+        gradients accumulate locally and the exchange + update happen on the iterations with `iter % iter_size == 0`
+        (the reference's rule, first iteration included).
+
+        The update of step t is applied lazily (inside the next run_step, behind the frozen forward).  Anything that
+        reads the weights between steps -- `model.state_dict()`, `optimizer.state_dict()`, a checkpoint / eval / TTA
+        hook -- must see them after optimizer.step() as in the reference (hooks run after run_step there): state-dict
+        pre-hooks on the model and the optimizer call `synchronize()`; code that reads parameters directly calls
+        `synchronize()` (= `flush()`) itself."""
         if grad_wire not in ("fp32", "bf16"):
             raise ValueError(f"grad_wire must be 'fp32' or 'bf16', got {grad_wire!r}")
         if grad_wire == "bf16" and not isinstance(optimizer, HipSGD):
@@ -134,10 +144,19 @@ class HotPathTrainer:
         self.overlap = overlap
         self._pending = None  # list of (work, param) of the in-flight exchange
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.iter_size = int(iter_size)
+        self.iter = 0
+        if self.iter_size < 1:
+            raise ValueError(f"iter_size must be >= 1, got {iter_size}")
         for p in self.params:
             p._wire_grad = None
-        if self.exchange and grad_wire == "bf16" and self.params:
-            self._setup_early_exchange()
+        if self.exchange and grad_wire == "bf16" and self.params and self.iter_size == 1:
+            self._setup_early_exchange()  # (with accumulation the early block would miss the earlier micro-steps)
+        self._hooks = []
+        if hasattr(model, "register_state_dict_pre_hook"):
+            self._hooks.append(model.register_state_dict_pre_hook(lambda *_a, **_k: self.synchronize()))
+        if hasattr(optimizer, "register_state_dict_pre_hook"):
+            self._hooks.append(optimizer.register_state_dict_pre_hook(lambda *_a, **_k: self.synchronize()))
         if isinstance(optimizer, HipSGD):
             optimizer.grad_scale = 1.0 / self.world
 
@@ -245,7 +264,14 @@ class HotPathTrainer:
         st = self.model.forward_frozen(data)
         self._finish_pending()
         loss_dict = self.model.forward_trainable(st)
-        sum(loss_dict.values()).backward()
+        losses = sum(loss_dict.values())
+        if self.iter_size > 1:
+            losses = losses / self.iter_size
+        losses.backward()
+        step_now = self.iter % self.iter_size == 0
+        self.iter += 1
+        if not step_now:  # gradients keep accumulating in p.grad; nothing goes on the wire
+            return loss_dict
         works = []
         if self.exchange and self.grad_wire == "bf16":
             works = self._exchange_bf16()
@@ -261,4 +287,7 @@ class HotPathTrainer:
         return loss_dict
 
     def flush(self):
+        """Apply the update of the last run_step (waits for its gradient exchange)."""
         self._finish_pending()
+
+    synchronize = flush

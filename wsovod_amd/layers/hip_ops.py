@@ -501,6 +501,19 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
     return o
 
 
+def subsample_labels(labels, keys, seg_offsets, max_rows, num_samples, positive_fraction, bg_label):
+    """detectron2 subsample_labels on the device for every image at once (include/wsovod_hip.h): rows that are not
+    sampled come back as -1.  `keys` (float32, one per row) order the rows inside their group."""
+    require_gpu(labels, keys, seg_offsets)
+    labels = labels.to(torch.int64).contiguous()
+    keys = keys.to(torch.float32).contiguous()
+    out = torch.empty_like(labels)
+    check(lib().wsovod_subsample_labels(ptr(labels), ptr(keys), ptr(seg_offsets), seg_offsets.numel() - 1, int(max_rows),
+                                        int(num_samples), int(num_samples * positive_fraction), int(bg_label), ptr(out),
+                                        stream()), "subsample_labels")
+    return out
+
+
 def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None, out_plain=None,
                    colsum=None):
     """dA = dy * [y>0] * scale -> (dA (M, ld_plain>=N) or None, dAt (N, ld_t>=M) or None), zero padded.

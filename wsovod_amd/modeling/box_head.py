@@ -21,7 +21,7 @@ __all__ = ["DiscriminativeAdaptationNeck", "build_box_head"]
 @ROI_BOX_HEAD_REGISTRY.register()
 class DiscriminativeAdaptationNeck(nn.Sequential):
     @configurable
-    def __init__(self, input_shape: ShapeSpec, *, conv_dims: List[int], fc_dims: List[int], conv_norm=""):
+    def __init__(self, input_shape: ShapeSpec, *, conv_dims: List[int], fc_dims: List[int], conv_norm="", seed: int = -1):
         super().__init__()
         assert len(conv_dims) + len(fc_dims) > 0
         if len(conv_dims):
@@ -41,22 +41,41 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
         for layer in self.fcs:
             torch.nn.init.normal_(layer.weight, std=0.005)
             torch.nn.init.constant_(layer.bias, 0.1)
+        # Counter-based dropout (mask = hash(seed, step, layer, row, unit)); the reference draws from per-process
+        # torch RNG streams seeded `cfg.SEED + rank` (detectron2 seed_all_rng): the base seed mixes cfg.SEED and the
+        # data-parallel rank (read at the first training forward, the process group may not exist yet), the step
+        # counter advances in training mode only and can be restored with `set_step(iteration)` on resume.
         self._step = 0
-        self.dropout_seed = 0x5EED
+        self._cfg_seed = int(seed)
+        self.dropout_seed = None
+
+    def set_step(self, iteration: int):
+        self._step = int(iteration)
+
+    def _base_seed(self):
+        if self.dropout_seed is None:
+            import torch.distributed as dist
+
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            base = self._cfg_seed if self._cfg_seed >= 0 else 0x5EED
+            self.dropout_seed = (base * 0x9E3779B1 + rank * 0x85EBCA77 + 0x5EED) & 0xFFFFFFFF
+        return self.dropout_seed
 
     @classmethod
     def from_config(cls, cfg, input_shape):
         return {"input_shape": input_shape, "conv_dims": [cfg.MODEL.ROI_BOX_HEAD.CONV_DIM] * cfg.MODEL.ROI_BOX_HEAD.NUM_CONV,
-                "fc_dims": cfg.MODEL.ROI_BOX_HEAD.DAN_DIM, "conv_norm": cfg.MODEL.ROI_BOX_HEAD.NORM}
+                "fc_dims": cfg.MODEL.ROI_BOX_HEAD.DAN_DIM, "conv_norm": cfg.MODEL.ROI_BOX_HEAD.NORM,
+                "seed": cfg.SEED}
 
     def forward(self, x):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
-        self._step += 1
+        if self.training:
+            self._step += 1
         for k, fc in enumerate(self.fcs):
             drop = getattr(self, "fc_dropout{}".format(k + 1))
             p = drop.p if (self.training and drop.training) else 0.0
-            seed = (self.dropout_seed * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF
+            seed = (self._base_seed() * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
             x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed)
         return x
 

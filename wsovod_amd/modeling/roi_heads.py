@@ -367,6 +367,11 @@ class WSOVODROIHeads(ROIHeads):
                                  self.pred_class_img_logits, self.num_classes, 0.5)
         return PseudoTargets(o, self._gt_off, [p.image_size for p in proposals])
 
+    def _sample_keys(self, num_rows, device):
+        """Sort keys of the random sub-sampling (uniform keys = the reference's randperm; tests substitute the row
+        index = a deterministic first-n rule on both sides)."""
+        return torch.rand((num_rows,), device=device)
+
     @torch.no_grad()
     def mine_and_label(self, k, prev_pred_scores, prev_pred_boxes, proposals, seg, nums):
         """get_pgt_top_k (top_k=1, no SAM) + label_and_sample_proposals_wsl fused in one kernel.
@@ -376,14 +381,17 @@ class WSOVODROIHeads(ROIHeads):
         gt_classes / gt_boxes / gt_scores / gt_weights per proposal)."""
         if not self.sampling_on:
             raise NotImplementedError("WSOVOD.SAMPLING.SAMPLING_ON=False is not used by the WSR configs")
-        if max(nums) > self.batch_size_per_images[k] or self.positive_sample_fractions[k] < 1.0:
-            raise NotImplementedError(
-                "random sub-sampling of proposals (R > SAMPLING.BATCH_SIZE_PER_IMAGE or POSITIVE_FRACTION < 1) "
-                "is not on the hot path; shipped configs keep every proposal (4096, 1.0)")
         m = self.proposal_matchers[k]
         assert len(m.thresholds) == 3 and m.labels == [0, 1], "hot path supports Matcher([thr], [0, 1])"
         o = H.pgt_mine_and_label(prev_pred_scores.to(torch.float32), prev_pred_boxes, seg, self._gt_cat,
                                  self._gt_off, self.pred_class_img_logits, self.num_classes, m.thresholds[1])
+        if max(nums) > self.batch_size_per_images[k] or self.positive_sample_fractions[k] < 1.0:
+            # _sample_proposals_wsl (roi_heads.py:1597-1610): rows outside the random sample are ignored (-1); every
+            # row stays in place, so the boxes / scores / weights above are untouched
+            o["gt_classes_all"] = o["gt_classes"]
+            o["gt_classes"] = H.subsample_labels(o["gt_classes"], self._sample_keys(sum(nums), seg.device), seg,
+                                                 max(nums), self.batch_size_per_images[k],
+                                                 self.positive_sample_fractions[k], self.num_classes)
         self._last_pgt = o
         proposals_k = []
         start = 0
