@@ -245,6 +245,9 @@ typedef struct wsovod_sgd_tensor {
   float lr, weight_decay;
   int grad_is_bf16; /* `grad` points at bf16 values (gradients that crossed the wire in bf16, see below) */
   int reserved_;
+  const float* used_flag; /* optional DEVICE scalar: 0 = no data-parallel rank produced a gradient for this tensor in
+                           * this step -> parameter and momentum stay untouched, as torch.optim.SGD skips `grad is None`
+                           * under DDP(find_unused_parameters=True) (engine/defaults.py:146-148); NULL = always update */
 } wsovod_sgd_tensor;
 int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
                               wsovod_stream_t stream);
@@ -378,6 +381,17 @@ int wsovod_pgt_mine_and_label(const float* scores, long long ld_scores, const fl
 int wsovod_subsample_labels(const long long* labels, const float* keys, const int* seg_offsets, int G, int max_rows,
                             int num_samples, int pos_cap, long long bg_label, long long* out_labels,
                             wsovod_stream_t stream);
+
+/* bf16x3 operand split (MODEL.HIP.PRECISION = bf16x3: the mode that meets the north star's 1e-3 logit bound on the bf16
+ * MFMA path).  An fp32 matrix src (rows, cols; row stride ld_src) becomes three bf16 blocks hi = bf16(x) and
+ * lo = bf16(x - hi) in the order  side 0 (A operand): hi, hi, lo;  side 1 (B operand): hi, lo, hi  -- so that an
+ * UNCHANGED bf16 contraction over the three-times-longer reduction index computes sum ah*bh + ah*bl + al*bh with fp32
+ * accumulation (relative error ~2^-16 per product instead of bf16's 2^-8).  Block b of row r is written at
+ * dst + b * block_stride + r * ld_dst: block_stride = cols puts the blocks side by side along K (Linear layers:
+ * fast_rcnn_open_vocabulary.py:318-367, open_vocabulary_classifier.py:79-105; NHWC conv channels: resnet_wsl.py),
+ * block_stride = padded_rows * ld_dst stacks them along the rows (weight-gradient contraction over proposals). */
+int wsovod_split3_bf16(const float* src, long long ld_src, int rows, int cols, void* dst, long long ld_dst,
+                       long long block_stride, int side, wsovod_stream_t stream);
 
 /* Backward prologue of Linear+ReLU(+Dropout) (box_head.py:60-66): dA = dy * [y > 0] * scale
  * written as [M][N] and/or transposed [N][ldt] (either output may be NULL; y NULL = no mask). */

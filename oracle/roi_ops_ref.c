@@ -14,7 +14,8 @@
  *
  * Layout: input (N,C,H,W) fp32 contiguous, rois (R,5) fp32, output (R,C,PH,PW).
  * Pinned against oracle/_ref (the reference's own ROILoopPool_cpu.cpp compiled where it
- * lies) by tests/test_oracle_pinning.py and against the golden vectors in tests/golden/.
+ * lies) by tests/test_oracle_golden.py and against the golden vectors in tests/golden/; roi_align_* is checked
+ * against an independent fp64 evaluator written from the operator's definition (tests/test_oracle_properties.py).
  */
 #include <float.h>
 #include <math.h>

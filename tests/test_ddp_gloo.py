@@ -140,19 +140,20 @@ class _TwoSourceModel(nn.Module):
         return {"loss": self.heads[st["source"]](st["x"]).pow(2).mean()}
 
 
-def _worker_mixed(rank, world, port, q):
+def _worker_mixed(rank, world, port, q, same_source=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from wsovod_amd.engine import HotPathTrainer
 
     model = _TwoSourceModel()
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=0.05 if same_source else 0.0)
     tr = HotPathTrainer(model, opt, overlap=True, reduce_unused=True)
     tr.broadcast_parameters()
     g = torch.Generator().manual_seed(77 + rank)
     xs = [torch.randn(8, generator=g) for _ in range(3)]
-    for it in range(3):
-        src = (rank + it) % 2  # the two ranks always draw from DIFFERENT datasets
+    for it in range(4 if same_source else 3):
+        # different datasets on the two ranks every step / the same dataset on both (the other miner unused everywhere)
+        src = (0, 0, 1, 0)[it] if same_source else (rank + it) % 2
         tr.run_step([{"x": x, "dataset_id": src} for x in xs])
     tr.flush()
     q.put((rank, [h.weight.detach().tolist() for h in model.heads], [x.tolist() for x in xs]))
@@ -189,6 +190,63 @@ def test_mixed_dataset_ranks_with_different_sources_stay_in_lockstep():
         torch.testing.assert_close(h.weight.detach(), torch.tensor(w), rtol=1e-5, atol=1e-6)
 
 
+def test_tensors_unused_on_every_rank_are_skipped_like_sgd_none_grad():
+    """DDP(find_unused_parameters=True) + SGD in the reference (engine/defaults.py:146-148): a parameter that no rank
+    used keeps `grad is None`, so SGD applies neither weight decay nor momentum to it.  With reduce_unused the ranks
+    exchange a per-tensor used flag next to the zero gradients and skip such tensors."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 34100 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_mixed, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _TwoSourceModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, weight_decay=0.05)
+    for it in range(4):
+        opt.zero_grad(set_to_none=True)
+        total = 0
+        for r in range(2):
+            st = model.forward_frozen([{"x": torch.tensor(x), "dataset_id": (0, 0, 1, 0)[it]} for x in res[r][2]])
+            total = total + model.forward_trainable(st)["loss"] / 2
+        total.backward()
+        opt.step()  # the other head's grad is None: skipped
+    for h, w0, w1 in zip(model.heads, res[0][1], res[1][1]):
+        assert torch.equal(torch.tensor(w0), torch.tensor(w1))
+        torch.testing.assert_close(h.weight.detach(), torch.tensor(w0), rtol=1e-5, atol=1e-6)
+
+
+def test_state_read_between_steps_sees_the_applied_update_and_iter_size():
+    """The overlapped trainer applies step t's update lazily; state_dict() (checkpoint / eval hooks run after run_step
+    in the reference, engine/trainer.py:82-84) must see the weights AFTER optimizer.step().  ITER_SIZE > 1: same
+    accumulate-and-step rule as the plain run_step (`iter % iter_size == 0`)."""
+    from wsovod_amd.engine import HotPathTrainer, run_step
+
+    g = torch.Generator().manual_seed(5)
+    batches = [[{"x": torch.randn(8, generator=g)} for _ in range(3)] for _ in range(5)]
+    for iter_size in (1, 2, 3):
+        plain = _LossDictModel()
+        popt = torch.optim.SGD(plain.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+        lazy = _TwoPhaseModel()
+        lopt = torch.optim.SGD(lazy.parameters(), lr=0.1, momentum=0.9, weight_decay=1e-3)
+        # _TwoPhaseModel doubles x in its frozen half: feed the plain model the doubled inputs
+        tr = HotPathTrainer(lazy, lopt, overlap=True, iter_size=iter_size)
+        for it, b in enumerate(batches):
+            run_step(plain, popt, [{"x": d["x"] * 2.0} for d in b], iter_size=iter_size, it=it)
+            tr.run_step(b)
+            sd = lazy.state_dict()  # pre-hook flushes the pending update
+            torch.testing.assert_close(sd["fc.weight"], plain.fc.weight.detach(), rtol=1e-6, atol=1e-7)
+            mom = lopt.state_dict()["state"]
+            pm = popt.state_dict()["state"]
+            assert set(mom.keys()) == set(pm.keys())
+            for k in mom:
+                torch.testing.assert_close(mom[k]["momentum_buffer"], pm[k]["momentum_buffer"], rtol=1e-6, atol=1e-7)
+        tr.synchronize()
+
+
 def _worker_bf16_wire(rank, world, port, q):
     """grad_wire="bf16" on CPU/gloo: the two HIP kernels of that path (gradient pack, SGD on bf16 slices) are replaced
     by torch stand-ins with the same contract, so that the trainer's own logic -- flat buffer slices, one collective,
@@ -205,8 +263,10 @@ def _worker_bf16_wire(rank, world, port, q):
             dst.copy_(src.reshape(-1))
 
     def sgd(entries, momentum, grad_scale=1.0):
-        for p, g, buf, shadow, lr, wd in entries:
-            assert g.dtype == torch.bfloat16
+        for p, g, buf, shadow, lr, wd, used in entries:
+            assert g.dtype == torch.bfloat16 and used is not None
+            if float(used) == 0.0:  # no rank produced a gradient: the kernel leaves parameter and momentum alone
+                continue
             d = g.float().view_as(p) * grad_scale + wd * p
             buf.mul_(momentum).add_(d)
             p.sub_(lr * buf)
@@ -214,7 +274,10 @@ def _worker_bf16_wire(rank, world, port, q):
     H.pack_bf16_multi, H.sgd_momentum_multi = pack, sgd
     model = _TwoPhaseModel()
     model.unused = nn.Linear(3, 3)  # never touched by the loss: takes part with zeros (reduce_unused)
-    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.0} for p in model.parameters()], 0.1, momentum=0.9)
+    unused0 = model.unused.weight.detach().clone()
+    # weight decay ON: a tensor no rank touched must still stay put (SGD skips `grad is None` in the reference)
+    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.0 if p is model.fc.weight or p is model.fc.bias else 0.1}
+                  for p in model.parameters()], 0.1, momentum=0.9)
     tr = HotPathTrainer(model, opt, overlap=True, reduce_unused=True, grad_wire="bf16")
     tr.broadcast_parameters()
     g = torch.Generator().manual_seed(1234 + rank)
@@ -223,6 +286,7 @@ def _worker_bf16_wire(rank, world, port, q):
         tr.run_step(batch)
         assert all(p.grad is None for p in tr.params)
     tr.flush()
+    assert torch.equal(model.unused.weight.detach(), unused0), "a tensor unused on every rank must not decay"
     q.put((rank, model.fc.weight.detach().tolist(), model.unused.weight.detach().tolist(),
            [b["x"].tolist() for b in batch]))
     dist.barrier()
@@ -314,8 +378,8 @@ def _worker_early_block(rank, world, port, q):
             dst.copy_(src.reshape(-1))
 
     def sgd(entries, momentum, grad_scale=1.0):
-        for p, g, buf, shadow, lr, wd in entries:
-            assert g.dtype == torch.bfloat16 and g.numel() == p.numel()
+        for p, g, buf, shadow, lr, wd, used in entries:
+            assert g.dtype == torch.bfloat16 and g.numel() == p.numel() and used is None  # (no reduce_unused here)
             buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
             p.sub_(lr * buf)
 

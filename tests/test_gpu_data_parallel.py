@@ -1,0 +1,81 @@
+"""The real HIP model under data parallelism at world size 2 on ONE GPU: two processes share cuda:0 and exchange
+gradients over gloo (the N>1 code path of HotPathTrainer is backend-agnostic; RCCL itself needs one GPU per rank,
+which the test box does not have).  Reference semantics: DistributedDataParallel averages gradients over ranks
+(engine/defaults.py:143-152); the bf16 wire is the counterpart of its fp16 compression hook."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(mode):
+    port = str(29600 + os.getpid() % 300 + (7 if mode == "mixed" else 0))
+    tmp = tempfile.mkdtemp(prefix="wsovod_dp_")
+    outs = [os.path.join(tmp, f"rank{r}.pt") for r in range(2)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    procs = [subprocess.Popen([sys.executable, "-m", "tests.dp_gpu_worker", str(r), "2", port, outs[r], mode], cwd=ROOT,
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(out.decode(errors="replace")[-3000:])
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log
+    return [torch.load(o) for o in outs]
+
+
+def test_two_ranks_real_model_bf16_wire_equals_averaged_single_process(gpu):
+    from tests import dp_gpu_worker as W
+    from wsovod_amd.engine import build_optimizer
+
+    res = _launch("single")
+    a, b = res
+    assert a["calls"] == b["calls"], "ranks issued different collective sequences"
+    # per step: early fc1 block + the rest (2 bf16 all-reduces); parameters / buffers broadcast first
+    bf16_calls = [c for c in a["calls"] if c[0] == "torch.bfloat16"]
+    assert len(bf16_calls) == 2 * W.STEPS and a["early_steps"] == W.STEPS
+    assert bf16_calls[0][1] % (49 * 512) == 0 and bf16_calls[0][1] < bf16_calls[1][1]  # head = whole rows of fc1.weight
+    assert a["fingerprint"] == b["fingerprint"], "replicas diverged"
+    # single process: both shards through the same model, gradients averaged in fp32, same SGD
+    cfg, model = W.build("single")
+    opt = build_optimizer(cfg, model)
+    for it in range(W.STEPS):
+        for r in range(2):
+            (sum(model(W.shard(r, "single", it)).values()) * 0.5).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    moved = 0
+    for k, v in model.named_parameters():
+        if not v.requires_grad:
+            continue
+        want = W.sample(v)
+        # one bf16 rounding per rank gradient + one of their sum: |dw| <= steps * lr * 2^-7 * |g|
+        torch.testing.assert_close(a["sample"][k], want, rtol=0, atol=3e-6, msg=lambda m: f"{k}: {m}")
+        moved += 1
+    assert moved >= 15
+
+
+def test_two_ranks_mixed_datasets_identical_collective_sequence(gpu):
+    """Ranks on different datasets touch different object miners; reduce_unused keeps the collective sequence identical
+    (used-flag exchange + zeros for untouched tensors) and the replicas bit-identical."""
+    from tests import dp_gpu_worker as W
+
+    a, b = _launch("mixed")
+    assert a["calls"] == b["calls"] and len(a["calls"]) > 0
+    per_step = [c for c in a["calls"] if c[0] in ("torch.bfloat16",)]
+    assert len(per_step) == 2 * W.STEPS
+    assert sum(1 for c in a["calls"] if c == ("torch.float32", len(a["fingerprint"]))) >= W.STEPS  # the used flags
+    assert a["fingerprint"] == b["fingerprint"], "replicas diverged"

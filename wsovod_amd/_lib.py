@@ -88,6 +88,7 @@ SIGNATURES = {
     "wsovod_data_aware_forward": [_P, _I, _I, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P, _P, _P],
     "wsovod_data_aware_backward": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P],
     "wsovod_pgt_mine_and_label": [_P, _L, _P, _P, _I, _P, _P, _P, _I, _F] + [_P] * 11 + [_P],
+    "wsovod_split3_bf16": [_P, _L, _I, _I, _P, _L, _L, _I, _P],
     "wsovod_subsample_labels": [_P, _P, _P, _I, _I, _I, _I, _L, _P, _P],
     "wsovod_sgd_momentum_multi": [_P, _I, _F, _F, _P],
     "wsovod_pack_bf16_multi": [_P, _I, _P],
@@ -103,7 +104,7 @@ class SgdTensor(C.Structure):
     """wsovod_sgd_tensor (include/wsovod_hip.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
                 ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
-                ("reserved_", C.c_int)]
+                ("reserved_", C.c_int), ("used_flag", C.c_void_p)]
 
 
 class PackTensor(C.Structure):

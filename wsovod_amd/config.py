@@ -236,7 +236,9 @@ def add_wsovod_config(cfg):
     _C.SOLVER.BACKBONE_MULTIPLIER = 1.0
     # hot-path extensions of this implementation (not in the reference)
     _C.MODEL.HIP = C()
-    _C.MODEL.HIP.PRECISION = "bf16"  # "bf16" (MFMA bf16, fp32 accumulate) | "fp32" (exact-fp32 MFMA)
+    # "bf16" (bf16 MFMA, fp32 accumulate) | "fp32" (exact-fp32 MFMA) | "bf16x3" (fp32 tensors, bf16 MFMA on hi/lo-split
+    # operands: fp32-grade products at a third of the bf16 rate)
+    _C.MODEL.HIP.PRECISION = "bf16"
     return _C
 
 

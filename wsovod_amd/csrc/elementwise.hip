@@ -192,6 +192,60 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, lo
 }
 
 // ---------------------------------------------------------------------------------
+// bf16x3 operand split (MODEL.HIP.PRECISION "bf16x3": fp32-grade products on the bf16 MFMA path).
+// x = hi + lo + O(2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi).  A contraction sum_k a_k b_k is evaluated as
+// sum_k (ah*bh + ah*bl + al*bh) by handing the UNCHANGED bf16 kernels operands three times as long along the
+// reduction index:  A side [hi | hi | lo],  B side [hi | lo | hi]  (the al*bl term, 2^-16 relative to a product, is
+// dropped; accumulation stays fp32 inside the MFMA chain).  One pass: 4 B read, 6 B written per element.
+//   side 0 = A pattern (hi, hi, lo), side 1 = B pattern (hi, lo, hi);
+//   block b of row r lands at dst[b * block_stride + r * ld_dst + c]  (block_stride = cols: the blocks sit side by
+//   side along K -- NT GEMMs, NHWC conv channels; block_stride = rows_padded * ld_dst: stacked along the rows -- the
+//   operands of the transposed-read dW kernel, whose reduction index is the row).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split3_bf16_kernel(const float* __restrict__ src, long long ld_src, int rows,
+                                                          int cols, bf16_t* __restrict__ dst, long long ld_dst,
+                                                          long long block_stride, int side) {
+  const int cg = (cols + 7) >> 3;  // 8-element groups per row
+  const long long total = (long long)rows * cg;
+  const bool al = ((ld_src & 3) == 0) && ((((uintptr_t)src) & 15) == 0) && ((ld_dst & 7) == 0) &&
+                  ((block_stride & 7) == 0) && ((((uintptr_t)dst) & 15) == 0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cg), c = (int)(i - (long long)r * cg) * 8;
+    const float* s = src + (long long)r * ld_src + c;
+    bf16_t* d = dst + (long long)r * ld_dst + c;
+    float v[8];
+    const int n = min(8, cols - c);
+    if (al && n == 8) {
+      const f32x4 a = *(const f32x4*)s, b = *(const f32x4*)(s + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
+      v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = j < n ? s[j] : 0.f;
+    }
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      hi[j] = (bf16_t)v[j];
+      lo[j] = (bf16_t)(v[j] - (float)hi[j]);
+    }
+    const bf16x8 b1 = side ? lo : hi, b2 = side ? hi : lo;
+    if (al && n == 8) {
+      *(bf16x8*)d = hi;
+      *(bf16x8*)(d + block_stride) = b1;
+      *(bf16x8*)(d + 2 * block_stride) = b2;
+    } else {
+      for (int j = 0; j < n; ++j) {
+        d[j] = hi[j];
+        d[block_stride + j] = b1[j];
+        d[2 * block_stride + j] = b2[j];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Row L2 norm for the cosine-similarity head: row_scale[m] = T / max(||x_m||, eps)
 // (F.normalize eps=1e-12, open_vocabulary_classifier.py:91-92).  Wavefront per row.
 // ---------------------------------------------------------------------------------
@@ -382,6 +436,7 @@ struct SgdTable {
   int first_block[kSgdMax + 1];
   int count;
   unsigned g_bf16;  // bit k: g[k] points at bf16 values (gradients that travelled in the bf16 wire format)
+  const float* used[kSgdMax];  // optional device flag: 0 = no rank produced a gradient for the tensor -> left untouched
 };
 
 __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable t, float mu, float gscale) {
@@ -396,6 +451,7 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
   const float lr = t.lr[k], wd = t.wd[k];
   const bool gb = (t.g_bf16 >> k) & 1u;
   const bf16_t* __restrict__ g16 = (const bf16_t*)t.g[k];
+  if (t.used[k] && *t.used[k] == 0.f) return;  // torch.optim.SGD skips parameters whose grad is None
   const bool vec = ((((uintptr_t)p | (uintptr_t)buf) & 15) == 0) && (((uintptr_t)shadow & 7) == 0) &&
                    (((uintptr_t)g & (gb ? 7 : 15)) == 0);
   for (int e = threadIdx.x * 4; e < kSgdChunk; e += 256 * 4) {
@@ -775,6 +831,21 @@ int wsovod_cast(const void* src, int src_dtype, void* dst, int dst_dtype, long l
   return WSOVOD_OK;
 }
 
+int wsovod_split3_bf16(const float* src, long long ld_src, int rows, int cols, void* dst, long long ld_dst,
+                       long long block_stride, int side, wsovod_stream_t stream) {
+  if (rows == 0 || cols == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= cols && (side == 0 || side == 1),
+               "wsovod_split3_bf16: bad argument");
+  static int slot = wsovod::prof_slot("split3_bf16");
+  hipStream_t s = (hipStream_t)stream;
+  const long long groups = (long long)rows * ((cols + 7) / 8);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)rows * cols * 10.0);
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(grid_for(groups, 256)), dim3(256), 0, s, src, ld_src, rows, cols,
+                     (bf16_t*)dst, ld_dst, block_stride, side);
+  WS_CHECK_LAUNCH("wsovod_split3_bf16");
+  return WSOVOD_OK;
+}
+
 int wsovod_row_l2norm_scale(const void* x, int dtype, long long ld, int M, int D, float temperature, float eps,
                             float* row_scale, wsovod_stream_t stream) {
   if (M == 0) return WSOVOD_OK;
@@ -866,6 +937,7 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
       t.buf[k] = d.momentum_buf;
       t.shadow[k] = (bf16_t*)d.bf16_shadow;
       if (d.grad_is_bf16) t.g_bf16 |= 1u << k;
+      t.used[k] = d.used_flag;
       t.n[k] = d.numel;
       t.lr[k] = d.lr;
       t.wd[k] = d.weight_decay;

@@ -35,13 +35,14 @@ class HipSGD(torch.optim.Optimizer):
                 sh = getattr(p, "_hip_shadow", None)  # bf16 copy used by the MFMA kernels: refreshed in the same pass
                 shadow = sh[0] if (sh is not None and sh[1] == p._version and sh[0].dtype == torch.bfloat16) else None
                 by_momentum.setdefault(group["momentum"], []).append(
-                    (p.data, g, state["momentum_buffer"], shadow, group["lr"], group["weight_decay"], p))
+                    (p.data, g, state["momentum_buffer"], shadow, group["lr"], group["weight_decay"],
+                     getattr(p, "_used_flag", None), p))
         for mu, entries in by_momentum.items():  # every tensor of the model in one launch
-            H.sgd_momentum_multi([e[:6] for e in entries], mu, grad_scale=self.grad_scale)
+            H.sgd_momentum_multi([e[:7] for e in entries], mu, grad_scale=self.grad_scale)
             for e in entries:
                 # the kernel wrote through raw pointers: advance the version counter so that caches keyed on it (folded
                 # conv weights, class matrices) are rebuilt, and re-stamp the bf16 shadow the kernel refreshed itself
-                p, shadow = e[6], e[3]
+                p, shadow = e[7], e[3]
                 torch.autograd.graph.increment_version(p)
                 if shadow is not None:
                     p._hip_shadow = (shadow, p._version)
@@ -143,6 +144,7 @@ class HotPathTrainer:
         self.exchange = dist.is_initialized()  # a 1-rank group still goes through RCCL (exercised by the GPU tests)
         self.overlap = overlap
         self._pending = None  # list of (work, param) of the in-flight exchange
+        self._used = None  # per-tensor "some rank has a gradient" flags of the in-flight exchange (reduce_unused)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.iter_size = int(iter_size)
         self.iter = 0
@@ -171,6 +173,12 @@ class HotPathTrainer:
         for work in self._pending:
             if work is not None:
                 work.wait()
+        if self._used is not None and not isinstance(self.optimizer, HipSGD):
+            # a torch optimizer skips `grad is None`: restore that for tensors no rank touched (host read of a few flags;
+            # the HIP optimizer reads the flags on the device instead)
+            for p, u in zip(self.params, self._used.tolist()):
+                if u == 0:
+                    p.grad = None
         if self.world > 1 and not isinstance(self.optimizer, HipSGD):
             for p in self.params:
                 if p.grad is not None:
@@ -179,7 +187,21 @@ class HotPathTrainer:
         self.optimizer.zero_grad(set_to_none=True)
         for p in self.params:
             p._wire_grad = None
+            p._used_flag = None
+        self._used = None
         self._pending = None
+
+    def _exchange_used_flags(self):
+        """reduce_unused mode: one flag per tensor (this rank produced a gradient), summed over ranks.  Tensors unused on
+        EVERY rank keep parameter and momentum untouched, exactly as SGD skips `grad is None` under the reference's
+        DDP(find_unused_parameters=True) (engine/defaults.py:146-148) -- sending zeros alone would still apply weight
+        decay and momentum to them.  Must be called before the gradients are packed / released."""
+        host = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], dtype=torch.float32)
+        dev = self.params[0].device
+        self._used = H.h2d_small(host, dev) if dev.type == "cuda" else host
+        for i, p in enumerate(self.params):
+            p._used_flag = self._used[i:i + 1]
+        return dist.all_reduce(self._used, op=dist.ReduceOp.SUM, async_op=True)
 
     @staticmethod
     def split_rows(n_rows, n_cols, cus=256, tile=256):
@@ -273,8 +295,10 @@ class HotPathTrainer:
         if not step_now:  # gradients keep accumulating in p.grad; nothing goes on the wire
             return loss_dict
         works = []
+        if self.exchange and self.reduce_unused:
+            works.append(self._exchange_used_flags())
         if self.exchange and self.grad_wire == "bf16":
-            works = self._exchange_bf16()
+            works += self._exchange_bf16()
         elif self.exchange:
             for p in self.params:
                 if p.grad is None and self.reduce_unused:

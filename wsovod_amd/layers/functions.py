@@ -53,11 +53,17 @@ class _Linear(Function):
         # (rows, callback) set by a data-parallel trainer on ONE large weight: its gradient is produced in two row
         # blocks and the callback sees the first as soon as it is enqueued (engine/trainer.py: early exchange)
         ctx.dw_split = getattr(weight, "_dw_split", None)
+        ctx.x3 = H.x3_active()
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        with H.x3_mode(ctx.x3):
+            return _Linear._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         cd = x.dtype
         M, K = x.shape
@@ -119,11 +125,17 @@ class _LinearGroup(Function):
         ctx.meta = meta
         ctx.save_for_backward(x, *ws, *[y if meta[h][0] else None for h, y in enumerate(ys)])
         ctx.has_bias = [b is not None for b in bs]
+        ctx.x3 = H.x3_active()
         return tuple(ys)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, *dys):
+        with H.x3_mode(ctx.x3):
+            return _LinearGroup._backward(ctx, *dys)
+
+    @staticmethod
+    def _backward(ctx, *dys):
         heads = len(ctx.meta)
         saved = ctx.saved_tensors
         x, ws, ys = saved[0], saved[1:1 + heads], saved[1 + heads:]
@@ -261,11 +273,17 @@ class _CosineLogits(Function):
         logits = H.gemm_nt(z, wn, row_scale=rs, bias=bias_vec, out_dtype=torch.float32)
         ctx.save_for_backward(z, wnT)
         ctx.cfg = (temperature, normalize, bias_vec is not None)
+        ctx.x3 = H.x3_active()
         return logits
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dl):
+        with H.x3_mode(ctx.x3):
+            return _CosineLogits._backward(ctx, dl)
+
+    @staticmethod
+    def _backward(ctx, dl):
         z, wnT = ctx.saved_tensors
         temperature, normalize, has_bias = ctx.cfg
         cd = z.dtype

@@ -204,6 +204,87 @@ def roi_align_backward(grad_out, rois, spatial_scale, sampling_ratio, aligned, i
     return grad_in
 
 
+# ---------------------------------------------------------------------------------------
+# bf16x3 mode (MODEL.HIP.PRECISION = "bf16x3"): fp32 tensors everywhere, every contraction evaluated on the bf16 MFMA
+# kernels as sum ah*bh + ah*bl + al*bh over operands split by wsovod_split3_bf16 (include/wsovod_hip.h).
+# ---------------------------------------------------------------------------------------
+class _X3State:
+    active = False
+
+
+class x3_mode:
+    """Context manager: fp32 x fp32 contractions issued inside go through the bf16x3 split.  Model entry points enter
+    it when their precision is "bf16x3"; autograd Functions capture `x3_active()` in forward and re-enter it in
+    backward (the autograd engine runs backward outside the forward's context)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _X3State.active
+        _X3State.active = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _X3State.active = self.prev
+        return False
+
+
+def x3_active():
+    return _X3State.active
+
+
+def split3_bf16(src, side, stack_rows=False, rows_pad=None, out=None):
+    """(rows, cols) fp32 (row stride >= cols) -> bf16 blocks [hi | hi | lo] (side 0, A operand) or [hi | lo | hi]
+    (side 1, B operand): side by side along the columns -> (rows, 3 cols), or with stack_rows stacked along the rows
+    -> (3 rows_pad, cols) (rows_pad >= rows, padding rows zero)."""
+    require_gpu(src, out)
+    if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
+        raise RuntimeError("split3_bf16: source must be a 2-D fp32 matrix with a contiguous last dim")
+    rows, cols = src.shape
+    if stack_rows:
+        rp = rows if rows_pad is None else int(rows_pad)
+        if out is None:
+            out = (torch.zeros if rp != rows else torch.empty)((3 * rp, cols), dtype=torch.bfloat16, device=src.device)
+        ld_dst, block = out.stride(0), rp * out.stride(0)
+    else:
+        cp = (cols + 7) // 8 * 8  # every block starts 16-byte aligned; padding columns are zero (contribute nothing)
+        if out is None:
+            out = (torch.zeros if cp != cols else torch.empty)((rows, 3 * cp), dtype=torch.bfloat16, device=src.device)
+        ld_dst, block = out.stride(0), cp
+    check(lib().wsovod_split3_bf16(ptr(src), src.stride(0), rows, cols, ptr(out), ld_dst, block, int(side), stream()),
+          "split3_bf16")
+    return out
+
+
+def _split3_cached(t, side, view_rows_cols=None):
+    """B-side operands are usually weights: the split is cached on the tensor object, keyed by its version counter
+    (HipSGD bumps it after every update), so steady-state forwards re-split a weight once per step at most."""
+    key = (t._version, t.data_ptr(), side, view_rows_cols)
+    c = getattr(t, "_x3_split", None)
+    if c is not None and c[0] == key:
+        return c[1]
+    src = t.detach()
+    out = split3_bf16(src.reshape(view_rows_cols) if view_rows_cols is not None else src, side)
+    try:
+        t._x3_split = (key, out)
+    except AttributeError:
+        pass
+    return out
+
+
+def _gemm_nt_x3(A, B, conv=None, **kw):
+    if conv is not None:
+        cin = int(conv["Cin"])
+        a3 = split3_bf16(A.reshape(-1, cin), 0)
+        b3 = _split3_cached(B, 1, (B.numel() // cin, cin)).view(B.size(0), -1)
+        conv = dict(conv, Cin=3 * cin)
+        if conv.get("pool"):
+            raise RuntimeError("bf16x3: the fused-pool 64-channel conv is a bf16-only kernel")
+        return gemm_nt(a3, b3, conv=conv, **kw)
+    return gemm_nt(split3_bf16(A, 0), _split3_cached(B, 1), **kw)
+
+
 def _ld(t):
     if t.dim() != 2 or t.stride(1) != 1:
         raise RuntimeError("wsovod_hip gemm: operands must be 2-D with a contiguous last dim")
@@ -220,6 +301,13 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
     Returns `out` (or None if want_c is False).
     """
     require_gpu(A, B, out, out_t, row_scale, bias, residual, row_group, group_add, mask_src)
+    if _X3State.active and A.dtype == torch.float32 and B.dtype == torch.float32:
+        if M is not None or N is not None or K is not None:
+            raise RuntimeError("bf16x3: explicit M/N/K overrides are not supported")
+        return _gemm_nt_x3(A, B, conv=conv, out=out, out_dtype=out_dtype or torch.float32, out_t=out_t, alpha=alpha,
+                           row_scale=row_scale, bias=bias, residual=residual, relu=relu, dropout_p=dropout_p,
+                           dropout_seed=dropout_seed, row_group=row_group, group_add=group_add, mask_src=mask_src,
+                           mask_scale=mask_scale, accumulate=accumulate, tile_hint=tile_hint, want_c=want_c)
     d = GemmDesc()
     d.dtype_in = dtype_code(B.dtype)
     if A.dtype != B.dtype:
@@ -681,15 +769,18 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True):
 
 
 def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
-    """entries: list of (param, grad fp32 or bf16, momentum_buf, bf16_shadow or None, lr, weight_decay); one launch
-    per 32."""
+    """entries: list of (param, grad fp32 or bf16, momentum_buf, bf16_shadow or None, lr, weight_decay[, used_flag]);
+    one launch per 32.  used_flag: optional 1-element fp32 device tensor, 0 = leave the tensor untouched."""
     from .._lib import SgdTensor
 
     if not entries:
         return
     arr = (SgdTensor * len(entries))()
-    for d, (p, g, b, sh, lr, wd) in zip(arr, entries):
-        require_gpu(p, g, b, sh)
+    for d, e in zip(arr, entries):
+        p, g, b, sh, lr, wd = e[:6]
+        used = e[6] if len(e) > 6 else None
+        require_gpu(p, g, b, sh, used)
+        d.used_flag = used.data_ptr() if used is not None else None
         if g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != p.numel():
             raise RuntimeError("sgd_momentum_multi: gradient must be fp32 or bf16 with the parameter's element count")
         d.param, d.grad, d.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()

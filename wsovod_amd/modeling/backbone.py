@@ -284,7 +284,7 @@ class ResNet(nn.Module):
 
     @property
     def compute_dtype(self):
-        return torch.bfloat16 if self.precision == "bf16" else torch.float32
+        return torch.bfloat16 if self.precision == "bf16" else torch.float32  # "fp32" and "bf16x3" carry fp32 tensors
 
     def _check_frozen(self):
         if any(p.requires_grad for p in self._param_list()):
@@ -314,14 +314,20 @@ class ResNet(nn.Module):
         assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
         self._check_frozen()
         cd = self.compute_dtype
-        kstep = 64 if cd == torch.bfloat16 else 32
+        x3 = self.precision == "bf16x3"
+        kstep = 64 if (cd == torch.bfloat16 or x3) else 32
         xn = x.permute(0, 2, 3, 1).to(cd)
         xn = F.pad(xn, (0, kstep - xn.size(-1))).contiguous()  # Cin 3 -> one K-step (generic float entry)
-        return self._run(self.stem(xn))
+        with H.x3_mode(x3):
+            return self._run(self.stem(xn))
 
     @torch.no_grad()
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
+        with H.x3_mode(self.precision == "bf16x3"):
+            return self._forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
+
+    def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         self._check_frozen()
         if self.compute_dtype == torch.bfloat16 and self.stem.out_channels == 64 and self.stem.in_channels == 3:
             # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)

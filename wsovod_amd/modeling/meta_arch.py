@@ -146,8 +146,27 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             return self.inference(batched_inputs, classifier=classifier)
         return self.forward_trainable(self.forward_frozen(batched_inputs))
 
+    @property
+    def x3(self):
+        """MODEL.HIP.PRECISION == "bf16x3": fp32 tensors, contractions on the bf16 MFMA kernels over hi/lo-split operands
+        (layers/hip_ops.py:x3_mode) -- the fast mode that keeps the north star's 1e-3 logit bound."""
+        return getattr(self.backbone, "precision", "bf16") == "bf16x3"
+
     @torch.no_grad()
     def forward_frozen(self, batched_inputs):
+        with H.x3_mode(self.x3):
+            return self._forward_frozen(batched_inputs)
+
+    def forward_trainable(self, st):
+        with H.x3_mode(self.x3):
+            return self._forward_trainable(st)
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, classifier=None):
+        with H.x3_mode(self.x3):
+            return self._inference(batched_inputs, detected_instances, do_postprocess, classifier)
+
+    def _forward_frozen(self, batched_inputs):
         """Everything of the training forward that touches NO trainable parameter: input staging, the
         frozen backbone, GAP for the data-aware head, RoI pooling with the objectness scale.  Because it
         does not depend on the weights being updated, a data-parallel trainer may run it while the previous
@@ -177,7 +196,7 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
     def _select_source(self, batched_inputs, st):
         pass
 
-    def forward_trainable(self, st):
+    def _forward_trainable(self, st):
         """The trainable remainder: data-aware MLP, neck, object mining, refinement, losses."""
         self.roi_heads.image_level_gt = st["image_level_gt"]
         daf = self.data_aware_head.from_stats(st["gaps"]) if self.data_aware_head is not None else None
@@ -194,8 +213,7 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             losses.update(self.proposal_generator.get_losses(self.roi_heads.proposal_targets))
         return losses
 
-    @torch.no_grad()
-    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, classifier=None):
+    def _inference(self, batched_inputs, detected_instances=None, do_postprocess=True, classifier=None):
         assert not self.training
         assert detected_instances is None, "forward_with_given_boxes is not on the hot path"
         canvas, sizes_t, sizes = self._canvas(batched_inputs)

@@ -60,10 +60,16 @@ class _RPNHeadFn(Function):
         ctx.save_for_backward(x_nhwc, h2, wcat)
         ctx.conv, ctx.A, ctx.max_active = conv, A, max_active
         ctx.shapes = (w_obj.shape, w_del.shape)
+        ctx.x3 = H.x3_active()
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        with H.x3_mode(ctx.x3):
+            return _RPNHeadFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x, h2, wcat = ctx.saved_tensors
         conv, A = ctx.conv, ctx.A
         cd = x.dtype

@@ -42,6 +42,8 @@ def mixed_datasets_cfg(names=("voc_2007_train", "voc_2007_val", "coco_2017_train
     object miners shared per dataset family."""
     cfg = hot_path_cfg(K=max(Ks), D=D, **kw)
     cfg.merge_from_file(os.path.join(_CONFIG_DIR, "hot_path_wsr18_mixed.yaml"))
+    if kw.get("depth", 18) != 18:  # the mixed file is based on the WSR_18 one: put the requested backbone back
+        cfg.merge_from_list(["MODEL.RESNETS.DEPTH", kw["depth"], "MODEL.RESNETS.RES2_OUT_CHANNELS", 256])
     tmp = tempfile.mkdtemp(prefix="wsovod_emb_")
     paths = []
     for i, K in enumerate(Ks):
