@@ -25,7 +25,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md); x3 runs bf16 MFMAs
 HBM_PEAK_GBS = 8000.0
 
 
@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"],
+                    help="bf16 = BASELINE config 2 (bf16 MFMA, fp32 accumulate / master weights); fp32 = exact-fp32 MFMA "
+                         "(parity mode); bf16x3 = fp32 tensors, bf16 MFMA over hi/lo-split operands (meets the 1e-3 logit bound)")
     ap.add_argument("--depth", type=int, default=18)
     ap.add_argument("--proposals", type=int, default=512)
     ap.add_argument("--classes", type=int, default=20)
@@ -60,6 +62,13 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="launcher self-test (no GPU work): every rank joins the group, all-reduces its rank and rank 0 "
                          "prints {n_gpus, ranks_seen}; with --backend gloo it runs on a CPU-only host (tests/test_bench_launcher.py)")
+    ap.add_argument("--h2d", action="store_true",
+                    help="stage the uint8 images of every step from pinned host memory (asynchronous copy on a side "
+                         "stream, double buffered) instead of keeping the batch resident in HBM")
+    ap.add_argument("--no-side", action="store_true", help="skip the short side measurements (N=1 only)")
+    ap.add_argument("--side-steps", type=int, default=10)
+    ap.add_argument("--no-parity", action="store_true", help="skip the bf16 / bf16x3 vs fp32-HIP deviation measurement")
+    ap.add_argument("--parity-images", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -72,14 +81,19 @@ def pmc_traffic(kernel_name, args):
     profiled workload; otherwise null."""
     import re
 
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{args.batch}_bf16.json")  # written by tools/collect_profiles.sh
-    if not (os.path.exists(path) and args.precision == "bf16" and args.depth == 18 and args.proposals == 512):
-        return None
-    if getattr(args, "rpn", False):
-        return None
+    path = None
+    for rnd in ("r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
+        cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{args.batch}_bf16.json")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if not (path and args.precision == "bf16" and args.depth == 18 and args.proposals == 512):
+        return None, None
+    if getattr(args, "rpn", False) or args.pooler != "ROIPool" or args.h2d:
+        return None, None
     m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
     if not m:
-        return None
+        return None, None
     conv = m.group(1) == "conv_igemm"
     if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled
         tags = ("gemm256_8ph_kernelILb%d" % conv, "gemm256_8ph_kernel<%s>" % ("true" if conv else "false"))
@@ -89,7 +103,10 @@ def pmc_traffic(kernel_name, args):
     with open(path) as f:
         table = json.load(f)["kernels"]
     hits = [v for k, v in table.items() if any(t in k for t in tags)]
-    return hits[0]["traffic_bytes_per_launch"] if len(hits) == 1 else None
+    if len(hits) != 1:
+        return None, None
+    return hits[0]["traffic_bytes_per_launch"], (f"profiles/{os.path.basename(path)}: builder-run rocprofv3 --pmc FETCH_SIZE / "
+                                                 f"WRITE_SIZE passes of this command, NOT measured in this run")
 
 
 def to_device_batch(batch, dev):
@@ -144,9 +161,19 @@ def cpu_baseline(model, sd, batch, args):
         if time.time() - t0 > args.cpu_seconds or n >= 8:
             break
     dt = time.time() - t0
+    # share of the single-thread C RoIPool inside one step (so that nobody reads the GPU/CPU ratio as kernel credit)
+    from oracle import roi_ops
+    feat = torch.randn(1, 512 if args.depth == 18 else 2048, 75, 100)
+    rois = torch.cat([torch.zeros(len(sample[0]["boxes"]), 1), sample[0]["boxes"]], dim=1)
+    t1 = time.time()
+    roi_ops.roi_pool_forward(feat, rois, 0.125, (7, 7))
+    pool_s = time.time() - t1
     return {"value": n / dt, "unit": "images/sec", "cores": ncores, "kind": "port",
+            "roi_pool_share_of_step": round(pool_s / (dt / n), 3),
             "sample": f"{n} full fp32 training steps of 1 image x {args.proposals} proposals (oracle/wsovod_ref.py, "
-                      f"torch {torch.__version__} CPU, {ncores} of {host_cores} host threads = fastest of 16/32/64/all; RoIPool = single-thread C oracle)"}
+                      f"torch {torch.__version__} CPU, {ncores} of {host_cores} host threads = fastest of 16/32/64/all); "
+                      f"the RoIPool leg is the SINGLE-THREAD C oracle = {pool_s:.2f} s of the {dt / n:.2f} s step "
+                      f"({100 * pool_s / (dt / n):.0f} %): a baseline, not a tuned CPU implementation"}
 
 
 def eval_bench(args, cfg, model, dev, result_fd):
@@ -253,6 +280,200 @@ def launch_check(args, world, rank, result_fd):
     return 0
 
 
+def pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
+class H2DStager:
+    """The a1 input copy inside the timed region: the uint8 images (46 MB per 32 x 800x600 step) and the proposal
+    boxes of every step travel from pinned host memory on a side stream, double buffered, while the previous step
+    computes; the step's stream waits on the copy event (reference: rcnn_wsovod.py:321-328 `x["image"].to(device)`)."""
+
+    def __init__(self, host_batch, dev):
+        self.dev = dev
+        self.stream = torch.cuda.Stream(device=dev)
+        self.host = [{"image": x["image"].pin_memory(), "boxes": x["proposals"].proposal_boxes.tensor.pin_memory(),
+                      "logits": x["proposals"].objectness_logits.pin_memory(), "ref": x} for x in host_batch]
+        self.slots = [None, None]
+        self.events = [None, None]
+        self.i = 0
+        self._issue(0)
+
+    def _issue(self, k):
+        from wsovod_amd.structures import Boxes, Instances
+
+        with torch.cuda.stream(self.stream):
+            out = []
+            for h in self.host:
+                x = h["ref"]
+                props = Instances(x["proposals"].image_size,
+                                  proposal_boxes=Boxes(h["boxes"].to(self.dev, non_blocking=True)),
+                                  objectness_logits=h["logits"].to(self.dev, non_blocking=True))
+                out.append({"image": h["image"].to(self.dev, non_blocking=True), "proposals": props,
+                            "instances": x["instances"], "height": x["height"], "width": x["width"]})
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.slots[k], self.events[k] = out, ev
+
+    def next(self):
+        k = self.i & 1
+        torch.cuda.current_stream().wait_event(self.events[k])
+        batch = self.slots[k]
+        for x in batch:  # the caching allocator must not hand these buffers out before the consumer stream is done
+            x["image"].record_stream(torch.cuda.current_stream())
+        self.i += 1
+        self._issue(self.i & 1)
+        return batch
+
+
+def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, warmup, h2d=False, rpn=False,
+               want_roofline=False, keep=False):
+    """Build the model, run `warmup` + `steps` training steps, return the timing record (and the live objects if keep)."""
+    from wsovod_amd import _lib
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim, precision=precision,
+                                      pooler=pooler, device=str(dev), rpn=rpn)
+    if rpn:
+        model.roi_heads.iter = cfg.SOLVER.MAX_ITER // 2  # mid-training objectness ramp (rcnn_wsovod.py:181-184)
+    model.train()
+    optimizer = build_optimizer(cfg, model)
+    wire = ("bf16" if precision == "bf16" else "fp32") if args.grad_wire == "auto" else args.grad_wire
+    trainer = HotPathTrainer(model, optimizer, grad_wire=wire)  # async gradient all-reduce behind the next frozen forward
+    trainer.broadcast_parameters()
+    cpu_state = None
+    if keep and rank == 0 and world == 1 and not args.no_cpu_baseline:  # untrained weights for the CPU leg
+        cpu_state = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    host_batch = make_batch(batch_size, args.proposals, args.classes, seed=1234 + rank)
+    stager = H2DStager(host_batch, dev) if h2d else None
+    resident = None if h2d else to_device_batch(host_batch, dev)
+
+    def step():
+        return trainer.run_step(stager.next() if h2d else resident)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    sync()
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    events[0].record()
+    for i in range(steps):
+        step()
+        events[i + 1].record()
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
+    last = step()  # outside the timed region: the run must have stayed finite
+    final_losses = {k: float(v.detach()) for k, v in last.items()}
+    if not all(v == v and abs(v) != float("inf") for v in final_losses.values()):
+        raise RuntimeError(f"training diverged during the benchmark: {final_losses}")
+    rec = {"elapsed": elapsed, "per_step_ms": per_step, "final_losses": final_losses, "wire": wire}
+
+    if want_roofline:
+        # second pass over the same K steps with every launch bracketed by hipEvents on its stream
+        _lib.profile_reset()
+        _lib.profile_enable(True)
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        table = _lib.profile_collect()
+        _lib.profile_enable(False)
+        rec["kernel_table"] = sorted([e for e in table if e["launches"] > 0], key=lambda e: -e["ms"])
+    trainer.flush()
+    if keep:
+        rec.update(model=model, cpu_state=cpu_state, host_batch=host_batch)
+    else:
+        del trainer, optimizer, model, resident, stager
+        torch.cuda.empty_cache()
+    return rec
+
+
+def side_measurements(args, dev):
+    """Short runs in the SAME process as the headline line (N = 1): the reference's own per-GPU batch (1), 8 images,
+    the north star's pooler, the two parity-grade precisions, and the variant with the input copy inside the step."""
+    out = []
+    variants = [
+        ("b1 (the reference's images per GPU)", dict(batch_size=1)),
+        ("b8", dict(batch_size=8)),
+        ("ROIAlignV2 pooler (north-star wording)", dict(pooler="ROIAlignV2")),
+        ("fp32 parity mode (exact-fp32 MFMA)", dict(precision="fp32", steps=max(3, args.side_steps // 3), warmup=2)),
+        ("bf16x3 parity-grade mode", dict(precision="bf16x3", steps=max(3, args.side_steps // 2), warmup=2)),
+        ("H2D-inclusive (uint8 images + boxes copied from pinned host memory every step)", dict(h2d=True)),
+    ]
+    for name, kw in variants:
+        cfgv = dict(precision=args.precision, batch_size=args.batch, pooler=args.pooler, steps=args.side_steps,
+                    warmup=3, h2d=False)
+        cfgv.update(kw)
+        try:
+            r = run_config(args, dev, 0, 1, **cfgv)
+        except Exception as e:  # a side line must never take the headline down
+            out.append({"name": name, "error": f"{type(e).__name__}: {e}"[:300]})
+            continue
+        ms = r["per_step_ms"]
+        out.append({"name": name, "precision": cfgv["precision"], "images_per_step": cfgv["batch_size"],
+                    "pooler": cfgv["pooler"], "steps": cfgv["steps"],
+                    "images_per_sec": cfgv["batch_size"] * cfgv["steps"] / r["elapsed"],
+                    "ms_per_step": r["elapsed"] / cfgv["steps"] * 1e3, "median_ms": pct(ms, 0.5), "p10_ms": pct(ms, 0.1),
+                    "p90_ms": pct(ms, 0.9)})
+    return out
+
+
+def parity_block(args, dev):
+    """What error the timed precision has: ONE training step on the same `--parity-images` full-size images
+    (800x600, `--proposals` boxes each), same weights, dropout off, in the fp32 HIP path (pinned to the reference's
+    golden vectors at ~1e-5, tests/test_gpu_model_parity.py) and in the other modes."""
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_hot_path_model, capture_step
+
+    batch = make_batch(args.parity_images, args.proposals, args.classes, seed=4321)
+    res, state = {}, None
+    for prec in ("fp32", "bf16", "bf16x3"):
+        cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim, precision=prec,
+                                          pooler=args.pooler, device=str(dev))
+        if state is None:
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            model.load_state_dict(state)
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.eval()
+        losses, scores, logits = capture_step(model, to_device_batch(batch, dev))
+        res[prec] = ({k: float(v) for k, v in losses.items()}, scores.float().cpu(), logits.float().cpu())
+        del model
+        torch.cuda.empty_cache()
+    ref = res["fp32"]
+    out = {"vs": "fp32 HIP path (pinned to the reference's golden vectors, observed ~1e-5)",
+           "workload": f"{args.parity_images} x 800x600 images x {args.proposals} proposals, one training step, dropout off, "
+                       f"identical weights", "north_star_bound": 1e-3, "modes": {}}
+    for prec in ("bf16", "bf16x3"):
+        l, sc, lg = res[prec]
+        out["modes"][prec] = {
+            "max_abs_logit_err": float((lg - ref[2]).abs().max()), "max_abs_score_err": float((sc - ref[1]).abs().max()),
+            "max_rel_loss_err": max(abs(l[k] - ref[0][k]) / max(abs(ref[0][k]), 1e-12) for k in ref[0]),
+            "meets_1e-3_logit_bound": bool(float((lg - ref[2]).abs().max()) < 1e-3)}
+    timed = "bf16" if args.precision == "bf16" else args.precision
+    out["mode"] = args.precision
+    if timed in out["modes"]:
+        out["max_abs_logit_err"] = out["modes"][timed]["max_abs_logit_err"]
+        out["max_abs_score_err"] = out["modes"][timed]["max_abs_score_err"]
+    else:
+        out["max_abs_logit_err"] = out["max_abs_score_err"] = 0.0
+    return out
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ:
@@ -286,116 +507,98 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != world:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, expected {world}")
 
-    from wsovod_amd import _lib
-    from wsovod_amd.data import make_batch
-    from wsovod_amd.engine import HotPathTrainer, build_optimizer
-    from wsovod_amd.testing import build_hot_path_model
-
-    cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim,
-                                      precision=args.precision, pooler=args.pooler, device=f"cuda:{local_rank}",
-                                      rpn=args.rpn)
     if args.rpn:
         args.no_cpu_baseline = True
-        model.roi_heads.iter = cfg.SOLVER.MAX_ITER // 2  # mid-training objectness ramp (rcnn_wsovod.py:181-184)
     if args.eval:
+        from wsovod_amd.testing import build_hot_path_model
+
+        cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim,
+                                          precision=args.precision, pooler=args.pooler, device=f"cuda:{local_rank}",
+                                          rpn=args.rpn)
         return eval_bench(args, cfg, model, dev, result_fd)
-    model.train()
-    optimizer = build_optimizer(cfg, model)
-    wire = args.precision if args.grad_wire == "auto" else args.grad_wire
-    # async gradient all-reduce overlapped with the next step's frozen forward
-    trainer = HotPathTrainer(model, optimizer, grad_wire=wire)
-    trainer.broadcast_parameters()
 
-    def run_step(_m, _o, data):
-        return trainer.run_step(data)
-
-    ddp = model
-    cpu_state = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # snapshot of the untrained weights for the CPU leg
-        cpu_state = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-    host_batch = make_batch(args.batch, args.proposals, args.classes, seed=1234 + rank)
-    batch = to_device_batch(host_batch, dev)
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        run_step(ddp, optimizer, batch)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(ddp, optimizer, batch)
-    sync()
-    elapsed = time.perf_counter() - t0
-    last = run_step(ddp, optimizer, batch)  # outside the timed region: the run must have stayed finite
-    final_losses = {k: float(v.detach()) for k, v in last.items()}
-    if not all(v == v and abs(v) != float("inf") for v in final_losses.values()):
-        raise RuntimeError(f"training diverged during the benchmark: {final_losses}")
+    rec = run_config(args, dev, rank, world, precision=args.precision, batch_size=args.batch, pooler=args.pooler,
+                     steps=args.steps, warmup=args.warmup, h2d=args.h2d, rpn=args.rpn,
+                     want_roofline=not args.no_roofline, keep=True)
+    elapsed, my_ms = rec["elapsed"], rec["elapsed"] / args.steps * 1e3
+    rank_ms = [my_ms]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
+        elapsed = max(float(x.item()) for x in allt)  # the job is as slow as its slowest rank
 
     roofline = None
-    if not args.no_roofline:
-        # second pass over the same K steps with every launch bracketed by hipEvents on its stream
-        _lib.profile_reset()
-        _lib.profile_enable(True)
-        for _ in range(args.steps):
-            run_step(ddp, optimizer, batch)
-        torch.cuda.synchronize()
-        table = _lib.profile_collect()
-        _lib.profile_enable(False)
-        table = [e for e in table if e["launches"] > 0]
-        table.sort(key=lambda e: -e["ms"])
-        if rank == 0 and table:
-            top = table[0]
-            mfma = top["flops"] > 0 and ("gemm" in top["name"] or "conv" in top["name"])
-            avg_ms = top["ms"] / top["launches"]
-            if mfma:
-                ach = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "achieved": ach, "peak": PEAK[args.precision], "unit": "TFLOP/s",
-                            "frac": ach / PEAK[args.precision], "traffic": None}
-            else:
-                ach = top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9
-                roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": ach / HBM_PEAK_GBS, "traffic": None}
-            roofline["traffic"] = pmc_traffic(top["name"], args)
-            roofline["algorithmic_per_launch"] = (top["flops"] if mfma else top["bytes"]) / top["launches"]
-            roofline.update(kernel=top["name"], launches_per_step=top["launches"] / args.steps,
-                            avg_launch_ms=avg_ms, share_of_kernel_time=top["ms"] / sum(e["ms"] for e in table),
-                            kernels=[{"name": e["name"], "ms_per_step": e["ms"] / args.steps,
-                                      "launches_per_step": e["launches"] / args.steps,
-                                      "tflops": (e["flops"] / (e["ms"] * 1e-3) / 1e12) if e["flops"] and e["ms"] else None,
-                                      "gbs": (e["bytes"] / (e["ms"] * 1e-3) / 1e9) if e["bytes"] and e["ms"] else None}
-                                     for e in table[:12]])
+    table = rec.get("kernel_table")
+    if rank == 0 and table:
+        top = table[0]
+        mfma = top["flops"] > 0 and ("gemm" in top["name"] or "conv" in top["name"])
+        avg_ms = top["ms"] / top["launches"]
+        peak = PEAK[args.precision] if mfma else HBM_PEAK_GBS
+        ach = ((top["flops"] if mfma else top["bytes"]) / top["launches"] / (avg_ms * 1e-3)) / (1e12 if mfma else 1e9)
+        traffic, source = pmc_traffic(top["name"], args)
+        roofline = {"bound": "mfma" if mfma else "hbm", "achieved": ach, "peak": peak,
+                    "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / peak, "traffic": traffic,
+                    "traffic_source": source,
+                    "algorithmic_per_launch": (top["flops"] if mfma else top["bytes"]) / top["launches"],
+                    "kernel": top["name"], "launches_per_step": top["launches"] / args.steps, "avg_launch_ms": avg_ms,
+                    "share_of_kernel_time": top["ms"] / sum(e["ms"] for e in table),
+                    "kernels": [{"name": e["name"], "ms_per_step": e["ms"] / args.steps,
+                                 "launches_per_step": e["launches"] / args.steps,
+                                 "tflops": (e["flops"] / (e["ms"] * 1e-3) / 1e12) if e["flops"] and e["ms"] else None,
+                                 "gbs": (e["bytes"] / (e["ms"] * 1e-3) / 1e9) if e["bytes"] and e["ms"] else None}
+                                for e in table[:14]]}
 
     if rank == 0:
         images = world * args.batch * args.steps
+        ms = rec["per_step_ms"]
+        rccl = None
+        if dist.is_initialized() and args.backend == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
         out = {
             "metric": "images/sec (512 proposals/img) WSR_18_DC5 fwd+bwd at 1/2/4/8 MI355X",
             "value": images / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "median_ms": pct(ms, 0.5),
+            "p10_ms": pct(ms, 0.1), "p90_ms": pct(ms, 0.9), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"VOC07 WSOVOD_WSR_{args.depth}_DC5_1x, {args.proposals} proposals/img, "
                                    f"{args.classes}-class embeddings (D={args.embed_dim}), 800x600 images, "
                                    f"{'RPN + loaded proposals' if args.rpn else 'proposals-only mode'}, {args.pooler}, "
                                    f"full training step (fwd+bwd+SGD)",
                        "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
-                       "parallelism": f"dp{world}", "grad_allreduce": f"{wire} over RCCL" if dist.is_initialized() else "none (1 GPU)",
-                       "final_losses": final_losses},
+                       "parallelism": f"dp{world}",
+                       "grad_allreduce": f"{rec['wire']} over {'RCCL ' + str(rccl) if rccl else args.backend}"
+                       if dist.is_initialized() else "none (1 GPU)",
+                       "inputs": "uint8 images + boxes copied from pinned host memory inside every step (async, double "
+                                 "buffered)" if args.h2d else "resident in HBM before the timed region",
+                       "per_step_percentiles": "hipEvent time between consecutive steps on rank 0's stream",
+                       "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms), "all": rank_ms},
+                       "final_losses": rec["final_losses"]},
         }
         if roofline is not None:
             out["roofline"] = roofline
+        model, cpu_state, host_batch = rec.pop("model"), rec.pop("cpu_state"), rec.pop("host_batch")
+        del rec
+        torch.cuda.empty_cache()
+        if world == 1 and not args.rpn:
+            if not args.no_parity:
+                out["parity"] = parity_block(args, dev)
+            if not args.no_side:
+                out["side"] = side_measurements(args, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cpu_state, host_batch, args)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":

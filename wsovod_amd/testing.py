@@ -73,3 +73,30 @@ def build_hot_path_model(seed=0, calibrate_synthetic=True, **kw):
         with torch.no_grad():
             model.backbone.stem.conv1.norm.weight.fill_(1.0 / 64.0)
     return cfg, model
+
+
+def capture_step(model, batched_inputs):
+    """One training forward + backward; returns (loss dict, object-mining scores (R,K), refinement logits (R,K+1)) --
+    the two tensors the north star's "MIL-head logits within 1e-3" bound is about."""
+    captured = {}
+    rh = model.roi_heads
+    orig_m, orig_r = rh.object_miner.forward, rh.box_refinery[0].forward
+
+    def cap(name, fn):
+        def wrapped(*a, **k):
+            o = fn(*a, **k)
+            captured[name] = o
+            return o
+        return wrapped
+
+    rh.object_miner.forward = cap("miner", orig_m)
+    rh.box_refinery[0].forward = cap("refine", orig_r)
+    try:
+        losses = model(batched_inputs)
+    finally:
+        rh.object_miner.forward, rh.box_refinery[0].forward = orig_m, orig_r
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    model.zero_grad(set_to_none=True)
+    return ({k: v.detach() for k, v in losses.items()}, captured["miner"][0].detach(),
+            captured["refine"][0].detach())
