@@ -1,22 +1,29 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the round's bench line, the rocprofv3 kernel-trace summary of the same command and
-# the two PMC passes behind roofline.traffic.  Everything lands under gpurun_out/final/ (copy to profiles/ afterwards).
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
+# the PMC passes behind roofline.traffic and the MFMA-utilisation table.  Counters are collected in their own runs with
+# --kernel-trace only (no sys/hip/hsa trace domains).  Everything lands under gpurun_out/final/ (copy to profiles/).
+#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh'
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/final
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
+SHORT="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-side --no-parity"
 python3 "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_b32_bf16.json" 2> "$OUT/bench_b32_bf16.err"
-python3 "$ROOT/bench.py" --steps 10 --warmup 3 --precision fp32 --no-cpu-baseline > "$OUT/bench_b32_fp32.json" 2>> "$OUT/bench_b32_bf16.err"
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
+    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-side --no-parity > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
 cp /tmp/prof_kt/*kernel_stats.csv "$OUT/kernel_stats.csv"
-for C in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/prof_$C && rocprofv3 --pmc $C --kernel-trace --output-format csv -d /tmp/prof_$C -o pmc -- \
-      python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-roofline > "$OUT/pmc_$C.log" 2>&1
-  cp /tmp/prof_$C/*counter_collection.csv "$OUT/pmc_$C.csv"
+declare -A PASS
+PASS[FETCH_SIZE]="FETCH_SIZE"
+PASS[WRITE_SIZE]="WRITE_SIZE"
+PASS[SQ]="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
+PASS[LDS]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS TCC_HIT_sum TCC_MISS_sum"
+ARGS=""
+for C in FETCH_SIZE WRITE_SIZE SQ LDS; do
+  rm -rf /tmp/prof_$C && rocprofv3 --pmc ${PASS[$C]} --kernel-trace --output-format csv -d /tmp/prof_$C -o pmc -- \
+      python3 "$ROOT/bench.py" $SHORT > "$OUT/pmc_$C.log" 2>&1
+  cp /tmp/prof_$C/*counter_collection.csv "$OUT/pmc_$C.csv" 2>/dev/null && ARGS="$ARGS $C=$OUT/pmc_$C.csv"
 done
-python3 "$ROOT/tools/pmc_aggregate.py" "$OUT/pmc_traffic_b32_bf16.json" FETCH_SIZE="$OUT/pmc_FETCH_SIZE.csv" WRITE_SIZE="$OUT/pmc_WRITE_SIZE.csv"
+python3 "$ROOT/tools/pmc_aggregate.py" "$OUT/pmc_b32_bf16.json" $ARGS
 rm -f "$OUT"/pmc_*.csv
 ls -la "$OUT"
