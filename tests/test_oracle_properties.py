@@ -168,3 +168,83 @@ def test_subsample_labels_quotas_and_membership():
         assert len(p) == min(len(pos_set), int(num * frac)) and len(n) == min(len(neg_set), num - len(p))
         assert set(p.tolist()) <= pos_set and set(n.tolist()) <= neg_set
         assert len(set(p.tolist())) == len(p) and len(set(n.tolist())) == len(n)  # without replacement
+
+
+def _mask_roi_loop_pool(feat, rois, scale, out_hw, ratio=1.8):
+    """The reference's 3-output ROILoopPool (layers/ROILoopPool/ROILoopPool_cuda.cu:9-204; its CPU source implements
+    only the first output and the .cu file needs CUDA headers, so it cannot be built here) from its definition, with
+    window slices and boolean masks instead of the kernel's scalar loops.
+      region : max(0, max over the bin)                       (accumulator starts at 0: inputs are post-ReLU)
+      frame  : the same bin without the cells STRICTLY inside the roi shrunk by `ratio` about its centre
+      context: the bin of the roi GROWN by `ratio`, without the cells strictly inside the roi itself
+    argmax = first cell in row-major order that reaches the (strictly positive) maximum, else -1."""
+    f = feat.numpy()
+    N, C, H, W = f.shape
+    ph, pw = out_hw
+    R = len(rois)
+    out = np.zeros((3 * R, C, ph, pw), dtype=np.float32)
+    arg = np.full((3 * R, C, ph, pw), -1, dtype=np.int32)
+    f32 = np.float32
+
+    def rnd(v):  # C round(): half away from zero
+        return int(np.sign(v) * np.floor(np.abs(np.float32(v)) + np.float32(0.5)))
+
+    def pool(n, b, rect, hole, slot):
+        x1, y1, x2, y2 = rect
+        sw, sh, ew, eh = rnd(f32(x1) * f32(scale)), rnd(f32(y1) * f32(scale)), rnd(f32(x2) * f32(scale)), rnd(f32(y2) * f32(scale))
+        hx1, hy1, hx2, hy2 = (rnd(f32(v) * f32(scale)) for v in hole) if hole is not None else (0, 0, 0, 0)
+        rw, rh = max(ew - sw + 1, 1), max(eh - sh + 1, 1)
+        bh, bw = f32(rh) / f32(ph), f32(rw) / f32(pw)
+        for p in range(ph):
+            for q in range(pw):
+                hs = min(max(int(np.floor(f32(p) * bh)) + sh, 0), H)
+                he = min(max(int(np.ceil(f32(p + 1) * bh)) + sh, 0), H)
+                ws = min(max(int(np.floor(f32(q) * bw)) + sw, 0), W)
+                we = min(max(int(np.ceil(f32(q + 1) * bw)) + sw, 0), W)
+                if he <= hs or we <= ws:
+                    continue
+                win = f[b, :, hs:he, ws:we].copy()
+                if hole is not None:
+                    hh, ww = np.arange(hs, he)[:, None], np.arange(ws, we)[None, :]
+                    inside = (hh > hy1) & (hh < hy2) & (ww > hx1) & (ww < hx2)
+                    win[:, inside] = -np.inf
+                flat = win.reshape(C, -1)
+                best = flat.max(axis=1)
+                first = flat.argmax(axis=1)  # first maximum in row-major order
+                hit = best > 0
+                out[slot * R + n, hit, p, q] = best[hit]
+                idx = (hs + first // (we - ws)) * W + ws + first % (we - ws)
+                arg[slot * R + n, hit, p, q] = idx[hit]
+
+    lim_x, lim_y = f32(1.0 * W / scale), f32(1.0 * H / scale)
+    for n, roi in enumerate(rois.numpy().astype(np.float32)):
+        b, x1, y1, x2, y2 = int(roi[0]), *roi[1:]
+        rw, rh = x2 - x1, y2 - y1
+        iw, ih = rw - rw / f32(ratio), rh - rh / f32(ratio)
+        ow, oh = rw * f32(ratio) - rw, rh * f32(ratio) - rh
+        clipx = lambda v: min(max(v, f32(0)), lim_x)
+        clipy = lambda v: min(max(v, f32(0)), lim_y)
+        inner = (clipx(x1 + iw / 2), clipy(y1 + ih / 2), clipx(x2 - iw / 2), clipy(y2 - ih / 2))
+        outer = (clipx(x1 - ow / 2), clipy(y1 - oh / 2), clipx(x2 + ow / 2), clipy(y2 + oh / 2))
+        pool(n, b, (x1, y1, x2, y2), None, 0)
+        pool(n, b, (x1, y1, x2, y2), inner, 1)
+        pool(n, b, outer, (x1, y1, x2, y2), 2)
+    return torch.from_numpy(out), torch.from_numpy(arg)
+
+
+def test_roi_loop_pool_c_oracle_against_mask_definition():
+    """oracle/roi_ops_ref.c:roi_loop_pool_forward (frame / context outputs) against the mask-based evaluator above:
+    values and argmax exact, on post-ReLU-like features (the op's stated assumption) incl. zero cells and boxes that
+    leave the map."""
+    g = torch.Generator().manual_seed(8)
+    feat = torch.relu(torch.randn(2, 5, 38, 50, generator=g))
+    rois = random_rois(40, 2, 38 * 8, 50 * 8, seed=12)
+    got, got_arg = roi_ops.roi_loop_pool_forward(feat, rois, 0.125, (7, 7))
+    want, want_arg = _mask_roi_loop_pool(feat, rois, 0.125, (7, 7))
+    R = len(rois)
+    for slot, name in enumerate(("region", "frame", "context")):
+        sl = slice(slot * R, (slot + 1) * R)
+        assert torch.equal(got[sl], want[sl]), name
+        assert torch.equal(got_arg[sl], want_arg[sl]), name
+    assert float(want[R:2 * R].sum()) > 0 and float(want[2 * R:].sum()) > 0
+    assert not torch.equal(want[:R], want[R:2 * R]) and not torch.equal(want[:R], want[2 * R:])
