@@ -37,3 +37,21 @@ def test_a_dead_rank_fails_the_launch():
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert p.stdout.strip() == ""
+
+
+def test_driver_launch_form_under_torch_distributed_run():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- bench.py must take RANK / WORLD_SIZE from the launcher and not spawn again."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--launch-check",
+                        "--backend", "gloo"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [x for x in p.stdout.splitlines() if x.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 0b11
