@@ -332,14 +332,16 @@ class H2DStager:
 
 
 def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, warmup, h2d=False, rpn=False,
-               want_roofline=False, keep=False):
+               want_roofline=False, keep=False, depth=None, proposals=None, classes=None, embed_dim=None):
     """Build the model, run `warmup` + `steps` training steps, return the timing record (and the live objects if keep)."""
     from wsovod_amd import _lib
     from wsovod_amd.data import make_batch
     from wsovod_amd.engine import HotPathTrainer, build_optimizer
     from wsovod_amd.testing import build_hot_path_model
 
-    cfg, model = build_hot_path_model(seed=0, depth=args.depth, K=args.classes, D=args.embed_dim, precision=precision,
+    depth, proposals = depth or args.depth, proposals or args.proposals
+    classes, embed_dim = classes or args.classes, embed_dim or args.embed_dim
+    cfg, model = build_hot_path_model(seed=0, depth=depth, K=classes, D=embed_dim, precision=precision,
                                       pooler=pooler, device=str(dev), rpn=rpn)
     if rpn:
         model.roi_heads.iter = cfg.SOLVER.MAX_ITER // 2  # mid-training objectness ramp (rcnn_wsovod.py:181-184)
@@ -351,7 +353,7 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     cpu_state = None
     if keep and rank == 0 and world == 1 and not args.no_cpu_baseline:  # untrained weights for the CPU leg
         cpu_state = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
-    host_batch = make_batch(batch_size, args.proposals, args.classes, seed=1234 + rank)
+    host_batch = make_batch(batch_size, proposals, classes, seed=1234 + rank)
     stager = H2DStager(host_batch, dev) if h2d else None
     resident = None if h2d else to_device_batch(host_batch, dev)
 
@@ -411,6 +413,9 @@ def side_measurements(args, dev):
         ("fp32 parity mode (exact-fp32 MFMA)", dict(precision="fp32", steps=max(3, args.side_steps // 3), warmup=2)),
         ("bf16x3 parity-grade mode", dict(precision="bf16x3", steps=max(3, args.side_steps // 2), warmup=2)),
         ("H2D-inclusive (uint8 images + boxes copied from pinned host memory every step)", dict(h2d=True)),
+        ("BASELINE config 2 shapes: K = 80 classes, D = 768 (CLIP ViT-L/14)", dict(classes=80, embed_dim=768)),
+        ("BASELINE config 3 shapes: WSR_50, 1024 proposals, K = 80, 8 images/step", dict(depth=50, proposals=1024, classes=80,
+                                                                                   batch_size=8, steps=max(3, args.side_steps // 2))),
     ]
     for name, kw in variants:
         cfgv = dict(precision=args.precision, batch_size=args.batch, pooler=args.pooler, steps=args.side_steps,
@@ -423,7 +428,8 @@ def side_measurements(args, dev):
             continue
         ms = r["per_step_ms"]
         out.append({"name": name, "precision": cfgv["precision"], "images_per_step": cfgv["batch_size"],
-                    "pooler": cfgv["pooler"], "steps": cfgv["steps"],
+                    "pooler": cfgv["pooler"], "steps": cfgv["steps"], "depth": cfgv.get("depth") or args.depth,
+                    "proposals": cfgv.get("proposals") or args.proposals,
                     "images_per_sec": cfgv["batch_size"] * cfgv["steps"] / r["elapsed"],
                     "ms_per_step": r["elapsed"] / cfgv["steps"] * 1e3, "median_ms": pct(ms, 0.5), "p10_ms": pct(ms, 0.1),
                     "p90_ms": pct(ms, 0.9)})
