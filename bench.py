@@ -419,7 +419,7 @@ def side_measurements(args, dev):
     ]
     for name, kw in variants:
         cfgv = dict(precision=args.precision, batch_size=args.batch, pooler=args.pooler, steps=args.side_steps,
-                    warmup=3, h2d=False)
+                    warmup=5, h2d=False)
         cfgv.update(kw)
         try:
             r = run_config(args, dev, 0, 1, **cfgv)
