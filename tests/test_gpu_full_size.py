@@ -118,3 +118,43 @@ def test_full_size_training_step_properties(gpu):
     losses_r = model(batch[::-1])
     for k in losses:
         torch.testing.assert_close(losses_r[k], losses[k], rtol=2e-3, atol=1e-5)
+
+
+def test_full_size_precision_modes_against_the_fp32_path(gpu):
+    """The deviation of the timed precision at the FULL benchmark size (4 x 800x600 x 512 proposals; the goldens pin
+    the fp32 HIP path at plumbing size to ~1e-5): identical weights, dropout off, one training step per mode.
+      bf16   : refinement logits within 0.5 (= 1e-2 on the cosine), mining scores 2e-2, losses 5 %   -- misses the
+               north star's 1e-3 logit bound, and says by how much;
+      bf16x3 : logits and scores within 1e-3 (the bound), losses 1e-3.
+    The same numbers travel in bench.py's `parity` block."""
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_hot_path_model, capture_step
+
+    host = make_batch(4, 512, 20, seed=4321)
+    batch = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
+              "height": x["height"], "width": x["width"]} for x in host]
+    res, state = {}, None
+    for prec in ("fp32", "bf16", "bf16x3"):
+        cfg, model = build_hot_path_model(seed=0, precision=prec, device="cuda:0")
+        if state is None:
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        else:
+            model.load_state_dict(state)
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.eval()
+        losses, scores, logits = capture_step(model, batch)
+        res[prec] = ({k: float(v) for k, v in losses.items()}, scores.float().cpu(), logits.float().cpu())
+        del model
+        torch.cuda.empty_cache()
+    ref = res["fp32"]
+    report = {}
+    for prec, lim_logit, lim_score, lim_loss in (("bf16", 0.5, 2e-2, 5e-2), ("bf16x3", 1e-3, 1e-3, 1e-3)):
+        l, sc, lg = res[prec]
+        e_logit, e_score = float((lg - ref[2]).abs().max()), float((sc - ref[1]).abs().max())
+        e_loss = max(abs(l[k] - ref[0][k]) / max(abs(ref[0][k]), 1e-12) for k in ref[0])
+        report[prec] = (e_logit, e_score, e_loss)
+        assert e_logit < lim_logit and e_score < lim_score and e_loss < lim_loss, (prec, e_logit, e_score, e_loss)
+    print("full-size deviation vs fp32 HIP (max|dlogit|, max|dscore|, max rel loss):", report)
+    assert report["bf16"][0] > 1e-3  # the plain bf16 mode does NOT meet the north star's bound: keep saying so
