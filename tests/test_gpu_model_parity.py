@@ -815,3 +815,47 @@ def test_config5_wsr50_mixed_large_vocabulary_matches_oracle(gpu):
 def R_train(sd, batch, depth, K):
     sdc = {k: v.clone() for k, v in sd.items()}
     return R.train_forward(sdc, batch, depth=depth, num_classes=K, pixel_std=gen.PIXEL_STD)
+
+
+@pytest.mark.parametrize("variant", ["roialign", "r50", "eval"])
+def test_bf16x3_variants_track_the_fp32_path(gpu, variant):
+    """bf16x3 through the other routes of the path (ROIAlignV2 pooler, bottleneck backbone, inference with the NMS
+    tail): same seeded weights as the exact-fp32 mode, results within the 1e-3 logit / score bound of it."""
+    from wsovod_amd.testing import build_hot_path_model, capture_step
+
+    kw = dict(pooler="ROIAlignV2") if variant == "roialign" else dict(depth=50) if variant == "r50" else {}
+    H_, W_ = (160, 224) if variant == "r50" else (256, 352)
+    batch = to_inputs(gen.seeded_batch(2, 48, 20, H_, W_, seed=71))
+    dev_batch = [{"image": b["image"].to(gpu), "proposals": b["proposals"].to(gpu), "instances": b["instances"],
+                  "height": b["height"], "width": b["width"]} for b in batch]
+    out, state = {}, None
+    for prec in ("fp32", "bf16x3"):
+        cfg, model = build_hot_path_model(seed=0, precision=prec, device="cuda:0", **kw)
+        if state is None:
+            state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            if variant == "r50":  # keep the random 50-layer backbone's features O(1) (see the config-5 test)
+                state["roi_heads.box_head.fc1.weight"] = state["roi_heads.box_head.fc1.weight"] * 1e-2
+        model.load_state_dict(state)
+        if variant == "eval":
+            model.eval()
+            clf = torch.randn(20, 512, generator=torch.Generator().manual_seed(5)).to(gpu)
+            res, sc, bx = model.inference(dev_batch, do_postprocess=False, classifier=clf)
+            out[prec] = (torch.cat([s[0] for s in sc]).cpu(), torch.cat([b[0] for b in bx]).cpu(), [len(r) for r in res])
+        else:
+            model.train()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.eval()
+            losses, scores, logits = capture_step(model, dev_batch)
+            out[prec] = (scores.float().cpu(), logits.float().cpu(), {k: float(v) for k, v in losses.items()})
+        del model
+        torch.cuda.empty_cache()
+    a, b = out["fp32"], out["bf16x3"]
+    assert float((a[0] - b[0]).abs().max()) < 1e-3, variant
+    if variant == "eval":
+        assert float((a[1] - b[1]).abs().max()) < 5e-2  # decoded boxes, pixels
+        assert a[2] == b[2] and sum(a[2]) > 0
+    else:
+        assert float((a[1] - b[1]).abs().max()) < 1e-3, variant
+        for k in a[2]:
+            assert abs(a[2][k] - b[2][k]) <= 2e-3 * max(abs(a[2][k]), 1e-6) + 1e-6, (variant, k)

@@ -239,3 +239,25 @@ def test_shipped_proposal_counts_with_rpn_subsample_like_the_reference(gpu, monk
     for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
         torch.testing.assert_close(losses[k].detach().cpu(), ref_losses[k].detach(), rtol=5e-3, atol=1e-5,
                                    msg=lambda m: f"{k}: {m}")
+
+
+def test_bf16x3_rpn_step_matches_reference_golden(gpu, monkeypatch):
+    """The RPN branch in bf16x3 (fp32 tensors, bf16 MFMA over hi/lo-split operands; incl. the sparse-row weight-gradient
+    GEMMs of the RPN head): the reference's golden step to the fp32-mode tolerances."""
+    g = load_golden("g12_rpn_train_step")
+    cfg, model, sd, sampling = build_rpn_model("bf16x3")
+    first_k_keys(model, monkeypatch)
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
+    losses = model(to_inputs(batch))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    pg = model.proposal_generator
+    torch.testing.assert_close(pg.pred_objectness_logits[0].detach().cpu(), g["rpn_logits"], rtol=1e-3, atol=1e-3)
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0", "loss_rpn_cls", "loss_rpn_loc"):
+        torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=5e-3, atol=1e-5,
+                                   msg=lambda m: f"{k}: {m}")
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            ref = float(g["gradnorm/" + k])
+            got = float(q.grad.double().norm())
+            assert abs(got - ref) <= 2e-2 * ref + 1e-6, (k, got, ref)
