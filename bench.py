@@ -324,8 +324,11 @@ class H2DStager:
         k = self.i & 1
         torch.cuda.current_stream().wait_event(self.events[k])
         batch = self.slots[k]
+        cur = torch.cuda.current_stream()
         for x in batch:  # the caching allocator must not hand these buffers out before the consumer stream is done
-            x["image"].record_stream(torch.cuda.current_stream())
+            x["image"].record_stream(cur)
+            x["proposals"].proposal_boxes.tensor.record_stream(cur)
+            x["proposals"].objectness_logits.record_stream(cur)
         self.i += 1
         self._issue(self.i & 1)
         return batch
