@@ -725,7 +725,14 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
   } else {
     bf16_t* o = (bf16_t*)out + obase;
-    if (vec)
+    if (vec && (nvalid & 7) == 0 && (obase & 7) == 0)
+      for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
+        const f32x4 q0 = *(const f32x4*)(sval + i), q1 = *(const f32x4*)(sval + i + 4);
+        const bf16x8 pk = {(bf16_t)q0[0], (bf16_t)q0[1], (bf16_t)q0[2], (bf16_t)q0[3],
+                           (bf16_t)q1[0], (bf16_t)q1[1], (bf16_t)q1[2], (bf16_t)q1[3]};
+        __builtin_nontemporal_store(pk, (bf16x8*)(o + i));  // as the RoIPool kernel: streamed once, keep the map in L2
+      }
+    else if (vec)
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) {
         const float4 q = *(const float4*)(sval + i);
         bf16x4 pk = {(bf16_t)q.x, (bf16_t)q.y, (bf16_t)q.z, (bf16_t)q.w};
