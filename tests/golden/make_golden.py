@@ -613,7 +613,7 @@ def golden_tta(r):
         return image, TL(tf)
 
     cfg, model, post = _eval_reference_model(r)
-    _mod("detectron2.data.detection_utils", read_image=None)
+    sys.modules["detectron2.data.detection_utils"].read_image = None  # (extend the shim module; later generators read others)
     _mod("detectron2.data.transforms", RandomFlip=RandomFlip, ResizeShortestEdge=ResizeShortestEdge,
          ResizeTransform=lambda h, w, nh, nw: TL([P.ResizeTransform(h, w, nh, nw)]),
          apply_augmentations=apply_augmentations)
@@ -671,6 +671,7 @@ def golden_subsample(r):
     than BATCH_SIZE_PER_IMAGE (the shipped RPN form: 4000 loaded + 1024 RPN boxes against 4096) and with
     POSITIVE_FRACTION < 1.  detectron2's random subsample_labels (un-vendored) is replaced by the deterministic
     first-k rule of tests/golden/gen.py (randperm cannot be reproduced across implementations)."""
+    orig_subsample = r.roi_heads.subsample_labels
     r.roi_heads.subsample_labels = gen.first_k_subsample
     cfg, model, sd, shapes = build_ref_model(r, 18, 20, 512, seed=1)
     rh = model.roi_heads
@@ -691,6 +692,7 @@ def golden_subsample(r):
         full[matched_labels == 0] = rh.num_classes
         arrays[f"case{i}/params"] = np.array([R_, num, frac, rh.num_classes], dtype=np.float64)
         arrays[f"case{i}/labels_in"], arrays[f"case{i}/labels_out"] = full, lab
+    r.roi_heads.subsample_labels = orig_subsample
     save("g16_subsample", **arrays)
 
 
