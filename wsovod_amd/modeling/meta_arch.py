@@ -89,8 +89,14 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         images = [x["image"] for x in batched_inputs]
         sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         Hp, Wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
-        if len(images) == 1 or all(s == sizes[0] for s in sizes):
-            canvas = torch.stack([im.to(self.device, non_blocking=True) for im in images])
+        if all(im.device == self.device for im in images) and all(s == sizes[0] for s in sizes):
+            canvas = torch.stack(images)  # already resident: one gather pass
+        elif all(s == sizes[0] for s in sizes):
+            # host images (the DatasetMapper's format): each one is copied straight into its slot of the batch tensor --
+            # no per-image device temporary and no second (stack) pass over the batch
+            canvas = torch.empty((len(images), 3, Hp, Wp), dtype=images[0].dtype, device=self.device)
+            for i, im in enumerate(images):
+                canvas[i].copy_(im, non_blocking=True)
         else:
             canvas = torch.zeros((len(images), 3, Hp, Wp), dtype=torch.uint8, device=self.device)
             for i, im in enumerate(images):
