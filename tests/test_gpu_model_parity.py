@@ -106,6 +106,29 @@ def test_bf16x3_step_meets_the_north_star_logit_bound(gpu):
         assert (gen.strided_sample(gr, 2048) - ref).abs().max() <= 3e-2 * ref.abs().max() + 1e-6, k
 
 
+def test_bf16x3f_forward_meets_the_logit_bound_with_bf16_grade_gradients(gpu):
+    """MODEL.HIP.PRECISION = bf16x3f: the hi/lo split in the forward pass only.  Forward quantities as in bf16x3
+    (logits / scores within 1e-3 of the reference's golden step, labels exact, losses 1e-3); the backward runs as plain
+    bf16 on casts of the saved fp32 tensors, so gradients have the bf16 mode's grade (norms within 15 %)."""
+    g = load_golden("g8_train_step_r18_k20")
+    cfg, model, sd = build_seeded_hip_model("bf16x3f")
+    batch = gen.seeded_batch(4, 64, 20, 320, 416, seed=2)
+    losses, cap, pgt = _run(model, batch)
+    scores = cap["miner"][0].detach().cpu()
+    logits = cap["refine"][0].detach().cpu()
+    assert float((logits - g["refine_logits"]).abs().max()) < 1e-3
+    assert float((scores - g["mining_scores"]).abs().max()) < 1e-3
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+        torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=1e-3, atol=1e-5)
+    assert torch.equal(pgt["gt_classes"].cpu(), g["label/gt_classes"])
+    assert torch.equal(pgt["gt_boxes"].cpu(), g["label/gt_boxes"])
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+            ref = float(g["gradnorm/" + k])
+            assert abs(float(p.grad.float().norm()) - ref) <= 0.15 * ref + 1e-4, k
+
+
 def test_split3_kernel_is_the_exact_hi_lo_decomposition(gpu):
     """wsovod_split3_bf16: hi = bf16(x), lo = bf16(x - hi) in the A order [hi|hi|lo] / B order [hi|lo|hi]; side by side
     along the columns (zero-padded to 8) or stacked along the rows; x - (hi + lo) <= 2^-16 |x|."""
@@ -861,7 +884,7 @@ def test_bf16x3_variants_track_the_fp32_path(gpu, variant):
             assert abs(a[2][k] - b[2][k]) <= 2e-3 * max(abs(a[2][k]), 1e-6) + 1e-6, (variant, k)
 
 
-@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3", "bf16x3f"])
 def test_training_on_a_fixed_batch_reduces_the_loss(gpu, precision):
     """End-to-end sanity of forward + backward + fused SGD through the overlapped trainer: 12 steps on ONE fixed batch
     at lr 1e-3 (the config's 1e-2 needs the reference's warm-up on this synthetic model) take the summed loss from

@@ -237,7 +237,8 @@ def add_wsovod_config(cfg):
     # hot-path extensions of this implementation (not in the reference)
     _C.MODEL.HIP = C()
     # "bf16" (bf16 MFMA, fp32 accumulate) | "fp32" (exact-fp32 MFMA) | "bf16x3" (fp32 tensors, bf16 MFMA on hi/lo-split
-    # operands: fp32-grade products at a third of the bf16 rate)
+    # operands: fp32-grade products at a third of the bf16 rate) | "bf16x3f" (the split in the forward pass only, plain
+    # bf16 backward: fp32-grade logits, bf16-grade gradients)
     _C.MODEL.HIP.PRECISION = "bf16"
     return _C
 

@@ -59,12 +59,15 @@ class _Linear(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        with H.x3_mode(ctx.x3):
+        with H.x3_mode(ctx.x3 if ctx.x3 != "fwd" else False):
             return _Linear._backward(ctx, dy)
 
     @staticmethod
     def _backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
+        in_dtype = x.dtype
+        if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
+            x = H.cast(x, torch.bfloat16)
         cd = x.dtype
         M, K = x.shape
         N = weight.size(0)
@@ -98,7 +101,7 @@ class _Linear(Function):
             dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
         if need_dx:
             wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
-            dx = H.gemm_nt(dA, wt, out_dtype=cd)  # (M,K)
+            dx = H.gemm_nt(dA, wt, out_dtype=in_dtype)  # (M,K)
         return dx, dw, db, None, None, None, None
 
 
@@ -131,7 +134,7 @@ class _LinearGroup(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, *dys):
-        with H.x3_mode(ctx.x3):
+        with H.x3_mode(ctx.x3 if ctx.x3 != "fwd" else False):
             return _LinearGroup._backward(ctx, *dys)
 
     @staticmethod
@@ -139,6 +142,9 @@ class _LinearGroup(Function):
         heads = len(ctx.meta)
         saved = ctx.saved_tensors
         x, ws, ys = saved[0], saved[1:1 + heads], saved[1 + heads:]
+        in_dtype = x.dtype
+        if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
+            x = H.cast(x, torch.bfloat16)
         cd = x.dtype
         M, K = x.shape
         Ns = [w.size(0) for w in ws]
@@ -161,7 +167,7 @@ class _LinearGroup(Function):
             wcat[offs[h]:offs[h] + Ns[h]] = ws[h]
         dx = None
         if need_dx:
-            dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=cd)  # (M,K) = dA_cat @ W_cat
+            dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=in_dtype)  # (M,K) = dA_cat @ W_cat
         grads = [None] * (2 * heads)
         if need_dw:
             if _USE_TN and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 \
@@ -279,7 +285,7 @@ class _CosineLogits(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dl):
-        with H.x3_mode(ctx.x3):
+        with H.x3_mode(ctx.x3 if ctx.x3 != "fwd" else False):
             return _CosineLogits._backward(ctx, dl)
 
     @staticmethod
@@ -287,13 +293,16 @@ class _CosineLogits(Function):
         z, wnT = ctx.saved_tensors
         temperature, normalize, has_bias = ctx.cfg
         cd = z.dtype
+        if ctx.x3 == "fwd" and wnT.dtype == torch.float32:  # bf16x3f: the class matrix of the backward GEMM in bf16
+            wnT = H.cast(wnT, torch.bfloat16)
+            cd = torch.bfloat16
         dl = _contig2d(dl)
         M, K1 = dl.shape
         dA, _ = H.mask_transpose(dl, None, 1.0, cd, want_plain=True, want_t=False, ld_plain=wnT.size(1))
         u = H.gemm_nt(dA, wnT, out_dtype=torch.float32)  # (M,D) = dL/d(zn)
         dz = H.row_l2norm_backward(z, u, temperature, relu_mask=False) if normalize else u
-        if cd != torch.float32:
-            dz = H.cast(dz, cd)
+        if z.dtype != torch.float32:
+            dz = H.cast(dz, z.dtype)
         db = None
         if has_bias and ctx.needs_input_grad[5]:
             seg = H.const_tensor((0, M), torch.int32, z.device)

@@ -214,11 +214,13 @@ class _X3State:
 
 class x3_mode:
     """Context manager: fp32 x fp32 contractions issued inside go through the bf16x3 split.  Model entry points enter
-    it when their precision is "bf16x3"; autograd Functions capture `x3_active()` in forward and re-enter it in
+    it when their precision is "bf16x3" (mode "full") or "bf16x3f" (mode "fwd": the split only in the forward pass;
+    the backward contractions then run as plain bf16 on casts of the saved fp32 tensors -- forward logits of fp32
+    grade, gradients of the bf16 mode's grade).  Autograd Functions capture `x3_active()` in forward and act on it in
     backward (the autograd engine runs backward outside the forward's context)."""
 
     def __init__(self, on=True):
-        self.on = bool(on)
+        self.on = ("full" if on is True else on) if on else False
 
     def __enter__(self):
         self.prev = _X3State.active

@@ -65,7 +65,7 @@ class _RPNHeadFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        with H.x3_mode(ctx.x3):
+        with H.x3_mode(bool(ctx.x3)):  # (the RPN head keeps the split in its backward also in the "fwd" mode)
             return _RPNHeadFn._backward(ctx, dout)
 
     @staticmethod
