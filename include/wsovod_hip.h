@@ -170,6 +170,12 @@ typedef struct {
   wsovod_conv_geom geom;      /* used when conv != 0; M = n_img*Ho*Wo, K = KH*KW*Cin */
   int tile_hint;              /* 0 = auto; else BM*1000+BN (e.g. 128128, 128064, 64064) */
   int prof_tag;               /* 0 = generic; >0 selects a named profiling slot */
+  /* conv only: a second NHWC input A2 (n_img, Ho, Wo, Cin2) contracted 1x1 / stride 1 in the SAME accumulation -- the
+   * block's projection shortcut (resnet_wsl.py:94-106: out = conv2(...) + shortcut(x)) folded into its last conv: B rows
+   * are [W (KH*KW*Cin) | Wshortcut (Cin2)], K = KH*KW*Cin + Cin2, bias = the sum of the two folded biases.  The shortcut's
+   * output is never written, rounded or re-read as a residual.  NULL = off. */
+  const void* A2;
+  int Cin2;
 } wsovod_gemm_desc;
 
 int wsovod_gemm_nt(const wsovod_gemm_desc* desc_host, wsovod_stream_t stream);

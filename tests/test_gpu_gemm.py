@@ -383,3 +383,40 @@ def test_gemm_split_k_matches_unsplit_tile(gpu):
     assert torch.equal(ct[:, :M], o1.t())  # the transposed copy carries the stored value (after the accumulate)
     b16 = hip_ops.gemm_nt(A, B, bias=bias, relu=True, out_dtype=torch.bfloat16)
     torch.testing.assert_close(b16.float(), torch.relu(A.float() @ B.float().t() + bias), rtol=2e-2, atol=0.2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("k,dil", [(3, 2), (1, 1)])
+def test_conv_with_fused_projection_shortcut(gpu, dtype, tol, k, dil):
+    """wsovod_gemm_desc.A2: out = relu(conv(h) + conv1x1(x) + biases) as ONE contraction (K = k*k*C + Cin2) against the
+    two-launch form (shortcut conv, then conv with the residual epilogue) and against torch's conv2d in fp32."""
+    import torch.nn.functional as F
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(11)
+    n, Hh, Ww, C, Cin2 = 2, 19, 27, 128, 64
+    h = torch.randn(n, Hh, Ww, C, generator=g)
+    x = torch.randn(n, Hh, Ww, Cin2, generator=g)
+    w = torch.randn(C, k, k, C, generator=g) * 0.05
+    wsc = torch.randn(C, Cin2, generator=g) * 0.1
+    b, bsc = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    pad = dil * (k // 2)
+    want = F.relu(F.conv2d(h.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, padding=pad, dilation=dil)
+                  + F.conv2d(x.permute(0, 3, 1, 2), wsc.view(C, Cin2, 1, 1), bsc)).permute(0, 2, 3, 1)
+    hd, xd = h.to(gpu).to(dtype).contiguous(), x.to(gpu).to(dtype).contiguous()
+    wcat = torch.cat([w.reshape(C, -1), wsc], dim=1).to(gpu).to(dtype).contiguous()
+    geom = dict(n_img=n, H=Hh, W=Ww, Cin=C, Ho=Hh, Wo=Ww, KH=k, KW=k, stride=1, pad=pad, dil=dil)
+    fused = H.gemm_nt(hd, wcat, conv=geom, bias=(b + bsc).to(gpu), relu=True, out_dtype=torch.float32, A2=xd)
+    geom1 = dict(n_img=n, H=Hh, W=Ww, Cin=Cin2, Ho=Hh, Wo=Ww, KH=1, KW=1, stride=1, pad=0, dil=1)
+    sc = H.gemm_nt(xd, wsc.to(gpu).to(dtype).contiguous(), conv=geom1, bias=bsc.to(gpu), out_dtype=torch.float32)
+    two = H.gemm_nt(hd, w.reshape(C, -1).to(gpu).to(dtype).contiguous(), conv=geom, bias=b.to(gpu), relu=True,
+                    residual=sc, out_dtype=torch.float32)
+    scale = float(want.abs().max())
+    assert float((fused.view(n, Hh, Ww, C).cpu() - want).abs().max()) <= tol * scale
+    assert float((fused - two).abs().max()) <= (1e-5 if dtype == torch.float32 else 1e-3) * scale  # same products, other order
+    for hint in (256128, 128128, 64064):  # the other tile shapes of the same kernel
+        alt = H.gemm_nt(hd, wcat, conv=geom, bias=(b + bsc).to(gpu), relu=True, out_dtype=torch.float32, A2=xd, tile_hint=hint)
+        assert float((alt - fused).abs().max()) <= 1e-5 * scale + (0 if dtype == torch.float32 else 1e-3 * scale)
+    with pytest.raises(RuntimeError, match="fused-shortcut"):
+        H.gemm_nt(hd.to(torch.bfloat16), wcat.to(torch.bfloat16), conv=geom, A2=xd.to(torch.bfloat16), tile_hint=8256256,
+                  out_dtype=torch.float32)

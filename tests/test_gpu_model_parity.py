@@ -911,3 +911,24 @@ def test_training_on_a_fixed_batch_reduces_the_loss(gpu, precision):
     assert all(h == h and abs(h) != float("inf") for h in hist)
     assert abs(hist[0] - 0.991) < 5e-3  # same start as the fp32 mode
     assert min(hist[-3:]) < 0.45 * hist[0], hist
+
+
+@pytest.mark.parametrize("depth", [18, 50])
+def test_backbone_with_fused_shortcuts_equals_the_separate_launches(gpu, depth, monkeypatch):
+    """The projection shortcuts of res3-res5 ride in the block's last conv (K extended by Cin): same res5 map as with
+    the separate 1x1 launch + residual epilogue, up to the one rounding of the shortcut output the fused form skips."""
+    from wsovod_amd.testing import build_hot_path_model
+
+    x = torch.randint(0, 256, (2, 3, 160, 224), dtype=torch.uint8)
+    for prec, tol in (("fp32", 1e-5), ("bf16", 3e-2)):
+        cfg, model = build_hot_path_model(seed=0, depth=depth, precision=prec, device="cuda:0")
+        inp = [{"image": im} for im in x]
+        outs = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("WSOVOD_FUSE_SHORTCUT", fuse)
+            canvas, sizes_t, sizes = model._canvas(inp)
+            outs[fuse] = model.backbone.forward_uint8(canvas, sizes_t, model._mean, model._std)["res5"].float()
+        scale = float(outs["0"].abs().max())
+        assert scale > 0 and float((outs["1"] - outs["0"]).abs().max()) <= tol * scale, (prec, depth)
+        del model
+        torch.cuda.empty_cache()

@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("accumulate", C.c_int),
         ("conv", C.c_int), ("geom", ConvGeom),
         ("tile_hint", C.c_int), ("prof_tag", C.c_int),
+        ("A2", C.c_void_p), ("Cin2", C.c_int),
     ]
 
 

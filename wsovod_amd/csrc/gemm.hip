@@ -75,8 +75,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
   int a_off[RA];  // byte offset of this lane's chunk at k = 0 (plain) / of the image (conv); <0 = invalid row
   int hi0[RA], wi0[RA];
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrcA2;
+  [[maybe_unused]] int pix2_off[RA];  // conv + fused shortcut: this lane's chunk of its output pixel in A2, <0 = row past M
   if (CONV) {
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    rsrcA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0), 0x00020000);
   } else {
     const long long rows = min(BM, p.M - m0);
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * esz), 0,
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);  // invalid row: every tap falls outside
       wi0[i] = wo * p.stride - p.pad;
       a_off[i] = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
+      pix2_off[i] = ok ? (((img * p.Ho + ho) * p.Wo + wo) * p.Cin2 + lchunk * EPC) * esz : -1;
     } else {
       hi0[i] = wi0[i] = 0;
       a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
@@ -146,6 +150,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       // the same input pixels shifted by the dilation, so the re-reads come one K-step after each other (the chunk's
       // slice of the tile block, ~1 MB per XCD, stays in L2) instead of one full channel sweep (~4 MB) apart.
       const int taps = p.KH * p.KW;
+      const int nk_main = taps * (p.Cin / BKE);
+      if (kt >= nk_main) {  // fused 1x1 shortcut: K-steps past the filter read the second input at the output pixel
+        const int c2 = (kt - nk_main) * BKE;
+        kbase = taps * p.Cin + c2;
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+          ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA2, pix2_off[i] >= 0 ? pix2_off[i] + c2 * esz : -1, 0, 0);
+      } else {
       const int chunk = kt / taps;
       const int tap = kt - chunk * taps;
       const int c0 = chunk * BKE;
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 #pragma unroll
       for (int i = 0; i < RA; ++i)
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, ((vmask[i] >> tap) & 1u) ? pix_off[i] + delta : -1, 0, 0);
+      }
     }
     const bool k_ok = kbase + lchunk * EPC < p.K;
     if (!CONV) {
@@ -186,18 +199,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     char* dA = sA + buf * BM * 128 + wave_u * 1024;
     char* dB = sB + buf * BN * 128 + wave_u * 1024;
     int tap = 0, delta = 0;
+    bool second = false;  // fused 1x1 shortcut K-steps (wave-uniform)
     if (CONV) {  // (channel chunk, tap) order, tap innermost: see load_global
       const int taps = p.KH * p.KW;
-      const int chunk = kt / taps;
-      tap = kt - chunk * taps;
-      const int c0 = chunk * BKE;
-      const int r = tap / p.KW;
-      const int q = tap - r * p.KW;
-      kbase = tap * p.Cin + c0;
-      delta = (((r * p.W + q) * p.dil) * p.Cin + c0) * esz;  // wave-uniform
+      const int nk_main = taps * (p.Cin / BKE);
+      second = kt >= nk_main;
+      if (second) {
+        delta = (kt - nk_main) * BKE * esz;
+        kbase = taps * p.Cin + (kt - nk_main) * BKE;
+      } else {
+        const int chunk = kt / taps;
+        tap = kt - chunk * taps;
+        const int c0 = chunk * BKE;
+        const int r = tap / p.KW;
+        const int q = tap - r * p.KW;
+        kbase = tap * p.Cin + c0;
+        delta = (((r * p.W + q) * p.dil) * p.Cin + c0) * esz;  // wave-uniform
+      }
     }
     const bool k_ok = kbase + lchunk * EPC < p.K;
-    if (CONV) {
+    if (CONV && second) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void*)(dA + LR * i * 128), 16,
+                                                 pix2_off[i] >= 0 ? pix2_off[i] + delta : -1, 0, 0, 0);
+    } else if (CONV) {
 #pragma unroll
       for (int i = 0; i < RA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dA + LR * i * 128), 16,
@@ -815,7 +841,9 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     const wsovod_conv_geom& g = d->geom;
     const int bke = d->dtype_in == WSOVOD_BF16 ? 64 : 32;
     WS_CHECK_ARG(g.Cin > 0 && g.Cin % bke == 0, "wsovod_gemm_nt(conv): Cin=%d must be a multiple of %d", g.Cin, bke);
-    WS_CHECK_ARG(d->K == g.KH * g.KW * g.Cin, "wsovod_gemm_nt(conv): K=%d != KH*KW*Cin", d->K);
+    WS_CHECK_ARG(!d->A2 || (d->Cin2 > 0 && d->Cin2 % bke == 0 && ((uintptr_t)d->A2 & 15) == 0),
+                 "wsovod_gemm_nt(conv): the fused shortcut input needs Cin2 (%d) a multiple of %d and 16-byte alignment", d->Cin2, bke);
+    WS_CHECK_ARG(d->K == g.KH * g.KW * g.Cin + (d->A2 ? d->Cin2 : 0), "wsovod_gemm_nt(conv): K=%d != KH*KW*Cin (+ Cin2)", d->K);
     WS_CHECK_ARG(g.KH * g.KW <= 32, "wsovod_gemm_nt(conv): filters of more than 32 taps are not supported (per-tap validity mask)");
     WS_CHECK_ARG((long long)d->M == (long long)g.n_img * g.Ho * g.Wo, "wsovod_gemm_nt(conv): M=%d != n_img*Ho*Wo", d->M);
     WS_CHECK_ARG(g.stride >= 1 && g.dil >= 1 && g.pad >= 0, "wsovod_gemm_nt(conv): bad stride/dil/pad");
@@ -831,8 +859,15 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     a.dil = g.dil;
     a.pool = g.pool;
     a.a_bytes = (long long)g.n_img * g.H * g.W * g.Cin * esz;
+    if (d->A2) {
+      a.A2 = (const char*)d->A2;
+      a.Cin2 = d->Cin2;
+      a.a2_bytes = (long long)g.n_img * g.Ho * g.Wo * d->Cin2 * esz;
+      WS_CHECK_ARG(a.a2_bytes < (1ll << 31), "wsovod_gemm_nt(conv): fused shortcut input exceeds the 2 GiB buffer-addressing limit");
+      WS_CHECK_ARG(!(d->tile_hint == 8256256), "wsovod_gemm_nt(conv): the 8-phase tile has no fused-shortcut path");
+    }
     WS_CHECK_ARG(a.a_bytes < (1ll << 31), "wsovod_gemm_nt(conv): input of %lld bytes exceeds the 2 GiB buffer-addressing limit", a.a_bytes);
-    bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K) * esz;
+    bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K + (d->A2 ? (double)g.n_img * g.Ho * g.Wo * d->Cin2 : 0.0)) * esz;
   } else {
     WS_CHECK_ARG(d->lda % epc == 0, "wsovod_gemm_nt: lda=%lld must be a multiple of %d elements", d->lda, epc);
     WS_CHECK_ARG(128ll * d->lda * esz < (1ll << 31), "wsovod_gemm_nt: lda too large for buffer addressing");
@@ -842,7 +877,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   const double flops = 2.0 * d->M * d->N * d->K;
   hipStream_t s = (hipStream_t)stream;
   if (d->conv && d->tile_hint == 0 && d->dtype_in == WSOVOD_BF16 && a.Cin == 64 && d->N == 64 && a.KH == 3 &&
-      a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W && d->C && !d->Ct &&
+      a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W && d->C && !d->Ct && !d->A2 &&
       !d->row_scale && !d->group_add && !d->mask_src && !d->accumulate && d->dropout_p == 0.f) {
     static int slot = wsovod::prof_slot("conv3x3_c64_halo_bf16");
     if (a.pool) {

@@ -462,6 +462,10 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
     (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
+  if (conv && a.A2) {
+    wsovod::set_error("wsovod_gemm_nt(conv): the 8-phase tile has no fused-shortcut path");
+    return WSOVOD_ERR_UNSUPPORTED;
+  }
   GemmArgs args = a;
   args.tiles_m = ceil_div(a.M, 256);
   args.tiles_n = ceil_div(a.N, 256);

@@ -44,6 +44,10 @@ struct GemmArgs {
   long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
   int tiles_m, tiles_n;
   int group_m;  // tile-order group height (see the XCD remap in the kernel)
+  // conv: optional second input contracted 1x1 / stride 1 after the KH*KW*Cin main K range (fused projection shortcut)
+  const char* A2;
+  int Cin2;
+  long long a2_bytes;
 };
 
 template <typename T>

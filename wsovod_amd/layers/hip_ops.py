@@ -295,17 +295,19 @@ def _ld(t):
 
 def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=None, bias=None, residual=None,
             relu=False, dropout_p=0.0, dropout_seed=0, row_group=None, group_add=None, mask_src=None,
-            mask_scale=1.0, accumulate=False, M=None, N=None, K=None, conv=None, tile_hint=0, want_c=True):
+            mask_scale=1.0, accumulate=False, M=None, N=None, K=None, conv=None, tile_hint=0, want_c=True, A2=None):
     """C[M][N] = epilogue(sum_k A[m][k]*B[n][k]); see include/wsovod_hip.h for the epilogue order.
 
     A: (M,K) or, with `conv` (a dict of geometry), the NHWC input tensor.  B: (N,K).
     `out_t` is an optional (N, >=M) tensor that receives the transposed copy.
+    `A2` (conv only): a second NHWC input (n_img, Ho, Wo, Cin2) contracted 1x1 in the same accumulation (the block's
+    projection shortcut); B rows are then [W | Wshortcut].
     Returns `out` (or None if want_c is False).
     """
     require_gpu(A, B, out, out_t, row_scale, bias, residual, row_group, group_add, mask_src)
     if _X3State.active and A.dtype == torch.float32 and B.dtype == torch.float32:
-        if M is not None or N is not None or K is not None:
-            raise RuntimeError("bf16x3: explicit M/N/K overrides are not supported")
+        if M is not None or N is not None or K is not None or A2 is not None:
+            raise RuntimeError("bf16x3: explicit M/N/K overrides / a fused shortcut input are not supported")
         return _gemm_nt_x3(A, B, conv=conv, out=out, out_dtype=out_dtype or torch.float32, out_t=out_t, alpha=alpha,
                            row_scale=row_scale, bias=bias, residual=residual, relu=relu, dropout_p=dropout_p,
                            dropout_seed=dropout_seed, row_group=row_group, group_add=group_add, mask_src=mask_src,
@@ -324,6 +326,12 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
         d.conv = 1
         d.M = g.n_img * g.Ho * g.Wo
         d.A, d.lda = A.data_ptr(), g.Cin
+        if A2 is not None:
+            require_gpu(A2)
+            if A2.dtype != A.dtype or not A2.is_contiguous() or A2.numel() != d.M * A2.shape[-1]:
+                raise RuntimeError("wsovod_hip gemm: the fused shortcut input must be NHWC-contiguous (n_img, Ho, Wo, Cin2) "
+                                   "in the dtype of A")
+            d.A2, d.Cin2 = A2.data_ptr(), int(A2.shape[-1])
     else:
         d.M = A.size(0) if M is None else M
         d.A, d.lda = A.data_ptr(), _ld(A)

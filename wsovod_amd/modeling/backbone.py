@@ -12,6 +12,8 @@ directly.
 Scope: every shipped WSR config freezes the whole backbone (FREEZE_AT: 5), so only the
 forward exists; a trainable stage raises NotImplementedError instead of silently using torch.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -87,7 +89,19 @@ class Conv2d(nn.Module):
         return self._folded[1], self._folded[2]
 
 
-def hip_conv(x, conv, relu=False, residual=None, pool2=False):
+def _folded_with_shortcut(conv, shortcut, dtype):
+    """[W (kh*kw*Cin) | Wshortcut (Cin2)] rows + the summed folded biases: the operand of the conv that contracts the
+    block's 1x1 projection shortcut in the same accumulation (wsovod_gemm_desc.A2)."""
+    key = (dtype, conv.weight._version, shortcut.weight._version, conv.weight.device)
+    c = getattr(conv, "_folded_sc", None)
+    if c is None or c[0] != key:
+        w, b = conv.folded(dtype)
+        ws, bs = shortcut.folded(dtype)
+        conv._folded_sc = c = (key, torch.cat([w, ws], dim=1).contiguous(), (b + bs).contiguous())
+    return c[1], c[2]
+
+
+def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None):
     """x: (N,H,W,Cin) NHWC contiguous in the compute dtype -> (N,Ho,Wo,Cout); with pool2 the MaxPool2d(2, 2) that
     follows the conv in the stem / block tail is applied too -> (N,Ho//2,Wo//2,Cout).  The 64-channel bf16 kernel pools
     in its epilogue (the full-resolution map is never written); every other conv is followed by the pool kernel."""
@@ -97,6 +111,13 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False):
     Wo = (Ww + 2 * p - d * (k - 1) - 1) // s + 1
     wq, b = conv.folded(x.dtype, cin_pad=Cin)
     geom = dict(n_img=N, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=s, pad=p, dil=d)
+    if shortcut is not None:
+        # `shortcut` = (block input, its 1x1 projection conv): out = conv(x) + projection(input), one accumulation
+        x2, sc = shortcut
+        assert residual is None and not pool2 and x2.shape[:3] == (N, Ho, Wo) and x2.shape[3] == sc.in_channels
+        wq, b = _folded_with_shortcut(conv, sc, x.dtype)
+        out = H.gemm_nt(x, wq, conv=geom, bias=b, relu=relu, out_dtype=x.dtype, A2=x2)
+        return out.view(N, Ho, Wo, conv.out_channels)
     res2d = residual.view(N * Ho * Wo, conv.out_channels) if residual is not None else None
     fused = (pool2 and x.dtype == torch.bfloat16 and Cin == 64 and conv.out_channels == 64 and (k, s, p, d) == (3, 1, 1, 1)
              and (residual is None or residual.dtype == torch.bfloat16))
@@ -107,6 +128,15 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False):
     out = H.gemm_nt(x, wq, conv=geom, bias=b, relu=relu, residual=res2d, out_dtype=x.dtype)
     out = out.view(N, Ho, Wo, conv.out_channels)
     return H.maxpool2x2_nhwc(out, 2) if pool2 else out
+
+
+def _fusable_shortcut(sc, x):
+    """The block's projection shortcut can ride in its last conv's accumulation: 1x1, stride 1, a whole number of
+    K-steps of channels, bf16 / exact-fp32 operands (the bf16x3 modes split their operands and keep the separate launch)."""
+    if sc is None or H.x3_active() or os.environ.get("WSOVOD_FUSE_SHORTCUT", "1") == "0":
+        return False
+    kstep = 64 if x.dtype == torch.bfloat16 else 32
+    return sc.kernel_size == 1 and sc.stride == 1 and sc.padding == 0 and sc.in_channels % kstep == 0 and x.is_contiguous()
 
 
 class CNNBlockBase(nn.Module):
@@ -153,6 +183,10 @@ class BasicBlock(CNNBlockBase, _PoolMixin):
 
     def forward(self, x):
         out = hip_conv(x, self.conv1, relu=True)
+        if _fusable_shortcut(self.shortcut, x) and not (self.has_pool and self.pool_stride == 2):
+            # projection shortcut contracted inside conv2 (K = 9*C + Cin): no separate 1x1 launch, its output is neither
+            # written nor rounded nor re-read as a residual
+            return self._pool(hip_conv(out, self.conv2, relu=True, shortcut=(x, self.shortcut)))
         shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
         if self.has_pool and self.pool_stride == 2:  # stride-2 tail pool (res2): fused where the kernel has it
             return hip_conv(out, self.conv2, relu=True, residual=shortcut, pool2=True)
@@ -188,6 +222,8 @@ class BottleneckBlock(CNNBlockBase, _PoolMixin):
     def forward(self, x):
         out = hip_conv(x, self.conv1, relu=True)
         out = hip_conv(out, self.conv2, relu=True)
+        if _fusable_shortcut(self.shortcut, x) and out.shape[:3] == x.shape[:3]:
+            return self._pool(hip_conv(out, self.conv3, relu=True, shortcut=(x, self.shortcut)))
         shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
         out = hip_conv(out, self.conv3, relu=True, residual=shortcut)
         return self._pool(out)
