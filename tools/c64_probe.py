@@ -7,6 +7,7 @@ if os.environ.get("WSOVOD_LIB"):
     _L.LIB_PATH = os.environ["WSOVOD_LIB"]
 from wsovod_amd.layers import hip_ops
 n=32
+torch.manual_seed(0)
 for (H,W,pool) in ((300,400,0),(300,400,2),(150,200,0),(150,200,2)):
     x = (torch.rand(n, H, W, 64, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = ((torch.rand(64, 9*64, device="cuda") * 2 - 1) * 0.05).to(torch.bfloat16)
@@ -20,4 +21,5 @@ for (H,W,pool) in ((300,400,0),(300,400,2),(150,200,0),(150,200,2)):
         for _ in range(5): hip_ops.gemm_nt(x, w, conv=geom, bias=bias, relu=True, out_dtype=torch.bfloat16)
         e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)/5)
     med=sorted(ts)[3]; fl=2.0*n*H*W*64*9*64
-    print(f"c64 {H}x{W} pool={pool}: {med:.3f} ms {fl/med/1e9:.0f} TF", flush=True)
+    chk = int(out.view(torch.int16).to(torch.int64).sum())  # bit-level checksum for old-vs-new comparisons
+    print(f"c64 {H}x{W} pool={pool}: {med:.3f} ms {fl/med/1e9:.0f} TF  checksum {chk}", flush=True)

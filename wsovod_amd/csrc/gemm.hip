@@ -486,6 +486,122 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 constexpr int C64_TH = 8, C64_TW = 32, C64_PW = C64_TW + 2, C64_PH = C64_TH + 2, C64_NPIX = C64_PW * C64_PH;
 constexpr int C64_PATCH_BYTES = ((C64_NPIX + 31) / 32 * 32) * 128;  // padded to whole 32-pixel DMA passes
 
+// Epilogue of the 64-channel 3x3 kernels (one-tile and persistent form): bias + residual + ReLU (+ fused 2x2 max pool).
+__device__ __forceinline__ void c64_load_bias(const GemmArgs& p, const int fq, f32x4 (&b4)[4]) {
+  // this lane's 16 output channels (16*fq ..): loaded once, ahead of the MFMAs, so the epilogue never waits for them
+  const bool al = ((uintptr_t)p.bias & 15) == 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* b = p.bias + 16 * fq + 4 * j;
+    b4[j] = !p.bias ? f32x4{0.f, 0.f, 0.f, 0.f} : al ? *(const f32x4*)b : f32x4{b[0], b[1], b[2], b[3]};
+  }
+}
+
+__device__ __forceinline__ void c64_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], const f32x4 (&bias4)[4],
+                                             const int img, const int y0, const int x0, const int wave, const int frow,
+                                             const int fq) {
+  // epilogue: bias + residual + ReLU.  Operands were swapped in the MFMA and the weight rows permuted at staging, so
+  // lane (frow, fq) holds, for pixel group i, the 16 consecutive output channels 16*fq + 4*j + r of pixel frow: its
+  // 32 bytes (bf16) go out as two 16-byte stores and the four lanes of a pixel cover its whole 128-byte row.
+  const bool vec = (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.bias & 15) == 0 &&
+                   (!p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0));
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  const int n0c = 16 * fq;
+  if (p.pool) {
+    // Fused MaxPool2d(2, 2) (stem tail resnet_wsl.py:418-420, block tail :85-92,107-108): the wavefront's two image rows
+    // are the two rows of one pooled row (y0 and wave*2 are even), the horizontal partner is the neighbouring lane
+    // (frow ^ 1, same channels).  Values are rounded to bf16 first, as the unfused conv output was, so the pooled map has
+    // the same bits as conv -> maxpool2x2_nhwc; the full-resolution map is never written.  (launcher: bf16, aligned)
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float best[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
+#pragma unroll
+      for (int iv = 0; iv < 2; ++iv) {
+        const int i = ih + 2 * iv;
+        const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
+        const long long m = ((long long)img * p.H + y) * p.W + x;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+        if (p.residual) {
+          const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
+          const bf16x8 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] += (float)r0[e];
+            v[8 + e] += (float)r1[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], (float)(bf16_t)fmaxf(v[e], lo));
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
+      const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
+      if ((frow & 1) == 0 && py < Hp && px < Wp) {
+        bf16x8 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o0[e] = (bf16_t)best[e];
+          o1[e] = (bf16_t)best[8 + e];
+        }
+        bf16x8* dst = (bf16x8*)((bf16_t*)p.C + (((long long)img * Hp + py) * Wp + px) * p.ldc + n0c);
+        dst[0] = o0;
+        dst[1] = o1;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + wave * 2 + (i >> 1);
+    const int x = x0 + (i & 1) * 16 + frow;
+    if (y >= p.H || x >= p.W) continue;
+    const long long m = ((long long)img * p.H + y) * p.W + x;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha;
+    if (vec && p.dtype_c == WSOVOD_BF16 && (!p.residual || p.dtype_r == WSOVOD_BF16)) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * j + r] += bias4[j][r];
+      if (p.residual) {
+        const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
+        const bf16x8 r0 = rp[0], r1 = rp[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] += (float)r0[e];
+          v[8 + e] += (float)r1[e];
+        }
+      }
+      bf16x8 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o0[e] = (bf16_t)fmaxf(v[e], lo);
+        o1[e] = (bf16_t)fmaxf(v[8 + e], lo);
+      }
+      bf16x8* dst = (bf16x8*)((bf16_t*)p.C + m * p.ldc + n0c);
+      dst[0] = o0;
+      dst[1] = o1;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float u = v[e] + (p.bias ? p.bias[n0c + e] : 0.f);
+        if (p.residual) u += load_as_f32(p.residual, m * p.ldr + n0c + e, p.dtype_r);
+        store_from_f32(p.C, m * p.ldc + n0c + e, p.dtype_c, fmaxf(u, lo));
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int tiles_x, int tiles_y) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sP = smem;                    // halo patch [pixel][128 B]
@@ -535,12 +651,14 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
   stage_weights(0, 0);
   __syncthreads();
 
+  const int frow = lane & 15, fq = lane >> 4;
+  f32x4 bias4[4];
+  c64_load_bias(p, fq, bias4);
   f32x4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frow = lane & 15, fq = lane >> 4;
 #pragma unroll 1
   for (int tap = 0; tap < 9; ++tap) {
     const int cur = tap & 1;
@@ -571,112 +689,220 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
     }
     __syncthreads();
   }
-  // epilogue: bias + residual + ReLU.  Operands were swapped in the MFMA and the weight rows permuted at staging, so
-  // lane (frow, fq) holds, for pixel group i, the 16 consecutive output channels 16*fq + 4*j + r of pixel frow: its
-  // 32 bytes (bf16) go out as two 16-byte stores and the four lanes of a pixel cover its whole 128-byte row.
-  const bool vec = (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0 && ((uintptr_t)p.bias & 15) == 0 &&
-                   (!p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0));
-  const float lo = p.relu ? 0.f : -__builtin_inff();
-  const int n0c = 16 * fq;
-  if (p.pool) {
-    // Fused MaxPool2d(2, 2) (stem tail resnet_wsl.py:418-420, block tail :85-92,107-108): the wavefront's two image rows
-    // are the two rows of one pooled row (y0 and wave*2 are even), the horizontal partner is the neighbouring lane
-    // (frow ^ 1, same channels).  Values are rounded to bf16 first, as the unfused conv output was, so the pooled map has
-    // the same bits as conv -> maxpool2x2_nhwc; the full-resolution map is never written.  (launcher: bf16, aligned)
-    const int Hp = p.H >> 1, Wp = p.W >> 1;
+  c64_epilogue(p, acc, bias4, img, y0, x0, wave, frow, fq);
+}
+
+// ---------------------------------------------------------------------------------
+// Persistent form of the 64-channel 3x3 kernel (round 2).  One workgroup per CU walks its tiles (8 x 32 output pixels
+// each); what the one-tile kernel above pays per tile or per tap is paid once or hidden:
+//   * all nine 64x64 weight slices are staged ONCE per workgroup and stay resident (72 KiB) -- no per-tap staging, no
+//     per-tap barrier;
+//   * two halo-patch buffers (2 x 43 KiB): the LDS-DMA of the next tile's patch is issued before the current tile's
+//     MFMAs and lands behind them and the epilogue; one barrier per tile;
+//   * fragment reads are inline asm (hipcc would otherwise drain the in-flight DMA with s_waitcnt vmcnt(0) in front of
+//     every ds_read it can see), software-pipelined one (tap, k-half) step ahead of the MFMAs with counted lgkmcnt
+//     waits; every LDS address is loop-invariant (36 + 4 registers), so the tile loop issues no address arithmetic.
+// 160 KiB of LDS = 72 KiB weights + 2 x 43 KiB patches: one workgroup (4 wavefronts, one per SIMD) per CU.
+// Same products in the same order as the one-tile kernel: bit-identical outputs.
+// ---------------------------------------------------------------------------------
+// Ablation build switch (tools/c64_ablate.sh; results in profiles/r02_c64_persistent.md), never set in the product
+// build: bit 0 drops the fragment-read + MFMA loop, 1 the epilogue, 2 the patch staging of every tile but the first,
+// 3 the fragment reads and their waits (MFMAs on stale registers), 4 only the waits.  The `alpha` comparisons keep
+// the dropped code reachable for the compiler, so the rest of the kernel compiles as in the product build.
+#ifndef C64P_ABL
+#define C64P_ABL 0
+#endif
+constexpr int C64P_W_BYTES = 9 * 8192;
+constexpr int C64P_LDS_BYTES = C64P_W_BYTES + 2 * C64_PATCH_BYTES;
+
+__global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int tiles_x, int tiles_y, int n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sW = smem;                  // 9 x [64 cout][128 B]
+  char* sP = smem + C64P_W_BYTES;   // 2 x halo patch [pixel][128 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int tpi = tiles_x * tiles_y;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(64 * p.ldb * 2), 0x00020000);
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // resident weights: the LDS image of the one-tile kernel's slice, nine times
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      float best[16];
+  for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
-#pragma unroll
-      for (int iv = 0; iv < 2; ++iv) {
-        const int i = ih + 2 * iv;
-        const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
-        const long long m = ((long long)img * p.H + y) * p.W + x;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 b4 = p.bias ? *(const f32x4*)(p.bias + n0c + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + b4[r];
-        }
-        if (p.residual) {
-          const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
-          const bf16x8 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            v[e] += (float)r0[e];
-            v[8 + e] += (float)r1[e];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], (float)(bf16_t)fmaxf(v[e], lo));
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
-      const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
-      if ((frow & 1) == 0 && py < Hp && px < Wp) {
-        bf16x8 o0, o1;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          o0[e] = (bf16_t)best[e];
-          o1[e] = (bf16_t)best[8 + e];
-        }
-        bf16x8* dst = (bf16x8*)((bf16_t*)p.C + (((long long)img * Hp + py) * Wp + px) * p.ldc + n0c);
-        dst[0] = o0;
-        dst[1] = o1;
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int chunk = (tid & 7) ^ ((row >> 1) & 7);
+      const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);
+      const int off = (int)((cout * p.ldb + tap * 64 + chunk * 8) * 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + tap * 8192 + i * 4096 + wave_u * 1024), 16, off, 0,
+                                               0, 0);
     }
-    return;
+#endif
+  // tile-invariant part of the patch staging: this thread's 11 halo pixels (row, column packed) and its 16-byte chunk
+  constexpr int C64P_NLOAD = (C64_NPIX + 31) / 32;
+  int pyx[C64P_NLOAD], pchunk[C64P_NLOAD];
+#pragma unroll
+  for (int k = 0; k < C64P_NLOAD; ++k) {
+    const int q = k * 32 + (tid >> 3);
+    const int py = q / C64_PW, px = q - py * C64_PW;
+    pyx[k] = q < C64_NPIX ? (py << 16) | px : (0x4000 << 16);  // past the patch: a row no image has
+    pchunk[k] = ((tid & 7) ^ ((q >> 1) & 7)) * 16;
   }
+  auto stage_patch = [&](int tile, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int img = tile / tpi;
+    const int t = tile - img * tpi;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int y0 = ty * C64_TH - 1, x0 = tx * C64_TW - 1;
+    char* dst = sP + buf * C64_PATCH_BYTES + wave_u * 1024;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int y = y0 + wave * 2 + (i >> 1);
-    const int x = x0 + (i & 1) * 16 + frow;
-    if (y >= p.H || x >= p.W) continue;
-    const long long m = ((long long)img * p.H + y) * p.W + x;
-    float v[16];
+    for (int k = 0; k < C64P_NLOAD; ++k) {
+      const int y = y0 + (pyx[k] >> 16), x = x0 + (pyx[k] & 0xffff);
+      const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const int off = ((img * p.H + y) * p.W + x) * 128 + pchunk[k];
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(dst + k * 4096), 16, ok ? off : -1, 0, 0, 0);
+    }
+#endif
+  };
+  int tile = blockIdx.x;
+  stage_patch(tile, 0);
+
+  // loop-invariant LDS byte offsets of this lane's fragments (k-half 1 = the same offset ^ 64)
+  unsigned aoff[9][4], boff[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int tap = 0; tap < 9; ++tap) {
+    const int r = tap / 3, s3 = tap - r * 3;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha;
-    if (vec && p.dtype_c == WSOVOD_BF16 && (!p.residual || p.dtype_r == WSOVOD_BF16)) {
-      if (p.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x4 b4 = *(const f32x4*)(p.bias + n0c + 4 * j);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * j + r] += b4[r];
-        }
-      }
-      if (p.residual) {
-        const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
-        const bf16x8 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] += (float)r0[e];
-          v[8 + e] += (float)r1[e];
-        }
-      }
-      bf16x8 o0, o1;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o0[e] = (bf16_t)fmaxf(v[e], lo);
-        o1[e] = (bf16_t)fmaxf(v[8 + e], lo);
-      }
-      bf16x8* dst = (bf16x8*)((bf16_t*)p.C + m * p.ldc + n0c);
-      dst[0] = o0;
-      dst[1] = o1;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        float u = v[e] + (p.bias ? p.bias[n0c + e] : 0.f);
-        if (p.residual) u += load_as_f32(p.residual, m * p.ldr + n0c + e, p.dtype_r);
-        store_from_f32(p.C, m * p.ldc + n0c + e, p.dtype_c, fmaxf(u, lo));
-      }
+    for (int i = 0; i < 4; ++i) {
+      const int q = (wave * 2 + (i >> 1) + r) * C64_PW + (i & 1) * 16 + frow + s3;
+      aoff[tap][i] = (unsigned)(q * 128 + ((fq ^ ((q >> 1) & 7)) << 4));
     }
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = j * 16 + frow;
+    boff[j] = (unsigned)(row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(3))) const char lds_cchar;
+  const unsigned ldsW = (unsigned)(size_t)(lds_cchar*)sW, ldsP = (unsigned)(size_t)(lds_cchar*)sP;
+#if (C64P_ABL & 8)
+#define C64P_READ(dst, addr) asm volatile("; no read %0 %1" : "=v"(dst) : "v"(addr))
+#define C64P_WAIT1(N, R) asm volatile("; no wait" : "+v"(R))
+#define C64P_WAIT2(N, R0, R1) asm volatile("; no wait" : "+v"(R0), "+v"(R1))
+#elif (C64P_ABL & 16)
+#define C64P_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define C64P_WAIT1(N, R) asm volatile("; no wait" : "+v"(R))
+#define C64P_WAIT2(N, R0, R1) asm volatile("; no wait" : "+v"(R0), "+v"(R1))
+#else
+#define C64P_READ(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr))
+#define C64P_WAIT1(N, R) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(R))
+#define C64P_WAIT2(N, R0, R1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(R0), "+v"(R1))
+#endif
+#else
+  const unsigned ldsW = 0, ldsP = 0;
+#define C64P_READ(dst, addr) (void)0
+#define C64P_WAIT1(N, R) (void)0
+#define C64P_WAIT2(N, R0, R1) (void)0
+#endif
+#define C64P_RD_B(S, J, TAP, KS) C64P_READ(fb[S][J], (ldsW + (TAP) * 8192 + boff[J]) ^ ((KS) ? 64u : 0u))
+#define C64P_RD_A(S, I, TAP, KS) C64P_READ(fa[S][I], (pbase + aoff[TAP][I]) ^ ((KS) ? 64u : 0u))
+#define C64P_MF(S, M)                                                                                              \
+  acc[(M) >> 2][(M) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[S][(M) & 3]),     \
+                                                                   __builtin_bit_cast(bf16x8, fa[S][(M) >> 2]),    \
+                                                                   acc[(M) >> 2][(M) & 3], 0, 0, 0)
+#define C64P_SB __builtin_amdgcn_sched_barrier(0)
+// The 8 fragment reads of a (tap, k-half) step always issue in the order  B0 A0 B1 B2 B3 A1 A2 A3  -- the order its
+// MFMAs (m = 4*i + j uses A_i, B_j) first need them.
+#define C64P_READ_STEP(S, TAP, KS)                                                                               \
+  C64P_RD_B(S, 0, TAP, KS); C64P_RD_A(S, 0, TAP, KS); C64P_RD_B(S, 1, TAP, KS); C64P_RD_B(S, 2, TAP, KS);         \
+  C64P_RD_B(S, 3, TAP, KS); C64P_RD_A(S, 1, TAP, KS); C64P_RD_A(S, 2, TAP, KS); C64P_RD_A(S, 3, TAP, KS)
+// One step: 16 MFMAs on register set S; the NEXT step's reads (set N = 1 - S) go out one behind every second MFMA, so
+// the four wavefronts load the LDS array evenly (one ds_read_b128 per wavefront per 16-cycle MFMA already saturates
+// it) and each fragment is 10-14 MFMAs old when it is needed.  Every wait is counted: it leaves in flight exactly the
+// reads issued after the fragment it is for (LDS reads return in order).
+#define C64P_STEP(S, N, NTAP, NKS)                                                                                \
+  C64P_WAIT2(6, fb[S][0], fa[S][0]); C64P_SB;                                                                      \
+  C64P_MF(S, 0); C64P_RD_B(N, 0, NTAP, NKS); C64P_SB;                                                              \
+  C64P_WAIT1(6, fb[S][1]); C64P_MF(S, 1); C64P_SB;                                                                 \
+  C64P_WAIT1(5, fb[S][2]); C64P_MF(S, 2); C64P_RD_A(N, 0, NTAP, NKS); C64P_SB;                                     \
+  C64P_WAIT1(5, fb[S][3]); C64P_MF(S, 3); C64P_SB;                                                                 \
+  C64P_WAIT1(4, fa[S][1]); C64P_MF(S, 4); C64P_RD_B(N, 1, NTAP, NKS); C64P_SB;                                     \
+  C64P_MF(S, 5); C64P_SB;                                                                                          \
+  C64P_MF(S, 6); C64P_RD_B(N, 2, NTAP, NKS); C64P_SB;                                                              \
+  C64P_MF(S, 7); C64P_SB;                                                                                          \
+  C64P_WAIT1(5, fa[S][2]); C64P_MF(S, 8); C64P_RD_B(N, 3, NTAP, NKS); C64P_SB;                                     \
+  C64P_MF(S, 9); C64P_SB;                                                                                          \
+  C64P_MF(S, 10); C64P_RD_A(N, 1, NTAP, NKS); C64P_SB;                                                             \
+  C64P_MF(S, 11); C64P_SB;                                                                                         \
+  C64P_WAIT1(6, fa[S][3]); C64P_MF(S, 12); C64P_RD_A(N, 2, NTAP, NKS); C64P_SB;                                    \
+  C64P_MF(S, 13); C64P_SB;                                                                                         \
+  C64P_MF(S, 14); C64P_RD_A(N, 3, NTAP, NKS); C64P_SB;                                                             \
+  C64P_MF(S, 15); C64P_SB
+#define C64P_LAST_STEP(S)                                                                                         \
+  C64P_WAIT2(6, fb[S][0], fa[S][0]); C64P_SB; C64P_MF(S, 0); C64P_SB;                                              \
+  C64P_WAIT1(5, fb[S][1]); C64P_MF(S, 1); C64P_SB;                                                                 \
+  C64P_WAIT1(4, fb[S][2]); C64P_MF(S, 2); C64P_SB;                                                                 \
+  C64P_WAIT1(3, fb[S][3]); C64P_MF(S, 3); C64P_SB;                                                                 \
+  C64P_WAIT1(2, fa[S][1]); C64P_MF(S, 4); C64P_MF(S, 5); C64P_MF(S, 6); C64P_MF(S, 7); C64P_SB;                    \
+  C64P_WAIT1(1, fa[S][2]); C64P_MF(S, 8); C64P_MF(S, 9); C64P_MF(S, 10); C64P_MF(S, 11); C64P_SB;                  \
+  C64P_WAIT1(0, fa[S][3]); C64P_MF(S, 12); C64P_MF(S, 13); C64P_MF(S, 14); C64P_MF(S, 15); C64P_SB
+
+  f32x4 bias4[4];
+  c64_load_bias(p, fq, bias4);
+  __syncthreads();  // weights and the first patch have landed (hipcc drains vmcnt(0) in front of the barrier)
+  for (int cur = 0;; cur ^= 1) {
+    const int next = tile + (int)gridDim.x;
+    if (next < n_tiles && !((C64P_ABL & 4) && p.alpha != 12345.f)) stage_patch(next, cur ^ 1);  // lands behind this tile's MFMAs and epilogue
+    const int img = tile / tpi;
+    const int t = tile - img * tpi;
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int y0 = ty * C64_TH, x0 = tx * C64_TW;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned pbase = ldsP + (unsigned)(cur * C64_PATCH_BYTES);
+    u32x4 fa[2][4], fb[2][4];
+    __builtin_amdgcn_sched_barrier(0);
+    if (!((C64P_ABL & 1) && p.alpha != 12345.f)) {
+    C64P_READ_STEP(0, 0, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      C64P_STEP(0, 1, tap, 1);
+      if (tap < 8) {
+        C64P_STEP(1, 0, tap + 1 < 9 ? tap + 1 : 8, 0);
+      } else {
+        C64P_LAST_STEP(1);
+      }
+    }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The next patch has had the whole MFMA loop to land.  Waiting here, BEFORE the epilogue, keeps this tile's stores
+    // out of the wait (gfx9 counts stores in vmcnt): they retire behind the next tile's MFMAs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    if (!((C64P_ABL & 2) && p.alpha != 12345.f)) c64_epilogue(p, acc, bias4, img, y0, x0, wave, frow, fq);
+    if (next >= n_tiles) break;
+    __builtin_amdgcn_s_barrier();  // every wavefront is done reading patch `cur` and has seen its share of the next land
+    tile = next;
+  }
+#undef C64P_READ
+#undef C64P_WAIT1
+#undef C64P_WAIT2
+#undef C64P_READ_STEP
+#undef C64P_RD_A
+#undef C64P_RD_B
+#undef C64P_MF
+#undef C64P_SB
+#undef C64P_STEP
+#undef C64P_LAST_STEP
 }
 
 template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
@@ -888,8 +1114,20 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     }
     const int lds_bytes = C64_PATCH_BYTES + 2 * 8192;
     const int tiles_x = ceil_div(a.W, C64_TW), tiles_y = ceil_div(a.H, C64_TH);
+    const int n_tiles = d->geom.n_img * tiles_x * tiles_y;
+    static const bool persist = []() { const char* e = getenv("WSOVOD_C64_PERSIST"); return !(e && e[0] == '0'); }();
     wsovod::ProfScope prof(slot, s, flops, bytes);
-    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(d->geom.n_img * tiles_x * tiles_y), dim3(256), lds_bytes, s, a, tiles_x,
+    if (persist && n_tiles >= 512) {  // enough tiles for two per CU: resident weights + double-buffered patches
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES);
+        attr = true;
+      }
+      hipLaunchKernelGGL(conv3x3_c64p_kernel, dim3(256), dim3(256), C64P_LDS_BYTES, s, a, tiles_x, tiles_y, n_tiles);
+      WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64 persistent)");
+      return WSOVOD_OK;
+    }
+    hipLaunchKernelGGL(conv3x3_c64_kernel, dim3(n_tiles), dim3(256), lds_bytes, s, a, tiles_x,
                        tiles_y);
     WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64)");
     return WSOVOD_OK;
