@@ -336,6 +336,38 @@ def test_conv3x3_c64_fused_maxpool_equals_conv_then_pool(gpu, shape, with_res):
                                               dil=1, pool=2), out_dtype=torch.bfloat16)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 300, 400), (8, 121, 163)])
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("pool", [0, 2])
+def test_conv3x3_c64_persistent_kernel_equals_one_tile_kernel(gpu, shape, with_res, pool, monkeypatch):
+    """From 512 tiles up the 64-channel 3x3 conv runs as one persistent workgroup per CU (weights resident in LDS,
+    double-buffered halo patches, residual rows fetched ahead of the MFMAs).  Same products in the same order as the
+    one-tile kernel: the outputs are bit-identical, ragged image edges, residual and fused pool included; and both agree
+    with an fp64 convolution."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(13)
+    n, H, W = shape
+    x = torch.randn(n, H, W, 64, device=gpu).to(torch.bfloat16)
+    w = (torch.randn(64, 9 * 64, device=gpu) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(64, device=gpu)
+    res = torch.randn(n * H * W, 64, device=gpu).to(torch.bfloat16) if with_res else None
+    geom = dict(n_img=n, H=H, W=W, Cin=64, Ho=H, Wo=W, KH=3, KW=3, stride=1, pad=1, dil=1, pool=pool)
+    monkeypatch.setenv("WSOVOD_C64_PERSIST", "0")
+    one = hip_ops.gemm_nt(x, w, conv=geom, bias=bias, relu=True, residual=res, out_dtype=torch.bfloat16)
+    monkeypatch.setenv("WSOVOD_C64_PERSIST", "1")
+    per = hip_ops.gemm_nt(x, w, conv=geom, bias=bias, relu=True, residual=res, out_dtype=torch.bfloat16)
+    assert torch.equal(one, per)
+    if not pool:
+        img = 1
+        ref = F.conv2d(x[img].permute(2, 0, 1)[None].double(), w.view(64, 3, 3, 64).permute(0, 3, 1, 2).double(),
+                       bias.double(), 1, 1)[0]
+        if with_res:
+            ref = ref + res.view(n, H, W, 64)[img].permute(2, 0, 1).double()
+        torch.testing.assert_close(per.view(n, H, W, 64)[img].permute(2, 0, 1).double(), F.relu(ref), rtol=1e-2, atol=2e-2)
+
+
 def test_gemm_tn_tail_split_matches_unsplit(gpu):
     """More than one round of 256x256 tiles with a small last round: the tail tiles are reduced in K slices that meet
     by atomic adds.  Same result as the unsplit launch up to fp32 summation order; accumulate keeps the old contents;

@@ -497,9 +497,27 @@ __device__ __forceinline__ void c64_load_bias(const GemmArgs& p, const int fq, f
   }
 }
 
+// Residual rows of this lane's four pixels (clamped into the image: an outside pixel's row is loaded and never used),
+// issued ahead of the MFMA loop by the persistent kernel so that the epilogue does not sit out their latency.
+__device__ __forceinline__ bool c64_residual_preloadable(const GemmArgs& p) {
+  return p.residual && p.dtype_r == WSOVOD_BF16 && (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0;
+}
+__device__ __forceinline__ void c64_load_residual(const GemmArgs& p, const int img, const int y0, const int x0,
+                                                  const int wave, const int frow, const int fq, bf16x8 (&rres)[4][2]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = min(y0 + wave * 2 + (i >> 1), p.H - 1), x = min(x0 + (i & 1) * 16 + frow, p.W - 1);
+    const long long m = ((long long)img * p.H + y) * p.W + x;
+    const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + 16 * fq);
+    rres[i][0] = rp[0];
+    rres[i][1] = rp[1];
+  }
+}
+
+template <bool PRE = false>
 __device__ __forceinline__ void c64_epilogue(const GemmArgs& p, const f32x4 (&acc)[4][4], const f32x4 (&bias4)[4],
                                              const int img, const int y0, const int x0, const int wave, const int frow,
-                                             const int fq) {
+                                             const int fq, const bf16x8 (*rres)[2] = nullptr) {
   // epilogue: bias + residual + ReLU.  Operands were swapped in the MFMA and the weight rows permuted at staging, so
   // lane (frow, fq) holds, for pixel group i, the 16 consecutive output channels 16*fq + 4*j + r of pixel frow: its
   // 32 bytes (bf16) go out as two 16-byte stores and the four lanes of a pixel cover its whole 128-byte row.
@@ -530,7 +548,7 @@ __device__ __forceinline__ void c64_epilogue(const GemmArgs& p, const f32x4 (&ac
           for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
         if (p.residual) {
           const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
-          const bf16x8 r0 = rp[0], r1 = rp[1];
+          const bf16x8 r0 = PRE ? rres[i][0] : rp[0], r1 = PRE ? rres[i][1] : rp[1];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             v[e] += (float)r0[e];
@@ -575,7 +593,7 @@ __device__ __forceinline__ void c64_epilogue(const GemmArgs& p, const f32x4 (&ac
         for (int r = 0; r < 4; ++r) v[4 * j + r] += bias4[j][r];
       if (p.residual) {
         const bf16x8* rp = (const bf16x8*)((const bf16_t*)p.residual + m * p.ldr + n0c);
-        const bf16x8 r0 = rp[0], r1 = rp[1];
+        const bf16x8 r0 = PRE ? rres[i][0] : rp[0], r1 = PRE ? rres[i][1] : rp[1];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           v[e] += (float)r0[e];
@@ -855,6 +873,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 
   f32x4 bias4[4];
   c64_load_bias(p, fq, bias4);
+  const bool res_pre = c64_residual_preloadable(p);
   __syncthreads();  // weights and the first patch have landed (hipcc drains vmcnt(0) in front of the barrier)
   for (int cur = 0;; cur ^= 1) {
     const int next = tile + (int)gridDim.x;
@@ -869,6 +888,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const unsigned pbase = ldsP + (unsigned)(cur * C64_PATCH_BYTES);
+    bf16x8 rres[4][2];
+    if (res_pre) c64_load_residual(p, img, y0, x0, wave, frow, fq, rres);
     u32x4 fa[2][4], fb[2][4];
     __builtin_amdgcn_sched_barrier(0);
     if (!((C64P_ABL & 1) && p.alpha != 12345.f)) {
@@ -888,7 +909,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
     // out of the wait (gfx9 counts stores in vmcnt): they retire behind the next tile's MFMAs.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-    if (!((C64P_ABL & 2) && p.alpha != 12345.f)) c64_epilogue(p, acc, bias4, img, y0, x0, wave, frow, fq);
+    if (!((C64P_ABL & 2) && p.alpha != 12345.f)) {
+      if (res_pre)
+        c64_epilogue<true>(p, acc, bias4, img, y0, x0, wave, frow, fq, rres);
+      else
+        c64_epilogue(p, acc, bias4, img, y0, x0, wave, frow, fq);
+    }
     if (next >= n_tiles) break;
     __builtin_amdgcn_s_barrier();  // every wavefront is done reading patch `cur` and has seen its share of the next land
     tile = next;
@@ -1115,7 +1141,8 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     const int lds_bytes = C64_PATCH_BYTES + 2 * 8192;
     const int tiles_x = ceil_div(a.W, C64_TW), tiles_y = ceil_div(a.H, C64_TH);
     const int n_tiles = d->geom.n_img * tiles_x * tiles_y;
-    static const bool persist = []() { const char* e = getenv("WSOVOD_C64_PERSIST"); return !(e && e[0] == '0'); }();
+    const char* pe = getenv("WSOVOD_C64_PERSIST");  // "0": always the one-tile kernel (A/B runs, tests)
+    const bool persist = !(pe && pe[0] == '0');
     wsovod::ProfScope prof(slot, s, flops, bytes);
     if (persist && n_tiles >= 512) {  // enough tiles for two per CU: resident weights + double-buffered patches
       static bool attr = false;
