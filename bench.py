@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="gradient all-reduce format at N>1: auto = the compute precision (bf16 run -> bf16 wire, the "
                          "counterpart of the reference's fp16 compression hook; master weights/momentum stay fp32)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "ring", "direct"],
+                    help="bf16 wire at N>1: ring = RCCL all-reduce (running sum rounded to bf16 at every hop); direct = "
+                         "all-to-all of shards over the xGMI mesh + fp32 sum with one rounding + all-gather; "
+                         "auto = direct from 3 ranks up")
     ap.add_argument("--one-rank-group", action="store_true",
                     help="debug/measurement: at N=1 still create a 1-rank RCCL group, so that the whole exchange path "
                          "(gradient pack, split weight-gradient launch, collectives, SGD on the wire slices) runs and "
@@ -356,7 +360,8 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     cfg.SOLVER.BASE_LR = 1e-3
     optimizer = build_optimizer(cfg, model)
     wire = ("bf16" if precision == "bf16" else "fp32") if args.grad_wire == "auto" else args.grad_wire
-    trainer = HotPathTrainer(model, optimizer, grad_wire=wire)  # async gradient all-reduce behind the next frozen forward
+    # asynchronous gradient exchange behind the next step's frozen forward
+    trainer = HotPathTrainer(model, optimizer, grad_wire=wire, exchange=args.exchange if wire == "bf16" else "ring")
     trainer.broadcast_parameters()
     cpu_state = None
     if keep and rank == 0 and world == 1 and not args.no_cpu_baseline:  # untrained weights for the CPU leg
@@ -389,7 +394,8 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     final_losses = {k: float(v.detach()) for k, v in last.items()}
     if not all(v == v and abs(v) != float("inf") for v in final_losses.values()):
         raise RuntimeError(f"training diverged during the benchmark: {final_losses}")
-    rec = {"elapsed": elapsed, "per_step_ms": per_step, "final_losses": final_losses, "wire": wire}
+    rec = {"elapsed": elapsed, "per_step_ms": per_step, "final_losses": final_losses, "wire": wire,
+           "exchange": trainer.exchange_algo}
 
     if want_roofline:
         # second pass over the same K steps with every launch bracketed by hipEvents on its stream
@@ -590,7 +596,9 @@ def main():
                                    f"full training step (fwd+bwd+SGD)",
                        "images_per_gpu_per_step": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}",
-                       "grad_allreduce": f"{rec['wire']} over {'RCCL ' + str(rccl) if rccl else args.backend}"
+                       "grad_allreduce": (f"{rec['wire']} over {'RCCL ' + str(rccl) if rccl else args.backend}, "
+                                          + ("all-to-all + fp32 shard sum (one rounding) + all-gather"
+                                             if rec["exchange"] == "direct" else "all-reduce"))
                        if dist.is_initialized() else "none (1 GPU)",
                        "inputs": "uint8 images + boxes copied from pinned host memory inside every step (async, double "
                                  "buffered)" if args.h2d else "resident in HBM before the timed region",

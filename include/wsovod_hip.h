@@ -268,6 +268,13 @@ typedef struct wsovod_pack_tensor {
 } wsovod_pack_tensor;
 int wsovod_pack_bf16_multi(const wsovod_pack_tensor* tensors, int count, wsovod_stream_t stream);
 
+/* Direct (all-link) form of that exchange -- the reference has no counterpart, its DDP leaves the algorithm to NCCL
+ * (engine/defaults.py:143-152): all-to-all of the wire buffer's shards over the point-to-point xGMI links, then this
+ * kernel, then an all-gather.  src holds n_shards bf16 copies of this rank's shard, shard_elems (a multiple of 8) apart;
+ * dst[e] = bf16(sum_j float(src[j * shard_elems + e])): fp32 accumulation, ONE rounding of the sum whatever the world
+ * size (a ring all-reduce on bf16 rounds the running sum world-1 times). */
+int wsovod_sum_shards_bf16(const void* src, int n_shards, long long shard_elems, void* dst, wsovod_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * Proposal-concept MIL head.  Per-image segments: proposals of image g are rows
  * [seg_offsets[g], seg_offsets[g+1]).

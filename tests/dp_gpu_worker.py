@@ -1,7 +1,8 @@
 """Worker of tests/test_gpu_data_parallel.py: one data-parallel rank of the REAL HIP model.  Two of these share
 cuda:0 on the 1-GPU box (gloo backend; the collective code path of HotPathTrainer is the same one RCCL runs).
 
-    python -m tests.dp_gpu_worker <rank> <world> <port> <out.pt> <mode>      mode: single | mixed
+    python -m tests.dp_gpu_worker <rank> <world> <port> <out.pt> <mode>      mode: single | mixed | direct
+(direct = single with exchange="direct": all-to-all + fp32 shard sum + all-gather instead of the all-reduce)
 """
 import os
 import sys
@@ -40,7 +41,7 @@ def shard(rank, mode, it=0):
         for b in batch:
             b["dataset_id"] = src
         return to_inputs(batch)
-    return to_inputs(gen.seeded_batch(2, 32, 20, 256, 352, seed=6 + rank))
+    return to_inputs(gen.seeded_batch(2, 32, 20, 256, 352, seed=6 + rank))  # single, direct
 
 
 def build(mode):
@@ -82,8 +83,14 @@ def main():
         return orig(t, *a, **k)
 
     dist.all_reduce = traced
+    for name in ("all_to_all_single", "all_gather_into_tensor"):
+        def wrap(out_t, in_t, *a, _f=getattr(dist, name), _n=name, **k):
+            calls.append((_n, in_t.numel()))
+            return _f(out_t, in_t, *a, **k)
+        setattr(dist, name, wrap)
     cfg, model = build(mode)
-    tr = HotPathTrainer(model, build_optimizer(cfg, model), grad_wire="bf16", reduce_unused=(mode == "mixed"))
+    tr = HotPathTrainer(model, build_optimizer(cfg, model), grad_wire="bf16", reduce_unused=(mode == "mixed"),
+                        exchange="direct" if mode == "direct" else "ring")
     assert tr._split is not None, "the early fc1 block must be active (bf16 wire, TN weight gradient)"
     tr.broadcast_parameters()
     early = 0

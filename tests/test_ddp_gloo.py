@@ -349,10 +349,10 @@ class _SplitLinearFn(torch.autograd.Function):
 
 
 class _SplitModel(nn.Module):
-    def __init__(self):
+    def __init__(self, cols=16):
         super().__init__()
         torch.manual_seed(0)
-        self.big = nn.Parameter(torch.randn(24, 16) * 0.1)
+        self.big = nn.Parameter(torch.randn(24, cols) * 0.1)
         self.small = nn.Linear(24, 3)
 
     def forward_frozen(self, batch):
@@ -441,3 +441,88 @@ def test_two_rank_bf16_wire_early_block():
                 p.sub_(0.1 * buf[n])
     torch.testing.assert_close(torch.tensor(res[0][1]), model.big.detach(), rtol=0, atol=2e-3)
     torch.testing.assert_close(torch.tensor(res[0][2]), model.small.weight.detach(), rtol=0, atol=2e-3)
+
+
+def _worker_direct(rank, world, port, q):
+    """exchange="direct" on the bf16 wire: all-to-all of the shards, fp32 sum of the `world` copies with ONE rounding,
+    all-gather -- for the early row block of the split weight and for the rest.  The HIP kernels are replaced by torch
+    stand-ins with the same contract; three ranks, so that shards, padding and the rounding count are all non-trivial."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import HotPathTrainer
+    from wsovod_amd.engine.trainer import HipSGD
+    from wsovod_amd.layers import hip_ops as H
+
+    def pack(pairs):
+        for src, dst in pairs:
+            dst.copy_(src.reshape(-1))
+
+    def sgd(entries, momentum, grad_scale=1.0):
+        for p, g, buf, shadow, lr, wd, used in entries:
+            assert g.dtype == torch.bfloat16 and g.numel() == p.numel()
+            buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
+            p.sub_(lr * buf)
+
+    def sum_shards(src, n, dst):
+        assert src.dtype == torch.bfloat16 and src.numel() == n * dst.numel() and dst.numel() % 8 == 0
+        dst.copy_(src.view(n, -1).float().sum(0))
+        return dst
+
+    H.pack_bf16_multi, H.sgd_momentum_multi, H.sum_shards_bf16 = pack, sgd, sum_shards
+    HotPathTrainer.split_on_cpu = True
+    HotPathTrainer.split_rows = staticmethod(lambda n_rows, n_cols, cus=256, tile=256: 8)
+    calls = []
+    real_a2a, real_ag, real_ar = dist.all_to_all_single, dist.all_gather_into_tensor, dist.all_reduce
+    dist.all_to_all_single = lambda out, inp, *a, **k: (calls.append(("a2a", inp.numel())), real_a2a(out, inp, *a, **k))[1]
+    dist.all_gather_into_tensor = lambda out, inp, *a, **k: (calls.append(("ag", out.numel())), real_ag(out, inp, *a, **k))[1]
+    dist.all_reduce = lambda t, *a, **k: (calls.append(("ar", t.numel())), real_ar(t, *a, **k))[1]
+    model = _SplitModel(cols=48)
+    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.0} for p in model.parameters()], 0.1, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True, grad_wire="bf16", exchange="auto")
+    assert tr.exchange_algo == "direct" and tr._split is not None and tr._split[2] == 8 * 48
+    tr.broadcast_parameters()
+    calls.clear()
+    g = torch.Generator().manual_seed(7 + rank)
+    batch = [{"x": torch.randn(48, generator=g)} for _ in range(4)]
+    for it in range(3):
+        tr.run_step(batch)
+    tr.flush()
+    total = tr._wire_slices()[0].numel()
+    assert total % (8 * world) == 0 and total >= 24 * 48 + 3 * 24 + 3
+    head = 8 * 48
+    assert calls == [("a2a", head), ("ag", head), ("a2a", total - head), ("ag", total - head)] * 3, calls
+    q.put((rank, model.big.detach().tolist(), model.small.weight.detach().tolist(), [b["x"].tolist() for b in batch]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_direct_exchange_sums_in_fp32_and_rounds_once():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    world = 3
+    procs = [ctx.Process(target=_worker_direct, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res), "replicas diverged"
+    model = _SplitModel(cols=48)
+    model.big._dw_split = (8, lambda rows: None)
+    buf = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+    batches = [[{"x": torch.tensor(x)} for x in r[3]] for r in res]
+    for it in range(3):
+        grads = []
+        for b in batches:
+            model.zero_grad()
+            sum(model.forward_trainable(model.forward_frozen(b)).values()).backward()
+            grads.append({n: p.grad.to(torch.bfloat16) for n, p in model.named_parameters()})
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                gsum = sum(g[n].float() for g in grads).to(torch.bfloat16)  # fp32 sum of the bf16 copies, ONE rounding
+                buf[n].mul_(0.9).add_(gsum.float() * (1.0 / world))
+                p.sub_(0.1 * buf[n])
+    torch.testing.assert_close(torch.tensor(res[0][1]), model.big.detach(), rtol=0, atol=1e-6)
+    torch.testing.assert_close(torch.tensor(res[0][2]), model.small.weight.detach(), rtol=0, atol=1e-6)

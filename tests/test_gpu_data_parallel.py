@@ -69,6 +69,25 @@ def test_two_ranks_real_model_bf16_wire_equals_averaged_single_process(gpu):
     assert moved >= 15
 
 
+def test_two_ranks_direct_exchange_equals_the_all_reduce(gpu):
+    """exchange="direct" on the real model, two ranks on one GPU: per step two all-to-all / shard-sum (HIP kernel) /
+    all-gather chains (early fc1 block, rest) on the side stream instead of two all-reduces.  At two ranks a ring's
+    single addition and the fp32 sum round once each, so the trained parameters must equal the all-reduce run's bit
+    for bit."""
+    from tests import dp_gpu_worker as W
+
+    ring = _launch("single")
+    direct = _launch("direct")
+    a, b = direct
+    assert a["calls"] == b["calls"], "ranks issued different collective sequences"
+    names = [c[0] for c in a["calls"] if c[0] in ("all_to_all_single", "all_gather_into_tensor")]
+    assert names == ["all_to_all_single", "all_gather_into_tensor"] * (2 * W.STEPS), names
+    assert not [c for c in a["calls"] if c[0] == "torch.bfloat16"], "no bf16 all-reduce in direct mode"
+    assert a["early_steps"] == W.STEPS
+    assert a["fingerprint"] == b["fingerprint"], "replicas diverged"
+    assert a["fingerprint"] == ring[0]["fingerprint"], "direct exchange and all-reduce must agree bit for bit at 2 ranks"
+
+
 def test_two_ranks_mixed_datasets_identical_collective_sequence(gpu):
     """Ranks on different datasets touch different object miners; reduce_unused keeps the collective sequence identical
     (used-flag exchange + zeros for untouched tensors) and the replicas bit-identical."""

@@ -589,10 +589,11 @@ def test_bf16_gradient_wire_matches_fp32_exchange(gpu):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
-        for wire in ("fp32", "bf16"):
+        for wire, algo in (("fp32", "ring"), ("bf16", "ring"), ("bf16", "direct")):
             cfg, model, sd = build_seeded_hip_model("fp32")
             cfg.SOLVER.BASE_LR = 1e-4
-            tr = HotPathTrainer(model, build_optimizer(cfg, model), grad_wire=wire)
+            tr = HotPathTrainer(model, build_optimizer(cfg, model), grad_wire=wire, exchange=algo)
+            assert tr.exchange_algo == algo
             tr.broadcast_parameters()
             for it in range(3):
                 losses = tr.run_step(batch)
@@ -608,9 +609,33 @@ def test_bf16_gradient_wire_matches_fp32_exchange(gpu):
         a, b = outs[0][0][k], outs[1][0][k]
         torch.testing.assert_close(a, b, rtol=0, atol=2e-6, msg=lambda m: f"{k}: {m}")
         moved += int(not torch.equal(a, sd[k].to(a)))
+        # one rank: the direct exchange (all-to-all, shard sum kernel, all-gather through RCCL, on the side stream)
+        # hands the SGD the very bf16 values the all-reduce does
+        assert torch.equal(outs[1][0][k], outs[2][0][k]), k
     assert moved > 0
     for k in outs[0][1]:
         assert abs(outs[0][1][k] - outs[1][1][k]) <= 1e-4 * max(1.0, abs(outs[0][1][k])), k
+
+
+def test_sum_shards_kernel_accumulates_in_fp32_and_rounds_once(gpu):
+    """The local reduction of the direct gradient exchange: bf16(sum_j float(src[j])) -- against torch, bit for bit; and
+    not what a bf16 running sum gives (the thing a ring all-reduce does at every hop)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(3)
+    for n, shard in ((1, 8), (2, 4096), (3, 100000), (8, 1 << 20)):
+        src = (torch.randn(n, shard, device="cuda") * 3).to(torch.bfloat16)
+        dst = torch.empty(shard, dtype=torch.bfloat16, device="cuda")
+        H.sum_shards_bf16(src.view(-1), n, dst)
+        assert torch.equal(dst, src.float().sum(0).to(torch.bfloat16))
+        if n == 8:
+            run = src[0].clone()
+            for j in range(1, n):
+                run = (run.float() + src[j].float()).to(torch.bfloat16)
+            assert not torch.equal(run, dst)  # seven roundings of the running sum differ from one
+    with pytest.raises(RuntimeError):
+        H.sum_shards_bf16(torch.zeros(12, dtype=torch.bfloat16, device="cuda"), 3,
+                          torch.zeros(4, dtype=torch.bfloat16, device="cuda"))  # shards are whole 16-byte groups
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 0.12)])

@@ -93,6 +93,7 @@ SIGNATURES = {
     "wsovod_subsample_labels": [_P, _P, _P, _I, _I, _I, _I, _L, _P, _P],
     "wsovod_sgd_momentum_multi": [_P, _I, _F, _F, _P],
     "wsovod_pack_bf16_multi": [_P, _I, _P],
+    "wsovod_sum_shards_bf16": [_P, _I, _L, _P, _P],
     "wsovod_format_rois": [_P, _P, _I, _I, _P, _P, _P, _P],
     "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_nms_segments": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],

@@ -515,6 +515,29 @@ __global__ __launch_bounds__(256) void pack_bf16_multi_kernel(const PackTable t)
 }
 
 // ---------------------------------------------------------------------------------
+// Direct gradient exchange, middle step: after the all-to-all every rank holds `n_shards` bf16 copies of ITS shard of
+// the wire buffer (one per rank).  Their sum is taken in fp32 -- exact: 8 bf16 values add without rounding error that
+// bf16 could see -- and rounded to bf16 once; the all-gather then distributes the reduced shards.  HBM-bound:
+// (n_shards + 1) * 2 bytes per element.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_shards_bf16_kernel(const bf16_t* __restrict__ src, int n_shards,
+                                                              long long shard, bf16_t* __restrict__ dst) {
+  const long long stride = (long long)gridDim.x * 256 * 8;
+  for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 8; e < shard; e += stride) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < n_shards; ++j) {
+      const bf16x8 v = __builtin_nontemporal_load((const bf16x8*)(src + j * shard + e));
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += (float)v[q];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (bf16_t)acc[q];
+    *(bf16x8*)(dst + e) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // Backward prologue of Linear+ReLU(+Dropout): dA = dy * [y > 0] * scale, written both as
 // [M][N] (operand of the dX contraction) and transposed [N][ldt] (operand of the dW
 // contraction, reduction dim = proposals).  y == NULL means no mask.
@@ -982,6 +1005,22 @@ int wsovod_pack_bf16_multi(const wsovod_pack_tensor* tensors, int count, wsovod_
     hipLaunchKernelGGL(pack_bf16_multi_kernel, dim3(blocks), dim3(256), 0, s, t);
     WS_CHECK_LAUNCH("wsovod_pack_bf16_multi");
   }
+  return WSOVOD_OK;
+}
+
+int wsovod_sum_shards_bf16(const void* src, int n_shards, long long shard_elems, void* dst, wsovod_stream_t stream) {
+  WS_CHECK_ARG(n_shards >= 1 && shard_elems >= 0 && (shard_elems == 0 || (src && dst)), "wsovod_sum_shards_bf16: bad arguments");
+  WS_CHECK_ARG((shard_elems & 7) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0,
+               "wsovod_sum_shards_bf16: shards are whole 16-byte groups (shard_elems %% 8 == 0, 16-byte aligned pointers)");
+  if (shard_elems == 0) return WSOVOD_OK;
+  static int slot = wsovod::prof_slot("sum_shards_bf16");
+  hipStream_t s = (hipStream_t)stream;
+  const long long groups = shard_elems / 8;
+  const int blocks = (int)std::min<long long>(ceil_div_ll(groups, 256), 256 * 8);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)shard_elems * 2.0 * (n_shards + 1));
+  hipLaunchKernelGGL(sum_shards_bf16_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, n_shards, shard_elems,
+                     (bf16_t*)dst);
+  WS_CHECK_LAUNCH("wsovod_sum_shards_bf16");
   return WSOVOD_OK;
 }
 

@@ -108,7 +108,8 @@ class HotPathTrainer:
 
     split_on_cpu = False  # tests: let the early-exchange logic run on a CPU stand-in model
 
-    def __init__(self, model, optimizer, overlap=True, reduce_unused=False, grad_wire="fp32", iter_size=1):
+    def __init__(self, model, optimizer, overlap=True, reduce_unused=False, grad_wire="fp32", iter_size=1,
+                 exchange="ring"):
         """reduce_unused: parameters that received no gradient this step (mixed-dataset mode: the other
         datasets' object miners) still take part in the exchange with zeros, so that every rank issues the same
         collectives -- the job `find_unused_parameters=True` does in the reference (engine/defaults.py:146-148).
@@ -119,6 +120,15 @@ class HotPathTrainer:
         instead of 498 MB on R18 -- what matters at 2 and 4 ranks, where a ring has one / three xGMI links per GPU
         to work with), and the SGD kernel reads the reduced bf16 slices; master weights, momentum and the update
         stay fp32.
+
+        exchange (bf16 wire only): "ring" = one RCCL all-reduce per block of the wire buffer, the library picks the
+        algorithm and the running sum is rounded to bf16 at every hop (world - 1 roundings).  "direct" spells the
+        reduce-scatter / all-gather out over the point-to-point xGMI mesh: an all-to-all hands every rank its shard of
+        every other rank's buffer (each pair talks over its own link, all seven at once, one hop), a kernel sums the
+        `world` copies in fp32 and rounds ONCE, an all-gather distributes the reduced shards -- the same bytes per GPU
+        as a ring, one rounding of the sum whatever the world size.  "auto" = direct from 3 ranks up (at 2 ranks a
+        ring's single addition rounds once as well).  The chain runs on a side stream, so the next step's frozen
+        forward overlaps all three stages.
 
         iter_size: WSOVOD.ITER_SIZE (engine/trainer.py:72-84 of the reference): losses are divided by iter_size,
         gradients accumulate locally and the exchange + update happen on the iterations with `iter % iter_size == 0`
@@ -133,8 +143,14 @@ class HotPathTrainer:
             raise ValueError(f"grad_wire must be 'fp32' or 'bf16', got {grad_wire!r}")
         if grad_wire == "bf16" and not isinstance(optimizer, HipSGD):
             raise ValueError("grad_wire='bf16' needs the HIP optimizer (it reads the bf16 slices)")
+        if exchange not in ("ring", "direct", "auto"):
+            raise ValueError(f"exchange must be 'ring', 'direct' or 'auto', got {exchange!r}")
+        if exchange == "direct" and grad_wire != "bf16":
+            raise ValueError("exchange='direct' is defined on the bf16 wire buffer (grad_wire='bf16')")
         self.grad_wire = grad_wire
         self._wire = None
+        self._direct = None  # (recv buffer, reduced-shard buffer) of the direct exchange
+        self._side = None
         self._split = None  # (param, rows, elements) of the weight whose gradient is exchanged in two pieces
         self._early = None
         self.reduce_unused = reduce_unused
@@ -146,6 +162,9 @@ class HotPathTrainer:
         self._pending = None  # list of (work, param) of the in-flight exchange
         self._used = None  # per-tensor "some rank has a gradient" flags of the in-flight exchange (reduce_unused)
         self.params = [p for p in model.parameters() if p.requires_grad]
+        if exchange == "auto":
+            exchange = "direct" if grad_wire == "bf16" and self.world > 2 else "ring"
+        self.exchange_algo = exchange if self.exchange else "none"
         self.iter_size = int(iter_size)
         self.iter = 0
         if self.iter_size < 1:
@@ -225,6 +244,8 @@ class HotPathTrainer:
             return
         cus = torch.cuda.get_device_properties(p.device).multi_processor_count if p.is_cuda else 256
         ra = self.split_rows(p.shape[0], p.shape[1], cus)
+        if ra and self.exchange_algo == "direct" and (ra * p.shape[1]) % (8 * self.world):
+            ra = 0  # the early block must be whole 16-byte groups per shard (fc1: 25088 columns = 64 * 392, always is)
         if ra:
             self._split = (p, ra, ra * p.shape[1])
             p._dw_split = (ra, self._early_block)
@@ -235,7 +256,7 @@ class HotPathTrainer:
         n = self._split[2]
         assert dw_rows.numel() == n
         H.pack_bf16_multi([(dw_rows.reshape(-1), flat[:n])])
-        self._early = dist.all_reduce(flat[:n], op=dist.ReduceOp.SUM, async_op=True)
+        self._early = self._reduce_block(0, n)
 
     def _wire_slices(self):
         """One flat bf16 buffer; every tensor owns a slice whose offset is rounded up to 8 elements (16-byte aligned).
@@ -248,9 +269,38 @@ class HotPathTrainer:
             for p in order:
                 offs[id(p)] = total
                 total += (p.numel() + 7) // 8 * 8
+            if self.exchange_algo == "direct":  # every block of the buffer splits into `world` shards of 16-byte groups
+                g = 8 * self.world
+                total = (total + g - 1) // g * g
             flat = torch.zeros(total, dtype=torch.bfloat16, device=self.params[0].device)
             self._wire = (flat, [flat[offs[id(p)]:offs[id(p)] + p.numel()] for p in self.params])
         return self._wire
+
+    def _reduce_block(self, lo, hi):
+        """Sum flat[lo:hi] over the ranks, asynchronously; returns the work whose wait() makes the result visible."""
+        flat, _ = self._wire_slices()
+        if self.exchange_algo != "direct":
+            return dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        n = self.world
+        assert (hi - lo) % (8 * n) == 0 and lo % (8 * n) == 0, (lo, hi, n)
+        if self._direct is None:
+            self._direct = (torch.empty_like(flat), torch.empty(flat.numel() // n, dtype=flat.dtype, device=flat.device))
+            if flat.is_cuda:
+                self._side = torch.cuda.Stream(device=flat.device)
+        recv, mine = self._direct
+        shard = (hi - lo) // n
+        m = mine[lo // n:lo // n + shard]
+        if flat.is_cuda:
+            # a stream of its own: the three stages are ordered among themselves and behind the gradient pack, and the
+            # main stream goes on with the next step's frozen forward (the buffers are persistent: no allocator hazard)
+            self._side.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(self._side):
+                dist.all_to_all_single(recv[lo:hi], flat[lo:hi], async_op=True).wait()
+                H.sum_shards_bf16(recv[lo:hi], n, m)
+                return dist.all_gather_into_tensor(flat[lo:hi], m, async_op=True)
+        dist.all_to_all_single(recv[lo:hi], flat[lo:hi], async_op=True).wait()
+        H.sum_shards_bf16(recv[lo:hi], n, m)
+        return dist.all_gather_into_tensor(flat[lo:hi], m, async_op=True)
 
     def _exchange_bf16(self):
         flat, slices = self._wire_slices()
@@ -278,9 +328,8 @@ class HotPathTrainer:
         if self._split is not None and early is None:
             # the early block did not come (e.g. a non-TN contraction): keep the collective sequence of the other ranks
             head = self._split[2]
-            early = dist.all_reduce(flat[:head], op=dist.ReduceOp.SUM, async_op=True)
-        return [early, dist.all_reduce(flat[head:], op=dist.ReduceOp.SUM, async_op=True)] if head else \
-            [dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)]
+            early = self._reduce_block(0, head)
+        return [early, self._reduce_block(head, flat.numel())] if head else [self._reduce_block(0, flat.numel())]
 
     def run_step(self, data):
         st = self.model.forward_frozen(data)

@@ -816,3 +816,14 @@ def pack_bf16_multi(pairs):
             raise RuntimeError("pack_bf16_multi: (fp32, bf16) contiguous pairs of equal size expected")
         d.src, d.dst, d.numel = src.data_ptr(), dst.data_ptr(), src.numel()
     check(lib().wsovod_pack_bf16_multi(arr, len(pairs), stream()), "pack_bf16_multi")
+
+
+def sum_shards_bf16(src, n_shards, dst):
+    """dst[e] = bf16(sum_j float(src[j * len(dst) + e])): the local reduction of the direct gradient exchange
+    (all-to-all -> this -> all-gather); fp32 accumulation, one rounding."""
+    require_gpu(src, dst)
+    if src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16 or not (src.is_contiguous() and dst.is_contiguous()) \
+            or src.numel() != n_shards * dst.numel():
+        raise RuntimeError("sum_shards_bf16: contiguous bf16 src of n_shards * dst.numel() elements expected")
+    check(lib().wsovod_sum_shards_bf16(src.data_ptr(), n_shards, dst.numel(), dst.data_ptr(), stream()), "sum_shards_bf16")
+    return dst
