@@ -1,0 +1,186 @@
+"""GPU parity, randomised sweeps: every case draws shape, layout, dtype and box statistics from a seeded generator, so the
+kernels meet sizes no hand-written case names (odd channel counts, 1-cell maps, boxes far outside the image, ragged
+segments with empty images, reduction lengths that end inside a tile).  Same bars as the fixed cases: indices and copied
+values bit-exact, fp32 arithmetic to the stated tolerance.  The checker is the CPU oracle (test infrastructure)."""
+import pytest
+import torch
+
+from oracle import roi_ops as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rois(g, R, n_img, Hi, Wi):
+    """Boxes in image pixels: ordinary ones plus a random third of degenerate forms (outside, inverted, sub-cell,
+    huge, exactly on .5 cell boundaries)."""
+    x0 = (torch.rand(R, generator=g) * 1.4 - 0.2) * Wi
+    y0 = (torch.rand(R, generator=g) * 1.4 - 0.2) * Hi
+    w = torch.rand(R, generator=g) ** 2 * Wi
+    h = torch.rand(R, generator=g) ** 2 * Hi
+    kind = torch.randint(0, 9, (R,), generator=g)
+    w = torch.where(kind == 0, torch.zeros_like(w), w)              # zero width
+    h = torch.where(kind == 1, -h, h)                               # inverted
+    w = torch.where(kind == 2, torch.full_like(w, 3.0), w)          # smaller than a cell at scale 1/8
+    x0 = torch.where(kind == 3, (x0 / 4).round() * 4 + 0.5 * 8, x0)  # lands on x.5 after the 1/8 scale
+    b = torch.randint(0, n_img, (R,), generator=g).float()
+    return torch.stack([b, x0, y0, x0 + w, y0 + h], 1)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_roi_pool_fuzz_bit_exact(gpu, seed):
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(1000 + seed)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]
+    C = pick([1, 5, 32, 64, 100, 130, 256, 512])
+    Hf, Wf = int(torch.randint(1, 48, (1,), generator=g)), int(torch.randint(1, 64, (1,), generator=g))
+    n_img, R = pick([1, 2, 5]), pick([1, 3, 64, 257])
+    scale = pick([0.125, 0.0625, 0.25, 0.37])
+    size = (pick([1, 2, 7, 9]), pick([1, 3, 7, 8]))
+    dtype, cl = pick([torch.float32, torch.bfloat16]), pick([False, True])
+    feat = torch.randn(n_img, C, Hf, Wf, generator=g).to(dtype)
+    feat[torch.rand(feat.shape, generator=g) < 0.05] = float("-inf")  # -inf cells: an all -inf bin must stay -inf
+    rois = _rois(g, R, n_img, Hf / scale, Wf / scale)
+    ref_out, ref_arg = O.roi_pool_forward(feat.float(), rois, scale, size)
+    f = feat.to(gpu)
+    if cl:
+        f = f.contiguous(memory_format=torch.channels_last)
+    out, arg = H.roi_pool_forward(f, rois.to(gpu), scale, size, out_dtype=torch.float32)
+    assert torch.equal(arg.cpu(), ref_arg), (C, Hf, Wf, size, scale)
+    assert torch.equal(out.cpu(), ref_out)
+    # backward: scatter by argmax -- fp32 atomic adds in another order than the oracle's loop
+    go = torch.randn(ref_out.shape, generator=g)
+    ref_gi = O.roi_pool_backward(go, rois, ref_arg, feat.shape)
+    gi = H.roi_pool_backward(go.to(gpu), rois.to(gpu), arg, feat.shape, channels_last=cl)
+    torch.testing.assert_close(gi.cpu().contiguous(), ref_gi, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_roi_align_fuzz(gpu, seed):
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(2000 + seed)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]
+    C = pick([1, 6, 64, 96, 256])
+    Hf, Wf = int(torch.randint(1, 40, (1,), generator=g)), int(torch.randint(1, 50, (1,), generator=g))
+    n_img, R = pick([1, 3]), pick([1, 2, 65, 200])
+    scale, ratio, aligned = pick([0.125, 0.0625, 0.3]), pick([0, 1, 2, 3]), pick([False, True])
+    size = (pick([1, 7]), pick([2, 7]))
+    cl = pick([False, True])
+    feat = torch.randn(n_img, C, Hf, Wf, generator=g)
+    rois = _rois(g, R, n_img, Hf / scale, Wf / scale)
+    ref = O.roi_align_forward(feat, rois, scale, size, ratio, aligned)
+    f = feat.to(gpu)
+    if cl:
+        f = f.contiguous(memory_format=torch.channels_last)
+    out = H.roi_align_forward(f, rois.to(gpu), scale, size, ratio, aligned)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=5e-5)  # fp32 bilinear; FMA contraction differs
+    go = torch.randn(ref.shape, generator=g)
+    ref_gi = O.roi_align_backward(go, rois, scale, ratio, aligned, feat.shape)
+    gi = H.roi_align_backward(go.to(gpu), rois.to(gpu), scale, ratio, aligned, feat.shape, channels_last=cl)
+    # adaptive sampling (ratio 0) on a huge box averages thousands of samples per bin: scale the bar with the gradient
+    torch.testing.assert_close(gi.cpu().contiguous(), ref_gi, rtol=1e-4, atol=1e-4 * max(1.0, float(ref_gi.abs().max())))
+
+
+def _greedy_nms(boxes, thr):
+    """O(n^2) greedy NMS on score-sorted boxes, written from the definition (keep a box iff no kept box overlaps it by
+    more than thr); IoU in fp32 with the reference's area / intersection formulas."""
+    keep = []
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    for i in range(len(boxes)):
+        ok = True
+        for j in keep:
+            iw = torch.clamp(torch.min(boxes[i, 2], boxes[j, 2]) - torch.max(boxes[i, 0], boxes[j, 0]), min=0)
+            ih = torch.clamp(torch.min(boxes[i, 3], boxes[j, 3]) - torch.max(boxes[i, 1], boxes[j, 1]), min=0)
+            inter = iw * ih
+            iou = inter / (area[i] + area[j] - inter)
+            if float(iou) > thr:
+                ok = False
+                break
+        if ok:
+            keep.append(i)
+    return keep
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_nms_fuzz_against_definition(gpu, seed):
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(3000 + seed)
+    sizes = [int(s) for s in torch.randint(0, 150, (int(torch.randint(1, 6, (1,), generator=g)),), generator=g)]
+    thr = [0.3, 0.5, 0.7][seed % 3]
+    segs = []
+    for s in sizes:
+        c = torch.rand(s, 2, generator=g) * 60
+        wh = torch.rand(s, 2, generator=g) * 40 + 1
+        bx = torch.cat([c, c + wh], 1)
+        if s > 4:
+            bx[1] = bx[0]            # exact duplicate: IoU = 1
+            bx[3, 2:] = bx[3, :2]    # zero area: IoU 0/0 against itself, 0 against the rest
+        segs.append(bx)
+    boxes = torch.cat(segs) if sum(sizes) else torch.zeros(0, 4)
+    offs = [0]
+    for s in sizes:
+        offs.append(offs[-1] + s)
+    keep, count = H.nms_segments(boxes.to(gpu), torch.tensor(offs, dtype=torch.int32, device=gpu), max(sizes + [1]), thr)
+    keep, count = keep.cpu().tolist(), count.cpu().tolist()
+    ref = O.nms_segments(boxes, offs, thr)
+    for k, s in enumerate(sizes):
+        got = keep[offs[k]:offs[k] + count[k]]
+        assert got == _greedy_nms(segs[k], thr), (k, s)
+        assert got == ref[k].tolist()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_gemm_nt_fuzz(gpu, seed):
+    """Ragged M / N / K (K only whole 16-byte groups, the ABI's rule), every epilogue term on or off at random, bf16 and
+    exact-fp32 MFMA paths, against an fp64 contraction."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(4000 + seed)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]
+    dtype = pick([torch.float32, torch.bfloat16])
+    M = pick([1, 15, 64, 257, 700, 1031])
+    N = pick([1, 8, 63, 128, 300, 513])
+    K = pick([1, 2, 7, 40, 129]) * (4 if dtype == torch.float32 else 8)
+    A = (torch.rand(M, K, generator=g) * 2 - 1).to(dtype)
+    B = (torch.rand(N, K, generator=g) * 2 - 1).to(dtype)
+    bias = torch.randn(N, generator=g) if pick([0, 1]) else None
+    res = torch.randn(M, N, generator=g) if pick([0, 1]) else None
+    relu, alpha = bool(pick([0, 1])), pick([1.0, 0.5, -2.0])
+    ref = alpha * (A.double() @ B.double().t())
+    if bias is not None:
+        ref = ref + bias.double()
+    if res is not None:
+        ref = ref + res.double()
+    if relu:
+        ref = ref.clamp(min=0)
+    out = H.gemm_nt(A.to(gpu), B.to(gpu), alpha=alpha, bias=None if bias is None else bias.to(gpu),
+                    residual=None if res is None else res.to(gpu), relu=relu, out_dtype=torch.float32)
+    # fp32 accumulation of K products of magnitude <= 1 (inputs are exact in both dtypes)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=2e-6 * K ** 0.5 * abs(alpha) + 1e-6)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mil_forward_fuzz_ragged_segments(gpu, seed):
+    """softmax over classes x softmax over the proposals of each image (fast_rcnn_open_vocabulary.py:342-354) with
+    ragged segments: images with one proposal, with thousands, and logits spread over +-30."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(5000 + seed)
+    K = [3, 2, 20, 80, 300, 1203][seed]
+    nums = [int(n) for n in torch.randint(1, 40, (int(torch.randint(1, 7, (1,), generator=g)),), generator=g)]
+    nums[0] = 1
+    if seed % 2:
+        nums.append(2500)
+    R = sum(nums)
+    logits = torch.randn(R, 2 * K, generator=g) * [1.0, 10.0, 30.0][seed % 3]
+    offs = [0]
+    for n in nums:
+        offs.append(offs[-1] + n)
+    seg = torch.tensor(offs, dtype=torch.int32, device=gpu)
+    got = H.mil_forward(logits.to(gpu), seg, K)
+    scores = got[0] if isinstance(got, (tuple, list)) else got
+    c, d = logits[:, :K].double(), logits[:, K:].double()
+    ref = torch.cat([torch.softmax(c[a:b], 1) * torch.softmax(d[a:b], 0) for a, b in zip(offs[:-1], offs[1:])])
+    torch.testing.assert_close(scores.cpu().double(), ref, rtol=1e-4, atol=1e-8)
