@@ -184,3 +184,37 @@ def test_mil_forward_fuzz_ragged_segments(gpu, seed):
     c, d = logits[:, :K].double(), logits[:, K:].double()
     ref = torch.cat([torch.softmax(c[a:b], 1) * torch.softmax(d[a:b], 0) for a, b in zip(offs[:-1], offs[1:])])
     torch.testing.assert_close(scores.cpu().double(), ref, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_conv_implicit_gemm_fuzz(gpu, seed):
+    """conv2d + bias + (residual) + ReLU as one implicit GEMM on random geometry (kernel 1 / 3, stride 1 / 2, dilation
+    1 / 2 / 4, with and without padding, maps a few pixels wide, output channels off every tile size) against fp64."""
+    import torch.nn.functional as F
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(6000 + seed)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]
+    dtype = pick([torch.float32, torch.bfloat16])
+    Cin, Cout = pick([64, 128, 192]), pick([8, 64, 100, 256, 300])
+    k, stride, dil = pick([1, 3]), pick([1, 2]), pick([1, 2, 4])
+    pad = pick([0, dil * (k // 2)])
+    n = pick([1, 2, 3])
+    Hh = int(torch.randint(dil * (k - 1) + 1, 46, (1,), generator=g))
+    Ww = int(torch.randint(dil * (k - 1) + 1, 46, (1,), generator=g))
+    x = (torch.rand(n, Cin, Hh, Ww, generator=g) * 2 - 1).to(dtype)
+    w = ((torch.rand(Cout, Cin, k, k, generator=g) * 2 - 1) * 0.1).to(dtype)
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), stride, pad, dil)
+    Ho, Wo = ref.shape[2:]
+    res = torch.randn(n, Ho, Wo, Cout, generator=g) if pick([0, 1]) else None
+    if res is not None:
+        ref = ref + res.permute(0, 3, 1, 2).double()
+    ref = ref.clamp(min=0)
+    geom = dict(n_img=n, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=stride, pad=pad, dil=dil)
+    out = H.gemm_nt(x.permute(0, 2, 3, 1).contiguous().to(gpu), w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(gpu),
+                    conv=geom, bias=bias.to(gpu), relu=True, out_dtype=torch.float32,
+                    residual=None if res is None else res.view(-1, Cout).to(gpu))
+    out = out.view(n, Ho, Wo, Cout).permute(0, 3, 1, 2).cpu().double()
+    # inputs are exact in both dtypes; fp32 accumulation over k*k*Cin products of magnitude <= 0.1
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6 * (k * k * Cin) ** 0.5)
