@@ -368,6 +368,26 @@ def test_conv3x3_c64_persistent_kernel_equals_one_tile_kernel(gpu, shape, with_r
         torch.testing.assert_close(per.view(n, H, W, 64)[img].permute(2, 0, 1).double(), F.relu(ref), rtol=1e-2, atol=2e-2)
 
 
+def test_gemm_tn_reduction_longer_than_one_buffer_resource(gpu, monkeypatch):
+    """Operands past the 2 GiB a buffer resource addresses (96 images x 512 proposals x 25088 features) are reduced in
+    row blocks that accumulate: same result as the single launch up to fp32 summation order, `accumulate` and `alpha`
+    respected on the first block only / on every block."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(9)
+    P = torch.randn(1000, 64, device=gpu).to(torch.bfloat16)
+    Q = torch.randn(1000, 136, device=gpu).to(torch.bfloat16)
+    base = torch.randn(64, 136, device=gpu)
+    want = hip_ops.gemm_tn(P, Q, out=base.clone(), alpha=0.5, accumulate=True, split_tail=False)
+    monkeypatch.setattr(hip_ops, "GEMM_TN_MAX_OPERAND_BYTES", 200 * 136 * 2)  # 200 rows of Q -> blocks of 192 rows
+    got = hip_ops.gemm_tn(P, Q, out=base.clone(), alpha=0.5, accumulate=True, split_tail=False)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-4)
+    ref = base.double() + 0.5 * (P.double().t() @ Q.double())
+    torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-4)
+    fresh = hip_ops.gemm_tn(P, Q, alpha=1.0, split_tail=False)
+    torch.testing.assert_close(fresh.double(), P.double().t() @ Q.double(), rtol=1e-5, atol=1e-4)
+
+
 def test_gemm_tn_tail_split_matches_unsplit(gpu):
     """More than one round of 256x256 tiles with a small last round: the tail tiles are reduced in K slices that meet
     by atomic adds.  Same result as the unsplit launch up to fp32 summation order; accumulate keeps the old contents;

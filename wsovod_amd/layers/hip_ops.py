@@ -764,6 +764,9 @@ def rpn_label_anchors(anchors, gt_boxes, gt_start, gt_count, thr_lo, thr_hi):
     return labels, best_gt, best_iou
 
 
+GEMM_TN_MAX_OPERAND_BYTES = (1 << 31) - 1  # one buffer resource per operand (tests lower it to exercise the row blocks)
+
+
 def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True):
     """out (NI, NJ) fp32 (+)= alpha * P^T @ Q for row-major bf16 P (Mred, NI) and Q (Mred, NJ): the weight-gradient
     contraction over the operands' slow index, no transposed copies (transposed LDS reads).
@@ -773,8 +776,15 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True):
     Mred, NI, NJ = P.shape[0], P.shape[1], Q.shape[1]
     if out is None:
         out = torch.empty((NI, NJ), dtype=torch.float32, device=P.device)
-    check(lib().wsovod_gemm_tn(ptr(P), _ld(P), ptr(Q), _ld(Q), Mred, NI, NJ, ptr(out), _ld(out), C.c_float(alpha),
-                               int(bool(accumulate)) | (0 if split_tail else 2), stream()), "gemm_tn")
+    # the kernel addresses an operand through one buffer resource (< 2 GiB): longer reductions (e.g. 96 images x 512
+    # proposals x 25088 pooled features = 2.5 GB) are cut into row blocks that accumulate into `out`
+    limit = GEMM_TN_MAX_OPERAND_BYTES // (2 * max(_ld(P), _ld(Q), 1))
+    step = max(64, limit // 64 * 64) if Mred > limit else max(Mred, 1)
+    for r0 in range(0, max(Mred, 1), step):
+        r1 = min(Mred, r0 + step)
+        check(lib().wsovod_gemm_tn(ptr(P[r0:r1]), _ld(P), ptr(Q[r0:r1]), _ld(Q), r1 - r0, NI, NJ, ptr(out), _ld(out),
+                                   C.c_float(alpha), int(bool(accumulate) or r0 > 0) | (0 if split_tail else 2), stream()),
+              "gemm_tn")
     return out
 
 
