@@ -959,3 +959,23 @@ def test_backbone_with_fused_shortcuts_equals_the_separate_launches(gpu, depth, 
         assert scale > 0 and float((outs["1"] - outs["0"]).abs().max()) <= tol * scale, (prec, depth)
         del model
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("depth", [18, 50])
+def test_backbone_in_image_blocks_equals_the_single_launch(gpu, depth, monkeypatch):
+    """Batches whose NHWC maps pass the 2 GiB one buffer resource addresses (> 139 images of 800x600 at the stem) run
+    every conv in image blocks.  With the limit lowered so that 5 small images already need blocks of 2, 2 and 1, the
+    res5 map equals the single-launch one bit for bit (images are independent; residual, fused shortcut and fused pool
+    paths included)."""
+    from wsovod_amd.modeling import backbone as B
+    from wsovod_amd.testing import build_hot_path_model
+
+    x = torch.randint(0, 256, (5, 3, 96, 128), dtype=torch.uint8)
+    cfg, model = build_hot_path_model(seed=0, depth=depth, precision="bf16", device="cuda:0")
+    inp = [{"image": im} for im in x]
+    canvas, sizes_t, sizes = model._canvas(inp)
+    want = model.backbone.forward_uint8(canvas, sizes_t, model._mean, model._std)["res5"]
+    # largest per-image map after conv1: 48 x 64 x 64 channels x 2 bytes
+    monkeypatch.setattr(B, "CONV_MAX_OPERAND_BYTES", 2 * 48 * 64 * 64 * 2 + 1)
+    got = model.backbone.forward_uint8(canvas, sizes_t, model._mean, model._std)["res5"]
+    assert got.shape == want.shape and torch.equal(got, want)

@@ -101,6 +101,9 @@ def _folded_with_shortcut(conv, shortcut, dtype):
     return c[1], c[2]
 
 
+CONV_MAX_OPERAND_BYTES = (1 << 31) - 1  # one buffer resource per NHWC operand (tests lower it to exercise the image blocks)
+
+
 def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None):
     """x: (N,H,W,Cin) NHWC contiguous in the compute dtype -> (N,Ho,Wo,Cout); with pool2 the MaxPool2d(2, 2) that
     follows the conv in the stem / block tail is applied too -> (N,Ho//2,Wo//2,Cout).  The 64-channel bf16 kernel pools
@@ -109,6 +112,17 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None):
     k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     Ho = (Hh + 2 * p - d * (k - 1) - 1) // s + 1
     Wo = (Ww + 2 * p - d * (k - 1) - 1) // s + 1
+    # the kernels address the NHWC input through one buffer resource (< 2 GiB): larger batches (> 139 images of
+    # 800x600 at the 64-channel stem maps) go through in image blocks -- images are independent
+    per_image = max(Hh * Ww * Cin, Ho * Wo * conv.out_channels) * x.element_size()
+    max_n = max(1, CONV_MAX_OPERAND_BYTES // max(per_image, 1))
+    if N > max_n:
+        parts = []
+        for i in range(0, N, max_n):
+            j = min(N, i + max_n)
+            parts.append(hip_conv(x[i:j], conv, relu=relu, residual=None if residual is None else residual[i:j],
+                                  pool2=pool2, shortcut=None if shortcut is None else (shortcut[0][i:j], shortcut[1])))
+        return torch.cat(parts)
     wq, b = conv.folded(x.dtype, cin_pad=Cin)
     geom = dict(n_img=N, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=s, pad=p, dil=d)
     if shortcut is not None:
