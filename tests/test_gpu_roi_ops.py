@@ -135,3 +135,46 @@ def test_roi_loop_pool_three_outputs_bit_exact(gpu, channels_last, dtype):
     gi = H.roi_pool_backward(grad.to(gpu), rois.repeat(3, 1).to(gpu), arg, (2, 16, 38, 50))
     ref_gi = O.roi_pool_backward(grad, rois.repeat(3, 1), ref_arg, (2, 16, 38, 50))
     torch.testing.assert_close(gi.cpu(), ref_gi, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C", [512, 1024])
+@pytest.mark.parametrize("aligned,sampling_ratio", [(True, 0), (False, 2)])
+def test_roi_align_512_channel_bf16_form(gpu, C, aligned, sampling_ratio):
+    """bf16 maps with a multiple of 512 channels and bf16 output (res5 of both depths: the bench's ROIAlignV2 line)
+    take the 16-bytes-per-lane form of the row kernel with a bf16 transpose tile.  Per channel it issues the same
+    FMAs in the same order as the 4-channel form: bit-identical to that form's fp32 output rounded to bf16, and within
+    bf16 rounding of the oracle; edge-case rois and the objectness scale included."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(8)
+    feat = torch.randn(2, C, 30, 41).to(torch.bfloat16)
+    rois = random_rois(70, 2, 240, 328, seed=21)
+    sc = torch.rand(70) + 1.0
+    f = feat.to(gpu).contiguous(memory_format=torch.channels_last)
+    wide = hip_ops.roi_align_forward(f, rois.to(gpu), 0.125, (7, 7), sampling_ratio, aligned, roi_scale=sc.to(gpu),
+                                     out_dtype=torch.bfloat16)
+    narrow = hip_ops.roi_align_forward(f, rois.to(gpu), 0.125, (7, 7), sampling_ratio, aligned, roi_scale=sc.to(gpu),
+                                       out_dtype=torch.float32)
+    assert wide.dtype == torch.bfloat16 and torch.equal(wide, narrow.to(torch.bfloat16))
+    ref = O.roi_align_forward(feat.float(), rois, 0.125, (7, 7), sampling_ratio, aligned) * sc.view(-1, 1, 1, 1)
+    torch.testing.assert_close(wide.float().cpu(), ref, rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("C", [512, 2048])
+def test_roi_pool_512_channel_bf16_form(gpu, C):
+    """The training step's pooling of the frozen backbone's res5 map: bf16 map of 512 (R18) / 2048 (R50) channels, bf16
+    output, no argmax, objectness scale applied.  Values are copies of map cells times the scale: bit-identical to the
+    oracle's fp32 result rounded to bf16."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(12)
+    feat = torch.randn(2, C, 38, 50).to(torch.bfloat16)
+    rois = random_rois(90, 2, 304, 400, seed=31)
+    sc = torch.rand(90) + 1.0
+    ref, _ = O.roi_pool_forward(feat.float(), rois, 0.125, (7, 7))
+    f = feat.to(gpu).contiguous(memory_format=torch.channels_last)
+    out, arg = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), roi_scale=sc.to(gpu), out_dtype=torch.bfloat16,
+                                        need_argmax=False)
+    assert arg is None and torch.equal(out.cpu(), (ref * sc.view(-1, 1, 1, 1)).to(torch.bfloat16))
+    plain, _ = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), out_dtype=torch.bfloat16, need_argmax=False)
+    assert torch.equal(plain.cpu(), ref.to(torch.bfloat16))

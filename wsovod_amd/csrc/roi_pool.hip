@@ -16,6 +16,7 @@
 #include <float.h>
 
 #include "common.h"
+#include <type_traits>
 
 // Index results (bins, keep sets, labels) must match the reference bit for bit: no mul+add fusion anywhere in this
 // file (HIP's __fmul_rn & co. are plain operators and would still be contracted under the default fp-contract=fast).
@@ -540,7 +541,7 @@ constexpr int kAlignMaxGrid = 64;  // sample columns per bin the row kernel keep
 constexpr int kSepMax = 24;        // cells per bin and axis of the separable form (rois up to ~150 cells wide / high)
 constexpr int kAlignTabBytes = 7 * kAlignMaxGrid * 16 + (7 + 16) * kSepMax * 4 + (2 * 7 + 2 * 16 + 1) * 4 + 12;
 
-template <typename T, int PWT, int CPL>
+template <typename T, int PWT, int CPL, bool OBF = false>
 __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
                                                                const float* __restrict__ roi_scale, int C, int H, int W,
                                                                int PH, float spatial_scale, int sampling_ratio,
@@ -550,13 +551,16 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int nbins = PH * PWT;
-  float* sval = (float*)smem;
+  // output transpose tile [channel][bin]: fp32, or (OBF: bf16 output) already rounded -- half the LDS, so that the
+  // 512-channel form of the kernel (16-byte loads) still fits two to three workgroups per CU
+  typedef typename std::conditional<OBF, bf16_t, float>::type sval_t;
+  sval_t* sval = (sval_t*)smem;
   // The sample columns are the same for every lane (lane = channels), every pooled row and every sample row of the
   // roi: their bilinear set-up (x position with its fp32 division, clamping, weights) is computed ONCE per workgroup
   // by PWT*grid_w lanes into this table and read back as LDS broadcasts, instead of ~20 VALU instructions per bin and
   // loop iteration on all 64 lanes (the kernel was VALU-bound on exactly that).  Record = {lo*C, hi*C, l, h}; lo < 0
   // marks a sample outside the map.
-  int4* xtab = (int4*)(sval + CG * nbins);
+  int4* xtab = (int4*)(smem + (((size_t)CG * nbins * sizeof(sval_t) + 15) & ~(size_t)15));
   const int r = blockIdx.x / cgroups;
   const int c0 = (blockIdx.x - r * cgroups) * CG;
   const int c = c0 + lane * CPL;
@@ -710,14 +714,22 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
       const float v = acc[pw][q] * a.inv_count;
-      sval[(lane * CPL + q) * nbins + ph * PWT + pw] = roi_scale ? v * scale : v;
+      sval[(lane * CPL + q) * nbins + ph * PWT + pw] = (sval_t)(roi_scale ? v * scale : v);
     }
   __syncthreads();
   const int nthreads = blockDim.x, tid = threadIdx.x;
   const int nvalid = min(CG, C - c0) * nbins;
   const long long obase = ((long long)r * C + c0) * nbins;
   const bool vec = (nvalid & 3) == 0 && (obase & 3) == 0;
-  if (out_dtype == WSOVOD_F32) {
+  if constexpr (OBF) {  // (launcher: out_dtype is bf16) the tile already holds the output bits
+    bf16_t* o = (bf16_t*)out + obase;
+    if ((nvalid & 7) == 0 && (obase & 7) == 0)
+      for (int i = tid * 8; i < nvalid; i += nthreads * 8)
+        __builtin_nontemporal_store(*(const bf16x8*)(sval + i), (bf16x8*)(o + i));
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+    return;
+  } else if (out_dtype == WSOVOD_F32) {
     float* o = (float*)out + obase;
     if (vec)
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
@@ -1008,10 +1020,19 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
     wsovod::ProfScope prof(slot, s, 0.0, bytes);
     if (pw == 7 && ph >= 7 && ph <= 8 && ((uintptr_t)feat & 7) == 0 && C % (dtype == WSOVOD_BF16 ? 4 : 2) == 0) {
       // fast path: workgroup per (roi, 64*CPL channels), wavefront per pooled row, 8-byte loads, 28 taps in flight
-      const int cg = dtype == WSOVOD_BF16 ? 256 : 128;
+      // bf16 maps of 512 channels and more (res5 of both depths) with bf16 output: 8 channels = 16 bytes per lane and
+      // load, half the load instructions and L2 requests of the 4-channel form (2.15 -> 1.39 ms at the bench shape)
+      const bool wide = dtype == WSOVOD_BF16 && out_dtype == WSOVOD_BF16 && C % 512 == 0 && ((uintptr_t)feat & 15) == 0;
+      const int cg = dtype == WSOVOD_BF16 ? (wide ? 512 : 256) : 128;
       const int groups = ceil_div(C, cg);
-      const int lds7 = cg * ph * pw * 4 + kAlignTabBytes;  // output transpose tile + sample-column table + separable weights
-      if (dtype == WSOVOD_BF16) {
+      // output transpose tile + sample-column table + separable weights
+      const int lds7 = ((cg * ph * pw * (wide ? 2 : 4) + 15) & ~15) + kAlignTabBytes;
+      if (wide) {
+        auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 8, true>;
+        if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
+                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups);
+      } else if (dtype == WSOVOD_BF16) {
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
