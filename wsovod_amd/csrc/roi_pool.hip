@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nhwc(const T* __restrict__ f
 // scan order inside every bin is still (h ascending, w ascending) with a strict '>' --
 // the reference's first-maximum argmax semantics (ROILoopPool_cpu.cpp:63-71).
 // ---------------------------------------------------------------------------------
-template <typename T, bool ARGMAX, int PWT, int CPL>
+template <typename T, bool ARGMAX, int PWT, int CPL, bool OBF = false>
 __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
                                        const float* __restrict__ roi_scale, int C, int H, int W, int PH,
                                        float spatial_scale, void* out, int out_dtype, int* __restrict__ argmax,
@@ -155,8 +155,11 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int nbins = PH * PWT;
-  float* sval = (float*)smem;
-  int* sarg = (int*)(sval + CG * nbins);
+  // output transpose tile [channel][bin]: fp32, or (OBF: bf16 output, no argmax) the output bits themselves: half the
+  // LDS per workgroup, twice the workgroups (wavefronts with loads in flight) per CU
+  typedef typename std::conditional<OBF, bf16_t, float>::type sval_t;
+  sval_t* sval = (sval_t*)smem;
+  int* sarg = (int*)(smem + (size_t)CG * nbins * sizeof(sval_t));
   const int r = blockIdx.x / cgroups;
   const int c0 = (blockIdx.x - r * cgroups) * CG;
   const int c = c0 + lane * CPL;
@@ -207,7 +210,7 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
   for (int pw = 0; pw < PWT; ++pw)
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
-      sval[(lane * CPL + q) * nbins + ph * PWT + pw] = roi_scale ? maxv[pw][q] * scale : maxv[pw][q];
+      sval[(lane * CPL + q) * nbins + ph * PWT + pw] = (sval_t)(roi_scale ? maxv[pw][q] * scale : maxv[pw][q]);
       if (ARGMAX) sarg[(lane * CPL + q) * nbins + ph * PWT + pw] = maxi[pw][q];
     }
   __syncthreads();
@@ -215,7 +218,15 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
   const int nvalid = min(CG, C - c0) * nbins;
   const long long obase = ((long long)r * C + c0) * nbins;
   const bool vec = (nvalid & 3) == 0 && (obase & 3) == 0;
-  if (out_dtype == WSOVOD_F32) {
+  if constexpr (OBF) {  // (launcher: bf16 output, no argmax) the tile already holds the output bits
+    bf16_t* o = (bf16_t*)out + obase;
+    if ((nvalid & 7) == 0 && (obase & 7) == 0)
+      for (int i = tid * 8; i < nvalid; i += nthreads * 8)
+        __builtin_nontemporal_store(*(const bf16x8*)(sval + i), (bf16x8*)(o + i));
+    else
+      for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+    return;
+  } else if (out_dtype == WSOVOD_F32) {
     float* o = (float*)out + obase;
     if (vec)
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
@@ -919,7 +930,8 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
       const bool wide = dtype == WSOVOD_BF16 && (C & 3) == 0 && !argmax;  // measured: 4 channels per lane pay off only without argmax registers (C = 2048: 1.83 -> 1.66 ms; with argmax 0.70 -> 1.07)
       const int cg = wide ? 256 : 128;
       const int cgroups = ceil_div(C, cg);
-      const int lds7 = cg * ph * pw * 4 * (argmax ? 2 : 1);
+      const bool obf = wide && out_dtype == WSOVOD_BF16;  // bf16 transpose tile: 25 instead of 50 KiB per workgroup (0.833 -> 0.817 ms)
+      const int lds7 = obf ? cg * ph * pw * 2 : cg * ph * pw * 4 * (argmax ? 2 : 1);
       const int grid7 = R * cgroups;
       WS_CHECK_ARG(lds7 <= 160 * 1024, "wsovod_roi_pool_forward: pooled tile too large for LDS");
 #define LAUNCH_ROWS(T, AM, CPL)                                                                                    \
@@ -929,7 +941,11 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     hipLaunchKernelGGL(k, dim3(grid7), dim3(64 * ph), lds7, s, (const T*)feat, rois, roi_scale, C, H, W, ph,        \
                        spatial_scale, out, out_dtype, argmax, cgroups);                                            \
   } while (0)
-      if (wide) {
+      if (obf) {
+        auto k = roi_pool_fwd_nhwc_rows<bf16_t, false, 7, 4, true>;
+        hipLaunchKernelGGL(k, dim3(grid7), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
+                           spatial_scale, out, out_dtype, argmax, cgroups);
+      } else if (wide) {
         LAUNCH_ROWS(bf16_t, false, 4);
       } else if (dtype == WSOVOD_BF16) {
         if (argmax) LAUNCH_ROWS(bf16_t, true, 2); else LAUNCH_ROWS(bf16_t, false, 2);
