@@ -2,6 +2,9 @@
 time per launch and effective gather rate.  python tools/roi_probe.py [iters] [C] [R] [N]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wsovod_amd._lib as _L
+if os.environ.get("WSOVOD_LIB"):  # another build of the library for an A/B on one box
+    _L.LIB_PATH = os.environ["WSOVOD_LIB"]
 from wsovod_amd.data import make_batch
 from wsovod_amd.layers import hip_ops as H
 
