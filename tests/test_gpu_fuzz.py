@@ -218,3 +218,80 @@ def test_conv_implicit_gemm_fuzz(gpu, seed):
     out = out.view(n, Ho, Wo, Cout).permute(0, 3, 1, 2).cpu().double()
     # inputs are exact in both dtypes; fp32 accumulation over k*k*Cin products of magnitude <= 0.1
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=2e-6 * (k * k * Cin) ** 0.5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_refinement_losses_fuzz(gpu, seed):
+    """Weighted cross-entropy and the class-specific weighted smooth-L1 box loss (fast_rcnn_open_vocabulary.py:812-905)
+    on random row counts, vocabulary sizes, ignore labels (-1), zero weights and beta, forward and backward, against
+    the oracle."""
+    from oracle import wsovod_ref as R
+    from wsovod_amd.layers import functions as Fn
+
+    g = torch.Generator().manual_seed(7000 + seed)
+    pick = lambda xs: xs[int(torch.randint(0, len(xs), (1,), generator=g))]
+    M, K = pick([1, 2, 63, 64, 257, 1500]), pick([1, 20, 80, 1203])
+    weighted, beta = bool(pick([0, 1])), pick([0.0, 0.5, 1.0])
+    logits = torch.randn(M, K + 1, generator=g) * pick([1.0, 6.0, 20.0])
+    gt = torch.randint(-1, K + 1, (M,), generator=g)
+    w = torch.rand(M, generator=g)
+    w[torch.rand(M, generator=g) < 0.1] = 0.0
+    pb = torch.rand(M, 4, generator=g) * 100
+    pb[:, 2:] += pb[:, :2] + 5
+    gb = torch.rand(M, 4, generator=g) * 100
+    gb[:, 2:] += gb[:, :2] + 5
+    pred = torch.randn(M, 4, generator=g)
+    lc, pc = logits.clone().requires_grad_(True), pred.clone().requires_grad_(True)
+    ref_c, ref_b = R.refinement_losses(lc, pc, gt, w, pb, gb, K, beta=beta, cross_entropy_weighted=weighted,
+                                       box_loss_type="smooth_l1_weighted" if weighted else "smooth_l1")
+    (ref_c + ref_b).backward()
+    lg, pg = logits.clone().to(gpu).requires_grad_(True), pred.clone().to(gpu).requires_grad_(True)
+    wk = w.clone()
+    wk[gt == -1] = 0
+    loss_c = Fn.weighted_cross_entropy(lg, gt.to(gpu), w.to(gpu), weighted)
+    loss_b = Fn.weighted_l1_box_loss(pg, pb.to(gpu), gb.to(gpu), gt.to(gpu), wk.to(gpu), K, (10., 10., 5., 5.), beta,
+                                     weighted=weighted)
+    (loss_c + loss_b).backward()
+    torch.testing.assert_close(loss_c.detach().cpu(), ref_c.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(loss_b.detach().cpu(), ref_b.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(lg.grad.cpu(), lc.grad, rtol=1e-3, atol=1e-7)
+    torch.testing.assert_close(pg.grad.cpu(), pc.grad, rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_pgt_mining_and_labelling_fuzz_exact(gpu, seed):
+    """Pseudo ground-truth mining + IoU labelling (roi_heads.py:1480-1610, get_pgt_top_k) on random image counts, ragged
+    proposal counts (1 .. 700), vocabulary sizes, duplicate boxes, tiny boxes (area <= 20) and tied scores: every index,
+    class, box and weight bit-exact against the oracle."""
+    from oracle import wsovod_ref as R
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(8000 + seed)
+    K = [2, 20, 80, 300][seed % 4]
+    nums = [int(n) for n in torch.randint(1, 200, (int(torch.randint(1, 6, (1,), generator=g)),), generator=g)]
+    if seed % 3 == 0:
+        nums.append(700)
+    boxes_list, scores_list, gts = [], [], []
+    for n in nums:
+        x0, y0 = torch.rand(n, generator=g) * 300, torch.rand(n, generator=g) * 200
+        b = torch.stack([x0, y0, x0 + 2 + torch.rand(n, generator=g) ** 2 * 200, y0 + 2 + torch.rand(n, generator=g) ** 2 * 150], 1)
+        if n > 3:
+            b[2] = b[1]  # duplicate boxes: IoU ties
+        sc = torch.rand(n, K, generator=g) * 0.05
+        if n > 5:
+            sc[4] = sc[3]  # tied scores: the first one wins
+        boxes_list.append(b)
+        scores_list.append(sc)
+        gts.append(torch.unique(torch.randint(0, K, (int(torch.randint(1, 4, (1,), generator=g)),), generator=g)))
+    img_logits = torch.rand(len(nums), K, generator=g).clamp(1e-6, 1 - 1e-6)
+    targets = R.get_pgt_top_k(boxes_list, scores_list, gts, img_logits, K)
+    lab = R.label_and_sample_proposals_wsl(boxes_list, targets, K)
+    seg = torch.tensor([0] + list(torch.tensor(nums).cumsum(0)), dtype=torch.int32, device=gpu)
+    goff = torch.tensor([0] + list(torch.tensor([len(x) for x in gts]).cumsum(0)), dtype=torch.int32, device=gpu)
+    o = H.pgt_mine_and_label(torch.cat(scores_list).to(gpu), torch.cat(boxes_list).to(gpu), seg, torch.cat(gts).to(gpu),
+                             goff, img_logits.to(gpu), K, 0.5)
+    assert o["pgt_count"].cpu().tolist() == [len(t["gt_classes"]) for t in targets]
+    for key, ref_key in (("gt_classes", "gt_classes"), ("gt_boxes", "gt_boxes"), ("gt_weights", "gt_weights"),
+                         ("gt_scores", "gt_scores")):
+        assert torch.equal(o[key].cpu(), torch.cat([l[ref_key] for l in lab])), key
+    assert torch.equal(o["matched"].cpu().long(), torch.cat([l["matched_idxs"] for l in lab]))
