@@ -526,3 +526,90 @@ def test_three_rank_direct_exchange_sums_in_fp32_and_rounds_once():
                 p.sub_(0.1 * buf[n])
     torch.testing.assert_close(torch.tensor(res[0][1]), model.big.detach(), rtol=0, atol=1e-6)
     torch.testing.assert_close(torch.tensor(res[0][2]), model.small.weight.detach(), rtol=0, atol=1e-6)
+
+
+def _worker_direct_unused_iter(rank, world, port, q):
+    """Direct exchange together with reduce_unused (a tensor no rank touches keeps parameter and momentum, weight decay
+    on) and ITER_SIZE = 2 (gradients accumulate locally, exchange + update every second iteration): three ranks."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from wsovod_amd.engine import HotPathTrainer
+    from wsovod_amd.engine.trainer import HipSGD
+    from wsovod_amd.layers import hip_ops as H
+
+    def pack(pairs):
+        for src, dst in pairs:
+            dst.copy_(src.reshape(-1))
+
+    def sgd(entries, momentum, grad_scale=1.0):
+        for p, g, buf, shadow, lr, wd, used in entries:
+            assert used is not None
+            if float(used) == 0.0:
+                continue
+            buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
+            p.sub_(lr * buf)
+
+    def sum_shards(src, n, dst):
+        dst.copy_(src.view(n, -1).float().sum(0))
+        return dst
+
+    H.pack_bf16_multi, H.sgd_momentum_multi, H.sum_shards_bf16 = pack, sgd, sum_shards
+    calls = []
+    real = dist.all_to_all_single
+    dist.all_to_all_single = lambda out, inp, *a, **k: (calls.append(inp.numel()), real(out, inp, *a, **k))[1]
+    model = _TwoPhaseModel()
+    model.unused = nn.Linear(5, 3)
+    unused0 = model.unused.weight.detach().clone()
+    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 0.05} for p in model.parameters()], 0.1, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True, reduce_unused=True, grad_wire="bf16", exchange="direct", iter_size=2)
+    assert tr.exchange_algo == "direct" and tr._split is None  # accumulation: no early block
+    tr.broadcast_parameters()
+    calls.clear()
+    g = torch.Generator().manual_seed(300 + rank)
+    batches = [[{"x": torch.randn(8, generator=g)} for _ in range(3)] for _ in range(4)]
+    for b in batches:
+        tr.run_step(b)
+    tr.flush()
+    total = tr._wire_slices()[0].numel()
+    assert total % (8 * world) == 0 and calls == [total, total], calls  # iterations 0 and 2 exchange, 1 and 3 accumulate
+    assert torch.equal(model.unused.weight.detach(), unused0), "a tensor unused on every rank must not move"
+    q.put((rank, model.fc.weight.detach().tolist(), [[d["x"].tolist() for d in b] for b in batches]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_direct_exchange_with_unused_tensors_and_iter_size():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + os.getpid() % 2000
+    world = 3
+    procs = [ctx.Process(target=_worker_direct_unused_iter, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] == res[0][1] for r in res), "replicas diverged"
+    # reference: iteration 0 steps on its own gradient; iterations 1 and 2 accumulate (each loss / 2) and step at 2;
+    # iteration 3 accumulates and is never applied.  Per step: bf16 per rank, fp32 sum, one rounding, / world.
+    model = _TwoPhaseModel()
+    buf = {n: torch.zeros_like(p) for n, p in model.named_parameters()}
+
+    def rank_grads(its):
+        out = []
+        for r in res:
+            model.zero_grad()
+            for it in its:
+                (sum(model([{"x": torch.tensor(x)} for x in r[2][it]]).values()) / 2).backward()
+            out.append({n: p.grad.to(torch.bfloat16) for n, p in model.named_parameters()})
+        return out
+
+    for its in ([0], [1, 2]):
+        grads = rank_grads(its)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                gsum = sum(gr[n].float() for gr in grads).to(torch.bfloat16)
+                buf[n].mul_(0.9).add_(gsum.float() / world + 0.05 * p)
+                p.sub_(0.1 * buf[n])
+    torch.testing.assert_close(torch.tensor(res[0][1]), model.fc.weight.detach(), rtol=0, atol=1e-6)
