@@ -15,8 +15,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    """A port nobody listens on right now (a fixed one can still sit in TIME_WAIT from the previous launch)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def _launch(mode):
-    port = str(29600 + os.getpid() % 300 + (7 if mode == "mixed" else 0))
+    port = str(_free_port())
     tmp = tempfile.mkdtemp(prefix="wsovod_dp_")
     outs = [os.path.join(tmp, f"rank{r}.pt") for r in range(2)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}

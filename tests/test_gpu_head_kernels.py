@@ -299,3 +299,26 @@ def test_subsample_labels_random_keys(gpu):
         p = float(f.mean())
         sigma = (p * (1 - p) / trials) ** 0.5
         assert float((f - p).abs().max()) < 5 * sigma + 1e-9
+
+
+def test_column_sums_are_run_to_run_bit_identical(gpu):
+    """segment_colsum / the NHWC global average pool combine their workgroups' partial sums through 64-bit fixed-point
+    atomics: integer addition is associative, so the order in which the atomics land cannot change a bit.  (With fp32
+    atomics the pooled statistics moved in their last bits between runs; through near-tied mining scores that flipped a
+    pseudo ground-truth box on ~15 % of cold starts of the RPN golden test.)  Also: the value stays within fp32
+    rounding of an fp64 sum."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(21)
+    x = (torch.randn(8, 75 * 100, 512, device=gpu) * 3).to(torch.bfloat16)
+    first = H.global_avgpool_nhwc(x.view(8, 75, 100, 512))
+    for _ in range(30):
+        assert torch.equal(H.global_avgpool_nhwc(x.view(8, 75, 100, 512)), first)
+    torch.testing.assert_close(first.double().cpu(), x.double().mean(1).cpu(), rtol=2e-6, atol=1e-7)
+    rows = torch.randn(9000, 200, device=gpu)
+    seg = torch.tensor([0, 1, 4000, 4000, 9000], dtype=torch.int32, device=gpu)
+    s0 = H.segment_colsum(rows, seg)
+    for _ in range(30):
+        assert torch.equal(H.segment_colsum(rows, seg), s0)
+    want = torch.stack([rows[a:b].double().sum(0) for a, b in ((0, 1), (1, 4000), (4000, 4000), (4000, 9000))])
+    torch.testing.assert_close(s0.double().cpu(), want.cpu(), rtol=2e-6, atol=1e-4)  # fp32 partials of 5000 N(0,1) rows

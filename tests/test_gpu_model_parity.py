@@ -18,6 +18,16 @@ from tests.helpers import build_seeded_hip_model, load_golden, to_inputs
 pytestmark = pytest.mark.gpu
 
 
+
+def _free_port():
+    """A port nobody listens on right now (a fixed one can still sit in TIME_WAIT from an earlier process group)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
 def _run(model, batch):
     from wsovod_amd.modeling import roi_heads as RH
 
@@ -545,7 +555,7 @@ def test_overlapped_trainer_equals_plain_run_step(gpu):
             if mode == "rccl":  # the exchange through a real RCCL communicator (one rank: the sum is the identity)
                 import os
                 import torch.distributed as dist
-                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
+                os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
                 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
             try:
                 tr = HotPathTrainer(model, opt)
@@ -586,7 +596,7 @@ def test_bf16_gradient_wire_matches_fp32_exchange(gpu):
 
     batch = to_inputs(gen.seeded_batch(2, 32, 20, 256, 352, seed=6))
     outs = []
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29400 + os.getpid() % 500))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
         for wire, algo in (("fp32", "ring"), ("bf16", "ring"), ("bf16", "direct")):

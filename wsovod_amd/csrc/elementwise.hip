@@ -305,8 +305,7 @@ __global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const T* __restrict
 template <typename T>
 __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, long long ld,
                                                              const int* __restrict__ seg, int G, int uniform_rows,
-                                                             int M, int N, float scale, float* __restrict__ out,
-                                                             long long ldo) {
+                                                             int M, int N, unsigned long long* __restrict__ ws) {
   constexpr int RC = 128;            // rows per workgroup
   constexpr int V = 16 / sizeof(T);  // columns per lane: one 16-B load per row
   __shared__ float part[3][64][V + 1];
@@ -330,10 +329,15 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
   float acc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) acc[j] = 0.f;
+  // Partial sums meet in 64-bit FIXED-POINT cells (2^-30 units): integer addition is associative, so the result does
+  // not depend on the order in which the workgroups' atomics land -- run-to-run bit-identical sums (with fp32 atomics
+  // the last bits of the pooled statistics, and through them near-tied mining scores, changed with the timing of a
+  // cold first iteration).  Range +-8.6e9, resolution 9.3e-10: finer than fp32 for any sum above 0.016.
   auto flush = [&](int gg) {
 #pragma unroll
     for (int j = 0; j < V; ++j)
-      if (n0 + j < N && acc[j] != 0.f) atomicAdd(out + (long long)gg * ldo + n0 + j, acc[j] * scale);
+      if (n0 + j < N && acc[j] != 0.f)
+        atomicAdd(ws + (long long)gg * N + n0 + j, (unsigned long long)__double2ll_rn((double)acc[j] * 1073741824.0));
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
   };
@@ -789,17 +793,40 @@ int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C
   return WSOVOD_OK;
 }
 
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* __restrict__ ws, int G, int N, float scale,
+                                                              float* __restrict__ out, long long ldo, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)G * N) return;
+  const int g = (int)(i / N), n = (int)(i - (long long)g * N);
+  const float v = (float)((double)ws[i] * (1.0 / 1073741824.0)) * scale;
+  float* o = out + (long long)g * ldo + n;
+  *o = accumulate ? *o + v : v;
+}
+
 static int launch_colsum(const void* x, int dtype, long long ld, const int* seg, int G, int uniform_rows, int M, int N,
                          float scale, float* out, long long ldo, int accumulate, hipStream_t s) {
-  if (!accumulate) {
-    if (ldo == N) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * N, s);
-    else (void)hipMemset2DAsync(out, ldo * sizeof(float), 0, N * sizeof(float), G, s);
+  // grow-only fixed-point workspace of this process (single-stream use, as the rest of the library)
+  static unsigned long long* ws = nullptr;
+  static size_t ws_cells = 0;
+  const size_t cells = (size_t)G * N;
+  if (cells > ws_cells) {
+    if (ws) (void)hipFree(ws);  // (hipFree synchronises the device: no launch still uses the old buffer)
+    ws = nullptr;
+    ws_cells = 0;
+    if (hipMalloc((void**)&ws, cells * sizeof(unsigned long long)) != hipSuccess) {
+      wsovod::set_error("segment_colsum: cannot allocate the fixed-point workspace");
+      return WSOVOD_ERR_HIP;
+    }
+    ws_cells = cells;
   }
+  (void)hipMemsetAsync(ws, 0, cells * sizeof(unsigned long long), s);
   const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 128));
   if (dtype == WSOVOD_BF16)
-    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
+    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, ws);
   else
-    hipLaunchKernelGGL(segment_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, seg, G, uniform_rows, M, N, scale, out, ldo);
+    hipLaunchKernelGGL(segment_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, seg, G, uniform_rows, M, N, ws);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, (const long long*)ws, G, N,
+                     scale, out, ldo, accumulate);
   return 0;
 }
 
@@ -810,7 +837,7 @@ int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, 
   static int slot = wsovod::prof_slot("gap_nhwc");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)N * HW * C * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
-  launch_colsum(in, dtype, C, nullptr, N, HW, N * HW, C, 1.0f / (float)HW, out, C, 0, s);
+  if (launch_colsum(in, dtype, C, nullptr, N, HW, N * HW, C, 1.0f / (float)HW, out, C, 0, s) != 0) return WSOVOD_ERR_HIP;
   WS_CHECK_LAUNCH("wsovod_global_avgpool_nhwc");
   return WSOVOD_OK;
 }
@@ -908,7 +935,9 @@ int wsovod_segment_colsum(const void* x, int dtype, long long ld, const int* seg
   static int slot = wsovod::prof_slot("segment_colsum");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
-  if (M > 0) launch_colsum(x, dtype, ld, seg_offsets, G, 0, M, N, 1.0f, out, ldo, accumulate, s);
+  if (M > 0) {
+    if (launch_colsum(x, dtype, ld, seg_offsets, G, 0, M, N, 1.0f, out, ldo, accumulate, s) != 0) return WSOVOD_ERR_HIP;
+  }
   else if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * ldo, s);
   WS_CHECK_LAUNCH("wsovod_segment_colsum");
   return WSOVOD_OK;
