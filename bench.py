@@ -603,6 +603,7 @@ def main():
                        "inputs": "uint8 images + boxes copied from pinned host memory inside every step (async, double "
                                  "buffered)" if args.h2d else "resident in HBM before the timed region",
                        "per_step_percentiles": "hipEvent time between consecutive steps on rank 0's stream",
+                       "per_step_ms": [round(v, 3) for v in ms],
                        "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms), "all": rank_ms},
                        "final_losses": rec["final_losses"]},
         }
