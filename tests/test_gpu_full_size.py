@@ -1,6 +1,12 @@
-"""-m gpu: BASELINE.json's full sizes (800x600 images, 512 proposals, 20 classes, fc1 = 25088 -> 4096) through
-size-independent properties -- the oracle cannot run these sizes in seconds, the properties can be checked exactly or
-against O(size) fp64 checksums."""
+"""-m gpu: BASELINE.json's full sizes (800x600 images, 512 proposals, 20 classes, fc1 = 25088 -> 4096).
+
+(i) Against the ORACLE at the configs' own sizes: the CPU restatement (oracle/wsovod_ref.py, pinned to the
+    reference's golden vectors) runs a whole fp32 training step of an 800x600 x 512-proposal image in ~1.5 s, so the
+    headline config (2 images), WSR_50 x 1024 proposals x K = 80 (1 image) and the ROIAlignV2 pooler are compared with
+    it directly: shapes that only exist at full size (M = 1024..16384 rows in fc1, 75x100 maps, 7500-pixel GAP,
+    512-row MIL segments, tile tails, split-K) are pinned to the reference this way.
+(ii) Size-independent properties (checksums of checksums, shift equivariance, idempotence, order independence) at
+    batch sizes beyond what the oracle finishes in seconds."""
 import pytest
 import torch
 
@@ -158,3 +164,101 @@ def test_full_size_precision_modes_against_the_fp32_path(gpu):
         assert e_logit < lim_logit and e_score < lim_score and e_loss < lim_loss, (prec, e_logit, e_score, e_loss)
     print("full-size deviation vs fp32 HIP (max|dlogit|, max|dscore|, max rel loss):", report)
     assert report["bf16"][0] > 1e-3  # the plain bf16 mode does NOT meet the north star's bound: keep saying so
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the configs' own sizes against the oracle (reference: roi_heads.py:696-907, fast_rcnn_open_vocabulary.py:318-367,726-820)
+# ---------------------------------------------------------------------------------------------------------------
+def _oracle_vs_hip(gpu, precision, *, n_images, proposals, classes, depth=18, embed_dim=512, pooler="ROIPool", seed=4321):
+    from oracle import compare as OC
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_hot_path_model, capture_full_step
+
+    host = make_batch(n_images, proposals, classes, seed=seed)
+    cfg, model = build_hot_path_model(seed=0, depth=depth, K=classes, D=embed_dim, precision=precision, pooler=pooler,
+                                      device="cuda:0")
+    model.train()
+    for m in model.modules():  # dropout RNG streams cannot match the reference's: off on both sides
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
+    batch = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
+              "height": x["height"], "width": x["width"]} for x in host]
+    got = capture_full_step(model, batch)
+    del model
+    torch.cuda.empty_cache()
+    want = OC.oracle_step(sd, host, train_keys, depth=depth, num_classes=classes, pooler_type=pooler)
+    rep = OC.compare(got, want)
+    print(f"{precision} WSR_{depth} {n_images} x 800x600 x {proposals} proposals, K={classes}, {pooler} vs oracle:", rep)
+    return rep
+
+
+def _assert_parity(rep, grad_tol):
+    assert rep["max_abs_logit_err"] < 1e-3, rep  # the north star's bound on the MIL-head logits
+    assert rep["max_abs_score_err"] < 1e-3 and rep["max_abs_img_score_err"] < 1e-3, rep
+    assert rep["max_abs_delta_err"] < 1e-3, rep
+    assert rep["max_rel_loss_err"] < 1e-3, rep
+    assert rep["labels_exact"] and rep["label_boxes_exact"] and rep["pgt_exact"], rep  # proposal indexing: bit-exact
+    assert rep["max_rel_weight_err"] < 1e-3, rep
+    assert rep["max_rel_gradnorm_err"] < grad_tol, rep
+
+
+@pytest.mark.parametrize("precision,grad_tol", [("fp32", 2e-3), ("bf16x3", 5e-3)])
+def test_headline_config_matches_the_oracle_at_its_own_size(gpu, precision, grad_tol):
+    """BASELINE config 2 (WSR_18, 800x600, 512 proposals, K = 20) on 2 images, fp32 and bf16x3, against the oracle's
+    step on the same weights: mining scores / refinement logits / deltas < 1e-3, pseudo-GT indices and per-proposal labels
+    exact, losses 1e-3, every gradient norm 2e-3 (fp32) / 5e-3 (bf16x3)."""
+    _assert_parity(_oracle_vs_hip(gpu, precision, n_images=2, proposals=512, classes=20), grad_tol)
+
+
+def test_parity_mode_matches_the_oracle_at_full_size(gpu):
+    """MODEL.HIP.PRECISION = "parity" (the fast tolerance-meeting mode: split forward, bf16 backward): forward
+    quantities inside the north star's bound against the oracle at the headline size; gradients of the bf16 grade."""
+    rep = _oracle_vs_hip(gpu, "parity", n_images=2, proposals=512, classes=20)
+    assert rep["max_abs_logit_err"] < 1e-3 and rep["max_abs_score_err"] < 1e-3 and rep["max_abs_delta_err"] < 1e-3, rep
+    assert rep["max_rel_loss_err"] < 1e-3, rep
+    assert rep["labels_exact"] and rep["label_boxes_exact"] and rep["pgt_exact"], rep
+    assert rep["max_rel_gradnorm_err"] < 0.15, rep
+
+
+def test_config4_wsr50_1024_proposals_matches_the_oracle_at_full_size(gpu):
+    """BASELINE config 4 shapes at full size: WSR_50 (C5 = 2048, fc1 = 100352 -> 4096), 1024 proposals, K = 80, one
+    800x600 image, fp32 mode."""
+    _assert_parity(_oracle_vs_hip(gpu, "fp32", n_images=1, proposals=1024, classes=80, depth=50), 2e-3)
+
+
+def test_roi_align_v2_matches_the_oracle_at_full_size(gpu):
+    """The north star's pooler (POOLER_TYPE: ROIAlignV2) at the headline size, fp32 mode."""
+    _assert_parity(_oracle_vs_hip(gpu, "fp32", n_images=1, proposals=512, classes=20, pooler="ROIAlignV2"), 2e-3)
+
+
+def test_bf16_mode_deviation_from_the_oracle_at_full_size(gpu):
+    """The timed precision (bf16) against the oracle at the headline size: what it misses the bound by, kept honest."""
+    rep = _oracle_vs_hip(gpu, "bf16", n_images=2, proposals=512, classes=20)
+    assert rep["max_abs_logit_err"] < 0.5 and rep["max_abs_score_err"] < 2e-2 and rep["max_rel_loss_err"] < 5e-2, rep
+    assert rep["max_abs_logit_err"] > 1e-3  # plain bf16 does NOT meet the north star's bound: keep saying so
+
+
+def test_wsr50_1024_proposals_full_size_step_properties(gpu):
+    """Configs 3-5 at size in a test (not only a bench side line): WSR_50 x 1024 proposals x K = 80, 4 images, bf16:
+    finite losses / gradients, MIL score sums <= 1, bg logit == 0, labels inside the image-level classes."""
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_hot_path_model, capture_full_step
+
+    cfg, model = build_hot_path_model(seed=0, depth=50, K=80, D=512, precision="bf16", device="cuda:0")
+    model.train()
+    host = make_batch(4, 1024, 80, seed=99)
+    batch = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
+              "height": x["height"], "width": x["width"]} for x in host]
+    got = capture_full_step(model, batch)
+    sc = got["mining_scores"].view(4, 1024, 80)
+    assert bool((sc >= 0).all()) and bool((sc.sum(dim=1) <= 1 + 1e-4).all())
+    assert got["refine_logits"].shape == (4096, 81) and bool((got["refine_logits"][:, -1] == 0).all())
+    assert float(got["refine_logits"].abs().max()) <= 50.0 * 1.001
+    labels = got["gt_classes"].view(4, 1024)
+    for i, x in enumerate(host):
+        assert set(labels[i].tolist()) <= set(x["instances"].gt_classes.tolist()) | {80}
+    for k, v in got["losses"].items():
+        assert v == v and 0 <= v < float("inf"), k
+    assert all(v == v and v < float("inf") for v in got["grad_norms"].values())

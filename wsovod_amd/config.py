@@ -238,7 +238,8 @@ def add_wsovod_config(cfg):
     _C.MODEL.HIP = C()
     # "bf16" (bf16 MFMA, fp32 accumulate) | "fp32" (exact-fp32 MFMA) | "bf16x3" (fp32 tensors, bf16 MFMA on hi/lo-split
     # operands: fp32-grade products at a third of the bf16 rate) | "bf16x3f" (the split in the forward pass only, plain
-    # bf16 backward: fp32-grade logits, bf16-grade gradients)
+    # bf16 backward: fp32-grade logits, bf16-grade gradients) | "parity" (the fast tolerance-meeting mode: the forward
+    # split of "bf16x3f" on the activation format / kernels built for it -- DESIGN.md section 3)
     _C.MODEL.HIP.PRECISION = "bf16"
     return _C
 

@@ -364,7 +364,7 @@ class ResNet(nn.Module):
         assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
         self._check_frozen()
         cd = self.compute_dtype
-        x3 = self.precision in ("bf16x3", "bf16x3f")
+        x3 = self.precision in ("bf16x3", "bf16x3f", "parity")
         kstep = 64 if (cd == torch.bfloat16 or x3) else 32
         xn = x.permute(0, 2, 3, 1).to(cd)
         xn = F.pad(xn, (0, kstep - xn.size(-1))).contiguous()  # Cin 3 -> one K-step (generic float entry)
@@ -374,7 +374,7 @@ class ResNet(nn.Module):
     @torch.no_grad()
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
-        with H.x3_mode(self.precision in ("bf16x3", "bf16x3f")):
+        with H.x3_mode(self.precision in ("bf16x3", "bf16x3f", "parity")):
             return self._forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
 
     def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):

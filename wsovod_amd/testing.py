@@ -75,6 +75,46 @@ def build_hot_path_model(seed=0, calibrate_synthetic=True, **kw):
     return cfg, model
 
 
+def capture_full_step(model, batched_inputs):
+    """One training forward + backward with everything a parity check reads, moved to the host: losses, mining
+    scores, refinement logits / deltas, image-level scores, the mining kernel's labels and pseudo GT, and the L2 norm
+    of every trainable tensor's gradient.  Gradients are cleared afterwards."""
+    captured = {}
+    rh = model.roi_heads
+    orig_m, orig_r = rh.object_miner.forward, rh.box_refinery[0].forward
+
+    def cap(name, fn):
+        def wrapped(*a, **k):
+            o = fn(*a, **k)
+            captured[name] = o
+            return o
+        return wrapped
+
+    rh.object_miner.forward = cap("miner", orig_m)
+    rh.box_refinery[0].forward = cap("refine", orig_r)
+    try:
+        losses = model(batched_inputs)
+    finally:
+        rh.object_miner.forward, rh.box_refinery[0].forward = orig_m, orig_r
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    pgt = rh._last_pgt
+    counts = pgt["pgt_count"].cpu().tolist()
+    out = {
+        "losses": {k: float(v.detach()) for k, v in losses.items()},
+        "mining_scores": captured["miner"][0].detach().float().cpu(),
+        "refine_logits": captured["refine"][0].detach().float().cpu(),
+        "refine_deltas": captured["refine"][1].detach().float().cpu(),
+        "img_scores": rh.pred_class_img_logits.detach().float().cpu(),
+        "gt_classes": pgt["gt_classes"].cpu(), "gt_boxes": pgt["gt_boxes"].cpu(), "gt_weights": pgt["gt_weights"].cpu(),
+        "pgt_num": counts, "pgt_boxes": pgt["pgt_boxes"].cpu(), "pgt_classes": pgt["pgt_classes"].cpu(),
+        "grad_norms": {k: float(p.grad.detach().float().norm()) for k, p in model.named_parameters()
+                       if p.requires_grad and p.grad is not None},
+    }
+    model.zero_grad(set_to_none=True)
+    return out
+
+
 def capture_step(model, batched_inputs):
     """One training forward + backward; returns (loss dict, object-mining scores (R,K), refinement logits (R,K+1)) --
     the two tensors the north star's "MIL-head logits within 1e-3" bound is about."""
