@@ -208,8 +208,9 @@ int wsovod_stem_conv1(const unsigned char* img, const int* sizes, const float* m
  * resnet_wsl.py:85-92,408. */
 int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C, int stride,
                            int zero_pad_br, void* out, wsovod_stream_t stream);
-/* AdaptiveAvgPool2d(1) over NHWC -> (N,C) fp32 (data_aware_features_head.py:62,124). */
-int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out,
+/* AdaptiveAvgPool2d(1) over NHWC -> (N,C) fp32 (data_aware_features_head.py:62,124).  workspace: caller-owned fp32
+ * scratch sized by wsovod_colsum_workspace_floats for (G, M, N) = (N, N*HW, C) (see wsovod_segment_colsum). */
+int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out, float* workspace,
                                wsovod_stream_t stream);
 /* dst[c][r] = (dst_dtype) src[r][c]; leading dimensions in elements. */
 int wsovod_transpose_cast(const void* src, int src_dtype, long long ld_src, int R, int C, void* dst,
@@ -226,9 +227,14 @@ int wsovod_row_l2norm_backward(const void* z, int dtype, long long ldz, const fl
                                int M, int D, float temperature, float eps, int relu_mask, float* dz,
                                long long lddz, wsovod_stream_t stream);
 
-/* out[g][n] (+)= sum over rows m in [seg_offsets[g], seg_offsets[g+1]) of x[m][n]. */
+/* out[g][n] (+)= sum over rows m in [seg_offsets[g], seg_offsets[g+1]) of x[m][n]  (autograd's bias / broadcast-add
+ * gradients: fast_rcnn_open_vocabulary.py:318-367, roi_heads.py:762-763 under autograd).  A fixed-order two-stage
+ * reduction: per 128-row chunk one fp32 partial per column (no atomics), then one pass that adds a segment's chunk
+ * partials in chunk order -- run-to-run bit-identical, no quantisation, NaN / Inf propagate.  workspace: caller-owned
+ * fp32 scratch of as many elements as wsovod_colsum_workspace_floats returns for (G, M, N) (not shared between streams). */
+long long wsovod_colsum_workspace_floats(int G, int M, int N);
 int wsovod_segment_colsum(const void* x, int dtype, long long ld, const int* seg_offsets, int G, int M,
-                          int N, float* out, long long ldo, int accumulate, wsovod_stream_t stream);
+                          int N, float* out, long long ldo, int accumulate, float* workspace, wsovod_stream_t stream);
 /* x *= num[0] / den[0]; either pointer may be NULL (= 1). Device scalars: no host sync. */
 int wsovod_scale_by_device_scalar(float* x, long long n, const float* num, const float* den,
                                   wsovod_stream_t stream);

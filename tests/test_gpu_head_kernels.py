@@ -302,11 +302,13 @@ def test_subsample_labels_random_keys(gpu):
 
 
 def test_column_sums_are_run_to_run_bit_identical(gpu):
-    """segment_colsum / the NHWC global average pool combine their workgroups' partial sums through 64-bit fixed-point
-    atomics: integer addition is associative, so the order in which the atomics land cannot change a bit.  (With fp32
-    atomics the pooled statistics moved in their last bits between runs; through near-tied mining scores that flipped a
-    pseudo ground-truth box on ~15 % of cold starts of the RPN golden test.)  Also: the value stays within fp32
-    rounding of an fp64 sum."""
+    """segment_colsum / the NHWC global average pool are fixed-order two-stage reductions (per-chunk fp32 partials, then
+    one pass in chunk order): the same input gives the same bits whatever the launch timing, with no quantisation.  (With
+    fp32 atomics the pooled statistics moved in their last bits between runs; through near-tied mining scores that
+    flipped a pseudo ground-truth box on ~15 % of cold starts of the RPN golden test.  Round 2's 64-bit fixed-point
+    atomics fixed that but quantised at 2^-30 ABSOLUTE: gradient sums of magnitude 1e-8 lost everything, sums past 8.6e9
+    wrapped.)  Checked against fp64 at magnitudes 1e-8, 1 and 1e+9, for ragged segments incl. empty ones, segments
+    shorter than a chunk, and non-finite inputs."""
     from wsovod_amd.layers import hip_ops as H
 
     torch.manual_seed(21)
@@ -315,10 +317,30 @@ def test_column_sums_are_run_to_run_bit_identical(gpu):
     for _ in range(30):
         assert torch.equal(H.global_avgpool_nhwc(x.view(8, 75, 100, 512)), first)
     torch.testing.assert_close(first.double().cpu(), x.double().mean(1).cpu(), rtol=2e-6, atol=1e-7)
-    rows = torch.randn(9000, 200, device=gpu)
-    seg = torch.tensor([0, 1, 4000, 4000, 9000], dtype=torch.int32, device=gpu)
-    s0 = H.segment_colsum(rows, seg)
-    for _ in range(30):
-        assert torch.equal(H.segment_colsum(rows, seg), s0)
-    want = torch.stack([rows[a:b].double().sum(0) for a, b in ((0, 1), (1, 4000), (4000, 4000), (4000, 9000))])
-    torch.testing.assert_close(s0.double().cpu(), want.cpu(), rtol=2e-6, atol=1e-4)  # fp32 partials of 5000 N(0,1) rows
+    bounds = [0, 1, 4000, 4000, 4003, 4100, 4101, 9000]  # 1-row, empty, 3-row, sub-chunk and multi-chunk segments
+    seg = torch.tensor(bounds, dtype=torch.int32, device=gpu)
+    base = torch.rand(9000, 200, device=gpu) + 0.5  # positive: the sum's magnitude is the natural error scale
+    for scale in (1e-8, 1.0, 1e9):
+        rows = base * scale
+        s0 = H.segment_colsum(rows, seg)
+        for _ in range(10):
+            assert torch.equal(H.segment_colsum(rows, seg), s0)
+        want = torch.stack([rows[a:b].double().sum(0) for a, b in zip(bounds[:-1], bounds[1:])])
+        torch.testing.assert_close(s0.double().cpu(), want.cpu(), rtol=2e-6, atol=0.0)
+    mixed = torch.randn(9000, 200, device=gpu)  # mixed signs: error relative to the sum of magnitudes
+    got = H.segment_colsum(mixed, seg).double().cpu()
+    want = torch.stack([mixed[a:b].double().sum(0) for a, b in zip(bounds[:-1], bounds[1:])]).cpu()
+    mag = torch.stack([mixed[a:b].double().abs().sum(0) for a, b in zip(bounds[:-1], bounds[1:])]).cpu()
+    assert float(((got - want).abs() / mag.clamp(min=1e-30)).max()) < 2e-6
+    acc = torch.full((7, 200), 2.0, device=gpu)  # accumulate adds to the existing values
+    H.segment_colsum(mixed, seg, out=acc, accumulate=True)
+    torch.testing.assert_close(acc.double().cpu(), want + 2.0, rtol=1e-5, atol=1e-4)
+    bad = base.clone()
+    bad[4500, 7] = float("nan")
+    bad[10, 3] = float("inf")
+    sb = H.segment_colsum(bad, seg).cpu()
+    assert torch.isnan(sb[6, 7]) and torch.isinf(sb[1, 3]) and torch.isfinite(sb[0]).all()  # non-finite values propagate
+    rows_bf = (base * 3).to(torch.bfloat16)  # bf16 input form (8 columns per lane)
+    torch.testing.assert_close(H.segment_colsum(rows_bf, seg).double().cpu(),
+                               torch.stack([rows_bf[a:b].double().sum(0) for a, b in zip(bounds[:-1], bounds[1:])]).cpu(),
+                               rtol=2e-6, atol=0.0)

@@ -50,6 +50,7 @@ class ProfEntry(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+ABI_VERSION = 4  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
 
 # name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
 SIGNATURES = {
@@ -68,12 +69,13 @@ SIGNATURES = {
     "wsovod_stem_im2col": [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "wsovod_stem_conv1": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "wsovod_maxpool2x2_nhwc": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
-    "wsovod_global_avgpool_nhwc": [_P, _I, _I, _I, _I, _P, _P],
+    "wsovod_global_avgpool_nhwc": [_P, _I, _I, _I, _I, _P, _P, _P],
     "wsovod_transpose_cast": [_P, _I, _L, _I, _I, _P, _I, _L, _P],
     "wsovod_cast": [_P, _I, _P, _I, _L, _P],
     "wsovod_row_l2norm_scale": [_P, _I, _L, _I, _I, _F, _F, _P, _P],
     "wsovod_row_l2norm_backward": [_P, _I, _L, _P, _L, _I, _I, _F, _F, _I, _P, _L, _P],
-    "wsovod_segment_colsum": [_P, _I, _L, _P, _I, _I, _I, _P, _L, _I, _P],
+    "wsovod_segment_colsum": [_P, _I, _L, _P, _I, _I, _I, _P, _L, _I, _P, _P],
+    "wsovod_colsum_workspace_floats": [_I, _I, _I],
     "wsovod_scale_by_device_scalar": [_P, _L, _P, _P, _P],
     "wsovod_sgd_momentum": [_P, _P, _P, _L, _F, _F, _F, _F, _P, _P],
     "wsovod_mil_forward": [_P, _L, _P, _I, _I, _P, _P, _P, _I, _P],
@@ -133,6 +135,11 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = C.c_int
         _lib.wsovod_last_error.restype = C.c_char_p
+        _lib.wsovod_colsum_workspace_floats.restype = C.c_longlong
+        got = _lib.wsovod_abi_version()
+        if got != ABI_VERSION:  # the structs of include/wsovod_hip.h (gemm desc, sgd tensor) changed size across versions
+            raise RuntimeError(f"wsovod_amd: {LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION}: rebuild "
+                               "it (python -c 'import __graft_entry__ as g; g.build()')")
     return _lib
 
 

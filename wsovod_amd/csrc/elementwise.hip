@@ -295,92 +295,115 @@ __global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------
-// Segmented column sum: out[g][n] += scale * sum_{m in segment g} x[m][n]  (bias grads with one
-// segment; per-image data-aware-feature grads; global average pool with uniform segments).
-// Grid = (64-column groups) x (256-row chunks): lane = column (coalesced), the 4 wavefronts
-// stride the chunk's rows; a wavefront flushes its running sum with one atomicAdd per lane when
-// the segment changes and at the end, so the reduction over M is spread over the whole chip.
-// `out` is zero-filled by the launcher unless accumulating.
+// Segmented column sum: out[g][n] (+)= scale * sum_{m in segment g} x[m][n]  (bias grads with one segment; per-image
+// data-aware-feature grads; global average pool with uniform segments).  Deterministic AND unquantised: a fixed-order
+// two-stage reduction (round 3; it replaces the 64-bit fixed-point atomics of round 2, whose 2^-30 absolute quantum was
+// coarser than fp32 for small gradient partials, flushed |partials| < 4.7e-10 to zero and wrapped past 8.6e9).
+//   stage 1: grid = (column groups of 64 lanes x V columns) x (chunks of 128 rows).  A workgroup walks the segments
+//            that intersect its chunk in order; per piece its 4 wavefronts stride the rows (lane = V columns, one 16-byte
+//            load per row), combine through LDS in a fixed order and store ONE fp32 partial per column into the chunk's
+//            slot: `first` (the first segment that intersects the chunk), `last` (the last one, if different), or -- for a
+//            segment that lies wholly inside the chunk -- the segment's own `direct` row.  No atomics.
+//   stage 2: thread per (segment, column) adds the slots of the chunks the segment spans in chunk order (fp64
+//            accumulator), applies the scale and stores / accumulates.
+// Same input -> same bits, whatever the launch timing; NaN / Inf propagate as in any fp32 sum.
+// Workspace (caller-owned, fp32): [2 * chunks + G][N]  (first | last | direct).
 // ---------------------------------------------------------------------------------
+constexpr int CS_RC = 128;  // rows per chunk
+
+struct SegView {
+  const int* seg;
+  int G, uniform_rows, M;
+  __device__ __forceinline__ int at(int i) const { return seg ? seg[i] : min(i * uniform_rows, M); }
+  // segment that contains row x (seg[0] <= x < seg[G]): skips empty segments
+  __device__ __forceinline__ int containing(int x) const {
+    if (!seg) return x / uniform_rows;
+    int lo = 0, hi = G;  // invariant: seg[lo] <= x < seg[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (seg[mid] <= x) lo = mid; else hi = mid;
+    }
+    return lo;
+  }
+  // first / last segment intersecting rows [r0, r1); false if none
+  __device__ __forceinline__ bool span(int r0, int r1, int& gf, int& gl) const {
+    const int a = max(r0, at(0)), b = min(r1, at(G));
+    if (a >= b) return false;
+    gf = containing(a);
+    gl = containing(b - 1);
+    return true;
+  }
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, long long ld,
-                                                             const int* __restrict__ seg, int G, int uniform_rows,
-                                                             int M, int N, unsigned long long* __restrict__ ws) {
-  constexpr int RC = 128;            // rows per workgroup
+__global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict__ x, long long ld, const SegView sv, int N,
+                                                             int chunks, float* __restrict__ ws) {
   constexpr int V = 16 / sizeof(T);  // columns per lane: one 16-B load per row
   __shared__ float part[3][64][V + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n0 = (blockIdx.x * 64 + lane) * V;
-  const int r0 = blockIdx.y * RC, r1 = min(r0 + RC, M);
+  const int c = blockIdx.y;
+  const int r0 = c * CS_RC, r1 = min(r0 + CS_RC, sv.M);
   const bool col_ok = n0 < N;
   const bool vec = (n0 + V <= N) && ((ld * sizeof(T)) % 16 == 0) && (((uintptr_t)x & 15) == 0);
-  auto seg_of = [&](int row) {
-    if (!seg) return row / uniform_rows;
-    int lo = 0, hi = G;  // largest g with seg[g] <= row
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (seg[mid] <= row) lo = mid; else hi = mid;
-    }
-    return lo;
-  };
-  const int g_first = seg_of(r0), g_last = seg_of(r1 - 1);
-  const bool one_seg = g_first == g_last && (!seg || (r0 >= seg[g_first] && r1 <= seg[g_first + 1]));
-  int g = one_seg ? g_first : seg_of(min(r0 + wave, r1 - 1));
-  float acc[V];
-#pragma unroll
-  for (int j = 0; j < V; ++j) acc[j] = 0.f;
-  // Partial sums meet in 64-bit FIXED-POINT cells (2^-30 units): integer addition is associative, so the result does
-  // not depend on the order in which the workgroups' atomics land -- run-to-run bit-identical sums (with fp32 atomics
-  // the last bits of the pooled statistics, and through them near-tied mining scores, changed with the timing of a
-  // cold first iteration).  Range +-8.6e9, resolution 9.3e-10: finer than fp32 for any sum above 0.016.
-  auto flush = [&](int gg) {
-#pragma unroll
-    for (int j = 0; j < V; ++j)
-      if (n0 + j < N && acc[j] != 0.f)
-        atomicAdd(ws + (long long)gg * N + n0 + j, (unsigned long long)__double2ll_rn((double)acc[j] * 1073741824.0));
+  int gf, gl;
+  if (!sv.span(r0, r1, gf, gl)) return;
+  for (int g = gf; g <= gl; ++g) {
+    const int a = max(r0, sv.at(g)), b = min(r1, sv.at(g + 1));
+    if (a >= b) continue;  // empty segment
+    float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
-  };
-  if (col_ok)
-    for (int m = r0 + wave; m < r1; m += 4) {
-      if (!one_seg) {
-        int gm = g;
-        if (!seg) gm = m / uniform_rows;
-        else while (gm + 1 < G && m >= seg[gm + 1]) ++gm;
-        if (gm != g) {
-          flush(g);
-          g = gm;
+    if (col_ok)
+      for (int m = a + wave; m < b; m += 4) {
+        const T* row = x + (long long)m * ld + n0;
+        if (vec) {
+          const uint4 raw = *(const uint4*)row;
+          const T* e = (const T*)&raw;
+#pragma unroll
+          for (int j = 0; j < V; ++j) acc[j] += to_f32(e[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+            if (n0 + j < N) acc[j] += to_f32(row[j]);
         }
-        if (seg && (m < seg[g] || m >= seg[g + 1])) continue;  // rows outside every segment
       }
-      const T* row = x + (long long)m * ld + n0;
-      if (vec) {
-        const uint4 raw = *(const uint4*)row;
-        const T* e = (const T*)&raw;
+    if (wave > 0) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) acc[j] += to_f32(e[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < V; ++j)
-          if (n0 + j < N) acc[j] += to_f32(row[j]);
-      }
+      for (int j = 0; j < V; ++j) part[wave - 1][lane][j] = acc[j];
     }
-  if (!one_seg) {  // chunk straddles a segment boundary (rare): per-wavefront atomics
-    if (col_ok) flush(g);
-    return;
-  }
-  // common case: combine the 4 wavefronts through LDS, ONE atomic per column per workgroup (atomics that
-  // all target the same few rows serialise at the memory side, so their count is what matters)
-  if (wave > 0) {
+    __syncthreads();
+    if (wave == 0 && col_ok) {
+      float* dst = g == gf ? ws + (long long)c * N : g == gl ? ws + (long long)(chunks + c) * N
+                                                             : ws + (long long)(2 * chunks + g) * N;
 #pragma unroll
-    for (int j = 0; j < V; ++j) part[wave - 1][lane][j] = acc[j];
+      for (int j = 0; j < V; ++j)
+        if (n0 + j < N) dst[n0 + j] = (acc[j] + part[0][lane][j]) + (part[1][lane][j] + part[2][lane][j]);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (wave == 0 && col_ok) {
-#pragma unroll
-    for (int j = 0; j < V; ++j) acc[j] += part[0][lane][j] + part[1][lane][j] + part[2][lane][j];
-    flush(g);
+}
+
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ ws, const SegView sv, int N,
+                                                              int chunks, float scale, float* __restrict__ out,
+                                                              long long ldo, int accumulate) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)sv.G * N) return;
+  const int g = (int)(i / N), n = (int)(i - (long long)g * N);
+  const int a = sv.at(g), b = sv.at(g + 1);
+  double sum = 0.0;
+  if (a < b) {
+    for (int c = a / CS_RC; c <= (b - 1) / CS_RC; ++c) {
+      int gf, gl;
+      sv.span(c * CS_RC, min((c + 1) * CS_RC, sv.M), gf, gl);  // intersects segment g, so it has a span
+      const float* src = g == gf ? ws + (long long)c * N : g == gl ? ws + (long long)(chunks + c) * N
+                                                                   : ws + (long long)(2 * chunks + g) * N;
+      sum += (double)src[n];
+    }
   }
+  const float v = (float)(sum * (double)scale);
+  float* o = out + (long long)g * ldo + n;
+  *o = accumulate ? *o + v : v;
 }
 
 // x *= num[0] / den[0]  (device scalars: upstream loss grad / normaliser; no host sync)
@@ -793,51 +816,34 @@ int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C
   return WSOVOD_OK;
 }
 
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const long long* __restrict__ ws, int G, int N, float scale,
-                                                              float* __restrict__ out, long long ldo, int accumulate) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long long)G * N) return;
-  const int g = (int)(i / N), n = (int)(i - (long long)g * N);
-  const float v = (float)((double)ws[i] * (1.0 / 1073741824.0)) * scale;
-  float* o = out + (long long)g * ldo + n;
-  *o = accumulate ? *o + v : v;
-}
-
 static int launch_colsum(const void* x, int dtype, long long ld, const int* seg, int G, int uniform_rows, int M, int N,
-                         float scale, float* out, long long ldo, int accumulate, hipStream_t s) {
-  // grow-only fixed-point workspace of this process (single-stream use, as the rest of the library)
-  static unsigned long long* ws = nullptr;
-  static size_t ws_cells = 0;
-  const size_t cells = (size_t)G * N;
-  if (cells > ws_cells) {
-    if (ws) (void)hipFree(ws);  // (hipFree synchronises the device: no launch still uses the old buffer)
-    ws = nullptr;
-    ws_cells = 0;
-    if (hipMalloc((void**)&ws, cells * sizeof(unsigned long long)) != hipSuccess) {
-      wsovod::set_error("segment_colsum: cannot allocate the fixed-point workspace");
-      return WSOVOD_ERR_HIP;
-    }
-    ws_cells = cells;
-  }
-  (void)hipMemsetAsync(ws, 0, cells * sizeof(unsigned long long), s);
-  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), ceil_div(M, 128));
+                         float scale, float* out, long long ldo, int accumulate, float* workspace, hipStream_t s) {
+  const int chunks = ceil_div(M, CS_RC);
+  SegView sv{seg, G, uniform_rows, M};
+  const dim3 grid(ceil_div(N, 64 * (dtype == WSOVOD_BF16 ? 8 : 4)), chunks);
   if (dtype == WSOVOD_BF16)
-    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, seg, G, uniform_rows, M, N, ws);
+    hipLaunchKernelGGL(segment_colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, sv, N, chunks, workspace);
   else
-    hipLaunchKernelGGL(segment_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, seg, G, uniform_rows, M, N, ws);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, (const long long*)ws, G, N,
-                     scale, out, ldo, accumulate);
+    hipLaunchKernelGGL(segment_colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, sv, N, chunks, workspace);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)(((size_t)G * N + 255) / 256)), dim3(256), 0, s,
+                     (const float*)workspace, sv, N, chunks, scale, out, ldo, accumulate);
   return 0;
 }
 
-int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out, wsovod_stream_t stream) {
+long long wsovod_colsum_workspace_floats(int G, int M, int N) {
+  return (2ll * ceil_div(std::max(M, 0), CS_RC) + std::max(G, 0)) * std::max(N, 0);
+}
+
+int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out, float* workspace,
+                               wsovod_stream_t stream) {
   WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_global_avgpool_nhwc: bad dtype");
   if (N == 0) return WSOVOD_OK;
-  WS_CHECK_ARG(in && out && HW > 0 && C > 0, "wsovod_global_avgpool_nhwc: bad argument");
+  WS_CHECK_ARG(in && out && workspace && HW > 0 && C > 0, "wsovod_global_avgpool_nhwc: bad argument");
+  WS_CHECK_ARG((long long)N * HW < (1ll << 31), "wsovod_global_avgpool_nhwc: more than 2^31 pixels");
   static int slot = wsovod::prof_slot("gap_nhwc");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)N * HW * C * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
-  if (launch_colsum(in, dtype, C, nullptr, N, HW, N * HW, C, 1.0f / (float)HW, out, C, 0, s) != 0) return WSOVOD_ERR_HIP;
+  if (launch_colsum(in, dtype, C, nullptr, N, HW, N * HW, C, 1.0f / (float)HW, out, C, 0, workspace, s) != 0) return WSOVOD_ERR_HIP;
   WS_CHECK_LAUNCH("wsovod_global_avgpool_nhwc");
   return WSOVOD_OK;
 }
@@ -928,15 +934,15 @@ int wsovod_row_l2norm_backward(const void* z, int dtype, long long ldz, const fl
 }
 
 int wsovod_segment_colsum(const void* x, int dtype, long long ld, const int* seg_offsets, int G, int M, int N,
-                          float* out, long long ldo, int accumulate, wsovod_stream_t stream) {
+                          float* out, long long ldo, int accumulate, float* workspace, wsovod_stream_t stream) {
   if (G == 0 || N == 0) return WSOVOD_OK;
-  WS_CHECK_ARG(x && out && seg_offsets, "wsovod_segment_colsum: null pointer");
+  WS_CHECK_ARG(x && out && seg_offsets && (workspace || M == 0), "wsovod_segment_colsum: null pointer");
   WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_segment_colsum: bad dtype");
   static int slot = wsovod::prof_slot("segment_colsum");
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 2.0 : 4.0));
   if (M > 0) {
-    if (launch_colsum(x, dtype, ld, seg_offsets, G, 0, M, N, 1.0f, out, ldo, accumulate, s) != 0) return WSOVOD_ERR_HIP;
+    if (launch_colsum(x, dtype, ld, seg_offsets, G, 0, M, N, 1.0f, out, ldo, accumulate, workspace, s) != 0) return WSOVOD_ERR_HIP;
   }
   else if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)G * ldo, s);
   WS_CHECK_LAUNCH("wsovod_segment_colsum");

@@ -416,12 +416,19 @@ def maxpool2x2_nhwc(x, stride, zero_pad_br=False):
     return out
 
 
+def _colsum_workspace(G, M, N, device):
+    """fp32 scratch of the two-stage column sums (one partial per 128-row chunk and column): allocated per call from
+    torch's caching allocator, so it belongs to the calling stream like any other temporary."""
+    return torch.empty((max(1, int(lib().wsovod_colsum_workspace_floats(G, M, N))),), dtype=torch.float32, device=device)
+
+
 def global_avgpool_nhwc(x):
     """x: (N,H,W,C) contiguous -> (N,C) fp32."""
     require_gpu(x)
     N, H, W, Cc = x.shape
     out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
-    check(lib().wsovod_global_avgpool_nhwc(ptr(x), dtype_code(x.dtype), N, H * W, Cc, ptr(out), stream()), "gap")
+    ws = _colsum_workspace(N, N * H * W, Cc, x.device)
+    check(lib().wsovod_global_avgpool_nhwc(ptr(x), dtype_code(x.dtype), N, H * W, Cc, ptr(out), ptr(ws), stream()), "gap")
     return out
 
 
@@ -474,8 +481,9 @@ def segment_colsum(x, seg_offsets, out=None, accumulate=False):
     G = seg_offsets.numel() - 1
     if out is None:
         out = torch.empty((G, N), dtype=torch.float32, device=x.device)
+    ws = _colsum_workspace(G, M, N, x.device)
     check(lib().wsovod_segment_colsum(ptr(x), dtype_code(x.dtype), _ld(x), ptr(seg_offsets), G, M, N, ptr(out),
-                                      _ld(out), int(accumulate), stream()), "segment_colsum")
+                                      _ld(out), int(accumulate), ptr(ws), stream()), "segment_colsum")
     return out
 
 
