@@ -35,7 +35,15 @@ typedef enum {
   WSOVOD_ERR_UNSUPPORTED = 3
 } wsovod_status;
 
-typedef enum { WSOVOD_F32 = 0, WSOVOD_BF16 = 1 } wsovod_dtype;
+/* WSOVOD_BF16X2 ("bf16x2", MODEL.HIP.PRECISION = "parity"): an fp32-grade value stored as a PAIR of bf16 numbers,
+ * hi = bf16(x) and lo = bf16(x - hi) (x = hi + lo up to 2^-17 |x|), in the 4 bytes an fp32 element would take.  A row of
+ * K values (K a multiple of 32) is laid out in groups of 32: element k = 32 g + j has its hi at bf16 index 64 g + j and
+ * its lo at 64 g + 32 + j, so every 128-byte line holds the hi AND the lo halves of 32 consecutive elements and a
+ * contraction kernel stages a bf16x2 operand exactly like a bf16 operand of twice the length.  Leading dimensions of
+ * bf16x2 operands are counted in VALUES (4-byte slots), as for fp32.  A contraction over bf16x2 operands evaluates
+ * sum_k (ah*bh + ah*bl + al*bh) on the bf16 MFMA pipe with fp32 accumulation: relative error ~2^-16 per product
+ * instead of bf16's 2^-8 -- the precision the north star's 1e-3 logit bound needs. */
+typedef enum { WSOVOD_F32 = 0, WSOVOD_BF16 = 1, WSOVOD_BF16X2 = 2 } wsovod_dtype;
 /* Feature-map layout.  NCHW is the reference's layout; NHWC is what the HIP backbone
  * produces (torch.channels_last memory format on the Python side). */
 typedef enum { WSOVOD_NCHW = 0, WSOVOD_NHWC = 1 } wsovod_layout;
@@ -325,6 +333,11 @@ int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, cons
  * that meet by fp32 atomic adds, so that it fills the chip; the summation order of those tiles is then not fixed. */
 int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, int Mred, int NI, int NJ, float* C,
                    long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
+/* The same with Q in `q_dtype` = WSOVOD_BF16 or WSOVOD_BF16X2 (ldq in values): of a bf16x2 Q only the hi halves are read,
+ * i.e. Q is taken rounded to bf16 exactly as a cast would -- the bf16 weight gradient of the "parity" precision from the
+ * activations its forward pass left in bf16x2, without a cast pass. */
+int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
+                      float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
 
 /* Greedy non-maximum suppression over G independent segments of boxes that are already sorted by
  * descending score inside each segment.  Replaces torchvision.ops.nms / batched_nms (un-vendored; SURVEY
@@ -422,6 +435,24 @@ int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long lo
 int wsovod_mask_transpose_colsum(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype,
                                  int M, int N, float scale, void* dA, long long ldda, void* dAt, long long ldt,
                                  int out_dtype, float* colsum, wsovod_stream_t stream);
+/* General form: dy in `dy_dtype` (fp32 / bf16), the mask source y in `y_dtype` = dy_dtype or WSOVOD_BF16X2 (the layer's
+ * own output as the "parity" forward pass left it; ldy in values), colsum optional (NULL = none). */
+int wsovod_mask_transpose_ex(const void* dy, long long lddy, int dy_dtype, const void* y, long long ldy, int y_dtype, int M,
+                             int N, float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
+                             float* colsum, wsovod_stream_t stream);
+/* fp32 (rows, cols; row stride ld_src) <-> bf16x2 (row stride ld_dst / ld_src in values), cols a multiple of 32.  Weights
+ * are encoded once per optimizer step; activations are produced in bf16x2 by the kernels themselves
+ * (wsovod_gemm_nt with dtype_c = WSOVOD_BF16X2, wsovod_roi_pool_forward / wsovod_roi_align_forward with out_dtype =
+ * WSOVOD_BF16X2, wsovod_stem_conv1_x2, wsovod_maxpool2x2_nhwc / wsovod_add_group_rows with dtype = WSOVOD_BF16X2). */
+int wsovod_bf16x2_encode(const float* src, long long ld_src, int rows, int cols, void* dst, long long ld_dst,
+                         wsovod_stream_t stream);
+int wsovod_bf16x2_decode(const void* src, long long ld_src, int rows, int cols, float* dst, long long ld_dst,
+                         wsovod_stream_t stream);
+/* wsovod_stem_conv1 for the "parity" precision: w32x2 = the bf16x2 encoding of the folded (64, 32) fp32 weight, out =
+ * (N, Ho, Wo, 64) bf16x2 NHWC; the normalised image is split into hi / lo in LDS and every product is the three-MFMA
+ * sum w_hi*a_hi + w_lo*a_hi + w_hi*a_lo (resnet_wsl.py:375-383,410-413; rcnn_wsovod.py:321-328). */
+int wsovod_stem_conv1_x2(const unsigned char* img, const int* sizes, const float* mean_host, const float* std_host, int N,
+                         int Hp, int Wp, const void* w32x2, const float* bias, void* out, wsovod_stream_t stream);
 /* out[m][:] = x[m][:] + add[row_group[m]][:]  (box_features += data_aware_features,
  * roi_heads.py:762-763, without materialising the per-proposal repeat). */
 int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* row_group, const float* add,

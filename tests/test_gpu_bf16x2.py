@@ -1,0 +1,222 @@
+"""-m gpu: the bf16x2 activation format (include/wsovod_hip.h: WSOVOD_BF16X2; MODEL.HIP.PRECISION = "parity") kernel
+by kernel against fp64 / the C oracle.  A bf16x2 value is hi + lo with hi = bf16(x), lo = bf16(x - hi): ~16 significant
+bits, and a contraction over two such operands is three bf16 MFMA products with fp32 accumulation -- expected error
+~2^-16 per product, i.e. ~1e-5 relative to sum |a||b|, against bf16's ~4e-3."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _enc_ref(x):
+    """host model of the encoding: (hi, lo) as float tensors."""
+    hi = x.to(torch.bfloat16).float()
+    lo = (x - hi).to(torch.bfloat16).float()
+    return hi, lo
+
+
+def test_encode_decode_round_trip_and_layout(gpu):
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(0)
+    x = torch.randn(37, 96) * torch.logspace(-6, 6, 96)[None]
+    x[3, 5], x[4, 6], x[5, 7] = float("inf"), float("-inf"), 0.0
+    enc = H.x2_encode(x.to(gpu))
+    dec = H.x2_decode(enc).cpu()
+    hi, lo = _enc_ref(x)
+    fin = torch.isfinite(x)
+    assert torch.equal(dec[fin], (hi + lo)[fin])  # decode = hi + lo exactly
+    assert torch.equal(dec[~fin], x[~fin])  # an infinite value stays infinite
+    assert float(((dec - x).abs() / x.abs().clamp(min=1e-30))[fin].max()) < 2.0 ** -15
+    # layout: groups of 32 values as [32 hi | 32 lo] bf16 slots
+    raw = enc.view(torch.bfloat16).view(37, 3, 2, 32).float().cpu()
+    assert torch.equal(raw[:, :, 0, :].reshape(37, 96)[fin], hi[fin])
+    assert torch.equal(raw[:, :, 1, :].reshape(37, 96)[fin], lo[fin])
+    nan = torch.full((1, 32), float("nan"))
+    assert torch.isnan(H.x2_decode(H.x2_encode(nan.to(gpu)))).all()
+
+
+@pytest.mark.parametrize("tile", [0, 8256256, 256256, 256128, 1256064, 1128064, 1128128, 64064])
+@pytest.mark.parametrize("shape", [(512, 512, 1024), (300, 40, 256), (333, 129, 192), (64, 4, 4096), (1024, 4096, 512)])
+def test_gemm_x2_against_fp64(gpu, tile, shape):
+    """fp32-grade products on the bf16 MFMA pipe: error ~1e-5 of sum |a||b| (plain bf16: ~4e-3)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    M, N, K = shape
+    torch.manual_seed(1)
+    A, B = torch.randn(M, K), torch.randn(N, K)
+    out = H.gemm_nt(H.x2_encode(A.to(gpu)), H.x2_encode(B.to(gpu)), x2=True, out_dtype=torch.float32, tile_hint=tile)
+    ref = A.double() @ B.double().t()
+    scale = A.double().abs() @ B.double().abs().t()
+    err = float(((out.cpu().double() - ref).abs() / scale).max())
+    assert err < 3e-5, err
+    # the value computed is exactly the three-product form on the encoded operands (fp32 accumulation)
+    (ah, al), (bh, bl) = _enc_ref(A), _enc_ref(B)
+    model = (ah.double() @ bh.double().t()) + (ah.double() @ bl.double().t()) + (al.double() @ bh.double().t())
+    assert float(((out.cpu().double() - model).abs() / scale).max()) < 2e-6
+
+
+def test_gemm_x2_epilogue_and_x2_output(gpu):
+    from wsovod_amd.layers import hip_ops as H
+
+    M, N, K = 520, 256, 320
+    torch.manual_seed(2)
+    A, B, bias, res = torch.randn(M, K), torch.randn(N, K) * 0.1, torch.randn(N), torch.randn(M, N)
+    grp = torch.randint(0, 3, (M,), dtype=torch.int32)
+    ga = torch.randn(3, N)
+    ref = torch.relu((A.double() @ B.double().t()).float() + bias[None] + res)
+    a2, b2 = H.x2_encode(A.to(gpu)), H.x2_encode(B.to(gpu))
+    for tile in (0, 8256256, 128128):
+        out = H.gemm_nt(a2, b2, x2=True, out_dtype=H.X2, bias=bias.to(gpu), residual=H.x2_encode(res.to(gpu)),
+                        residual_x2=True, relu=True, tile_hint=tile)
+        got = H.x2_decode(out).cpu()
+        torch.testing.assert_close(got, ref, rtol=3e-5, atol=3e-4)
+        # slow epilogue path (group_add) with a bf16x2 output, fp32 residual
+        out = H.gemm_nt(a2, b2, x2=True, out_dtype=H.X2, bias=bias.to(gpu), residual=res.to(gpu), relu=True,
+                        row_group=grp.to(gpu), group_add=ga.to(gpu), tile_hint=tile)
+        torch.testing.assert_close(H.x2_decode(out).cpu(), ref + ga[grp.long()], rtol=3e-5, atol=3e-4)
+    # dropout: the same counter-based mask as the bf16 / fp32 kernels
+    y0 = H.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, dropout_p=0.5, dropout_seed=77)
+    y1 = H.x2_decode(H.gemm_nt(a2, b2, x2=True, out_dtype=H.X2, dropout_p=0.5, dropout_seed=77))
+    assert torch.equal(y0 == 0, y1 == 0)
+    with pytest.raises(RuntimeError, match="multiples of 32"):
+        H.gemm_nt(a2, H.x2_encode(B[:40].to(gpu)), x2=True, out_dtype=H.X2)
+
+
+@pytest.mark.parametrize("geom", [
+    dict(n=2, H=20, W=28, Cin=64, Cout=64, k=3, s=1, p=1, d=1),
+    dict(n=2, H=19, W=25, Cin=128, Cout=256, k=3, s=1, p=2, d=2),
+    dict(n=1, H=16, W=16, Cin=256, Cout=512, k=1, s=1, p=0, d=1),
+    dict(n=3, H=33, W=21, Cin=64, Cout=128, k=3, s=1, p=1, d=1),
+])
+@pytest.mark.parametrize("tile", [0, 256256, 8256256, 1256064])
+def test_conv_x2_against_fp64(gpu, geom, tile):
+    from wsovod_amd.layers import hip_ops as H
+
+    g = geom
+    if tile == 1256064 and g["Cout"] > 64:
+        pytest.skip("the tall 64-column tile is for 64 output channels")
+    torch.manual_seed(3)
+    x = torch.randn(g["n"], g["Cin"], g["H"], g["W"])
+    w = torch.randn(g["Cout"], g["Cin"], g["k"], g["k"]) * 0.05
+    b = torch.randn(g["Cout"])
+    ref = torch.relu(F.conv2d(x.double(), w.double(), b.double(), g["s"], g["p"], g["d"])).float()
+    Ho, Wo = ref.shape[-2:]
+    xn = H.x2_encode(x.permute(0, 2, 3, 1).reshape(-1, g["Cin"]).contiguous().to(gpu)).view(g["n"], g["H"], g["W"], g["Cin"])
+    wq = H.x2_encode(w.permute(0, 2, 3, 1).reshape(g["Cout"], -1).contiguous().to(gpu))
+    conv = dict(n_img=g["n"], H=g["H"], W=g["W"], Cin=g["Cin"], Ho=Ho, Wo=Wo, KH=g["k"], KW=g["k"], stride=g["s"],
+                pad=g["p"], dil=g["d"])
+    out = H.gemm_nt(xn, wq, conv=conv, x2=True, bias=b.to(gpu), relu=True, out_dtype=H.X2, tile_hint=tile)
+    got = H.x2_decode(out).view(g["n"], Ho, Wo, g["Cout"]).permute(0, 3, 1, 2).cpu()
+    scale = float(F.conv2d(x.abs().double(), w.abs().double(), None, g["s"], g["p"], g["d"]).max())
+    assert float((got - ref).abs().max()) < 3e-5 * scale
+    out32 = H.gemm_nt(xn, wq, conv=conv, x2=True, bias=b.to(gpu), relu=True, out_dtype=torch.float32, tile_hint=tile)
+    assert float((out32.view(g["n"], Ho, Wo, g["Cout"]).permute(0, 3, 1, 2).cpu() - ref).abs().max()) < 3e-5 * scale
+
+
+def test_conv_x2_with_fused_projection_shortcut(gpu):
+    """out = relu(conv3x3(h) + shortcut1x1(x)) as ONE implicit GEMM on bf16x2 operands (wsovod_gemm_desc.A2)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(4)
+    n, Hh, Ww, C1, C2, Co = 2, 18, 22, 128, 64, 128
+    h, x = torch.randn(n, C1, Hh, Ww), torch.randn(n, C2, Hh, Ww)
+    w, ws, b = torch.randn(Co, C1, 3, 3) * 0.05, torch.randn(Co, C2, 1, 1) * 0.1, torch.randn(Co)
+    ref = torch.relu(F.conv2d(h.double(), w.double(), b.double(), 1, 2, 2) + F.conv2d(x.double(), ws.double())).float()
+    enc = lambda t, c: H.x2_encode(t.permute(0, 2, 3, 1).reshape(-1, c).contiguous().to(gpu)).view(n, Hh, Ww, c)
+    wcat = torch.cat([w.permute(0, 2, 3, 1).reshape(Co, -1), ws.reshape(Co, C2)], dim=1).contiguous()
+    conv = dict(n_img=n, H=Hh, W=Ww, Cin=C1, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=2, dil=2)
+    out = H.gemm_nt(enc(h, C1), H.x2_encode(wcat.to(gpu)), conv=conv, x2=True, bias=b.to(gpu), relu=True,
+                    out_dtype=H.X2, A2=enc(x, C2))
+    got = H.x2_decode(out).view(n, Hh, Ww, Co).permute(0, 3, 1, 2).cpu()
+    assert float((got - ref).abs().max()) < 3e-4
+
+
+def test_maxpool_add_group_rows_and_mask_on_x2(gpu):
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(5)
+    x = torch.randn(2, 9, 11, 64)
+    xe = H.x2_encode(x.view(-1, 64).to(gpu)).view(2, 9, 11, 64)
+    xv = H.x2_decode(xe.view(-1, 64)).view(2, 9, 11, 64).cpu()  # the values the map really holds
+    for stride, pad in ((2, False), (1, True)):
+        got = H.maxpool2x2_nhwc(xe, stride, zero_pad_br=pad, x2=True)
+        src = xv.permute(0, 3, 1, 2)
+        if pad:
+            src = F.pad(src, (0, 1, 0, 1))
+        want = F.max_pool2d(src, 2, stride).permute(0, 2, 3, 1)
+        assert torch.equal(H.x2_decode(got.view(-1, 64)).view(want.shape).cpu(), want)
+    M, N = 77, 96
+    a = torch.randn(M, N)
+    grp = torch.randint(0, 4, (M,), dtype=torch.int32)
+    add = torch.randn(4, N)
+    ae = H.x2_encode(a.to(gpu))
+    got = H.x2_decode(H.add_group_rows(ae, grp.to(gpu), add.to(gpu), x2=True)).cpu()
+    torch.testing.assert_close(got, H.x2_decode(ae).cpu() + add[grp.long()], rtol=2e-5, atol=1e-6)
+    # backward mask from a bf16x2 layer output: identical to the mask of its fp32 values
+    y = torch.relu(torch.randn(M, N))
+    dy = torch.randn(M, N)
+    cs = torch.zeros(N, device=gpu)
+    dA, dAt = H.mask_transpose(dy.to(gpu), H.x2_encode(y.to(gpu)), 2.0, torch.bfloat16, want_plain=True, want_t=True, ld_t=128,
+                               colsum=cs, y_x2=True)
+    want = torch.where(y > 0, dy * 2.0, torch.zeros(()))
+    assert torch.equal(dA.float().cpu(), want.to(torch.bfloat16).float())
+    assert torch.equal(dAt.float().cpu()[:, :M], want.to(torch.bfloat16).float().t())
+    torch.testing.assert_close(cs.cpu(), want.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_tn_reads_the_hi_halves_of_a_bf16x2_operand(gpu):
+    """dW = dY^T X with X as the parity forward left it (bf16x2): bit-identical to the contraction on bf16(X)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(6)
+    Mred, NI, NJ = 1000, 256, 512
+    P = torch.randn(Mred, NI).to(torch.bfloat16).to(gpu)
+    X = torch.randn(Mred, NJ).to(gpu)
+    want = H.gemm_tn(P, X.to(torch.bfloat16), split_tail=False)
+    got = H.gemm_tn(P, H.x2_encode(X), split_tail=False, q_x2=True)
+    assert torch.equal(got, want)
+
+
+def test_roi_pool_and_align_emit_bf16x2(gpu):
+    from tests.util import random_rois
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(7)
+    n, Cc, Hh, Ww = 2, 512, 38, 50
+    feat = torch.randn(n, Hh, Ww, Cc).to(gpu).permute(0, 3, 1, 2)  # fp32 NHWC storage
+    rois = random_rois(96, n, 300, 400, seed=8).to(gpu)
+    scale = (torch.rand(96) + 1).to(gpu)
+    want = H.roi_pool_forward(feat, rois, 0.125, (7, 7), roi_scale=scale, need_argmax=False)[0]
+    got = H.roi_pool_forward(feat, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=H.X2, need_argmax=False)[0]
+    dec = H.x2_decode(got.view(96, -1)).view_as(want)
+    assert float(((dec - want).abs() / want.abs().clamp(min=1e-20)).max()) < 2.0 ** -15  # the fp32 pool, re-encoded
+    want = H.roi_align_forward(feat, rois, 0.125, (7, 7), 0, True, roi_scale=scale)
+    got = H.roi_align_forward(feat, rois, 0.125, (7, 7), 0, True, roi_scale=scale, out_dtype=H.X2)
+    dec = H.x2_decode(got.view(96, -1)).view_as(want)
+    assert float(((dec - want).abs() / want.abs().clamp(min=1e-20)).max()) < 2.0 ** -15
+
+
+def test_stem_conv1_x2_against_fp64(gpu):
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(9)
+    N, Hp, Wp = 2, 37, 45
+    img = torch.randint(0, 256, (N, 3, Hp, Wp), dtype=torch.uint8)
+    sizes = torch.tensor([[37, 45], [30, 41]], dtype=torch.int32)
+    mean, std = [102.9801, 115.9465, 122.7717], [1.0, 1.0, 1.0]
+    w = torch.randn(64, 3, 3, 3) * 0.02
+    b = torch.randn(64)
+    x = img.double()
+    for i in range(N):  # zero AFTER normalisation outside each image's own size
+        x[i] = (x[i] - torch.tensor(mean).view(3, 1, 1).double())
+        x[i, :, sizes[i, 0]:, :] = 0
+        x[i, :, :, sizes[i, 1]:] = 0
+    ref = torch.relu(F.conv2d(x, w.double(), b.double(), stride=2, padding=1)).float()
+    w32 = torch.zeros(64, 32)
+    w32[:, :27] = w.permute(0, 2, 3, 1).reshape(64, 27)  # k = (r*3+q)*3 + c
+    out = H.stem_conv1_x2(img.to(gpu), sizes.to(gpu), mean, std, H.x2_encode(w32.to(gpu)), b.to(gpu))
+    got = H.x2_decode(out.view(-1, 64)).view(N, ref.shape[2], ref.shape[3], 64).permute(0, 3, 1, 2).cpu()
+    scale = float(F.conv2d(x.abs(), w.abs().double(), None, stride=2, padding=1).max())
+    assert float((got - ref).abs().max()) < 3e-5 * scale

@@ -13,7 +13,7 @@ import torch  # must be imported first: the library resolves libamdhip64.so.7 to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwsovod_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X2 = 0, 1, 2  # wsovod_dtype (bf16x2: include/wsovod_hip.h)
 NCHW, NHWC = 0, 1
 
 
@@ -98,6 +98,11 @@ SIGNATURES = {
     "wsovod_sum_shards_bf16": [_P, _I, _L, _P, _P],
     "wsovod_format_rois": [_P, _P, _I, _I, _P, _P, _P, _P],
     "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
+    "wsovod_gemm_tn_ex": [_P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _F, _I, _P],
+    "wsovod_mask_transpose_ex": [_P, _L, _I, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P, _P],
+    "wsovod_bf16x2_encode": [_P, _L, _I, _I, _P, _L, _P],
+    "wsovod_bf16x2_decode": [_P, _L, _I, _I, _P, _L, _P],
+    "wsovod_stem_conv1_x2": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "wsovod_nms_segments": [_P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _P],
     "wsovod_rpn_label_anchors": [_P, _I, _P, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P, _P],
     "wsovod_im2col_rows": [_P, _I, _P, _I] + [_I] * 10 + [_P, _P],

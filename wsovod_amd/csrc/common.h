@@ -27,6 +27,11 @@ struct ProfScope {
   ~ProfScope();
 };
 
+// bf16x2 forms of elementwise entry points (bf16x2.hip), reached through the dtype argument of the public functions
+int x2_maxpool2x2(const void* in, int N, int H, int W, int C, int Ho, int Wo, int stride, int zero_pad, void* out, hipStream_t s);
+int x2_add_group_rows(const void* x, long long ldx, const int* row_group, const float* add, long long ld_add, int M, int N,
+                      void* out, long long ldo, hipStream_t s);
+
 }  // namespace wsovod
 
 #define WS_CHECK_ARG(cond, ...)                 \

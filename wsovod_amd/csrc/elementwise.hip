@@ -569,9 +569,11 @@ __global__ __launch_bounds__(256) void sum_shards_bf16_kernel(const bf16_t* __re
 // [M][N] (operand of the dX contraction) and transposed [N][ldt] (operand of the dW
 // contraction, reduction dim = proposals).  y == NULL means no mask.
 // ---------------------------------------------------------------------------------
-template <typename TI, typename TO>
+// Y_X2: y is a bf16x2 matrix (ldy in values); its hi halves decide the mask (hi = bf16(y) has y's sign and is zero only
+// where y is).
+template <typename TI, typename TO, typename TY = TI, bool Y_X2 = false>
 __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restrict__ dy, long long lddy,
-                                                             const TI* __restrict__ y, long long ldy, int M, int N,
+                                                             const TY* __restrict__ y, long long ldy, int M, int N,
                                                              float scale, TO* __restrict__ dA, long long ldda,
                                                              TO* __restrict__ dAt, long long ldt,
                                                              float* __restrict__ colsum) {
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restric
   const int tid = threadIdx.x;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   const bool dy_al = ((lddy * sizeof(TI)) % 16 == 0) && (((uintptr_t)dy & 15) == 0);
-  const bool y_al = y && ((ldy * sizeof(TI)) % 16 == 0) && (((uintptr_t)y & 15) == 0);
+  const bool y_al = y && (Y_X2 || (ldy * sizeof(TY)) % 16 == 0) && (((uintptr_t)y & 15) == 0);
   const bool da_al = dA && ((ldda * sizeof(TO)) % 16 == 0) && (((uintptr_t)dA & 15) == 0);
   const bool dt_al = dAt && ((ldt * sizeof(TO)) % 16 == 0) && (((uintptr_t)dAt & 15) == 0);
 #pragma unroll
@@ -594,7 +596,8 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const TI* __restric
       load8(dy + (long long)m * lddy + n, dy_al && full, N - n, v);
       if (y) {
         float yv[8];
-        load8(y + (long long)m * ldy + n, y_al && full, N - n, yv);
+        if constexpr (Y_X2) load8(y + 2 * (long long)m * ldy + ((n >> 5) << 6) + (n & 31), y_al && full, N - n, yv);
+        else load8(y + (long long)m * ldy + n, y_al && full, N - n, yv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = yv[j] > 0.f ? v[j] * scale : 0.f;
       } else {
@@ -688,15 +691,26 @@ extern "C" {
 
 static int mask_transpose_impl(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype, int M, int N,
                                float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
-                               float* colsum, wsovod_stream_t stream) {
+                               float* colsum, wsovod_stream_t stream, int y_dtype = -1) {
   if (M == 0 || N == 0) return WSOVOD_OK;
+  if (y_dtype < 0) y_dtype = in_dtype;
   WS_CHECK_ARG(dy && (dA || dAt || colsum), "wsovod_mask_transpose: null pointer");
   static int slot = wsovod::prof_slot("mask_transpose");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ceil_div(N, 64), ceil_div(M, 64));
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * 4.0 * 3);
 #define MT(TI, TO) hipLaunchKernelGGL((mask_transpose_kernel<TI, TO>), grid, dim3(256), 0, s, (const TI*)dy, lddy, (const TI*)y, ldy, M, N, scale, (TO*)dA, ldda, (TO*)dAt, ldt, colsum)
-  if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_F32) MT(float, float);
+  if (y && y_dtype == WSOVOD_BF16X2) {
+    WS_CHECK_ARG(in_dtype == WSOVOD_F32 && N % 8 == 0 && ldy % 4 == 0, "wsovod_mask_transpose: a bf16x2 y needs an fp32 dy and N a multiple of 8");
+#define MTX(TO) hipLaunchKernelGGL((mask_transpose_kernel<float, TO, bf16_t, true>), grid, dim3(256), 0, s, (const float*)dy, lddy, (const bf16_t*)y, ldy, M, N, scale, (TO*)dA, ldda, (TO*)dAt, ldt, colsum)
+    if (out_dtype == WSOVOD_F32) MTX(float);
+    else if (out_dtype == WSOVOD_BF16) MTX(bf16_t);
+    else { wsovod::set_error("wsovod_mask_transpose: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+#undef MTX
+  } else if (y && y_dtype != in_dtype) {
+    wsovod::set_error("wsovod_mask_transpose: y must have dy's dtype or be bf16x2");
+    return WSOVOD_ERR_INVALID_ARGUMENT;
+  } else if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_F32) MT(float, float);
   else if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_BF16) MT(float, bf16_t);
   else if (in_dtype == WSOVOD_BF16 && out_dtype == WSOVOD_BF16) MT(bf16_t, bf16_t);
   else if (in_dtype == WSOVOD_BF16 && out_dtype == WSOVOD_F32) MT(bf16_t, float);
@@ -719,6 +733,12 @@ int wsovod_mask_transpose_colsum(const void* dy, long long lddy, const void* y, 
   return mask_transpose_impl(dy, lddy, y, ldy, in_dtype, M, N, scale, dA, ldda, dAt, ldt, out_dtype, colsum, stream);
 }
 
+int wsovod_mask_transpose_ex(const void* dy, long long lddy, int dy_dtype, const void* y, long long ldy, int y_dtype, int M,
+                             int N, float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
+                             float* colsum, wsovod_stream_t stream) {
+  return mask_transpose_impl(dy, lddy, y, ldy, dy_dtype, M, N, scale, dA, ldda, dAt, ldt, out_dtype, colsum, stream, y_dtype);
+}
+
 int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* row_group, const float* add,
                           long long ld_add, int M, int N, void* out, long long ldo, wsovod_stream_t stream) {
   if (M == 0 || N == 0) return WSOVOD_OK;
@@ -727,7 +747,12 @@ int wsovod_add_group_rows(const void* x, long long ldx, int dtype, const int* ro
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)M * N * (dtype == WSOVOD_BF16 ? 4.0 : 8.0));
   const int grid = std::min(ceil_div(M, 8), 1 << 20);  // 8 rows per block step
-  if (dtype == WSOVOD_BF16)
+  if (dtype == WSOVOD_BF16X2) {
+    WS_CHECK_ARG(N % 32 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && ld_add % 4 == 0 &&
+                     (((uintptr_t)x | (uintptr_t)out | (uintptr_t)add) & 15) == 0,
+                 "wsovod_add_group_rows: bf16x2 rows need N a multiple of 32 and 16-byte aligned rows");
+    wsovod::x2_add_group_rows(x, ldx, row_group, add, ld_add, M, N, out, ldo, s);
+  } else if (dtype == WSOVOD_BF16)
     hipLaunchKernelGGL(add_group_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)x, ldx, row_group, add, ld_add, M, N, (bf16_t*)out, ldo);
   else if (dtype == WSOVOD_F32)
     hipLaunchKernelGGL(add_group_rows_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, ldx, row_group, add, ld_add, M, N, (float*)out, ldo);
@@ -793,9 +818,9 @@ int wsovod_stem_im2col(const unsigned char* img, const int* sizes, const float* 
 
 int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C, int stride, int zero_pad_br,
                            void* out, wsovod_stream_t stream) {
-  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_maxpool2x2_nhwc: bad dtype");
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16 || dtype == WSOVOD_BF16X2, "wsovod_maxpool2x2_nhwc: bad dtype");
   WS_CHECK_ARG(stride == 1 || stride == 2, "wsovod_maxpool2x2_nhwc: stride must be 1 or 2");
-  const int V = dtype == WSOVOD_BF16 ? 8 : 4;
+  const int V = dtype == WSOVOD_BF16 ? 8 : dtype == WSOVOD_BF16X2 ? 32 : 4;
   WS_CHECK_ARG(C % V == 0, "wsovod_maxpool2x2_nhwc: C=%d must be a multiple of %d", C, V);
   const int Hin = H + (zero_pad_br ? 1 : 0), Win = W + (zero_pad_br ? 1 : 0);
   const int Ho = (Hin - 2) / stride + 1, Wo = (Win - 2) / stride + 1;
@@ -806,7 +831,9 @@ int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C
   const long long total = (long long)N * Ho * Wo * (C / V);
   const double esz = dtype == WSOVOD_BF16 ? 2.0 : 4.0;
   wsovod::ProfScope prof(slot, s, 0.0, ((double)N * H * W * C + (double)N * Ho * Wo * C) * esz);
-  if (dtype == WSOVOD_BF16)
+  if (dtype == WSOVOD_BF16X2)
+    wsovod::x2_maxpool2x2(in, N, H, W, C, Ho, Wo, stride, zero_pad_br, out, s);
+  else if (dtype == WSOVOD_BF16)
     hipLaunchKernelGGL(maxpool2x2_nhwc_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16_t*)in,
                        N, H, W, C, Ho, Wo, stride, zero_pad_br, (bf16_t*)out);
   else

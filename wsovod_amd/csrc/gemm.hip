@@ -23,8 +23,12 @@
 
 namespace wsovod_gemm {
 
-template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
+// X3 (T = bf16 only): the operands are bf16x2 (include/wsovod_hip.h); the launcher hands them over as bf16 matrices of
+// twice the length (K, lda, ldb, Cin doubled), every 128-byte K-step row = [hi of 32 values | lo of the same 32], and a
+// K-step computes b_hi*a_hi + b_lo*a_hi + b_hi*a_lo from the two fragment reads the bf16 form makes (see gemm8.hip).
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p) {
+  static_assert(!X3 || (sizeof(T) == 2 && STAGES == 2), "X3 is a bf16, two-stage variant");
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BKE = Traits<T>::BKE;
   constexpr int NT = 64 * WM * WN;       // threads: WM x WN wavefronts
@@ -251,6 +255,44 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   auto compute = [&](int cur) {
     const char* cA = sA + cur * BM * 128 + (wm * (BM / WM)) * 128;
     const char* cB = sB + cur * BN * 128 + (wn * (BN / WN)) * 128;
+    if constexpr (X3) {
+      u32x4 ah[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = i * 16 + frow;
+        ah[i] = *(const u32x4*)(cA + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + frow;
+        bh[j] = *(const u32x4*)(cB + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+        bl[j] = *(const u32x4*)(cB + row * 128 + (((fq + 4) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]),
+                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {  // a_lo takes over a_hi's registers
+        const int row = i * 16 + frow;
+        ah[i] = *(const u32x4*)(cA + row * 128 + (((fq + 4) ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = fq + 4 * ks;
@@ -371,14 +413,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   // staging, so lane (frow, fq) holds, for row tile i, output row m = .. + frow and the 4*TN consecutive columns
   // n = ncol + 4*j + r: row-major outputs move as 16-byte stores, 16*TN contiguous elements per row and wavefront.
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const bool vec_c = p.C && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
-  const bool vec_r = !p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0);
+  const bool vec_c = p.C && (p.dtype_c == WSOVOD_BF16X2 ? vec4_ok(p.C, p.ldc, p.dtype_c)
+                                                        : (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0);
+  const bool vec_r = !p.residual || (p.dtype_r == WSOVOD_BF16X2 ? vec4_ok(p.residual, p.ldr, p.dtype_r)
+                                                                 : (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0);
   const int mrow = m0 + wm * (BM / WM) + frow;
   const int ncol = n0 + wn * (BN / WN) + 4 * TN * fq;
   // Fast path (bias / residual / ReLU / dropout, aligned row-major output, all tile columns in range): feature tests
   // hoisted out of the element loops, bias fetched once per column tile, residual and output as vector accesses.
   if (vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add && !p.mask_src &&
-      !p.accumulate && n0 + BN <= p.N && (TN % 2 == 0 || p.dtype_c == WSOVOD_F32)) {
+      !p.accumulate && n0 + BN <= p.N && (TN % 2 == 0 || p.dtype_c != WSOVOD_BF16)) {
     f32x4 b4[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) b4[j] = p.bias ? *(const f32x4*)(p.bias + ncol + 4 * j) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -393,14 +437,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         x[j] = acc[i][j] * p.alpha + b4[j];
-        if (has_res) {
-          if (p.dtype_r == WSOVOD_BF16) {
-            const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + ncol + 4 * j);
-            x[j] += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};
-          } else {
-            x[j] += *(const f32x4*)((const float*)p.residual + mm * p.ldr + ncol + 4 * j);
-          }
-        }
+        if (has_res) x[j] += load4_as_f32(p.residual, mm, p.ldr, ncol + 4 * j, p.dtype_r);
         x[j] = f32x4{fmaxf(x[j][0], lo), fmaxf(x[j][1], lo), fmaxf(x[j][2], lo), fmaxf(x[j][3], lo)};
         if (drop) {
           const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);
@@ -408,7 +445,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
           for (int r = 0; r < 4; ++r) x[j][r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;
         }
       }
-      if (p.dtype_c == WSOVOD_BF16) {
+      if (p.dtype_c == WSOVOD_BF16X2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) store4_from_f32(p.C, mm, p.ldc, ncol + 4 * j, WSOVOD_BF16X2, x[j]);
+      } else if (p.dtype_c == WSOVOD_BF16) {
 #pragma unroll
         for (int j = 0; j + 1 < TN; j += 2)
           *(bf16x8*)((bf16_t*)p.C + base + 4 * j) =
@@ -438,7 +478,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
         if (n < p.N) {
           if (p.row_scale) x *= rs;
           if (p.bias) x += p.bias[n];
-          if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+          if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
           if (p.relu) x = fmaxf(x, 0.f);
           if (p.dropout_p > 0.f) {
             const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
@@ -446,27 +486,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
           }
           if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
           if (p.mask_src)
-            x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+            x = load_as_f32(p.mask_src, m, p.ldm, n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
           if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
         }
         v[r] = x;
       }
       if (p.C) {
         if (vec_c && nb + 3 < p.N) {
-          if (p.dtype_c == WSOVOD_BF16)
-            *(bf16x4*)((bf16_t*)p.C + (long long)m * p.ldc + nb) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-          else
-            *(f32x4*)((float*)p.C + (long long)m * p.ldc + nb) = f32x4{v[0], v[1], v[2], v[3]};
+          store4_from_f32(p.C, m, p.ldc, nb, p.dtype_c, f32x4{v[0], v[1], v[2], v[3]});
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (nb + r < p.N) store_from_f32(p.C, (long long)m * p.ldc + nb + r, p.dtype_c, v[r]);
+            if (nb + r < p.N) store_from_f32(p.C, m, p.ldc, nb + r, p.dtype_c, v[r]);
         }
       }
       if (p.Ct) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nb + r < p.N) store_from_f32(p.Ct, (long long)(nb + r) * p.ldct + m, p.dtype_ct, v[r]);
+          if (nb + r < p.N) store_from_f32(p.Ct, nb + r, p.ldct, m, p.dtype_ct, v[r]);
       }
     }
   }
@@ -613,8 +650,8 @@ __device__ __forceinline__ void c64_epilogue(const GemmArgs& p, const f32x4 (&ac
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         float u = v[e] + (p.bias ? p.bias[n0c + e] : 0.f);
-        if (p.residual) u += load_as_f32(p.residual, m * p.ldr + n0c + e, p.dtype_r);
-        store_from_f32(p.C, m * p.ldc + n0c + e, p.dtype_c, fmaxf(u, lo));
+        if (p.residual) u += load_as_f32(p.residual, m, p.ldr, n0c + e, p.dtype_r);
+        store_from_f32(p.C, m, p.ldc, n0c + e, p.dtype_c, fmaxf(u, lo));
       }
     }
   }
@@ -931,12 +968,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 #undef C64P_LAST_STEP
 }
 
-template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2>
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
 int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
   static int slot = wsovod::prof_slot(slot_name);
   static bool attr_set = false;
   constexpr int lds_bytes = STAGES * (BM + BN) * 128;
-  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA, STAGES>;
+  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA, STAGES, X3>;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
@@ -1018,6 +1055,36 @@ int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, doub
   }
 }
 
+// bf16x2 operands (X3 kernels): the tiles the "parity" precision uses.  Slot names carry "bf16x2"; their FLOP figures
+// are the EXECUTED bf16 MFMA FLOPs (3 x 2 M N K of the layer).
+template <bool CONV>
+int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, double bytes) {
+  switch (tile) {
+    case 8256256:
+      return launch_gemm256_8ph(a, CONV, s, flops, bytes, false, true);
+    case 256256:
+      return launch<bf16_t, 256, 256, CONV, 4, 4, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x256" : "gemm_nt_bf16x2_256x256",
+                                                               flops, bytes);
+    case 256128:
+      return launch<bf16_t, 256, 128, CONV, 4, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x128" : "gemm_nt_bf16x2_256x128",
+                                                               flops, bytes);
+    case 1256064:
+      return launch<bf16_t, 256, 64, CONV, 4, 1, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x64" : "gemm_nt_bf16x2_256x64",
+                                                              flops, bytes);
+    case 1128064:
+      return launch<bf16_t, 128, 64, CONV, 2, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64" : "gemm_nt_bf16x2_128x64",
+                                                              flops, bytes);
+    case 1128128:
+    case 128128:
+      return launch<bf16_t, 128, 128, CONV, 2, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_128x128" : "gemm_nt_bf16x2_128x128",
+                                                               flops, bytes);
+    case 64064:
+    default:
+      return launch<bf16_t, 64, 64, CONV, 2, 2, false, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_64x64" : "gemm_nt_bf16x2_64x64",
+                                                              flops, bytes);
+  }
+}
+
 // Tile choice (measured on MI355X, tools/probe_kernels.py): the 256x256 LDS-direct tile moves 128 FLOP
 // per staged byte and wins whenever it still yields about one workgroup per CU; smaller problems
 // step down to tiles that keep the 256 CUs busy.
@@ -1040,17 +1107,21 @@ using namespace wsovod_gemm;
 
 extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream) {
   WS_CHECK_ARG(d != nullptr, "wsovod_gemm_nt: null descriptor");
-  WS_CHECK_ARG(d->dtype_in == WSOVOD_F32 || d->dtype_in == WSOVOD_BF16, "wsovod_gemm_nt: bad dtype_in %d", d->dtype_in);
+  WS_CHECK_ARG(d->dtype_in == WSOVOD_F32 || d->dtype_in == WSOVOD_BF16 || d->dtype_in == WSOVOD_BF16X2,
+               "wsovod_gemm_nt: bad dtype_in %d", d->dtype_in);
+  const bool x2 = d->dtype_in == WSOVOD_BF16X2;  // bf16x2 operands = bf16 matrices of twice the length for the kernels
   WS_CHECK_ARG(d->M >= 0 && d->N >= 0 && d->K >= 0, "wsovod_gemm_nt: negative dimension");
   if (d->M == 0 || d->N == 0) return WSOVOD_OK;
   WS_CHECK_ARG(d->A && d->B, "wsovod_gemm_nt: null operand");
   WS_CHECK_ARG(d->C || d->Ct, "wsovod_gemm_nt: no output");
-  const int esz = d->dtype_in == WSOVOD_BF16 ? 2 : 4;
-  const int epc = 16 / esz;
+  const int esz = d->dtype_in == WSOVOD_F32 ? 4 : 2;
+  const int epc = x2 ? 32 : 16 / esz;  // bf16x2: whole 32-value groups
+  const int xs = x2 ? 2 : 1;           // bf16 slots per value
   WS_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "wsovod_gemm_nt: A/B must be 16-byte aligned");
-  WS_CHECK_ARG(d->ldb % epc == 0, "wsovod_gemm_nt: ldb=%lld must be a multiple of %d elements", d->ldb, epc);
-  WS_CHECK_ARG(128ll * d->ldb * esz < (1ll << 31), "wsovod_gemm_nt: ldb too large for buffer addressing");
+  WS_CHECK_ARG(d->ldb % (x2 ? 4 : epc) == 0, "wsovod_gemm_nt: ldb=%lld: rows must be 16-byte aligned", d->ldb);
+  WS_CHECK_ARG(128ll * d->ldb * esz * xs < (1ll << 31), "wsovod_gemm_nt: ldb too large for buffer addressing");
   WS_CHECK_ARG(d->K % epc == 0, "wsovod_gemm_nt: K=%d must be a multiple of %d elements", d->K, epc);
+  WS_CHECK_ARG(!x2 || (d->dropout_p == 0.f || d->C), "wsovod_gemm_nt: bad bf16x2 call");
   WS_CHECK_ARG(!d->accumulate || (d->C && d->dtype_c == WSOVOD_F32), "wsovod_gemm_nt: accumulate needs an fp32 C");
   WS_CHECK_ARG(d->dropout_p >= 0.f && d->dropout_p < 1.f, "wsovod_gemm_nt: dropout_p must be in [0,1)");
   WS_CHECK_ARG(!d->group_add || d->row_group, "wsovod_gemm_nt: group_add needs row_group");
@@ -1059,11 +1130,11 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   memset(&a, 0, sizeof(a));
   a.A = (const char*)d->A;
   a.B = (const char*)d->B;
-  a.lda = d->lda;
-  a.ldb = d->ldb;
+  a.lda = d->lda * xs;
+  a.ldb = d->ldb * xs;
   a.M = d->M;
   a.N = d->N;
-  a.K = d->K;
+  a.K = d->K * xs;
   a.C = d->C;
   a.ldc = d->ldc;
   a.dtype_c = d->dtype_c;
@@ -1091,7 +1162,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   double bytes;
   if (d->conv) {
     const wsovod_conv_geom& g = d->geom;
-    const int bke = d->dtype_in == WSOVOD_BF16 ? 64 : 32;
+    const int bke = d->dtype_in == WSOVOD_BF16 ? 64 : 32;  // values per K-step (bf16x2: 32 values = 64 bf16 slots)
     WS_CHECK_ARG(g.Cin > 0 && g.Cin % bke == 0, "wsovod_gemm_nt(conv): Cin=%d must be a multiple of %d", g.Cin, bke);
     WS_CHECK_ARG(!d->A2 || (d->Cin2 > 0 && d->Cin2 % bke == 0 && ((uintptr_t)d->A2 & 15) == 0),
                  "wsovod_gemm_nt(conv): the fused shortcut input needs Cin2 (%d) a multiple of %d and 16-byte alignment", d->Cin2, bke);
@@ -1101,7 +1172,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     WS_CHECK_ARG(g.stride >= 1 && g.dil >= 1 && g.pad >= 0, "wsovod_gemm_nt(conv): bad stride/dil/pad");
     a.H = g.H;
     a.W = g.W;
-    a.Cin = g.Cin;
+    a.Cin = g.Cin * xs;
     a.Ho = g.Ho;
     a.Wo = g.Wo;
     a.KH = g.KH;
@@ -1110,23 +1181,28 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     a.pad = g.pad;
     a.dil = g.dil;
     a.pool = g.pool;
-    a.a_bytes = (long long)g.n_img * g.H * g.W * g.Cin * esz;
+    a.a_bytes = (long long)g.n_img * g.H * g.W * g.Cin * esz * xs;
     if (d->A2) {
       a.A2 = (const char*)d->A2;
-      a.Cin2 = d->Cin2;
-      a.a2_bytes = (long long)g.n_img * g.Ho * g.Wo * d->Cin2 * esz;
+      a.Cin2 = d->Cin2 * xs;
+      a.a2_bytes = (long long)g.n_img * g.Ho * g.Wo * d->Cin2 * esz * xs;
       WS_CHECK_ARG(a.a2_bytes < (1ll << 31), "wsovod_gemm_nt(conv): fused shortcut input exceeds the 2 GiB buffer-addressing limit");
       WS_CHECK_ARG(!(d->tile_hint == 8256256), "wsovod_gemm_nt(conv): the 8-phase tile has no fused-shortcut path");
     }
     WS_CHECK_ARG(a.a_bytes < (1ll << 31), "wsovod_gemm_nt(conv): input of %lld bytes exceeds the 2 GiB buffer-addressing limit", a.a_bytes);
-    bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K + (d->A2 ? (double)g.n_img * g.Ho * g.Wo * d->Cin2 : 0.0)) * esz;
+    bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K + (d->A2 ? (double)g.n_img * g.Ho * g.Wo * d->Cin2 : 0.0)) * esz * xs;
   } else {
-    WS_CHECK_ARG(d->lda % epc == 0, "wsovod_gemm_nt: lda=%lld must be a multiple of %d elements", d->lda, epc);
-    WS_CHECK_ARG(128ll * d->lda * esz < (1ll << 31), "wsovod_gemm_nt: lda too large for buffer addressing");
-    bytes = ((double)d->M * d->K + (double)d->N * d->K) * esz;
+    WS_CHECK_ARG(d->lda % (x2 ? 4 : epc) == 0, "wsovod_gemm_nt: lda=%lld: rows must be 16-byte aligned", d->lda);
+    WS_CHECK_ARG(128ll * d->lda * esz * xs < (1ll << 31), "wsovod_gemm_nt: lda too large for buffer addressing");
+    bytes = ((double)d->M * d->K + (double)d->N * d->K) * esz * xs;
   }
   bytes += (double)d->M * d->N * ((d->C ? (d->dtype_c == WSOVOD_BF16 ? 2 : 4) : 0) + (d->Ct ? (d->dtype_ct == WSOVOD_BF16 ? 2 : 4) : 0));
-  const double flops = 2.0 * d->M * d->N * d->K;
+  WS_CHECK_ARG((d->dtype_c != WSOVOD_BF16X2 || !d->C || (d->N % 32 == 0 && d->ldc % 32 == 0 && ((uintptr_t)d->C & 15) == 0)) &&
+                   d->dtype_ct != WSOVOD_BF16X2 && d->dtype_m != WSOVOD_BF16X2,
+               "wsovod_gemm_nt: a bf16x2 output needs N and ldc multiples of 32 (Ct / mask_src cannot be bf16x2)");
+  WS_CHECK_ARG(d->dtype_r != WSOVOD_BF16X2 || !d->residual || (d->N % 32 == 0 && d->ldr % 32 == 0 && ((uintptr_t)d->residual & 15) == 0),
+               "wsovod_gemm_nt: a bf16x2 residual needs N and ldr multiples of 32");
+  const double flops = (x2 ? 6.0 : 2.0) * d->M * d->N * d->K;  // bf16x2: three bf16 MFMA products per value pair
   hipStream_t s = (hipStream_t)stream;
   if (d->conv && d->tile_hint == 0 && d->dtype_in == WSOVOD_BF16 && a.Cin == 64 && d->N == 64 && a.KH == 3 &&
       a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W && d->C && !d->Ct && !d->A2 &&
@@ -1171,6 +1247,10 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
     tile = 8256256;
   a.ksplit = d->tile_hint == 0 ? -1 : 0;  // split-K may only change the summation order when the caller named no tile
+  if (x2) {
+    if (!d->tile_hint && tile == 256256 && !d->conv) tile = 8256256;
+    return d->conv ? dispatch_tile_x3<true>(a, tile, s, flops, bytes) : dispatch_tile_x3<false>(a, tile, s, flops, bytes);
+  }
   if (d->dtype_in == WSOVOD_BF16)
     return d->conv ? dispatch_tile<bf16_t, true>(a, tile, s, flops, bytes) : dispatch_tile<bf16_t, false>(a, tile, s, flops, bytes);
   return d->conv ? dispatch_tile<float, true>(a, tile, s, flops, bytes) : dispatch_tile<float, false>(a, tile, s, flops, bytes);

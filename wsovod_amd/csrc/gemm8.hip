@@ -30,7 +30,11 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <bool CONV>
+// X3 (bf16x2 operands, include/wsovod_hip.h): the 128-byte LDS row of a K-step holds the hi halves of 32 values in its
+// chunks 0-3 and their lo halves in chunks 4-7, so the SAME two fragment reads per tile (k-half 0 / 1 of the bf16 form)
+// deliver (a_hi, a_lo) and (b_hi, b_lo), and a quadrant phase issues 24 MFMAs -- bh*ah, bl*ah, bh*al -- on them instead of
+// 16: staging, LDS traffic and barriers of a bf16 GEMM over 2K elements, 1.5x its MFMA work (= 3x the bf16 GEMM over K).
+template <bool CONV, bool X3 = false>
 __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 256, BKE = 64, EPC = 8, esz = 2;
   constexpr int LR = 64;  // rows staged per DMA pass (512 threads x 16 B = 64 rows x 128 B)
@@ -192,10 +196,12 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const unsigned ldsA = 0, ldsB = 0;
 #endif
 
+  // bf16: k-halves (0,0), (1,1).  X3: (b_hi, a_hi), (b_lo, a_hi), (b_hi, a_lo) -- the lo*lo term (2^-16 of a product) is dropped
 #define WS_MFMA_QUAD(I0, BREG, J0)                                                                                   \
-  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)                      \
+  _Pragma("unroll") for (int ks = 0; ks < (X3 ? 3 : 2); ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)           \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
-          __builtin_bit_cast(bf16x8, BREG[j][ks]), __builtin_bit_cast(bf16x8, af[i][ks]), acc[(I0) + i][(J0) + j], 0, 0, 0)
+          __builtin_bit_cast(bf16x8, BREG[j][X3 ? (ks == 1) : ks]), __builtin_bit_cast(bf16x8, af[i][X3 ? (ks == 2) : ks]), \
+          acc[(I0) + i][(J0) + j], 0, 0, 0)
 
   // ---- DMA schedule (two instructions per phase; the LDS rows a pass overwrites were last read >= 2 phases ago):
   //   phase 1 (kt): B passes 0,1 of kt+1      phase 2 (kt): B passes 2,3 of kt+1, then vmcnt -> A_hi(kt) landed
@@ -320,7 +326,8 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     return;
   }
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
-  const bool vec_c = p.C && (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0;
+  const bool vec_c = p.C && (p.dtype_c == WSOVOD_BF16X2 ? vec4_ok(p.C, p.ldc, p.dtype_c)
+                                                        : (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0);
   const int ncol = n0 + wc * 64 + 16 * fq;
   auto emit = [&](const f32x4 a4, const int i, const int j) {
     const int m = m0 + wr * 128 + i * 16 + frow;
@@ -336,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       if (n < p.N) {
         if (p.row_scale) x *= rs;
         if (p.bias) x += p.bias[n];
-        if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+        if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
         if (p.relu) x = fmaxf(x, 0.f);
         if (p.dropout_p > 0.f) {
           const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
@@ -344,35 +351,31 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
         }
         if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
         if (p.mask_src)
-          x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+          x = load_as_f32(p.mask_src, m, p.ldm, n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
         if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
       }
       v[r] = x;
     }
     if (p.C) {
       if (vec_c && full) {
-        if (p.dtype_c == WSOVOD_BF16) {
-          bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-          *(bf16x4*)((bf16_t*)p.C + (long long)m * p.ldc + nb) = o;
-        } else {
-          *(f32x4*)((float*)p.C + (long long)m * p.ldc + nb) = f32x4{v[0], v[1], v[2], v[3]};
-        }
+        store4_from_f32(p.C, m, p.ldc, nb, p.dtype_c, f32x4{v[0], v[1], v[2], v[3]});
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nb + r < p.N) store_from_f32(p.C, (long long)m * p.ldc + nb + r, p.dtype_c, v[r]);
+          if (nb + r < p.N) store_from_f32(p.C, m, p.ldc, nb + r, p.dtype_c, v[r]);
       }
     }
     if (p.Ct) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        if (nb + r < p.N) store_from_f32(p.Ct, (long long)(nb + r) * p.ldct + m, p.dtype_ct, v[r]);
+        if (nb + r < p.N) store_from_f32(p.Ct, nb + r, p.ldct, m, p.dtype_ct, v[r]);
     }
   };
   // Fast path (bias / residual / ReLU / dropout, row-major output with 16-byte aligned rows, whole tile columns in
   // range): the feature tests are hoisted out of the element loops, bias is fetched once per column tile, residual
   // and output move as 16-byte accesses.
-  const bool vec_r = !p.residual || ((p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0);
+  const bool vec_r = !p.residual || (p.dtype_r == WSOVOD_BF16X2 ? vec4_ok(p.residual, p.ldr, p.dtype_r)
+                                                                 : (p.ldr & 7) == 0 && ((uintptr_t)p.residual & 15) == 0);
   const bool plain = vec_c && vec_r && ((uintptr_t)p.bias & 15) == 0 && !p.Ct && !p.row_scale && !p.group_add &&
                      !p.mask_src && !p.accumulate && n0 + BN <= p.N;
   if (plain) {
@@ -390,14 +393,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     f32x4 x[4];                                                                                               \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
       x[j] = acc[I][j] * p.alpha + b4[j];                                                                     \
-      if (has_res) {                                                                                          \
-        if (p.dtype_r == WSOVOD_BF16) {                                                                       \
-          const bf16x4 r4 = *(const bf16x4*)((const bf16_t*)p.residual + mm * p.ldr + ncol + 4 * j);          \
-          x[j] += f32x4{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]};                              \
-        } else {                                                                                              \
-          x[j] += *(const f32x4*)((const float*)p.residual + mm * p.ldr + ncol + 4 * j);                      \
-        }                                                                                                     \
-      }                                                                                                       \
+      if (has_res) x[j] += load4_as_f32(p.residual, mm, p.ldr, ncol + 4 * j, p.dtype_r);                      \
       x[j] = f32x4{fmaxf(x[j][0], lo), fmaxf(x[j][1], lo), fmaxf(x[j][2], lo), fmaxf(x[j][3], lo)};           \
       if (drop) {                                                                                             \
         const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);     \
@@ -405,7 +401,18 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
             x[j][r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;                 \
       }                                                                                                       \
     }                                                                                                         \
-    if (p.dtype_c == WSOVOD_BF16) {                                                                           \
+    if (p.dtype_c == WSOVOD_BF16X2) { /* 16 consecutive values: 32 B of hi, 32 B of lo one half-line further */  \
+      bf16_t* q = (bf16_t*)p.C + 2 * mm * p.ldc + x2_pos(ncol);                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; j += 2) {                                                      \
+        bf16x8 h, l;                                                                                          \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+          h[r] = (bf16_t)x[j][r];         l[r] = x2_lo(x[j][r], h[r]);                                        \
+          h[4 + r] = (bf16_t)x[j + 1][r]; l[4 + r] = x2_lo(x[j + 1][r], h[4 + r]);                            \
+        }                                                                                                     \
+        *(bf16x8*)(q + 4 * j) = h;                                                                            \
+        *(bf16x8*)(q + 32 + 4 * j) = l;                                                                       \
+      }                                                                                                       \
+    } else if (p.dtype_c == WSOVOD_BF16) {                                                                    \
       _Pragma("unroll") for (int j = 0; j < 4; j += 2)                                                        \
           *(bf16x8*)((bf16_t*)p.C + base + 4 * j) =                                                           \
               bf16x8{(bf16_t)x[j][0],     (bf16_t)x[j][1],     (bf16_t)x[j][2],     (bf16_t)x[j][3],          \
@@ -451,15 +458,19 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) 
 
 }  // namespace
 
-int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split) {
-  allow_split = allow_split || a.ksplit == -1;  // -1: the dispatcher chose this tile itself (no tile_hint)
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split, bool x3) {
+  allow_split = (allow_split || a.ksplit == -1) && !x3;  // -1: the dispatcher chose this tile itself (no tile_hint)
   static int slot_g = wsovod::prof_slot("gemm_nt_bf16_256x256_8ph");
   static int slot_c = wsovod::prof_slot("conv_igemm_bf16_256x256_8ph");
+  static int slot_g3 = wsovod::prof_slot("gemm_nt_bf16x2_256x256_8ph");
+  static int slot_c3 = wsovod::prof_slot("conv_igemm_bf16x2_256x256_8ph");
   static bool attr_set = false;
   constexpr int lds_bytes = 2 * (256 + 256) * 128;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
   }
   if (conv && a.A2) {
@@ -509,8 +520,12 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
       grid = ntiles * S;
     }
   }
-  wsovod::ProfScope prof(conv ? slot_c : slot_g, s, flops, bytes);
-  if (conv)
+  wsovod::ProfScope prof(x3 ? (conv ? slot_c3 : slot_g3) : (conv ? slot_c : slot_g), s, flops, bytes);
+  if (x3 && conv)
+    hipLaunchKernelGGL((gemm256_8ph_kernel<true, true>), dim3(grid), dim3(512), lds_bytes, s, args);
+  else if (x3)
+    hipLaunchKernelGGL((gemm256_8ph_kernel<false, true>), dim3(grid), dim3(512), lds_bytes, s, args);
+  else if (conv)
     hipLaunchKernelGGL(gemm256_8ph_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, args);
   else
     hipLaunchKernelGGL(gemm256_8ph_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, args);

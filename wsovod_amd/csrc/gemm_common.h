@@ -67,14 +67,65 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-__device__ __forceinline__ float load_as_f32(const void* p, long long idx, int dtype) {
-  return dtype == WSOVOD_BF16 ? (float)((const bf16_t*)p)[idx] : ((const float*)p)[idx];
+// ---- bf16x2 (include/wsovod_hip.h: WSOVOD_BF16X2): value k of a row sits at bf16 index x2_pos(k) (hi) and
+// x2_pos(k) + 32 (lo) of the row's 2 * ld bf16 slots
+__device__ __forceinline__ long long x2_pos(int k) { return ((long long)(k >> 5) << 6) | (k & 31); }
+__device__ __forceinline__ bf16_t x2_lo(float v, bf16_t hi) {
+  const float h = (float)hi;
+  return (bf16_t)(__builtin_isinf(h) ? 0.f : v - h);  // an infinite value stays infinite (inf - inf would store a NaN)
 }
-__device__ __forceinline__ void store_from_f32(void* p, long long idx, int dtype, float v) {
-  if (dtype == WSOVOD_BF16)
-    ((bf16_t*)p)[idx] = (bf16_t)v;
-  else
-    ((float*)p)[idx] = v;
+
+// element (m, n) of a row-major matrix with leading dimension ld (values) in any of the three dtypes
+__device__ __forceinline__ float load_as_f32(const void* p, long long m, long long ld, int n, int dtype) {
+  if (dtype == WSOVOD_BF16) return (float)((const bf16_t*)p)[m * ld + n];
+  if (dtype == WSOVOD_BF16X2) {
+    const bf16_t* q = (const bf16_t*)p + 2 * m * ld + x2_pos(n);
+    return (float)q[0] + (float)q[32];
+  }
+  return ((const float*)p)[m * ld + n];
+}
+__device__ __forceinline__ void store_from_f32(void* p, long long m, long long ld, int n, int dtype, float v) {
+  if (dtype == WSOVOD_BF16) {
+    ((bf16_t*)p)[m * ld + n] = (bf16_t)v;
+  } else if (dtype == WSOVOD_BF16X2) {
+    bf16_t* q = (bf16_t*)p + 2 * m * ld + x2_pos(n);
+    const bf16_t hi = (bf16_t)v;
+    q[0] = hi;
+    q[32] = x2_lo(v, hi);
+  } else {
+    ((float*)p)[m * ld + n] = v;
+  }
+}
+// 4 consecutive values n .. n+3 (n a multiple of 4; rows 8-byte (bf16, bf16x2) / 16-byte (fp32) aligned)
+__device__ __forceinline__ f32x4 load4_as_f32(const void* p, long long m, long long ld, int n, int dtype) {
+  if (dtype == WSOVOD_BF16) {
+    const bf16x4 r = *(const bf16x4*)((const bf16_t*)p + m * ld + n);
+    return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+  }
+  if (dtype == WSOVOD_BF16X2) {
+    const bf16_t* q = (const bf16_t*)p + 2 * m * ld + x2_pos(n);
+    const bf16x4 h = *(const bf16x4*)q, l = *(const bf16x4*)(q + 32);
+    return f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+  }
+  return *(const f32x4*)((const float*)p + m * ld + n);
+}
+__device__ __forceinline__ void store4_from_f32(void* p, long long m, long long ld, int n, int dtype, const f32x4 v) {
+  if (dtype == WSOVOD_BF16) {
+    *(bf16x4*)((bf16_t*)p + m * ld + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+  } else if (dtype == WSOVOD_BF16X2) {
+    bf16_t* q = (bf16_t*)p + 2 * m * ld + x2_pos(n);
+    const bf16x4 h = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *(bf16x4*)q = h;
+    *(bf16x4*)(q + 32) = bf16x4{x2_lo(v[0], h[0]), x2_lo(v[1], h[1]), x2_lo(v[2], h[2]), x2_lo(v[3], h[3])};
+  } else {
+    *(f32x4*)((float*)p + m * ld + n) = v;
+  }
+}
+// true when 4-value groups of rows of `p` can move as the vector accesses above
+__device__ __forceinline__ bool vec4_ok(const void* p, long long ld, int dtype) {
+  if (dtype == WSOVOD_F32) return (ld & 3) == 0 && ((uintptr_t)p & 15) == 0;
+  if (dtype == WSOVOD_BF16) return (ld & 3) == 0 && ((uintptr_t)p & 7) == 0;
+  return (ld & 31) == 0 && ((uintptr_t)p & 15) == 0;  // bf16x2: whole 32-value groups per row
 }
 
 // splitmix64 finaliser: counter-based, stateless dropout mask on (seed, m, n)
@@ -99,21 +150,22 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int nb
     float x = v[r] * p.alpha;
     if (p.row_scale) x *= rs;
     if (p.bias) x += p.bias[n];
-    if (p.residual) x += load_as_f32(p.residual, (long long)m * p.ldr + n, p.dtype_r);
+    if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
     if (p.relu) x = fmaxf(x, 0.f);
     if (p.dropout_p > 0.f) {
       const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
       x = u >= p.dropout_p ? x * keep_scale : 0.f;
     }
     if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
-    if (p.mask_src) x = load_as_f32(p.mask_src, (long long)m * p.ldm + n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
+    if (p.mask_src) x = load_as_f32(p.mask_src, m, p.ldm, n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
     if (p.C && p.accumulate) x += ((float*)p.C)[(long long)m * p.ldc + n];
-    if (p.C) store_from_f32(p.C, (long long)m * p.ldc + n, p.dtype_c, x);
-    if (p.Ct) store_from_f32(p.Ct, (long long)n * p.ldct + m, p.dtype_ct, x);
+    if (p.C) store_from_f32(p.C, m, p.ldc, n, p.dtype_c, x);
+    if (p.Ct) store_from_f32(p.Ct, n, p.ldct, m, p.dtype_ct, x);
   }
 }
 
 // gemm8.hip: bf16 256x256 tile, 8 wavefronts in two staggered groups (see the file header).
-int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split = false);
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split = false,
+                       bool x3 = false);
 
 }  // namespace wsovod_gemm

@@ -38,6 +38,8 @@ struct TnArgs {
   // split-K of the LAST, partial round of tiles: blocks [0, full_tiles) own a whole tile; after them every remaining tile
   // is cut into `ksplit` slices of `slice_steps` K-steps whose partial sums meet by fp32 atomic adds (0 = no split)
   int full_tiles, ksplit, slice_steps;
+  int q_x2;  // Q is a bf16x2 matrix (include/wsovod_hip.h): only the hi halves of its values are read, column k at bf16
+             // slot 64 (k / 32) + k % 32 of the row; ldq is then counted in bf16 slots (2 per value)
 };
 
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   for (int s = 0; s < 2; ++s) {
     const int ci = i0 + s * 128 + lchunk * 8, cj = j0 + s * 128 + lchunk * 8;
     pcol[s] = ci < p.NI ? ci * 2 : -1;
-    qcol[s] = cj < p.NJ ? cj * 2 : -1;
+    qcol[s] = cj < p.NJ ? (p.q_x2 ? (((cj >> 5) << 6) | (cj & 31)) : cj) * 2 : -1;
   }
   typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
   [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -280,9 +282,21 @@ __global__ __launch_bounds__(256) void tn_zero_tail_kernel(const TnArgs p) {
 }  // namespace
 }  // namespace wsovod_gemm
 
+extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI,
+                                 int NJ, float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
+
 extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, int Mred, int NI, int NJ,
                               float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream) {
+  return wsovod_gemm_tn_ex(P, ldp, Q, ldq, WSOVOD_BF16, Mred, NI, NJ, C, ldc, alpha, accumulate, stream);
+}
+
+extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI,
+                                 int NJ, float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream) {
   using namespace wsovod_gemm;
+  WS_CHECK_ARG(q_dtype == WSOVOD_BF16 || q_dtype == WSOVOD_BF16X2, "wsovod_gemm_tn: Q must be bf16 or bf16x2");
+  const bool q_x2 = q_dtype == WSOVOD_BF16X2;
+  WS_CHECK_ARG(!q_x2 || (NJ % 32 == 0 && ldq % 4 == 0), "wsovod_gemm_tn: a bf16x2 Q needs NJ a multiple of 32");
+  if (q_x2) ldq *= 2;  // bf16 slots per row
   WS_CHECK_ARG(Mred >= 0 && NI >= 0 && NJ >= 0, "wsovod_gemm_tn: negative dimension");
   if (NI == 0 || NJ == 0) return WSOVOD_OK;
   WS_CHECK_ARG(P && Q && C, "wsovod_gemm_tn: null pointer");
@@ -303,6 +317,7 @@ extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long 
   a.ldc = ldc;
   a.alpha = alpha;
   a.accumulate = accumulate & 1;
+  a.q_x2 = q_x2 ? 1 : 0;
   a.tiles_i = ceil_div(NI, 256);
   a.tiles_j = ceil_div(NJ, 256);
   {

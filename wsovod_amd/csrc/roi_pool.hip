@@ -232,6 +232,26 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
     else
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+  } else if (out_dtype == WSOVOD_BF16X2) {
+    // bf16x2 (include/wsovod_hip.h): the run [obase, obase + nvalid) covers whole 32-value groups (launcher); 8 values per
+    // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form
+    bf16_t* o = (bf16_t*)out;
+    for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
+      const f32x4 q0 = *(const f32x4*)(sval + i), q1 = *(const f32x4*)(sval + i + 4);
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16_t)q0[e];
+        hi[4 + e] = (bf16_t)q1[e];
+        const float h0 = (float)hi[e], h1 = (float)hi[4 + e];
+        lo[e] = (bf16_t)(__builtin_isinf(h0) ? 0.f : q0[e] - h0);
+        lo[4 + e] = (bf16_t)(__builtin_isinf(h1) ? 0.f : q1[e] - h1);
+      }
+      const long long k = obase + i;
+      bf16_t* d = o + ((k >> 5) << 6) + (k & 31);
+      __builtin_nontemporal_store(hi, (bf16x8*)d);
+      __builtin_nontemporal_store(lo, (bf16x8*)(d + 32));
+    }
   } else {
     bf16_t* o = (bf16_t*)out + obase;
     if (vec && (nvalid & 7) == 0 && (obase & 7) == 0)
@@ -746,6 +766,26 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
     else
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+  } else if (out_dtype == WSOVOD_BF16X2) {
+    // bf16x2 (include/wsovod_hip.h): the run [obase, obase + nvalid) covers whole 32-value groups (launcher); 8 values per
+    // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form
+    bf16_t* o = (bf16_t*)out;
+    for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
+      const f32x4 q0 = *(const f32x4*)(sval + i), q1 = *(const f32x4*)(sval + i + 4);
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        hi[e] = (bf16_t)q0[e];
+        hi[4 + e] = (bf16_t)q1[e];
+        const float h0 = (float)hi[e], h1 = (float)hi[4 + e];
+        lo[e] = (bf16_t)(__builtin_isinf(h0) ? 0.f : q0[e] - h0);
+        lo[4 + e] = (bf16_t)(__builtin_isinf(h1) ? 0.f : q1[e] - h1);
+      }
+      const long long k = obase + i;
+      bf16_t* d = o + ((k >> 5) << 6) + (k & 31);
+      __builtin_nontemporal_store(hi, (bf16x8*)d);
+      __builtin_nontemporal_store(lo, (bf16x8*)(d + 32));
+    }
   } else {
     bf16_t* o = (bf16_t*)out + obase;
     if (vec && (nvalid & 7) == 0 && (obase & 7) == 0)
@@ -890,7 +930,13 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
                             int out_dtype, int* argmax, wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_pool_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
   if (rc) return rc;
-  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16, "wsovod_roi_pool_forward: bad out_dtype");
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2,
+               "wsovod_roi_pool_forward: bad out_dtype");
+  // bf16x2 output: the wavefront-per-pooled-row kernel only (NHWC, 7 bins wide), whole 128-channel groups, so that every
+  // workgroup's run of outputs is whole 32-value groups
+  WS_CHECK_ARG(out_dtype != WSOVOD_BF16X2 || (layout == WSOVOD_NHWC && pw == 7 && ph <= 16 && C % 256 == 0 &&
+                                              (C * ph * pw) % 32 == 0 && ((uintptr_t)feat & 7) == 0 && ((uintptr_t)out & 15) == 0),
+               "wsovod_roi_pool_forward: bf16x2 output needs NHWC, pw = 7, C a multiple of 256");
   if (R == 0) return WSOVOD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int esz = dtype == WSOVOD_BF16 ? 2 : 4, osz = out_dtype == WSOVOD_BF16 ? 2 : 4;
@@ -1022,7 +1068,11 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
                              int aligned, void* out, int out_dtype, wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_align_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
   if (rc) return rc;
-  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16, "wsovod_roi_align_forward: bad out_dtype");
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2,
+               "wsovod_roi_align_forward: bad out_dtype");
+  WS_CHECK_ARG(out_dtype != WSOVOD_BF16X2 || (layout == WSOVOD_NHWC && pw == 7 && ph >= 7 && ph <= 8 && C % 256 == 0 &&
+                                              (C * ph * pw) % 32 == 0 && ((uintptr_t)feat & 7) == 0 && ((uintptr_t)out & 15) == 0),
+               "wsovod_roi_align_forward: bf16x2 output needs NHWC, 7x7 / 8x7 bins, C a multiple of 256");
   if (R == 0) return WSOVOD_OK;
   hipStream_t s = (hipStream_t)stream;
   const int esz = dtype == WSOVOD_BF16 ? 2 : 4, osz = out_dtype == WSOVOD_BF16 ? 2 : 4;

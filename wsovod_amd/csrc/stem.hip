@@ -96,6 +96,100 @@ __global__ __launch_bounds__(256) void stem_conv1_kernel(const uint8_t* __restri
   }
 }
 
+// The same layer for MODEL.HIP.PRECISION = "parity": operands and output in bf16x2 (include/wsovod_hip.h).  The
+// normalised patch is kept twice in LDS -- hi = bf16(v) and lo = bf16(v - hi) -- the folded weight arrives as the bf16x2
+// encoding of its (64, 32) matrix ([hi 32 | lo 32] per output channel), and every (pixel group, channel tile) takes
+// three MFMAs: w_hi*a_hi + w_lo*a_hi + w_hi*a_lo (fp32 accumulation; ~2^-16 relative per product instead of 2^-8).
+// Output: NHWC with 64 values = 128 bf16 slots per pixel, [hi 0-31 | lo 0-31 | hi 32-63 | lo 32-63].
+__global__ __launch_bounds__(256) void stem_conv1_x2_kernel(const uint8_t* __restrict__ img, const int* __restrict__ sizes,
+                                                            float m0, float m1, float m2, float s0, float s1, float s2,
+                                                            int N, int Hp, int Wp, int Ho, int Wo, int tiles_x, int tiles_y,
+                                                            const bf16_t* __restrict__ w32x2, const float* __restrict__ bias,
+                                                            bf16_t* __restrict__ out) {
+  __shared__ bf16_t patch_hi[3 * S_PR * S_PCP];
+  __shared__ bf16_t patch_lo[3 * S_PR * S_PCP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, g = lane >> 4;
+  const int tpi = tiles_x * tiles_y;
+  const int n = blockIdx.x / tpi;
+  const int t_in = blockIdx.x - n * tpi;
+  const int ty = t_in / tiles_x, tx = t_in - ty * tiles_x;
+  const int y0 = ty * S_TH, x0 = tx * S_TW;
+  const int hi = sizes[2 * n], wi = sizes[2 * n + 1];
+  const uint8_t* plane = img + (long long)n * 3 * Hp * Wp;
+  for (int e = tid; e < 3 * S_PR * S_PC; e += 256) {
+    const int c = e / (S_PR * S_PC);
+    const int rem = e - c * (S_PR * S_PC);
+    const int row = rem / S_PC, col = rem - row * S_PC;
+    const int h = 2 * y0 - 1 + row, w = 2 * x0 - 1 + col;
+    const bool ok = h >= 0 && w >= 0 && h < hi && w < wi;
+    const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+    const float v = ok ? ((float)plane[((long long)c * Hp + h) * Wp + w] - mean) / sd : 0.f;  // = wsovod_stem_im2col (fp32)
+    const bf16_t vh = (bf16_t)v;
+    patch_hi[(c * S_PR + row) * S_PCP + col] = vh;
+    patch_lo[(c * S_PR + row) * S_PCP + col] = (bf16_t)(v - (float)vh);
+  }
+  bf16x8 bwh[4], bwl[4];  // weight rows permuted as in the bf16 kernel: a lane ends up with 16 consecutive channels
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const bf16_t* wr = w32x2 + (16 * (frow >> 2) + 4 * j + (frow & 3)) * 64 + g * 8;
+    bwh[j] = *(const bf16x8*)wr;
+    bwl[j] = *(const bf16x8*)(wr + 32);
+  }
+  int toff[8];
+  bool real[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int k = 8 * g + t;
+    const int tap = k / 3, c = k - 3 * tap, r = tap / 3, q = tap - 3 * r;
+    real[t] = k < 27;
+    toff[t] = real[t] ? (c * S_PR + r) * S_PCP + q : 0;
+  }
+  __syncthreads();
+  const bf16_t zero = (bf16_t)0.f;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ly = wave * 2 + (i >> 1), lx = (i & 1) * 16 + frow;
+    const int po = (2 * ly) * S_PCP + 2 * lx;
+    bf16x8 ah, al;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      ah[t] = real[t] ? patch_hi[po + toff[t]] : zero;
+      al[t] = real[t] ? patch_lo[po + toff[t]] : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bwh[j], ah, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bwl[j], ah, c4, 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bwh[j], al, c4, 0, 0, 0);
+    }
+  }
+  f32x4 b4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b4[j] = *(const f32x4*)(bias + 16 * g + 4 * j);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + wave * 2 + (i >> 1), x = x0 + (i & 1) * 16 + frow;
+    if (y >= Ho || x >= Wo) continue;
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v0 = fmaxf(acc[i][0][r] + b4[0][r], 0.f), v1 = fmaxf(acc[i][1][r] + b4[1][r], 0.f);
+      const float v2 = fmaxf(acc[i][2][r] + b4[2][r], 0.f), v3 = fmaxf(acc[i][3][r] + b4[3][r], 0.f);
+      h0[r] = (bf16_t)v0; h0[4 + r] = (bf16_t)v1; h1[r] = (bf16_t)v2; h1[4 + r] = (bf16_t)v3;
+      l0[r] = (bf16_t)(v0 - (float)h0[r]); l0[4 + r] = (bf16_t)(v1 - (float)h0[4 + r]);
+      l1[r] = (bf16_t)(v2 - (float)h1[r]); l1[4 + r] = (bf16_t)(v3 - (float)h1[4 + r]);
+    }
+    // channels 16g .. 16g+15 of the pixel's 128 slots: group g>>1, hi at 16*(g&1), lo 32 slots further
+    bf16_t* dst = out + (((long long)n * Ho + y) * Wo + x) * 128 + 64 * (g >> 1) + 16 * (g & 1);
+    *(bf16x8*)dst = h0;
+    *(bf16x8*)(dst + 8) = h1;
+    *(bf16x8*)(dst + 32) = l0;
+    *(bf16x8*)(dst + 40) = l1;
+  }
+}
+
 }  // namespace
 
 extern "C" int wsovod_stem_conv1(const unsigned char* img, const int* sizes, const float* mean_host,
@@ -117,5 +211,27 @@ extern "C" int wsovod_stem_conv1(const unsigned char* img, const int* sizes, con
                      mean_host[0], mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, Ho, Wo,
                      tiles_x, tiles_y, (const bf16_t*)w32, bias, (bf16_t*)out);
   WS_CHECK_LAUNCH("wsovod_stem_conv1");
+  return WSOVOD_OK;
+}
+
+extern "C" int wsovod_stem_conv1_x2(const unsigned char* img, const int* sizes, const float* mean_host,
+                                    const float* std_host, int N, int Hp, int Wp, const void* w32x2, const float* bias,
+                                    void* out, wsovod_stream_t stream) {
+  WS_CHECK_ARG(N >= 0 && Hp > 0 && Wp > 0, "wsovod_stem_conv1_x2: bad shape");
+  if (N == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(img && sizes && mean_host && std_host && w32x2 && bias && out, "wsovod_stem_conv1_x2: null pointer");
+  WS_CHECK_ARG((((uintptr_t)w32x2 | (uintptr_t)bias | (uintptr_t)out) & 15) == 0,
+               "wsovod_stem_conv1_x2: weights / bias / output must be 16-byte aligned");
+  const int Ho = (Hp - 1) / 2 + 1, Wo = (Wp - 1) / 2 + 1;
+  const long long total = (long long)N * Ho * Wo;
+  const int tiles_x = (Wo + S_TW - 1) / S_TW, tiles_y = (Ho + S_TH - 1) / S_TH;
+  WS_CHECK_ARG((long long)N * tiles_x * tiles_y < (1ll << 31), "wsovod_stem_conv1_x2: too many tiles for one launch");
+  static int slot = wsovod::prof_slot("stem_conv1_fused_bf16x2");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 6.0 * total * 64 * 27, (double)N * 3 * Hp * Wp + (double)total * 256);
+  hipLaunchKernelGGL(stem_conv1_x2_kernel, dim3((unsigned)(N * tiles_x * tiles_y)), dim3(256), 0, s, img, sizes,
+                     mean_host[0], mean_host[1], mean_host[2], std_host[0], std_host[1], std_host[2], N, Hp, Wp, Ho, Wo,
+                     tiles_x, tiles_y, (const bf16_t*)w32x2, bias, (bf16_t*)out);
+  WS_CHECK_LAUNCH("wsovod_stem_conv1_x2");
   return WSOVOD_OK;
 }

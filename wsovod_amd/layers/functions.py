@@ -39,14 +39,32 @@ def weight_shadow(weight, cd):
     return t
 
 
+def _x2_mode():
+    """MODEL.HIP.PRECISION = "parity": the activations that reach the Linear fronts are bf16x2 tensors (hip_ops.X2)."""
+    return H.x3_active() == "x2"
+
+
+def _no_split(x3):
+    """The x3 state a backward pass runs under: the forward-only modes ("fwd", "x2") contract in plain bf16."""
+    return x3 if x3 not in ("fwd", "x2") else False
+
+
 class _Linear(Function):
-    """y = dropout(relu(x @ W^T + b)); x (M,K) in the compute dtype, W fp32 master (N,K)."""
+    """y = dropout(relu(x @ W^T + b)); x (M,K) in the compute dtype, W fp32 master (N,K).
+    "parity" precision: x is bf16x2, the products are three-MFMA sums on the bf16x2 weight, y is bf16x2 (out_dtype =
+    hip_ops.X2) or fp32; the backward is plain bf16 on the hi halves (mask from y's hi halves, dW by the transposed-read
+    kernel straight from the bf16x2 x)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype):
-        cd = x.dtype
-        wq = weight_shadow(weight, cd)
-        y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, out_dtype=out_dtype)
+        ctx.x2 = _x2_mode()
+        ctx.y_x2 = out_dtype == H.X2
+        if ctx.x2:
+            y = H.gemm_nt(x, H.x2_cached(weight), x2=True, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
+                          out_dtype=out_dtype)
+        else:
+            wq = weight_shadow(weight, x.dtype)
+            y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, out_dtype=out_dtype)
         ctx.relu, ctx.dropout_p = relu, dropout_p
         ctx.save_for_backward(x, weight, y if (relu or dropout_p > 0) else None)
         ctx.has_bias = bias is not None
@@ -59,7 +77,7 @@ class _Linear(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
-        with H.x3_mode(ctx.x3 if ctx.x3 != "fwd" else False):
+        with H.x3_mode(_no_split(ctx.x3)):
             return _Linear._backward(ctx, dy)
 
     @staticmethod
@@ -68,7 +86,7 @@ class _Linear(Function):
         in_dtype = x.dtype
         if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
             x = H.cast(x, torch.bfloat16)
-        cd = x.dtype
+        cd = torch.bfloat16 if ctx.x2 else x.dtype
         M, K = x.shape
         N = weight.size(0)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -78,23 +96,23 @@ class _Linear(Function):
         Mp, Np = _pad(M, 64), _pad(N, 8)
         # dW = dA^T X contracts over the slow (proposal) index of both row-major operands.  Large bf16 layers use the
         # transposed-read kernel on them as they are; the rest goes through explicit transposes + the NT kernel.
-        tn = (_USE_TN and need_dw and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0
-              and ((Np + 255) // 256) * ((K + 255) // 256) >= 128)
+        tn = ctx.x2 or (_USE_TN and need_dw and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1
+                        and x.stride(0) % 8 == 0 and ((Np + 255) // 256) * ((K + 255) // 256) >= 128)
         db = torch.zeros((N,), dtype=torch.float32, device=dy.device) if need_db else None  # summed in the same pass
         dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or tn, want_t=need_dw and not tn,
-                                   ld_t=Mp, ld_plain=Np, colsum=db)
+                                   ld_t=Mp, ld_plain=Np, colsum=db, y_x2=ctx.x2 and ctx.y_x2)
         dx = dw = None
         if tn:
             split = ctx.dw_split
             if split is not None and Np == N and 0 < split[0] < N and split[0] % 8 == 0:
                 ra = split[0]  # two launches over row blocks of dW; the first block is handed over before the second runs
                 dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
-                H.gemm_tn(dA[:, :ra], x, out=dw[:ra])
+                H.gemm_tn(dA[:, :ra], x, out=dw[:ra], q_x2=ctx.x2)
                 split[1](dw[:ra])
-                H.gemm_tn(dA[:, ra:], x, out=dw[ra:])
+                H.gemm_tn(dA[:, ra:], x, out=dw[ra:], q_x2=ctx.x2)
             else:
-                dw = H.gemm_tn(dA, x)  # (Np, K)
-                if Np != N:
+                dw = H.gemm_tn(dA, x, q_x2=ctx.x2) if need_dw else None  # (Np, K)
+                if dw is not None and Np != N:
                     dw = dw[:N]
         elif need_dw:
             xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
@@ -106,6 +124,7 @@ class _Linear(Function):
 
 
 def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=None):
+    """out_dtype: a torch dtype, or hip_ops.X2 for a bf16x2 output ("parity" precision; the default there is fp32)."""
     return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype)
 
 
@@ -122,9 +141,13 @@ class _LinearGroup(Function):
         heads = len(meta)
         ws, bs = wb[0::2], wb[1::2]
         ys = []
+        ctx.x2 = _x2_mode()
         for h in range(heads):
             relu, out_dtype = meta[h]
-            ys.append(H.gemm_nt(x, weight_shadow(ws[h], cd), bias=bs[h], relu=relu, out_dtype=out_dtype or cd))
+            if ctx.x2:  # bf16x2 input, three-MFMA products; a head's output is bf16x2 where the caller asks (hip_ops.X2)
+                ys.append(H.gemm_nt(x, H.x2_cached(ws[h]), x2=True, bias=bs[h], relu=relu, out_dtype=out_dtype or cd))
+            else:
+                ys.append(H.gemm_nt(x, weight_shadow(ws[h], cd), bias=bs[h], relu=relu, out_dtype=out_dtype or cd))
         ctx.meta = meta
         ctx.save_for_backward(x, *ws, *[y if meta[h][0] else None for h, y in enumerate(ys)])
         ctx.has_bias = [b is not None for b in bs]
@@ -134,7 +157,7 @@ class _LinearGroup(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, *dys):
-        with H.x3_mode(ctx.x3 if ctx.x3 != "fwd" else False):
+        with H.x3_mode(_no_split(ctx.x3)):
             return _LinearGroup._backward(ctx, *dys)
 
     @staticmethod
@@ -145,7 +168,7 @@ class _LinearGroup(Function):
         in_dtype = x.dtype
         if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
             x = H.cast(x, torch.bfloat16)
-        cd = x.dtype
+        cd = torch.bfloat16 if ctx.x2 else x.dtype
         M, K = x.shape
         Ns = [w.size(0) for w in ws]
         offs = [0]
@@ -159,7 +182,8 @@ class _LinearGroup(Function):
             if dys[h] is not None:
                 H.mask_transpose(_contig2d(dys[h]), ys[h], 1.0, cd, want_t=False,
                                  out_plain=dA[:, offs[h]:offs[h] + Ns[h]],
-                                 colsum=dbcat[offs[h]:offs[h] + Ns[h]] if want_db else None)
+                                 colsum=dbcat[offs[h]:offs[h] + Ns[h]] if want_db else None,
+                                 y_x2=ctx.x2 and ctx.meta[h][1] == H.X2)
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[2 + 2 * h] for h in range(heads))
         wcat = torch.zeros((Nt, K), dtype=cd, device=x.device)
@@ -170,7 +194,9 @@ class _LinearGroup(Function):
             dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=in_dtype)  # (M,K) = dA_cat @ W_cat
         grads = [None] * (2 * heads)
         if need_dw:
-            if _USE_TN and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 \
+            if ctx.x2:
+                dwcat = H.gemm_tn(dA, x, q_x2=True)
+            elif _USE_TN and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 \
                     and ((Nt + 255) // 256) * ((K + 255) // 256) >= 64:
                 dwcat = H.gemm_tn(dA, x)
             else:
@@ -276,7 +302,10 @@ class _CosineLogits(Function):
     @staticmethod
     def forward(ctx, z, wn, wnT, temperature, normalize, bias_vec):
         rs = H.row_l2norm_scale(z, temperature) if normalize else None
-        logits = H.gemm_nt(z, wn, row_scale=rs, bias=bias_vec, out_dtype=torch.float32)
+        if _x2_mode():  # z is a real fp32 tensor here (the norm reads it): encode it and the class matrix, 3-MFMA products
+            logits = H.gemm_nt(H.x2_encode(z), H.x2_cached(wn), x2=True, row_scale=rs, bias=bias_vec, out_dtype=torch.float32)
+        else:
+            logits = H.gemm_nt(z, wn, row_scale=rs, bias=bias_vec, out_dtype=torch.float32)
         ctx.save_for_backward(z, wnT)
         ctx.cfg = (temperature, normalize, bias_vec is not None)
         ctx.x3 = H.x3_active()
@@ -285,7 +314,7 @@ class _CosineLogits(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dl):
-        with H.x3_mode(ctx.x3 if ctx.x3 != "fwd" else False):
+        with H.x3_mode(_no_split(ctx.x3)):
             return _CosineLogits._backward(ctx, dl)
 
     @staticmethod
@@ -293,7 +322,7 @@ class _CosineLogits(Function):
         z, wnT = ctx.saved_tensors
         temperature, normalize, has_bias = ctx.cfg
         cd = z.dtype
-        if ctx.x3 == "fwd" and wnT.dtype == torch.float32:  # bf16x3f: the class matrix of the backward GEMM in bf16
+        if ctx.x3 in ("fwd", "x2") and wnT.dtype == torch.float32:  # forward-only split: the backward class matrix in bf16
             wnT = H.cast(wnT, torch.bfloat16)
             cd = torch.bfloat16
         dl = _contig2d(dl)
@@ -421,7 +450,7 @@ class _AddGroupRows(Function):
     @staticmethod
     def forward(ctx, x, add, row_group, seg_offsets):
         ctx.save_for_backward(seg_offsets)
-        return H.add_group_rows(x, row_group, add)
+        return H.add_group_rows(x, row_group, add, x2=_x2_mode())  # "parity": x and the result are bf16x2
 
     @staticmethod
     @once_differentiable

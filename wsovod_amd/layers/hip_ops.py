@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from .. import _lib
-from .._lib import BF16, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
+from .._lib import BF16, BF16X2, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
 
 
 _CONST_CACHE = {}
@@ -131,13 +131,13 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     ph, pw = output_size
     R = rois.size(0)
     out_dtype = out_dtype or feat.dtype
-    out = torch.empty((R, Cc, ph, pw), dtype=out_dtype, device=feat.device)
+    out = torch.empty((R, Cc, ph, pw), dtype=storage_dtype(out_dtype), device=feat.device)
     argmax = torch.empty((R, Cc, ph, pw), dtype=torch.int32, device=feat.device) if need_argmax else None
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     check(lib().wsovod_roi_pool_forward(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), ptr(out), dtype_code(out_dtype), ptr(argmax), stream()), "roi_pool_forward")
+        C.c_float(spatial_scale), ptr(out), fmt_code(out_dtype), ptr(argmax), stream()), "roi_pool_forward")
     return out, argmax
 
 
@@ -178,12 +178,12 @@ def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, al
     ph, pw = output_size
     R = rois.size(0)
     out_dtype = out_dtype or feat.dtype
-    out = torch.empty((R, Cc, ph, pw), dtype=out_dtype, device=feat.device)
+    out = torch.empty((R, Cc, ph, pw), dtype=storage_dtype(out_dtype), device=feat.device)
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     check(lib().wsovod_roi_align_forward(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out), dtype_code(out_dtype),
+        C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out), fmt_code(out_dtype),
         stream()), "roi_align_forward")
     return out
 
@@ -205,6 +205,72 @@ def roi_align_backward(grad_out, rois, spatial_scale, sampling_ratio, aligned, i
 
 
 # ---------------------------------------------------------------------------------------
+# bf16x2 activations (MODEL.HIP.PRECISION = "parity", include/wsovod_hip.h: WSOVOD_BF16X2).  A bf16x2 tensor is carried
+# as a torch.float32 tensor of the LOGICAL shape whose 4-byte slots hold (hi, lo) bf16 pairs in 32-value groups -- same
+# shapes, strides and byte sizes as fp32, so views / flatten / autograd's shape checks all work, but its numbers are
+# meaningless to torch ops: only the kernels that take the `X2` format tag may read it.
+# ---------------------------------------------------------------------------------------
+X2 = "bf16x2"  # format tag accepted wherever a kernel front takes an `out_dtype` / `x2=` argument
+
+
+def storage_dtype(fmt):
+    return torch.float32 if fmt == X2 else fmt
+
+
+def fmt_code(fmt):
+    return BF16X2 if fmt == X2 else dtype_code(fmt)
+
+
+def x2_encode(src, out=None):
+    """fp32 (rows, cols) with a contiguous last dim, cols % 32 == 0 -> bf16x2 tensor of the same shape."""
+    require_gpu(src, out)
+    if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1 or src.size(1) % 32:
+        raise RuntimeError("x2_encode: source must be a 2-D fp32 matrix with a contiguous last dim of a multiple of 32 columns")
+    rows, cols = src.shape
+    if out is None:
+        out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
+    check(lib().wsovod_bf16x2_encode(ptr(src), src.stride(0), rows, cols, ptr(out), out.stride(0), stream()), "bf16x2_encode")
+    return out
+
+
+def x2_decode(src):
+    """bf16x2 (rows, cols) -> the fp32 values hi + lo (tests, debugging)."""
+    require_gpu(src)
+    rows, cols = src.shape
+    out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
+    check(lib().wsovod_bf16x2_decode(ptr(src), src.stride(0), rows, cols, ptr(out), out.stride(0), stream()), "bf16x2_decode")
+    return out
+
+
+def x2_cached(t, view_rows_cols=None):
+    """bf16x2 encoding of a weight, cached on the tensor object and keyed by its version counter (one re-encode per
+    optimizer step at most; frozen backbone weights once)."""
+    key = (t._version, t.data_ptr(), view_rows_cols)
+    c = getattr(t, "_x2_enc", None)
+    if c is not None and c[0] == key:
+        return c[1]
+    src = t.detach()
+    out = x2_encode(src.reshape(view_rows_cols) if view_rows_cols is not None else src)
+    try:
+        t._x2_enc = (key, out)
+    except AttributeError:
+        pass
+    return out
+
+
+def stem_conv1_x2(images_u8, sizes, mean, std, w32_x2, bias):
+    """uint8 (N,3,Hp,Wp) images -> relu(conv1 3x3/s2 (folded BN)) as (N,Ho,Wo,64) bf16x2 NHWC (three-MFMA products)."""
+    require_gpu(images_u8, sizes, w32_x2, bias)
+    assert w32_x2.dtype == torch.float32 and tuple(w32_x2.shape) == (64, 32) and w32_x2.is_contiguous()
+    N, _, Hp, Wp = images_u8.shape
+    Ho, Wo = (Hp - 1) // 2 + 1, (Wp - 1) // 2 + 1
+    out = torch.empty((N, Ho, Wo, 64), dtype=torch.float32, device=images_u8.device)
+    check(lib().wsovod_stem_conv1_x2(ptr(images_u8), ptr(sizes), _f3(mean), _f3(std), N, Hp, Wp, ptr(w32_x2), ptr(bias),
+                                     ptr(out), stream()), "stem_conv1_x2")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
 # bf16x3 mode (MODEL.HIP.PRECISION = "bf16x3"): fp32 tensors everywhere, every contraction evaluated on the bf16 MFMA
 # kernels as sum ah*bh + ah*bl + al*bh over operands split by wsovod_split3_bf16 (include/wsovod_hip.h).
 # ---------------------------------------------------------------------------------------
@@ -214,7 +280,9 @@ class _X3State:
 
 class x3_mode:
     """Context manager: fp32 x fp32 contractions issued inside go through the bf16x3 split.  Model entry points enter
-    it when their precision is "bf16x3" (mode "full") or "bf16x3f" (mode "fwd": the split only in the forward pass;
+    it when their precision is "bf16x3" (mode "full"), "parity" (mode "x2": bf16x2 activations, see above; fp32 x fp32
+    contractions issued without the x2 tag -- the RPN head on the fp32 res5 map -- still take the split below) or "bf16x3f"
+    (mode "fwd": the split only in the forward pass;
     the backward contractions then run as plain bf16 on casts of the saved fp32 tensors -- forward logits of fp32
     grade, gradients of the bf16 mode's grade).  Autograd Functions capture `x3_active()` in forward and act on it in
     backward (the autograd engine runs backward outside the forward's context)."""
@@ -295,17 +363,22 @@ def _ld(t):
 
 def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=None, bias=None, residual=None,
             relu=False, dropout_p=0.0, dropout_seed=0, row_group=None, group_add=None, mask_src=None,
-            mask_scale=1.0, accumulate=False, M=None, N=None, K=None, conv=None, tile_hint=0, want_c=True, A2=None):
+            mask_scale=1.0, accumulate=False, M=None, N=None, K=None, conv=None, tile_hint=0, want_c=True, A2=None,
+            x2=False, residual_x2=False):
     """C[M][N] = epilogue(sum_k A[m][k]*B[n][k]); see include/wsovod_hip.h for the epilogue order.
 
     A: (M,K) or, with `conv` (a dict of geometry), the NHWC input tensor.  B: (N,K).
+    x2: A, B (and A2) are bf16x2 tensors (fp32-typed carriers, see above): three-MFMA products.  out_dtype = X2 asks
+    for a bf16x2 output (N a multiple of 32); residual_x2: the residual is bf16x2.
     `out_t` is an optional (N, >=M) tensor that receives the transposed copy.
     `A2` (conv only): a second NHWC input (n_img, Ho, Wo, Cin2) contracted 1x1 in the same accumulation (the block's
     projection shortcut); B rows are then [W | Wshortcut].
     Returns `out` (or None if want_c is False).
     """
     require_gpu(A, B, out, out_t, row_scale, bias, residual, row_group, group_add, mask_src)
-    if _X3State.active and A.dtype == torch.float32 and B.dtype == torch.float32:
+    if x2 and (A.dtype != torch.float32 or B.dtype != torch.float32):
+        raise RuntimeError("wsovod_hip gemm: bf16x2 operands travel as float32-typed tensors")
+    if not x2 and _X3State.active and A.dtype == torch.float32 and B.dtype == torch.float32:
         if M is not None or N is not None or K is not None or A2 is not None:
             raise RuntimeError("bf16x3: explicit M/N/K overrides / a fused shortcut input are not supported")
         return _gemm_nt_x3(A, B, conv=conv, out=out, out_dtype=out_dtype or torch.float32, out_t=out_t, alpha=alpha,
@@ -313,7 +386,7 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
                            dropout_seed=dropout_seed, row_group=row_group, group_add=group_add, mask_src=mask_src,
                            mask_scale=mask_scale, accumulate=accumulate, tile_hint=tile_hint, want_c=want_c)
     d = GemmDesc()
-    d.dtype_in = dtype_code(B.dtype)
+    d.dtype_in = BF16X2 if x2 else dtype_code(B.dtype)
     if A.dtype != B.dtype:
         raise RuntimeError(f"wsovod_hip gemm: A is {A.dtype} but B is {B.dtype}")
     d.N = B.size(0) if N is None else N
@@ -338,8 +411,9 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
     if want_c:
         if out is None:
             rows = d.M if not (conv is not None and d.geom.pool) else d.geom.n_img * (d.geom.Ho // 2) * (d.geom.Wo // 2)
-            out = torch.empty((rows, d.N), dtype=out_dtype or A.dtype, device=B.device)
-        d.C, d.ldc, d.dtype_c = out.data_ptr(), _ld(out), dtype_code(out.dtype)
+            out = torch.empty((rows, d.N), dtype=storage_dtype(out_dtype or (X2 if x2 else A.dtype)), device=B.device)
+        d.C, d.ldc = out.data_ptr(), _ld(out)
+        d.dtype_c = BF16X2 if (out_dtype == X2 or (out_dtype is None and x2)) else dtype_code(out.dtype)
     if out_t is not None:
         d.Ct, d.ldct, d.dtype_ct = out_t.data_ptr(), _ld(out_t), dtype_code(out_t.dtype)
     d.alpha = alpha
@@ -350,7 +424,8 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
             raise RuntimeError("wsovod_hip gemm: bias must be fp32")
         d.bias = bias.data_ptr()
     if residual is not None:
-        d.residual, d.ldr, d.dtype_r = residual.data_ptr(), _ld(residual), dtype_code(residual.dtype)
+        d.residual, d.ldr = residual.data_ptr(), _ld(residual)
+        d.dtype_r = BF16X2 if residual_x2 else dtype_code(residual.dtype)
     d.relu = int(bool(relu))
     d.dropout_p, d.dropout_seed = float(dropout_p), int(dropout_seed)
     if group_add is not None:
@@ -404,15 +479,15 @@ def stem_conv1(images_u8, sizes, mean, std, w32, bias):
     return out
 
 
-def maxpool2x2_nhwc(x, stride, zero_pad_br=False):
-    """x: (N,H,W,C) contiguous -> (N,Ho,Wo,C)."""
+def maxpool2x2_nhwc(x, stride, zero_pad_br=False, x2=False):
+    """x: (N,H,W,C) contiguous -> (N,Ho,Wo,C).  x2: x is a bf16x2 map (C a multiple of 32)."""
     require_gpu(x)
     N, H, W, Cc = x.shape
     Hin, Win = H + int(zero_pad_br), W + int(zero_pad_br)
     Ho, Wo = (Hin - 2) // stride + 1, (Win - 2) // stride + 1
     out = torch.empty((N, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
-    check(lib().wsovod_maxpool2x2_nhwc(ptr(x), dtype_code(x.dtype), N, H, W, Cc, stride, int(zero_pad_br), ptr(out),
-                                       stream()), "maxpool2x2_nhwc")
+    check(lib().wsovod_maxpool2x2_nhwc(ptr(x), BF16X2 if x2 else dtype_code(x.dtype), N, H, W, Cc, stride, int(zero_pad_br),
+                                       ptr(out), stream()), "maxpool2x2_nhwc")
     return out
 
 
@@ -621,7 +696,7 @@ def subsample_labels(labels, keys, seg_offsets, max_rows, num_samples, positive_
 
 
 def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=None, ld_plain=None, out_plain=None,
-                   colsum=None):
+                   colsum=None, y_x2=False):
     """dA = dy * [y>0] * scale -> (dA (M, ld_plain>=N) or None, dAt (N, ld_t>=M) or None), zero padded.
     out_plain: optional (M, N) view (contiguous last dim) of a wider buffer that receives dA in place.
     colsum: optional zero-filled fp32 (N,) that receives the column sums of dA (the bias gradient) in the same pass."""
@@ -640,6 +715,12 @@ def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=N
         dAt = (torch.zeros if ld != M else torch.empty)((N, ld), dtype=out_dtype, device=dy.device)
     if colsum is not None:
         assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
+    if y_x2 and y is not None:  # the mask source is the layer's bf16x2 output: its hi halves carry the sign
+        check(lib().wsovod_mask_transpose_ex(
+            ptr(dy), _ld(dy), dtype_code(dy.dtype), ptr(y), _ld(y), BF16X2, M, N, C.c_float(scale), ptr(dA), ldp, ptr(dAt),
+            _ld(dAt) if want_t else 0, dtype_code(out_dtype), ptr(colsum), stream()), "mask_transpose_ex")
+        return dA, dAt
+    if colsum is not None:
         check(lib().wsovod_mask_transpose_colsum(
             ptr(dy), _ld(dy), ptr(y), _ld(y) if y is not None else 0, dtype_code(dy.dtype), M, N, C.c_float(scale),
             ptr(dA), ldp, ptr(dAt), _ld(dAt) if want_t else 0, dtype_code(out_dtype), ptr(colsum), stream()),
@@ -651,12 +732,12 @@ def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=N
     return dA, dAt
 
 
-def add_group_rows(x, row_group, add):
+def add_group_rows(x, row_group, add, x2=False):
     require_gpu(x, row_group, add)
     M, N = x.shape
     out = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    check(lib().wsovod_add_group_rows(ptr(x), _ld(x), dtype_code(x.dtype), ptr(row_group), ptr(add), _ld(add), M, N,
-                                      ptr(out), N, stream()), "add_group_rows")
+    check(lib().wsovod_add_group_rows(ptr(x), _ld(x), BF16X2 if x2 else dtype_code(x.dtype), ptr(row_group), ptr(add),
+                                      _ld(add), M, N, ptr(out), N, stream()), "add_group_rows")
     return out
 
 
@@ -775,24 +856,25 @@ def rpn_label_anchors(anchors, gt_boxes, gt_start, gt_count, thr_lo, thr_hi):
 GEMM_TN_MAX_OPERAND_BYTES = (1 << 31) - 1  # one buffer resource per operand (tests lower it to exercise the row blocks)
 
 
-def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True):
+def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=False):
     """out (NI, NJ) fp32 (+)= alpha * P^T @ Q for row-major bf16 P (Mred, NI) and Q (Mred, NJ): the weight-gradient
     contraction over the operands' slow index, no transposed copies (transposed LDS reads).
     split_tail=False keeps a partial last round of tiles unsplit (fixed summation order, bit-reproducible)."""
     require_gpu(P, Q, out)
-    assert P.dtype == torch.bfloat16 and Q.dtype == torch.bfloat16 and P.shape[0] == Q.shape[0]
+    # q_x2: Q is a bf16x2 matrix (fp32-typed carrier); the kernel reads the hi halves = Q rounded to bf16
+    assert P.dtype == torch.bfloat16 and Q.dtype == (torch.float32 if q_x2 else torch.bfloat16) and P.shape[0] == Q.shape[0]
     Mred, NI, NJ = P.shape[0], P.shape[1], Q.shape[1]
     if out is None:
         out = torch.empty((NI, NJ), dtype=torch.float32, device=P.device)
     # the kernel addresses an operand through one buffer resource (< 2 GiB): longer reductions (e.g. 96 images x 512
     # proposals x 25088 pooled features = 2.5 GB) are cut into row blocks that accumulate into `out`
-    limit = GEMM_TN_MAX_OPERAND_BYTES // (2 * max(_ld(P), _ld(Q), 1))
+    limit = GEMM_TN_MAX_OPERAND_BYTES // (2 * max(_ld(P), _ld(Q) * (2 if q_x2 else 1), 1))
     step = max(64, limit // 64 * 64) if Mred > limit else max(Mred, 1)
     for r0 in range(0, max(Mred, 1), step):
         r1 = min(Mred, r0 + step)
-        check(lib().wsovod_gemm_tn(ptr(P[r0:r1]), _ld(P), ptr(Q[r0:r1]), _ld(Q), r1 - r0, NI, NJ, ptr(out), _ld(out),
-                                   C.c_float(alpha), int(bool(accumulate) or r0 > 0) | (0 if split_tail else 2), stream()),
-              "gemm_tn")
+        check(lib().wsovod_gemm_tn_ex(ptr(P[r0:r1]), _ld(P), ptr(Q[r0:r1]), _ld(Q), BF16X2 if q_x2 else BF16, r1 - r0, NI,
+                                      NJ, ptr(out), _ld(out), C.c_float(alpha),
+                                      int(bool(accumulate) or r0 > 0) | (0 if split_tail else 2), stream()), "gemm_tn")
     return out
 
 

@@ -89,6 +89,18 @@ class Conv2d(nn.Module):
         return self._folded[1], self._folded[2]
 
 
+def _x2():
+    """MODEL.HIP.PRECISION = "parity": feature maps between the convs are bf16x2 NHWC tensors (hip_ops.X2)."""
+    return H.x3_active() == "x2"
+
+
+def _folded_x2(conv, cin_pad=None):
+    """bf16x2 encoding of the folded fp32 weight rows ([Cout][kh*kw*Cin], Cin a multiple of 32: a tap's channels are
+    whole 32-value groups, so encoding the flat rows encodes every tap), cached with the fold."""
+    w, b = conv.folded(torch.float32, cin_pad=cin_pad)
+    return H.x2_cached(w), b
+
+
 def _folded_with_shortcut(conv, shortcut, dtype):
     """[W (kh*kw*Cin) | Wshortcut (Cin2)] rows + the summed folded biases: the operand of the conv that contracts the
     block's 1x1 projection shortcut in the same accumulation (wsovod_gemm_desc.A2)."""
@@ -104,7 +116,7 @@ def _folded_with_shortcut(conv, shortcut, dtype):
 CONV_MAX_OPERAND_BYTES = (1 << 31) - 1  # one buffer resource per NHWC operand (tests lower it to exercise the image blocks)
 
 
-def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None):
+def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None, out_fp32=False):
     """x: (N,H,W,Cin) NHWC contiguous in the compute dtype -> (N,Ho,Wo,Cout); with pool2 the MaxPool2d(2, 2) that
     follows the conv in the stem / block tail is applied too -> (N,Ho//2,Wo//2,Cout).  The 64-channel bf16 kernel pools
     in its epilogue (the full-resolution map is never written); every other conv is followed by the pool kernel."""
@@ -121,10 +133,26 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None):
         for i in range(0, N, max_n):
             j = min(N, i + max_n)
             parts.append(hip_conv(x[i:j], conv, relu=relu, residual=None if residual is None else residual[i:j],
-                                  pool2=pool2, shortcut=None if shortcut is None else (shortcut[0][i:j], shortcut[1])))
+                                  pool2=pool2, shortcut=None if shortcut is None else (shortcut[0][i:j], shortcut[1]),
+                                  out_fp32=out_fp32))
         return torch.cat(parts)
-    wq, b = conv.folded(x.dtype, cin_pad=Cin)
     geom = dict(n_img=N, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=s, pad=p, dil=d)
+    if _x2():
+        # x (and residual / shortcut input) are bf16x2 maps; three-MFMA products on the bf16x2 weights; the output is
+        # bf16x2 again, or real fp32 for the map that leaves the backbone (out_fp32)
+        fmt = torch.float32 if out_fp32 else H.X2
+        if shortcut is not None:
+            x2in, sc = shortcut
+            assert residual is None and not pool2 and x2in.shape[:3] == (N, Ho, Wo) and x2in.shape[3] == sc.in_channels
+            wq, b = _folded_with_shortcut(conv, sc, torch.float32)
+            out = H.gemm_nt(x, H.x2_cached(wq), conv=geom, x2=True, bias=b, relu=relu, out_dtype=fmt, A2=x2in)
+        else:
+            wq, b = _folded_x2(conv, cin_pad=Cin)
+            res2d = residual.view(N * Ho * Wo, conv.out_channels) if residual is not None else None
+            out = H.gemm_nt(x, wq, conv=geom, x2=True, bias=b, relu=relu, residual=res2d, residual_x2=True, out_dtype=fmt)
+        out = out.view(N, Ho, Wo, conv.out_channels)
+        return H.maxpool2x2_nhwc(out, 2, x2=not out_fp32) if pool2 else out
+    wq, b = conv.folded(x.dtype, cin_pad=Cin)
     if shortcut is not None:
         # `shortcut` = (block input, its 1x1 projection conv): out = conv(x) + projection(input), one accumulation
         x2, sc = shortcut
@@ -147,9 +175,9 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None):
 def _fusable_shortcut(sc, x):
     """The block's projection shortcut can ride in its last conv's accumulation: 1x1, stride 1, a whole number of
     K-steps of channels, bf16 / exact-fp32 operands (the bf16x3 modes split their operands and keep the separate launch)."""
-    if sc is None or H.x3_active() or os.environ.get("WSOVOD_FUSE_SHORTCUT", "1") == "0":
+    if sc is None or (H.x3_active() and not _x2()) or os.environ.get("WSOVOD_FUSE_SHORTCUT", "1") == "0":
         return False
-    kstep = 64 if x.dtype == torch.bfloat16 else 32
+    kstep = 64 if x.dtype == torch.bfloat16 else 32  # (bf16x2: 32 values = 64 bf16 slots)
     return sc.kernel_size == 1 and sc.stride == 1 and sc.padding == 0 and sc.in_channels % kstep == 0 and x.is_contiguous()
 
 
@@ -172,7 +200,7 @@ class _PoolMixin:
         if not self.has_pool:
             return out
         # stride 1: ZeroPad2d((0,1,0,1)) + MaxPool2d(2, 1); else MaxPool2d(2, stride)  (resnet_wsl.py:85-92)
-        return H.maxpool2x2_nhwc(out, self.pool_stride, zero_pad_br=self.pool_stride == 1)
+        return H.maxpool2x2_nhwc(out, self.pool_stride, zero_pad_br=self.pool_stride == 1, x2=_x2())
 
 
 class BasicBlock(CNNBlockBase, _PoolMixin):
@@ -196,15 +224,16 @@ class BasicBlock(CNNBlockBase, _PoolMixin):
                 c2_msra_fill(layer)
 
     def forward(self, x):
+        last = getattr(self, "_emits_fp32", False) and not self.has_pool  # "parity": the map that leaves the backbone is real fp32
         out = hip_conv(x, self.conv1, relu=True)
         if _fusable_shortcut(self.shortcut, x) and not (self.has_pool and self.pool_stride == 2):
             # projection shortcut contracted inside conv2 (K = 9*C + Cin): no separate 1x1 launch, its output is neither
             # written nor rounded nor re-read as a residual
-            return self._pool(hip_conv(out, self.conv2, relu=True, shortcut=(x, self.shortcut)))
+            return self._pool(hip_conv(out, self.conv2, relu=True, shortcut=(x, self.shortcut), out_fp32=last))
         shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
         if self.has_pool and self.pool_stride == 2:  # stride-2 tail pool (res2): fused where the kernel has it
             return hip_conv(out, self.conv2, relu=True, residual=shortcut, pool2=True)
-        out = hip_conv(out, self.conv2, relu=True, residual=shortcut)  # out += shortcut; relu
+        out = hip_conv(out, self.conv2, relu=True, residual=shortcut, out_fp32=last)  # out += shortcut; relu
         return self._pool(out)
 
 
@@ -234,12 +263,13 @@ class BottleneckBlock(CNNBlockBase, _PoolMixin):
                 c2_msra_fill(layer)
 
     def forward(self, x):
+        last = getattr(self, "_emits_fp32", False) and not self.has_pool
         out = hip_conv(x, self.conv1, relu=True)
         out = hip_conv(out, self.conv2, relu=True)
         if _fusable_shortcut(self.shortcut, x) and out.shape[:3] == x.shape[:3]:
-            return self._pool(hip_conv(out, self.conv3, relu=True, shortcut=(x, self.shortcut)))
+            return self._pool(hip_conv(out, self.conv3, relu=True, shortcut=(x, self.shortcut), out_fp32=last))
         shortcut = hip_conv(x, self.shortcut) if self.shortcut is not None else x
-        out = hip_conv(out, self.conv3, relu=True, residual=shortcut)
+        out = hip_conv(out, self.conv3, relu=True, residual=shortcut, out_fp32=last)
         return self._pool(out)
 
 
@@ -275,6 +305,9 @@ class BasicStem(CNNBlockBase):
         return wpad[1], b
 
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
+        if _x2():  # "parity": the fused kernel on the bf16x2 encoding of the (64, 32) fp32 weight, bf16x2 output
+            w32, b = self._im2col_weight(torch.float32)
+            return self._tail(H.stem_conv1_x2(images_u8, sizes, pixel_mean, pixel_std, H.x2_cached(w32), b))
         w32, b = self._im2col_weight(torch.bfloat16)
         return self._tail(H.stem_conv1(images_u8, sizes, pixel_mean, pixel_std, w32, b))
 
@@ -323,6 +356,10 @@ class ResNet(nn.Module):
             out_features = [name]
         self._out_features = out_features
         assert len(self._out_features)
+        if precision == "parity":  # bf16x2 maps inside, real fp32 for the one map that leaves the backbone
+            if list(out_features) != [self.stage_names[-1]]:
+                raise NotImplementedError('MODEL.HIP.PRECISION "parity" returns the last stage only (bf16x2 maps inside)')
+            list(self.stages[-1].children())[-1]._emits_fp32 = True
         children = [x[0] for x in self.named_children()]
         for out_feature in self._out_features:
             assert out_feature in children, "Available children: {}".format(", ".join(children))
@@ -364,7 +401,7 @@ class ResNet(nn.Module):
         assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
         self._check_frozen()
         cd = self.compute_dtype
-        x3 = self.precision in ("bf16x3", "bf16x3f", "parity")
+        x3 = {"bf16x3": "full", "bf16x3f": "fwd", "parity": "fwd"}.get(self.precision, False)  # (float entry: no bf16x2 stem)
         kstep = 64 if (cd == torch.bfloat16 or x3) else 32
         xn = x.permute(0, 2, 3, 1).to(cd)
         xn = F.pad(xn, (0, kstep - xn.size(-1))).contiguous()  # Cin 3 -> one K-step (generic float entry)
@@ -374,12 +411,12 @@ class ResNet(nn.Module):
     @torch.no_grad()
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
-        with H.x3_mode(self.precision in ("bf16x3", "bf16x3f", "parity")):
+        with H.x3_mode({"bf16x3": "full", "bf16x3f": "fwd", "parity": "x2"}.get(self.precision, False)):
             return self._forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
 
     def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         self._check_frozen()
-        if self.compute_dtype == torch.bfloat16 and self.stem.out_channels == 64 and self.stem.in_channels == 3:
+        if (self.compute_dtype == torch.bfloat16 or _x2()) and self.stem.out_channels == 64 and self.stem.in_channels == 3:
             # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)
             return self._run(self.stem.forward_uint8(images_u8, sizes, pixel_mean, pixel_std))
         a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)

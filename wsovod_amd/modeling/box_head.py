@@ -13,6 +13,7 @@ from torch import nn
 
 from ..config import ROI_BOX_HEAD_REGISTRY, configurable
 from ..layers import functions as Fn
+from ..layers import hip_ops as H
 from ..structures import ShapeSpec
 
 __all__ = ["DiscriminativeAdaptationNeck", "build_box_head"]
@@ -76,7 +77,9 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
             drop = getattr(self, "fc_dropout{}".format(k + 1))
             p = drop.p if (self.training and drop.training) else 0.0
             seed = (self._base_seed() * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
-            x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed)
+            # "parity" precision: x arrives as bf16x2 (the pooler wrote it) and every FC hands bf16x2 on
+            x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed,
+                          out_dtype=H.X2 if H.x3_active() == "x2" else None)
         return x
 
     @property

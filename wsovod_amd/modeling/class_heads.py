@@ -94,7 +94,8 @@ class OpenVocabularyClassifier(nn.Module):
         """x: (B, D_in) in the compute dtype; classifier: optional (C', D) raw embeddings; hidden: optional
         precomputed relu(projection[0](x)) (the ROI heads batch that layer with the other heads on x)."""
         l1, l2 = self.projection[0], self.projection[2]
-        x = hidden if hidden is not None else Fn.linear(x, l1.weight, l1.bias, relu=True)
+        x2 = H.x3_active() == "x2"  # "parity": x / hidden are bf16x2, the second layer's output z is real fp32
+        x = hidden if hidden is not None else Fn.linear(x, l1.weight, l1.bias, relu=True, out_dtype=H.X2 if x2 else None)
         x = Fn.linear(x, l2.weight, l2.bias, relu=True)
         wn, wnT = self._class_matrix(classifier, append_background, x.dtype)
         bias_vec = self.cls_bias.expand(wn.size(0)).contiguous() if self.use_bias else None

@@ -156,8 +156,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
     def x3(self):
         """MODEL.HIP.PRECISION "bf16x3" / "bf16x3f": fp32 tensors, contractions on the bf16 MFMA kernels over hi/lo-split
         operands (layers/hip_ops.py:x3_mode; "f" = in the forward pass only) -- the fast modes that keep the north star's
-        1e-3 logit bound."""
-        return {"bf16x3": "full", "bf16x3f": "fwd", "parity": "fwd"}.get(getattr(self.backbone, "precision", "bf16"), False)
+        1e-3 logit bound.  "parity" ("x2"): the forward split on bf16x2 activations (hip_ops.X2), produced by the kernels
+        themselves -- no stand-alone split passes, no fp32 activation traffic -- and a plain bf16 backward."""
+        return {"bf16x3": "full", "bf16x3f": "fwd", "parity": "x2"}.get(getattr(self.backbone, "precision", "bf16"), False)
 
     @torch.no_grad()
     def forward_frozen(self, batched_inputs):

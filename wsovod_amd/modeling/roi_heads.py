@@ -155,6 +155,11 @@ class WSOVODROIHeads(ROIHeads):
     def compute_dtype(self):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32
 
+    @property
+    def pool_dtype(self):
+        """What the pooler writes: the compute dtype, or bf16x2 (hip_ops.X2) under the "parity" precision."""
+        return H.X2 if H.x3_active() == "x2" else self.compute_dtype
+
     @classmethod
     def from_config(cls, cfg, input_shape):
         ret = super().from_config(cfg)
@@ -254,11 +259,13 @@ class WSOVODROIHeads(ROIHeads):
         boxes = self.boxes_cat(proposals)
         rois, roi_scale = H.format_rois(boxes, segment_offsets([len(p) for p in proposals], boxes.device),
                                         H.cat_rows([x.objectness_logits for x in proposals]))
+        if self.pooler_type == "ROILoopPool" and H.x3_active() == "x2":
+            raise NotImplementedError('MODEL.HIP.PRECISION "parity" does not cover POOLER_TYPE ROILoopPool (use "bf16x3f")')
         if self.pooler_type == "ROILoopPool":  # (3R, C, 7, 7) = [region | frame | context], roi_heads.py:727-739
             out = self.box_pooler(feats, [x.proposal_boxes for x in proposals], out_dtype=torch.float32, rois=rois)
             return (out * roi_scale.repeat(3).view(-1, 1, 1, 1)).to(self.compute_dtype)
         return self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
-                               out_dtype=self.compute_dtype, rois=rois)
+                               out_dtype=self.pool_dtype, rois=rois)
 
     def boxes_cat(self, proposals):
         """(sum R, 4) boxes of all images; concatenated once per step (pooling, mining and the box loss read it)."""
@@ -347,7 +354,7 @@ class WSOVODROIHeads(ROIHeads):
         for k in range(self.refine_K):
             r = self.box_refinery[k]
             l1 = r.cls.projection[0]
-            heads.append((l1.weight, l1.bias, True, None))
+            heads.append((l1.weight, l1.bias, True, H.X2 if H.x3_active() == "x2" else None))  # feeds the 2nd projection
             hid = len(heads) - 1
             reg = None
             if r.refine_reg[r.refine_k]:
