@@ -62,11 +62,10 @@ def compare(got, want):
     # gradient norms: relative, with an absolute floor of 1e-6 x the step's largest norm -- a tensor whose true gradient
     # is zero (the bias of `det`: softmax over the proposals is shift invariant) carries only rounding noise
     worst, worst_key = 0.0, None
-    top = max(float(g.norm()) for g in want["grads"].values() if g is not None)
-    for k, g in want["grads"].items():
-        if g is None:
-            continue
-        e = abs(float(got["grad_norms"][k]) - float(g.norm())) / max(float(g.norm()), 1e-6 * top, 1e-12)
+    norms = {k: float(g.double().norm()) for k, g in want["grads"].items() if g is not None}  # fp64 sums (103 M elements)
+    top = max(norms.values())
+    for k, nk in norms.items():
+        e = abs(float(got["grad_norms"][k]) - nk) / max(nk, 1e-6 * top, 1e-12)
         if e > worst:
             worst, worst_key = e, k
     rep["max_rel_gradnorm_err"], rep["worst_grad"] = worst, worst_key

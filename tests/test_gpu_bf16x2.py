@@ -220,3 +220,41 @@ def test_stem_conv1_x2_against_fp64(gpu):
     got = H.x2_decode(out.view(-1, 64)).view(N, ref.shape[2], ref.shape[3], 64).permute(0, 3, 1, 2).cpu()
     scale = float(F.conv2d(x.abs(), w.abs().double(), None, stride=2, padding=1).max())
     assert float((got - ref).abs().max()) < 3e-5 * scale
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_conv3x3_c64_halo_kernel_on_bf16x2(gpu, pool, with_res):
+    """The 64 -> 64 channel 3x3 halo-tile kernel in its bf16x2 form (stem conv2 / conv3, res2): against fp64, and against
+    the generic implicit-GEMM tile on the same operands (same products, another summation order); ragged tile edges."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(11)
+    n, Hh, Ww = 2, 22, 70  # not multiples of the 8 x 32 tile
+    x = torch.randn(n, 64, Hh, Ww)
+    w = torch.randn(64, 64, 3, 3) * 0.05
+    b = torch.randn(64)
+    res = torch.randn(n, 64, Hh, Ww)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, 1, 1)
+    if with_res:
+        ref = ref + res.double()
+    ref = torch.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    ref = ref.float()
+    enc = lambda t: H.x2_encode(t.permute(0, 2, 3, 1).reshape(-1, 64).contiguous().to(gpu)).view(n, Hh, Ww, 64)
+    wq = H.x2_encode(w.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(gpu))
+    conv = dict(n_img=n, H=Hh, W=Ww, Cin=64, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=1, dil=1)
+    kw = dict(x2=True, bias=b.to(gpu), relu=True, out_dtype=H.X2)
+    if with_res:
+        kw.update(residual=enc(res).view(-1, 64), residual_x2=True)
+    out = H.gemm_nt(enc(x), wq, conv=dict(conv, pool=2) if pool else conv, **kw)
+    Ho, Wo = ref.shape[-2:]
+    got = H.x2_decode(out).view(n, Ho, Wo, 64).permute(0, 3, 1, 2).cpu()
+    scale = float(F.conv2d(x.abs().double(), w.abs().double(), None, 1, 1, 1).max()) + 4.0
+    assert float((got - ref).abs().max()) < 3e-5 * scale
+    gen = H.gemm_nt(enc(x), wq, conv=conv, tile_hint=1256064, **kw)  # the generic tile, unpooled
+    gen = H.x2_decode(gen).view(n, Hh, Ww, 64).permute(0, 3, 1, 2)
+    if pool:
+        gen = F.max_pool2d(gen, 2, 2)
+    assert float((got - gen.cpu()).abs().max()) < 1e-5 * scale

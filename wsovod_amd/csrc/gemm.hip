@@ -968,6 +968,203 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 #undef C64P_LAST_STEP
 }
 
+// ---------------------------------------------------------------------------------
+// The 64 -> 64 channel 3x3 convolution on bf16x2 maps (MODEL.HIP.PRECISION = "parity"; include/wsovod_hip.h).  Same
+// decomposition as conv3x3_c64_kernel -- a workgroup owns 8 x 32 output pixels, its 10 x 34 halo patch is DMA-staged once
+// and all nine taps read their A fragments from it -- with 256-byte pixel rows (64 values = [hi 0-31 | lo 0-31 | hi 32-63 |
+// lo 32-63]) and a 16-KiB weight slice per tap (double buffered).  A tap is two K-steps of 32 values; a K-step reads
+// (a_hi, a_lo) for its 4 pixel groups and (b_hi, b_lo) for the 4 channel tiles (16 ds_read_b128) and issues 48 MFMAs
+// b_hi*a_hi + b_lo*a_hi + b_hi*a_lo: 3 MFMAs per fragment read against 2 in the bf16 kernel.
+// LDS rows of 256 B: the 16-byte chunk index is XORed with the low 4 bits of the row (pixel / weight row) index, on the
+// DMA source address and on the read address, so the 16 consecutive rows of a fragment read fall into 16 different slots.
+// The epilogue adds bias and the (bf16x2) residual, applies ReLU, optionally the 2x2 / stride-2 max pool (pool = 2),
+// and stores bf16x2.
+// ---------------------------------------------------------------------------------
+constexpr int C64X_NPIX_PAD = (C64_NPIX + 15) / 16 * 16;  // whole 16-pixel DMA passes (4 wavefronts x 4 pixels)
+constexpr int C64X_PATCH_BYTES = C64X_NPIX_PAD * 256;
+constexpr int C64X_W_BYTES = 64 * 256;
+constexpr int C64X_LDS_BYTES = C64X_PATCH_BYTES + 2 * C64X_W_BYTES;
+
+__global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sP = smem;                     // halo patch [pixel][256 B]
+  char* sW = smem + C64X_PATCH_BYTES;  // 2 x [64 cout][256 B] weight slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpi = tiles_x * tiles_y;
+  const int img = blockIdx.x / tpi;
+  const int t = blockIdx.x - img * tpi;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int y0 = ty * C64_TH, x0 = tx * C64_TW;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(64 * p.ldb * 2), 0x00020000);
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+
+  // a wavefront DMA instruction lands 4 rows x 256 B: lane -> (row lane >> 4, slot lane & 15)
+  auto stage_weights = [&](int tap, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i * 16 + wave_u * 4 + (lane >> 4);   // LDS row = MFMA tile j = row >> 4, tile row f = row & 15
+      const int chunk = (lane & 15) ^ (row & 15);          // swizzle on the source
+      const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);  // a lane ends up with 16 consecutive channels
+      const int off = (int)((cout * p.ldb + tap * 128 + chunk * 8) * 2);    // (p.ldb, in bf16 slots = 2 x 9 x 64)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + buf * C64X_W_BYTES + (i * 16 + wave_u * 4) * 256), 16,
+                                               off, 0, 0, 0);
+    }
+#endif
+  };
+#if defined(__HIP_DEVICE_COMPILE__)
+  for (int base = 0; base < C64X_NPIX_PAD; base += 16) {
+    const int q = base + wave_u * 4 + (lane >> 4);
+    const int py = q / C64_PW, px = q - py * C64_PW;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
+    const bool ok = q < C64_NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const int chunk = (lane & 15) ^ (q & 15);
+    const int off = (((img * p.H + y) * p.W + x) * 128 + chunk * 8) * 2;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sP + (base + wave_u * 4) * 256), 16, ok ? off : -1, 0, 0, 0);
+  }
+#endif
+  stage_weights(0, 0);
+  __syncthreads();
+
+  const int frow = lane & 15, fq = lane >> 4;
+  f32x4 bias4[4];
+  c64_load_bias(p, fq, bias4);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int cur = tap & 1;
+    if (tap + 1 < 9) stage_weights(tap + 1, cur ^ 1);
+    const int r = tap / 3, s3 = tap - r * 3;
+    const char* cW = sW + cur * C64X_W_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {  // 32-value group of the 64 input channels: chunks 8 kk + (0-3 hi | 4-7 lo)
+      u32x4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = (wave * 2 + (i >> 1) + r) * C64_PW + (i & 1) * 16 + frow + s3;
+        const char* row = sP + q * 256;
+        ah[i] = *(const u32x4*)(row + (((8 * kk + fq) ^ (q & 15)) << 4));
+        al[i] = *(const u32x4*)(row + (((8 * kk + 4 + fq) ^ (q & 15)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = j * 16 + frow;
+        bh[j] = *(const u32x4*)(cW + row * 256 + (((8 * kk + fq) ^ (row & 15)) << 4));
+        bl[j] = *(const u32x4*)(cW + row * 256 + (((8 * kk + 4 + fq) ^ (row & 15)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]),
+                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                              __builtin_bit_cast(bf16x8, al[i]), acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: lane (frow, fq) holds, for pixel group i, channels 16 fq + 4 j + r of pixel frow: slots
+  // 64 (fq >> 1) + 16 (fq & 1) (hi) and 32 further (lo) of the pixel's 128
+  const float lo_clip = p.relu ? 0.f : -__builtin_inff();
+  const int slot = 64 * (fq >> 1) + 16 * (fq & 1);
+  auto load16 = [&](const bf16_t* q, float (&v)[16]) {  // bf16x2 residual values of this lane's 16 channels
+    const bf16x8 h0 = *(const bf16x8*)q, h1 = *(const bf16x8*)(q + 8), l0 = *(const bf16x8*)(q + 32), l1 = *(const bf16x8*)(q + 40);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (float)h0[e] + (float)l0[e];
+      v[8 + e] = (float)h1[e] + (float)l1[e];
+    }
+  };
+  auto store16 = [&](bf16_t* q, const float (&v)[16]) {
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h0[e] = (bf16_t)v[e];
+      h1[e] = (bf16_t)v[8 + e];
+      l0[e] = x2_lo(v[e], h0[e]);
+      l1[e] = x2_lo(v[8 + e], h1[e]);
+    }
+    *(bf16x8*)q = h0;
+    *(bf16x8*)(q + 8) = h1;
+    *(bf16x8*)(q + 32) = l0;
+    *(bf16x8*)(q + 40) = l1;
+  };
+  if (p.pool) {  // MaxPool2d(2, 2): the wavefront's two image rows are one pooled row, the horizontal partner is lane frow ^ 1
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      float best[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
+#pragma unroll
+      for (int iv = 0; iv < 2; ++iv) {
+        const int i = ih + 2 * iv;
+        const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
+        const long long m = ((long long)img * p.H + y) * p.W + x;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+        if (p.residual) {
+          float rv[16];
+          load16((const bf16_t*)p.residual + 2 * m * p.ldr + slot, rv);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += rv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], fmaxf(v[e], lo_clip));
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
+      const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
+      if ((frow & 1) == 0 && py < Hp && px < Wp)
+        store16((bf16_t*)p.C + 2 * (((long long)img * Hp + py) * Wp + px) * p.ldc + slot, best);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int y = y0 + wave * 2 + (i >> 1);
+    const int x = x0 + (i & 1) * 16 + frow;
+    if (y >= p.H || x >= p.W) continue;
+    const long long m = ((long long)img * p.H + y) * p.W + x;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+    if (p.residual) {
+      float rv[16];
+      load16((const bf16_t*)p.residual + 2 * m * p.ldr + slot, rv);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += rv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], lo_clip);
+    store16((bf16_t*)p.C + 2 * m * p.ldc + slot, v);
+  }
+}
+
 template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
 int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
   static int slot = wsovod::prof_slot(slot_name);
@@ -1235,8 +1432,26 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64)");
     return WSOVOD_OK;
   }
-  WS_CHECK_ARG(!(d->conv && d->geom.pool), "wsovod_gemm_nt(conv): geom.pool is an epilogue of the bf16 64-channel 3x3 "
-               "kernel only (stride 1, pad 1, dilation 1, no tile_hint)");
+  if (d->conv && d->tile_hint == 0 && x2 && d->geom.Cin == 64 && d->N == 64 && a.KH == 3 && a.KW == 3 && a.stride == 1 &&
+      a.pad == 1 && a.dil == 1 && a.Ho == a.H && a.Wo == a.W && d->C && d->dtype_c == WSOVOD_BF16X2 && !d->Ct && !d->A2 &&
+      !d->row_scale && !d->group_add && !d->mask_src && !d->accumulate && d->dropout_p == 0.f && d->ldc % 32 == 0 &&
+      (!d->residual || (d->dtype_r == WSOVOD_BF16X2 && d->ldr % 32 == 0)) && (a.pool == 0 || a.pool == 2) &&
+      !(getenv("WSOVOD_C64_X3") && getenv("WSOVOD_C64_X3")[0] == '0')) {
+    static int slot = wsovod::prof_slot("conv3x3_c64_halo_bf16x2");
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64X_LDS_BYTES);
+      attr = true;
+    }
+    const int tiles_x = ceil_div(a.W, C64_TW), tiles_y = ceil_div(a.H, C64_TH);
+    const int n_tiles = d->geom.n_img * tiles_x * tiles_y;
+    wsovod::ProfScope prof(slot, s, flops, bytes);
+    hipLaunchKernelGGL(conv3x3_c64_x3_kernel, dim3(n_tiles), dim3(256), C64X_LDS_BYTES, s, a, tiles_x, tiles_y);
+    WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64 bf16x2)");
+    return WSOVOD_OK;
+  }
+  WS_CHECK_ARG(!(d->conv && d->geom.pool), "wsovod_gemm_nt(conv): geom.pool is an epilogue of the 64-channel 3x3 "
+               "kernels only (stride 1, pad 1, dilation 1, no tile_hint)");
   int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
   // plain bf16 contractions take the staggered 8-wavefront form of the 256x256 tile (measured +11-13 % on the FC
   // shapes, tools/gemm_ab.py); the implicit-GEMM conv stays on the 16-wavefront form (tools/conv_ab.py)

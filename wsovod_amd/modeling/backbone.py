@@ -149,6 +149,10 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None, out
         else:
             wq, b = _folded_x2(conv, cin_pad=Cin)
             res2d = residual.view(N * Ho * Wo, conv.out_channels) if residual is not None else None
+            if pool2 and not out_fp32 and Cin == 64 and conv.out_channels == 64 and (k, s, p, d) == (3, 1, 1, 1):
+                geom["pool"] = 2  # the 64-channel halo kernel pools in its epilogue: the full-resolution map is never written
+                out = H.gemm_nt(x, wq, conv=geom, x2=True, bias=b, relu=relu, residual=res2d, residual_x2=True, out_dtype=fmt)
+                return out.view(N, Ho // 2, Wo // 2, conv.out_channels)
             out = H.gemm_nt(x, wq, conv=geom, x2=True, bias=b, relu=relu, residual=res2d, residual_x2=True, out_dtype=fmt)
         out = out.view(N, Ho, Wo, conv.out_channels)
         return H.maxpool2x2_nhwc(out, 2, x2=not out_fp32) if pool2 else out
