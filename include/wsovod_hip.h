@@ -264,7 +264,8 @@ typedef struct wsovod_sgd_tensor {
   long long numel;
   float lr, weight_decay;
   int grad_is_bf16; /* `grad` points at bf16 values (gradients that crossed the wire in bf16, see below) */
-  int reserved_;
+  int shadow_is_bf16x2; /* `bf16_shadow` is a bf16x2 copy (4 bytes per element, numel a multiple of 32): the "parity"
+                         * precision's weight operand refreshed in the update pass instead of by wsovod_bf16x2_encode */
   const float* used_flag; /* optional DEVICE scalar: 0 = no data-parallel rank produced a gradient for this tensor in
                            * this step -> parameter and momentum stay untouched, as torch.optim.SGD skips `grad is None`
                            * under DDP(find_unused_parameters=True) (engine/defaults.py:146-148); NULL = always update */

@@ -37,7 +37,7 @@ def test_encode_decode_round_trip_and_layout(gpu):
     assert torch.isnan(H.x2_decode(H.x2_encode(nan.to(gpu)))).all()
 
 
-@pytest.mark.parametrize("tile", [0, 8256256, 256256, 256128, 1256064, 1128064, 1128128, 64064])
+@pytest.mark.parametrize("tile", [0, 8256256, 2256256, 256256, 256128, 1256064, 1128064, 1128128, 64064])
 @pytest.mark.parametrize("shape", [(512, 512, 1024), (300, 40, 256), (333, 129, 192), (64, 4, 4096), (1024, 4096, 512)])
 def test_gemm_x2_against_fp64(gpu, tile, shape):
     """fp32-grade products on the bf16 MFMA pipe: error ~1e-5 of sum |a||b| (plain bf16: ~4e-3)."""
@@ -67,7 +67,7 @@ def test_gemm_x2_epilogue_and_x2_output(gpu):
     ga = torch.randn(3, N)
     ref = torch.relu((A.double() @ B.double().t()).float() + bias[None] + res)
     a2, b2 = H.x2_encode(A.to(gpu)), H.x2_encode(B.to(gpu))
-    for tile in (0, 8256256, 128128):
+    for tile in (0, 8256256, 2256256, 128128):
         out = H.gemm_nt(a2, b2, x2=True, out_dtype=H.X2, bias=bias.to(gpu), residual=H.x2_encode(res.to(gpu)),
                         residual_x2=True, relu=True, tile_hint=tile)
         got = H.x2_decode(out).cpu()
@@ -90,7 +90,7 @@ def test_gemm_x2_epilogue_and_x2_output(gpu):
     dict(n=1, H=16, W=16, Cin=256, Cout=512, k=1, s=1, p=0, d=1),
     dict(n=3, H=33, W=21, Cin=64, Cout=128, k=3, s=1, p=1, d=1),
 ])
-@pytest.mark.parametrize("tile", [0, 256256, 8256256, 1256064])
+@pytest.mark.parametrize("tile", [0, 256256, 8256256, 2256256, 1256064])
 def test_conv_x2_against_fp64(gpu, geom, tile):
     from wsovod_amd.layers import hip_ops as H
 
@@ -127,10 +127,11 @@ def test_conv_x2_with_fused_projection_shortcut(gpu):
     enc = lambda t, c: H.x2_encode(t.permute(0, 2, 3, 1).reshape(-1, c).contiguous().to(gpu)).view(n, Hh, Ww, c)
     wcat = torch.cat([w.permute(0, 2, 3, 1).reshape(Co, -1), ws.reshape(Co, C2)], dim=1).contiguous()
     conv = dict(n_img=n, H=Hh, W=Ww, Cin=C1, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=2, dil=2)
-    out = H.gemm_nt(enc(h, C1), H.x2_encode(wcat.to(gpu)), conv=conv, x2=True, bias=b.to(gpu), relu=True,
-                    out_dtype=H.X2, A2=enc(x, C2))
-    got = H.x2_decode(out).view(n, Hh, Ww, Co).permute(0, 3, 1, 2).cpu()
-    assert float((got - ref).abs().max()) < 3e-4
+    for tile in (0, 256256, 8256256, 2256256):  # 16-wavefront tile, four-phase and two-phase 8-wavefront tiles
+        out = H.gemm_nt(enc(h, C1), H.x2_encode(wcat.to(gpu)), conv=conv, x2=True, bias=b.to(gpu), relu=True,
+                        out_dtype=H.X2, A2=enc(x, C2), tile_hint=tile)
+        got = H.x2_decode(out).view(n, Hh, Ww, Co).permute(0, 3, 1, 2).cpu()
+        assert float((got - ref).abs().max()) < 3e-4, tile
 
 
 def test_maxpool_add_group_rows_and_mask_on_x2(gpu):
@@ -258,3 +259,33 @@ def test_conv3x3_c64_halo_kernel_on_bf16x2(gpu, pool, with_res):
     if pool:
         gen = F.max_pool2d(gen, 2, 2)
     assert float((got - gen.cpu()).abs().max()) < 1e-5 * scale
+
+
+def test_sgd_refreshes_the_bf16x2_weight_operand(gpu):
+    """HipSGD keeps the cached bf16x2 encoding of a weight current inside the fused update (no re-encode pass)."""
+    from wsovod_amd.engine.trainer import HipSGD
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(12)
+    p = torch.nn.Parameter(torch.randn(96, 160, device=gpu))
+    q = torch.nn.Parameter(torch.randn(7, 5, device=gpu))  # numel not a multiple of 32: no bf16x2 shadow
+    opt = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 1e-3}, {"params": [q], "lr": 0.1, "weight_decay": 0.0}], 0.1,
+                 momentum=0.9)
+    enc0 = H.x2_cached(p)
+    for _ in range(3):
+        p.grad, q.grad = torch.randn_like(p), torch.randn_like(q)
+        opt.step()
+        enc = H.x2_cached(p)
+        assert enc.data_ptr() == enc0.data_ptr()  # the same buffer, refreshed by the update kernel
+        assert torch.equal(H.x2_decode(enc), H.x2_decode(H.x2_encode(p.detach())))
+    ref = torch.nn.Parameter(p.detach().clone())  # and the update itself is torch.optim.SGD's
+    ref_opt = torch.optim.SGD([ref], lr=0.1, momentum=0.9, weight_decay=1e-3)
+    p2 = torch.nn.Parameter(ref.detach().clone())
+    opt2 = HipSGD([{"params": [p2], "lr": 0.1, "weight_decay": 1e-3}], 0.1, momentum=0.9)
+    H.x2_cached(p2)
+    for _ in range(3):
+        g = torch.randn_like(ref)
+        ref.grad, p2.grad = g.clone(), g.clone()
+        ref_opt.step()
+        opt2.step()
+    torch.testing.assert_close(p2.detach(), ref.detach(), rtol=1e-6, atol=1e-6)

@@ -76,6 +76,8 @@ def test_gemm_8phase_tile(gpu, shape):
     # same summation order as the 16-wavefront tile: bit-identical
     out16 = hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, tile_hint=256256)
     assert torch.equal(out, out16)
+    # the two-phase form of the 8-wavefront tile: the same products in the same order
+    assert torch.equal(out, hip_ops.gemm_nt(A.to(gpu), B.to(gpu), out_dtype=torch.float32, tile_hint=2256256))
     with pytest.raises(RuntimeError, match="bf16 only"):
         hip_ops.gemm_nt(A.float().to(gpu), B.float().to(gpu), tile_hint=8256256)
 
@@ -469,6 +471,11 @@ def test_conv_with_fused_projection_shortcut(gpu, dtype, tol, k, dil):
     for hint in (256128, 128128, 64064):  # the other tile shapes of the same kernel
         alt = H.gemm_nt(hd, wcat, conv=geom, bias=(b + bsc).to(gpu), relu=True, out_dtype=torch.float32, A2=xd, tile_hint=hint)
         assert float((alt - fused).abs().max()) <= 1e-5 * scale + (0 if dtype == torch.float32 else 1e-3 * scale)
-    with pytest.raises(RuntimeError, match="fused-shortcut"):
-        H.gemm_nt(hd.to(torch.bfloat16), wcat.to(torch.bfloat16), conv=geom, A2=xd.to(torch.bfloat16), tile_hint=8256256,
-                  out_dtype=torch.float32)
+    # the 8-wavefront tile (four- and two-phase form) carries the fused shortcut too (round 3): same products, same order
+    b16 = lambda t: t.to(torch.bfloat16)
+    ref16 = H.gemm_nt(b16(hd), b16(wcat), conv=geom, A2=b16(xd), bias=(b + bsc).to(gpu), relu=True, tile_hint=256256,
+                      out_dtype=torch.float32)
+    for hint in (8256256, 2256256):
+        alt = H.gemm_nt(b16(hd), b16(wcat), conv=geom, A2=b16(xd), bias=(b + bsc).to(gpu), relu=True, tile_hint=hint,
+                        out_dtype=torch.float32)
+        assert torch.equal(alt, ref16), hint

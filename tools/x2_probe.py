@@ -60,8 +60,19 @@ if __name__ == "__main__":
     conv_case("stem 64->64 300x400 (c64 halo vs generic)", 300, 400, 64, 64, 3, 1, [0, 1256064])
     conv_case("res2 64->64 150x200", 150, 200, 64, 64, 3, 1, [0, 1256064], residual=True)
     conv_case("res3 128->128 75x100", 75, 100, 128, 128, 3, 1, [0, 256128, 256256, 8256256])
-    conv_case("res4 256->256 d2", 75, 100, 256, 256, 3, 2, [256256, 8256256, 256128])
-    conv_case("res5 512->512 d2", 75, 100, 512, 512, 3, 2, [256256, 8256256])
-    gemm_case("fc1", n * 512, 4096, 25088, [8256256, 256256])
-    gemm_case("fc2", n * 512, 4096, 4096, [8256256, 256256])
-    gemm_case("proj1", n * 512, 1024, 4096, [0, 8256256, 256128])
+    conv_case("res4 256->256 d2", 75, 100, 256, 256, 3, 2, [256256, 8256256, 2256256, 256128])
+    conv_case("res5 512->512 d2", 75, 100, 512, 512, 3, 2, [256256, 8256256, 2256256])
+    gemm_case("fc1", n * 512, 4096, 25088, [8256256, 2256256, 256256])
+    gemm_case("fc2", n * 512, 4096, 4096, [8256256, 2256256, 256256])
+    gemm_case("proj1", n * 512, 1024, 4096, [0, 8256256, 2256256, 256128])
+    # plain bf16 forms of the two 8-wavefront schedules (the headline precision)
+    A = torch.randn(n * 512, 25088, device=dev).to(torch.bfloat16)
+    B = (torch.randn(4096, 25088, device=dev) * 0.01).to(torch.bfloat16)
+    r = bench({str(t): (lambda t=t: H.gemm_nt(A, B, out_dtype=torch.bfloat16, tile_hint=t)) for t in (8256256, 2256256, 256256)})
+    print("fc1 bf16", {t: f"{ms:.3f} ms {2.0 * n * 512 * 4096 * 25088 / ms / 1e9:.0f} TF" for t, ms in r.items()}, flush=True)
+    x = torch.randn(n, 75, 100, 512, device=dev).to(torch.bfloat16)
+    w = (torch.randn(512, 9 * 512, device=dev) * 0.02).to(torch.bfloat16)
+    geom = dict(n_img=n, H=75, W=100, Cin=512, Ho=75, Wo=100, KH=3, KW=3, stride=1, pad=2, dil=2)
+    r = bench({str(t): (lambda t=t: H.gemm_nt(x, w, conv=geom, relu=True, out_dtype=torch.bfloat16, tile_hint=t))
+               for t in (256256, 8256256, 2256256)})
+    print("res5 bf16", {t: f"{ms:.3f} ms {2.0 * n * 7500 * 512 * 4608 / ms / 1e9:.0f} TF" for t, ms in r.items()}, flush=True)

@@ -113,7 +113,7 @@ class SgdTensor(C.Structure):
     """wsovod_sgd_tensor (include/wsovod_hip.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
                 ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
-                ("reserved_", C.c_int), ("used_flag", C.c_void_p)]
+                ("shadow_is_bf16x2", C.c_int), ("used_flag", C.c_void_p)]
 
 
 class PackTensor(C.Structure):

@@ -463,6 +463,7 @@ struct SgdTable {
   int first_block[kSgdMax + 1];
   int count;
   unsigned g_bf16;  // bit k: g[k] points at bf16 values (gradients that travelled in the bf16 wire format)
+  unsigned x2_shadow;  // bit k: shadow[k] is a bf16x2 copy of the parameter (include/wsovod_hip.h), n[k] a multiple of 32
   const float* used[kSgdMax];  // optional device flag: 0 = no rank produced a gradient for the tensor -> left untouched
 };
 
@@ -477,6 +478,7 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
   const long long n = t.n[k];
   const float lr = t.lr[k], wd = t.wd[k];
   const bool gb = (t.g_bf16 >> k) & 1u;
+  const bool sx2 = (t.x2_shadow >> k) & 1u;
   const bf16_t* __restrict__ g16 = (const bf16_t*)t.g[k];
   if (t.used[k] && *t.used[k] == 0.f) return;  // torch.optim.SGD skips parameters whose grad is None
   const bool vec = ((((uintptr_t)p | (uintptr_t)buf) & 15) == 0) && (((uintptr_t)shadow & 7) == 0) &&
@@ -498,14 +500,30 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
       pv -= lr * bv;
       __builtin_nontemporal_store(bv, (f32x4*)(buf + i));
       __builtin_nontemporal_store(pv, (f32x4*)(p + i));
-      if (shadow) *(bf16x4*)(shadow + i) = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+      if (shadow) {
+        const bf16x4 hi = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+        if (sx2) {  // hi at slot 64 (i / 32) + i % 32, lo 32 slots further (4 consecutive values never straddle a group)
+          bf16_t* q = shadow + ((i >> 5) << 6) + (i & 31);
+          *(bf16x4*)q = hi;
+          *(bf16x4*)(q + 32) = bf16x4{(bf16_t)(pv[0] - (float)hi[0]), (bf16_t)(pv[1] - (float)hi[1]),
+                                      (bf16_t)(pv[2] - (float)hi[2]), (bf16_t)(pv[3] - (float)hi[3])};
+        } else {
+          *(bf16x4*)(shadow + i) = hi;
+        }
+      }
     } else {
       for (long long q = i; q < min(i + 4, n); ++q) {
         const float b = mu * buf[q] + ((gb ? (float)g16[q] : g[q]) * gscale + wd * p[q]);
         buf[q] = b;
         const float pv = p[q] - lr * b;
         p[q] = pv;
-        if (shadow) shadow[q] = (bf16_t)pv;
+        if (shadow && sx2) {
+          bf16_t* d = shadow + ((q >> 5) << 6) + (q & 31);
+          d[0] = (bf16_t)pv;
+          d[32] = (bf16_t)(pv - (float)d[0]);
+        } else if (shadow) {
+          shadow[q] = (bf16_t)pv;
+        }
       }
     }
   }
@@ -1022,6 +1040,11 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
       t.buf[k] = d.momentum_buf;
       t.shadow[k] = (bf16_t*)d.bf16_shadow;
       if (d.grad_is_bf16) t.g_bf16 |= 1u << k;
+      if (d.shadow_is_bf16x2 && d.bf16_shadow) {
+        WS_CHECK_ARG(d.numel % 32 == 0 && ((uintptr_t)d.bf16_shadow & 15) == 0,
+                     "wsovod_sgd_momentum_multi: a bf16x2 shadow needs numel a multiple of 32 and 16-byte alignment");
+        t.x2_shadow |= 1u << k;
+      }
       t.used[k] = d.used_flag;
       t.n[k] = d.numel;
       t.lr[k] = d.lr;

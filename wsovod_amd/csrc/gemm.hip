@@ -1198,6 +1198,10 @@ int dispatch_tile(const GemmArgs& a, int tile, hipStream_t s, double flops, doub
       if constexpr (bf) return launch_gemm256_8ph(a, CONV, s, flops, bytes);
       wsovod::set_error("wsovod_gemm_nt: tile 8256256 is bf16 only");
       return WSOVOD_ERR_UNSUPPORTED;
+    case 2256256:  // the same tile with two phases per K-step
+      if constexpr (bf) return launch_gemm256_8ph(a, CONV, s, flops, bytes, false, false, true);
+      wsovod::set_error("wsovod_gemm_nt: tile 2256256 is bf16 only");
+      return WSOVOD_ERR_UNSUPPORTED;
     case 256256:  // 16 wavefronts (4x4), 128 KiB LDS, one workgroup per CU: 128 FLOP per staged byte
       return launch<T, 256, 256, CONV, 4, 4, true>(a, s, CONV ? (bf ? "conv_igemm_bf16_256x256" : "conv_igemm_f32_256x256")
                                                        : (bf ? "gemm_nt_bf16_256x256" : "gemm_nt_f32_256x256"),
@@ -1259,6 +1263,8 @@ int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, d
   switch (tile) {
     case 8256256:
       return launch_gemm256_8ph(a, CONV, s, flops, bytes, false, true);
+    case 2256256:  // the two-phase ("merged") form of that tile
+      return launch_gemm256_8ph(a, CONV, s, flops, bytes, false, true, true);
     case 256256:
       return launch<bf16_t, 256, 256, CONV, 4, 4, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x256" : "gemm_nt_bf16x2_256x256",
                                                                flops, bytes);
@@ -1315,7 +1321,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   const int epc = x2 ? 32 : 16 / esz;  // bf16x2: whole 32-value groups
   const int xs = x2 ? 2 : 1;           // bf16 slots per value
   WS_CHECK_ARG(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0, "wsovod_gemm_nt: A/B must be 16-byte aligned");
-  WS_CHECK_ARG(d->ldb % (x2 ? 4 : epc) == 0, "wsovod_gemm_nt: ldb=%lld: rows must be 16-byte aligned", d->ldb);
+  WS_CHECK_ARG(d->ldb % (x2 ? 4 : epc) == 0, "wsovod_gemm_nt: ldb=%lld must be a multiple of %d elements", d->ldb, x2 ? 4 : epc);
   WS_CHECK_ARG(128ll * d->ldb * esz * xs < (1ll << 31), "wsovod_gemm_nt: ldb too large for buffer addressing");
   WS_CHECK_ARG(d->K % epc == 0, "wsovod_gemm_nt: K=%d must be a multiple of %d elements", d->K, epc);
   WS_CHECK_ARG(!x2 || (d->dropout_p == 0.f || d->C), "wsovod_gemm_nt: bad bf16x2 call");
@@ -1384,12 +1390,11 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       a.Cin2 = d->Cin2 * xs;
       a.a2_bytes = (long long)g.n_img * g.Ho * g.Wo * d->Cin2 * esz * xs;
       WS_CHECK_ARG(a.a2_bytes < (1ll << 31), "wsovod_gemm_nt(conv): fused shortcut input exceeds the 2 GiB buffer-addressing limit");
-      WS_CHECK_ARG(!(d->tile_hint == 8256256), "wsovod_gemm_nt(conv): the 8-phase tile has no fused-shortcut path");
     }
     WS_CHECK_ARG(a.a_bytes < (1ll << 31), "wsovod_gemm_nt(conv): input of %lld bytes exceeds the 2 GiB buffer-addressing limit", a.a_bytes);
     bytes = ((double)g.n_img * g.H * g.W * g.Cin + (double)d->N * d->K + (d->A2 ? (double)g.n_img * g.Ho * g.Wo * d->Cin2 : 0.0)) * esz * xs;
   } else {
-    WS_CHECK_ARG(d->lda % (x2 ? 4 : epc) == 0, "wsovod_gemm_nt: lda=%lld: rows must be 16-byte aligned", d->lda);
+    WS_CHECK_ARG(d->lda % (x2 ? 4 : epc) == 0, "wsovod_gemm_nt: lda=%lld must be a multiple of %d elements", d->lda, x2 ? 4 : epc);
     WS_CHECK_ARG(128ll * d->lda * esz * xs < (1ll << 31), "wsovod_gemm_nt: lda too large for buffer addressing");
     bytes = ((double)d->M * d->K + (double)d->N * d->K) * esz * xs;
   }
@@ -1463,7 +1468,10 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     tile = 8256256;
   a.ksplit = d->tile_hint == 0 ? -1 : 0;  // split-K may only change the summation order when the caller named no tile
   if (x2) {
-    if (!d->tile_hint && tile == 256256 && !d->conv) tile = 8256256;
+    // plain contractions: the 8-wavefront tile in its two-phase form (48 MFMAs per phase; measured on the fc1 / fc2 /
+    // projection shapes: 6.63 -> 6.14, 1.12 -> 1.03, 0.274 -> 0.263 ms against the four-phase form, tools/x2_probe.py);
+    // the implicit-GEMM convs stay on the 16-wavefront tile (res5: 2.32 vs 2.40 ms)
+    if (!d->tile_hint && tile == 256256 && !d->conv) tile = 2256256;
     return d->conv ? dispatch_tile_x3<true>(a, tile, s, flops, bytes) : dispatch_tile_x3<false>(a, tile, s, flops, bytes);
   }
   if (d->dtype_in == WSOVOD_BF16)

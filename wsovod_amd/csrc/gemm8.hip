@@ -34,7 +34,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // chunks 0-3 and their lo halves in chunks 4-7, so the SAME two fragment reads per tile (k-half 0 / 1 of the bf16 form)
 // deliver (a_hi, a_lo) and (b_hi, b_lo), and a quadrant phase issues 24 MFMAs -- bh*ah, bl*ah, bh*al -- on them instead of
 // 16: staging, LDS traffic and barriers of a bf16 GEMM over 2K elements, 1.5x its MFMA work (= 3x the bf16 GEMM over K).
-template <bool CONV, bool X3 = false>
+// PH = 2 ("merged" form): a K-step is TWO phases -- (A rows 0-63 x all 64 columns) and (A rows 64-127 x all 64 columns) --
+// each [fragment reads, LDS-DMA issue, counted wait] barrier [32 (bf16) / 48 (X3) MFMAs] barrier: half the barriers and
+// wait points per MFMA of the four-phase form.  Every group measured ~450 cycles per phase in which its SIMD's matrix
+// pipe idles whatever the phase's MFMA count (bf16: 16 MFMAs = 256 cycles at 55 % busy; X3: 24 MFMAs = 384 cycles at
+// 61 %), so doubling the MFMAs per phase raises the busy share.  DMA schedule: phase A stages B and A_lo of K-step kt+1
+// (their LDS rows were last read two phases earlier) and waits for A_hi(kt); phase B stages A_hi(kt+1) and waits for the
+// six instructions of phase A.  Same products in the same order as PH = 4: bit-identical results.
+template <bool CONV, bool X3 = false, int PH = 4>
 __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 256, BKE = 64, EPC = 8, esz = 2;
   constexpr int LR = 64;  // rows staged per DMA pass (512 threads x 16 B = 64 rows x 128 B)
@@ -63,10 +70,12 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const int lrow = tid >> 3;
   const int lchunk = (tid & 7) ^ ((lrow >> 1) & 7);  // swizzle on the DMA source
 
-  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrcA, rsrcB;
+  [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrcA, rsrcB, rsrcA2;
   int a_off[4], hi0[4], wi0[4], b_off[4];
+  [[maybe_unused]] int pix2_off[4];  // conv + fused shortcut: this lane's chunk of its output pixel in A2, <0 = row past M
   if (CONV) {
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+    rsrcA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0), 0x00020000);
   } else {
     const long long rows = min(BM, p.M - m0);
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * esz), 0, (int)(rows * p.lda * esz),
@@ -91,6 +100,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       hi0[i] = ok ? ho * p.stride - p.pad : -(1 << 28);
       wi0[i] = wo * p.stride - p.pad;
       a_off[i] = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
+      pix2_off[i] = ok ? (((img * p.Ho + ho) * p.Wo + wo) * p.Cin2 + lchunk * EPC) * esz : -1;
     } else {
       hi0[i] = wi0[i] = 0;
       a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
@@ -128,8 +138,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   // the 64 columns of the wavefronts with wc == i.
   // conv: (filter row, filter column, first channel) of a K-step, advanced incrementally (scalar adds instead of the
   // two integer divisions per staged K-step)
-  struct Tap { int r, q, c0; };
+  struct Tap { int r, q, c0; };  // c0 >= Cin: the K-steps of the fused 1x1 shortcut (second input A2 at channel c0 - Cin)
   auto tap_next = [&](Tap t) {  // (channel chunk, tap) order with the tap innermost, as gemm.hip: the taps of a chunk
+    if (t.c0 >= p.Cin) { t.c0 += BKE; return t; }
     if (++t.q >= p.KW) {        // re-read the same input pixels while they are still in L2
       t.q = 0;
       if (++t.r >= p.KH) { t.r = 0; t.c0 += BKE; }
@@ -141,10 +152,15 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     const int kbase = (kt + kt_base) * BKE;
     char* dA = sA + buf * BM * 128 + wave_u * 1024 + LR * i * 128;
     if (CONV) {
-      const int tap = t.r * p.KW + t.q;
-      const int delta = (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;  // wave-uniform
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
-                                               ((vmask[i] >> tap) & 1u) ? pix_off[i] + delta : -1, 0, 0, 0);
+      if (t.c0 >= p.Cin) {  // fused shortcut: the second input at the output pixel (wave-uniform branch)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void*)dA, 16,
+                                                 pix2_off[i] >= 0 ? pix2_off[i] + (t.c0 - p.Cin) * esz : -1, 0, 0, 0);
+      } else {
+        const int tap = t.r * p.KW + t.q;
+        const int delta = (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;  // wave-uniform
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
+                                                 ((vmask[i] >> tap) & 1u) ? pix_off[i] + delta : -1, 0, 0, 0);
+      }
     } else {
       const bool k_ok = kbase + lchunk * EPC < p.K;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
@@ -154,7 +170,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   };
   auto stage_B = [&](int kt, int buf, int i, const Tap t) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int kbase = CONV ? (t.r * p.KW + t.q) * p.Cin + t.c0 : (kt + kt_base) * BKE;  // conv: weight rows are [kh][kw][Cin]
+    // conv: weight rows are [kh][kw][Cin] (+ [Cin2] of the fused shortcut behind them)
+    const int kbase = CONV ? (t.c0 >= p.Cin ? p.KH * p.KW * p.Cin + (t.c0 - p.Cin) : (t.r * p.KW + t.q) * p.Cin + t.c0)
+                           : (kt + kt_base) * BKE;
     const bool k_ok = kbase + lchunk * EPC < p.K;
     char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16,
@@ -183,6 +201,10 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #define WS_LGKM0_12() \
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), \
                "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]))
+#define WS_LGKM0_16() \
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), \
+               "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]), "+v"(bl[0][0]), "+v"(bl[0][1]), "+v"(bl[1][0]), "+v"(bl[1][1]), \
+               "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]))
 #define WS_LGKM0_A() \
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+v"(af[2][0]), \
                "+v"(af[2][1]), "+v"(af[3][0]), "+v"(af[3][1]))
@@ -190,6 +212,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0][0]), "+v"(bh[0][1]), "+v"(bh[1][0]), "+v"(bh[1][1]))
 #else
 #define WS_DS_READ(dst, addr) (void)0
+#define WS_LGKM0_16() (void)0
 #define WS_LGKM0_12() (void)0
 #define WS_LGKM0_A() (void)0
 #define WS_LGKM0_BH() (void)0
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   stage_A(0, 0, 0, t0); stage_A(0, 0, 2, t0);
   stage_B(0, 0, 0, t0); stage_B(0, 0, 1, t0); stage_B(0, 0, 2, t0); stage_B(0, 0, 3, t0);
   stage_A(0, 0, 1, t0); stage_A(0, 0, 3, t0);
-  if (nk > 1) { stage_A(1, 1, 0, t1); stage_A(1, 1, 2, t1); }
+  if (PH == 4 && nk > 1) { stage_A(1, 1, 0, t1); stage_A(1, 1, 2, t1); }
   WS_VMCNT(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second M-half runs one barrier behind
@@ -229,6 +252,64 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
     const unsigned bA = ldsA + cur * (BM * 128) + offA, bB = ldsB + cur * (BN * 128) + offB;
+    if constexpr (PH == 2) {
+      // ---- phase A: A rows 0-63 x all 64 columns of this wavefront (16 fragment reads)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        WS_DS_READ(bl[j][0], bB + j * 2048 + c0);
+        WS_DS_READ(bl[j][1], bB + j * 2048 + c1);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        WS_DS_READ(af[i][0], bA + i * 2048 + c0);
+        WS_DS_READ(af[i][1], bA + i * 2048 + c1);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        WS_DS_READ(bh[j][0], bB + (2 + j) * 2048 + c0);
+        WS_DS_READ(bh[j][1], bB + (2 + j) * 2048 + c1);
+      }
+      if (more) {  // rows last read two phases ago (phase A of kt-1)
+        stage_B(kt + 1, cur ^ 1, 0, t1); stage_B(kt + 1, cur ^ 1, 1, t1);
+        stage_B(kt + 1, cur ^ 1, 2, t1); stage_B(kt + 1, cur ^ 1, 3, t1);
+        stage_A(kt + 1, cur ^ 1, 0, t1); stage_A(kt + 1, cur ^ 1, 2, t1);
+        WS_VMCNT(6);  // younger: these six -> A_hi(kt) has landed (read in phase B)
+      } else {
+        WS_VMCNT(0);
+      }
+      __builtin_amdgcn_s_barrier();
+      WS_LGKM0_16();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      WS_MFMA_QUAD(0, bl, 0);
+      WS_MFMA_QUAD(0, bh, 2);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      // ---- phase B: A rows 64-127 (into the same registers) x all 64 columns
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        WS_DS_READ(af[i][0], bA + (4 + i) * 2048 + c0);
+        WS_DS_READ(af[i][1], bA + (4 + i) * 2048 + c1);
+      }
+      if (more) {  // rows last read two phases ago (phase B of kt-1)
+        stage_A(kt + 1, cur ^ 1, 1, t1); stage_A(kt + 1, cur ^ 1, 3, t1);
+        WS_VMCNT(2);  // younger: these two -> B(kt+1) and A_lo(kt+1) have landed (read in the next phase A)
+      } else {
+        WS_VMCNT(0);
+      }
+      __builtin_amdgcn_s_barrier();
+      WS_LGKM0_A();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      WS_MFMA_QUAD(4, bh, 2);
+      WS_MFMA_QUAD(4, bl, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      if (CONV) { t1 = tap_next(t1); }
+      continue;
+    }
     // ---- phase 1: A rows 0-63 + B cols 0-31 of this wavefront
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -431,6 +512,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #undef WS_EMIT_ROW
 #undef WS_DS_READ
 #undef WS_LGKM0_12
+#undef WS_LGKM0_16
 #undef WS_LGKM0_A
 #undef WS_LGKM0_BH
 #undef WS_MFMA_QUAD
@@ -458,7 +540,8 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) 
 
 }  // namespace
 
-int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split, bool x3) {
+int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split, bool x3,
+                       bool merged) {
   allow_split = (allow_split || a.ksplit == -1) && !x3;  // -1: the dispatcher chose this tile itself (no tile_hint)
   static int slot_g = wsovod::prof_slot("gemm_nt_bf16_256x256_8ph");
   static int slot_c = wsovod::prof_slot("conv_igemm_bf16_256x256_8ph");
@@ -471,11 +554,11 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
     (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     attr_set = true;
-  }
-  if (conv && a.A2) {
-    wsovod::set_error("wsovod_gemm_nt(conv): the 8-phase tile has no fused-shortcut path");
-    return WSOVOD_ERR_UNSUPPORTED;
   }
   GemmArgs args = a;
   args.tiles_m = ceil_div(a.M, 256);
@@ -521,14 +604,19 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
     }
   }
   wsovod::ProfScope prof(x3 ? (conv ? slot_c3 : slot_g3) : (conv ? slot_c : slot_g), s, flops, bytes);
-  if (x3 && conv)
-    hipLaunchKernelGGL((gemm256_8ph_kernel<true, true>), dim3(grid), dim3(512), lds_bytes, s, args);
-  else if (x3)
-    hipLaunchKernelGGL((gemm256_8ph_kernel<false, true>), dim3(grid), dim3(512), lds_bytes, s, args);
-  else if (conv)
-    hipLaunchKernelGGL(gemm256_8ph_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, args);
-  else
-    hipLaunchKernelGGL(gemm256_8ph_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, args);
+#define WS_L8(C, X, P) hipLaunchKernelGGL((gemm256_8ph_kernel<C, X, P>), dim3(grid), dim3(512), lds_bytes, s, args)
+  if (merged) {
+    if (x3 && conv) WS_L8(true, true, 2);
+    else if (x3) WS_L8(false, true, 2);
+    else if (conv) WS_L8(true, false, 2);
+    else WS_L8(false, false, 2);
+  } else {
+    if (x3 && conv) WS_L8(true, true, 4);
+    else if (x3) WS_L8(false, true, 4);
+    else if (conv) WS_L8(true, false, 4);
+    else WS_L8(false, false, 4);
+  }
+#undef WS_L8
   if (args.ksplit > 1) {
     const long long quads = (long long)a.M * ((a.N + 3) / 4);
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, args);

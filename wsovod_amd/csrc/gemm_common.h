@@ -165,7 +165,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int nb
 }
 
 // gemm8.hip: bf16 256x256 tile, 8 wavefronts in two staggered groups (see the file header).
+// x3: bf16x2 operands (three-MFMA products); merged: the two-phase form of the K-step (tile_hint 2256256)
 int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split = false,
-                       bool x3 = false);
+                       bool x3 = false, bool merged = false);
 
 }  // namespace wsovod_gemm

@@ -348,7 +348,18 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
   a.ksplit = a.slice_steps = 0;
   a.accumulate = accumulate & 1;
   int grid = ntiles;
-  if (!(accumulate & 2) && ntiles > cus && tail > 0 && tail <= cus / 2) {
+  if (!(accumulate & 2) && ntiles <= cus / 2 && nk >= 32) {
+    // Few output tiles (the 1024 -> 512 projection: 8; the stacked heads: 80): EVERY tile is cut along the reduction so
+    // that the grid fills the chip; the slices meet by the same fp32 atomic adds as a split tail round
+    const int S = std::min(std::min(8, cus / ntiles), nk / 16);
+    if (S >= 2) {
+      a.full_tiles = 0;
+      a.ksplit = S;
+      a.slice_steps = ceil_div(nk, S);
+      grid = ntiles * S;
+      if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(ntiles), dim3(256), 0, s, a);
+    }
+  } else if (!(accumulate & 2) && ntiles > cus && tail > 0 && tail <= cus / 2) {
     const int S = std::min(8, cus / tail);
     if (nk >= 8 * S) {
       a.full_tiles = ntiles - tail;

@@ -34,6 +34,9 @@ class HipSGD(torch.optim.Optimizer):
                 g = wire if wire is not None else (p.grad if p.grad.is_contiguous() else p.grad.contiguous())
                 sh = getattr(p, "_hip_shadow", None)  # bf16 copy used by the MFMA kernels: refreshed in the same pass
                 shadow = sh[0] if (sh is not None and sh[1] == p._version and sh[0].dtype == torch.bfloat16) else None
+                xe = getattr(p, "_x2_enc", None)  # "parity" precision: the bf16x2 operand (hip_ops.x2_cached) instead
+                if xe is not None and xe[0] == (p._version, p.data_ptr(), None) and p.numel() % 32 == 0:
+                    shadow = xe[1]
                 by_momentum.setdefault(group["momentum"], []).append(
                     (p.data, g, state["momentum_buffer"], shadow, group["lr"], group["weight_decay"],
                      getattr(p, "_used_flag", None), p))
@@ -44,7 +47,9 @@ class HipSGD(torch.optim.Optimizer):
                 # conv weights, class matrices) are rebuilt, and re-stamp the bf16 shadow the kernel refreshed itself
                 p, shadow = e[7], e[3]
                 torch.autograd.graph.increment_version(p)
-                if shadow is not None:
+                if shadow is not None and shadow.dtype == torch.float32:
+                    p._x2_enc = ((p._version, p.data_ptr(), None), shadow)
+                elif shadow is not None:
                     p._hip_shadow = (shadow, p._version)
 
 

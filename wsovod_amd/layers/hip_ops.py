@@ -880,7 +880,8 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=F
 
 def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
     """entries: list of (param, grad fp32 or bf16, momentum_buf, bf16_shadow or None, lr, weight_decay[, used_flag]);
-    one launch per 32.  used_flag: optional 1-element fp32 device tensor, 0 = leave the tensor untouched."""
+    one launch per 32.  used_flag: optional 1-element fp32 device tensor, 0 = leave the tensor untouched.
+    A float32-typed shadow is a bf16x2 copy of the parameter (X2 carrier): refreshed as (hi, lo) pairs."""
     from .._lib import SgdTensor
 
     if not entries:
@@ -895,6 +896,7 @@ def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
             raise RuntimeError("sgd_momentum_multi: gradient must be fp32 or bf16 with the parameter's element count")
         d.param, d.grad, d.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
         d.bf16_shadow = sh.data_ptr() if sh is not None else None
+        d.shadow_is_bf16x2 = 1 if (sh is not None and sh.dtype == torch.float32) else 0
         d.numel, d.lr, d.weight_decay = p.numel(), lr, wd
         d.grad_is_bf16 = 1 if g.dtype == torch.bfloat16 else 0
     check(lib().wsovod_sgd_momentum_multi(arr, len(entries), C.c_float(momentum), C.c_float(grad_scale), stream()),
