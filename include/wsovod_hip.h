@@ -93,6 +93,12 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
                             const float* roi_scale, int R, int N, int C, int H, int W, int ph,
                             int pw, float spatial_scale, void* out, int out_dtype, int* argmax,
                             wsovod_stream_t stream);
+/* The same with a bf16x2 output (out_dtype = WSOVOD_BF16X2) AND, in `out_hi` (R,C,ph,pw bf16, may be NULL), the plain bf16
+ * rounding of the same values: the operand of the bf16 weight-gradient contraction of the first FC layer in the "parity"
+ * precision, which would otherwise fetch the hi halves out of the bf16x2 rows as half lines (wsovod_gemm_tn_ex). */
+int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale,
+                                 int R, int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,
+                                 int out_dtype, int* argmax, void* out_hi, wsovod_stream_t stream);
 /* ROILoopPool in the 3-output form of the reference's CUDA op (wsovod/layers/ROILoopPool/ROILoopPool_cuda.cu:9-204,
  * bound as `_C.roi_loop_pool_forward`, wsovod/layers/roi_loop_pool.py:9-22; context_ratio is 1.8 there): out and
  * argmax are (3R, C, ph, pw) = [region | frame | context] fp32 / int32 (NCHW order).  The matching backward is
@@ -115,6 +121,10 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
                              const float* roi_scale, int R, int N, int C, int H, int W, int ph,
                              int pw, float spatial_scale, int sampling_ratio, int aligned,
                              void* out, int out_dtype, wsovod_stream_t stream);
+int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale,
+                                  int R, int N, int C, int H, int W, int ph, int pw, float spatial_scale,
+                                  int sampling_ratio, int aligned, void* out, int out_dtype, void* out_hi,
+                                  wsovod_stream_t stream);
 int wsovod_roi_align_backward(const float* grad_out, const float* rois, const float* roi_scale,
                               int R, int N, int C, int H, int W, int ph, int pw,
                               float spatial_scale, int sampling_ratio, int aligned, int layout,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "wsovod_profile_reset": [],
     "wsovod_profile_collect": [C.POINTER(ProfEntry), _I],
     "wsovod_roi_pool_forward": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P],
+    "wsovod_roi_pool_forward_x2hi": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
+    "wsovod_roi_align_forward_x2hi": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P, _P],
     "wsovod_roi_pool_backward": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "wsovod_roi_loop_pool_forward": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P, _P],
     "wsovod_roi_align_forward": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P, _I, _P],

@@ -256,41 +256,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
     const char* cA = sA + cur * BM * 128 + (wm * (BM / WM)) * 128;
     const char* cB = sB + cur * BN * 128 + (wn * (BN / WN)) * 128;
     if constexpr (X3) {
-      u32x4 ah[TM], bh[TN], bl[TN];
+      // Two fragment sets live at a time (a third costs the 16-wavefront tile spills at its 128-register budget): b_lo and
+      // a_hi first, then b_hi takes b_lo's registers, then a_lo takes a_hi's.
+      u32x4 af[TM], bfr[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int row = i * 16 + frow;
-        ah[i] = *(const u32x4*)(cA + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+        af[i] = *(const u32x4*)(cA + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int row = j * 16 + frow;
-        bh[j] = *(const u32x4*)(cB + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
-        bl[j] = *(const u32x4*)(cB + row * 128 + (((fq + 4) ^ ((row >> 1) & 7)) << 4));
+        bfr[j] = *(const u32x4*)(cB + row * 128 + (((fq + 4) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
-                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)  // b_lo * a_hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
+                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + frow;
+        bfr[j] = *(const u32x4*)(cB + row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]),
-                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)  // b_hi * a_hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
+                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {  // a_lo takes over a_hi's registers
+      for (int i = 0; i < TM; ++i) {
         const int row = i * 16 + frow;
-        ah[i] = *(const u32x4*)(cA + row * 128 + (((fq + 4) ^ ((row >> 1) & 7)) << 4));
+        af[i] = *(const u32x4*)(cA + row * 128 + (((fq + 4) ^ ((row >> 1) & 7)) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
-                                                              __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)  // b_hi * a_lo
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
+                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
       return;
     }
 #pragma unroll

@@ -148,7 +148,7 @@ template <typename T, bool ARGMAX, int PWT, int CPL, bool OBF = false>
 __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
                                        const float* __restrict__ roi_scale, int C, int H, int W, int PH,
                                        float spatial_scale, void* out, int out_dtype, int* __restrict__ argmax,
-                                       int cgroups) {
+                                       int cgroups, void* out_hi = nullptr) {
   // lane = CPL adjacent channels (one 8-byte load: 4 bf16 / 2 fp32), workgroup = 64*CPL channels of one roi
   typedef T vec2 __attribute__((ext_vector_type(CPL)));
   constexpr int CG = 64 * CPL;
@@ -251,6 +251,7 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
       bf16_t* d = o + ((k >> 5) << 6) + (k & 31);
       __builtin_nontemporal_store(hi, (bf16x8*)d);
       __builtin_nontemporal_store(lo, (bf16x8*)(d + 32));
+      if (out_hi) __builtin_nontemporal_store(hi, (bf16x8*)((bf16_t*)out_hi + k));  // plain bf16 copy (see the launcher)
     }
   } else {
     bf16_t* o = (bf16_t*)out + obase;
@@ -576,7 +577,8 @@ template <typename T, int PWT, int CPL, bool OBF = false>
 __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
                                                                const float* __restrict__ roi_scale, int C, int H, int W,
                                                                int PH, float spatial_scale, int sampling_ratio,
-                                                               int aligned, void* out, int out_dtype, int cgroups) {
+                                                               int aligned, void* out, int out_dtype, int cgroups,
+                                                               void* out_hi = nullptr) {
   typedef T vecc __attribute__((ext_vector_type(CPL)));
   constexpr int CG = 64 * CPL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -785,6 +787,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
       bf16_t* d = o + ((k >> 5) << 6) + (k & 31);
       __builtin_nontemporal_store(hi, (bf16x8*)d);
       __builtin_nontemporal_store(lo, (bf16x8*)(d + 32));
+      if (out_hi) __builtin_nontemporal_store(hi, (bf16x8*)((bf16_t*)out_hi + k));  // plain bf16 copy (see the launcher)
     }
   } else {
     bf16_t* o = (bf16_t*)out + obase;
@@ -928,7 +931,16 @@ int wsovod_format_rois(const float* boxes, const int* seg_offsets, int G, int M,
 int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
                             int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,
                             int out_dtype, int* argmax, wsovod_stream_t stream) {
+  return wsovod_roi_pool_forward_x2hi(feat, dtype, layout, rois, roi_scale, R, N, C, H, W, ph, pw, spatial_scale, out,
+                                      out_dtype, argmax, nullptr, stream);
+}
+
+int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                                 int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,
+                                 int out_dtype, int* argmax, void* out_hi, wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_pool_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
+  WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
+               "wsovod_roi_pool_forward_x2hi: the bf16 copy goes with a bf16x2 output");
   if (rc) return rc;
   WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2,
                "wsovod_roi_pool_forward: bad out_dtype");
@@ -988,7 +1000,7 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
     auto k = roi_pool_fwd_nhwc_rows<T, AM, 7, CPL>;                                                                \
     if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7); \
     hipLaunchKernelGGL(k, dim3(grid7), dim3(64 * ph), lds7, s, (const T*)feat, rois, roi_scale, C, H, W, ph,        \
-                       spatial_scale, out, out_dtype, argmax, cgroups);                                            \
+                       spatial_scale, out, out_dtype, argmax, cgroups, out_hi);                                    \
   } while (0)
       if (obf) {
         auto k = roi_pool_fwd_nhwc_rows<bf16_t, false, 7, 4, true>;
@@ -1071,7 +1083,16 @@ int wsovod_roi_pool_backward(const float* grad_out, const float* rois, const flo
 int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
                              int N, int C, int H, int W, int ph, int pw, float spatial_scale, int sampling_ratio,
                              int aligned, void* out, int out_dtype, wsovod_stream_t stream) {
+  return wsovod_roi_align_forward_x2hi(feat, dtype, layout, rois, roi_scale, R, N, C, H, W, ph, pw, spatial_scale,
+                                       sampling_ratio, aligned, out, out_dtype, nullptr, stream);
+}
+
+int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                                  int N, int C, int H, int W, int ph, int pw, float spatial_scale, int sampling_ratio,
+                                  int aligned, void* out, int out_dtype, void* out_hi, wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_align_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
+  WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
+               "wsovod_roi_align_forward_x2hi: the bf16 copy goes with a bf16x2 output");
   if (rc) return rc;
   WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2,
                "wsovod_roi_align_forward: bad out_dtype");
@@ -1107,12 +1128,12 @@ int wsovod_roi_align_forward(const void* feat, int dtype, int layout, const floa
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups);
+                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, out_hi);
       } else {
         auto k = roi_align_fwd_nhwc_rows<float, 7, 2>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const float*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups);
+                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, out_hi);
       }
     } else if (dtype == WSOVOD_BF16) {
       auto k = roi_align_fwd_nhwc<bf16_t>;

@@ -59,14 +59,17 @@ class _Linear(Function):
     def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype):
         ctx.x2 = _x2_mode()
         ctx.y_x2 = out_dtype == H.X2
+        x_hi = None
         if ctx.x2:
             y = H.gemm_nt(x, H.x2_cached(weight), x2=True, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
                           out_dtype=out_dtype)
+            x_hi = H.x2_hi_pop(x)  # the pooler's plain bf16 copy of x, if it wrote one: the operand of dW
         else:
             wq = weight_shadow(weight, x.dtype)
             y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, out_dtype=out_dtype)
         ctx.relu, ctx.dropout_p = relu, dropout_p
-        ctx.save_for_backward(x, weight, y if (relu or dropout_p > 0) else None)
+        ctx.save_for_backward(x if x_hi is None else x_hi.view(x.shape), weight, y if (relu or dropout_p > 0) else None)
+        ctx.x_is_hi = x_hi is not None
         ctx.has_bias = bias is not None
         # (rows, callback) set by a data-parallel trainer on ONE large weight: its gradient is produced in two row
         # blocks and the callback sees the first as soon as it is enqueued (engine/trainer.py: early exchange)
@@ -83,10 +86,11 @@ class _Linear(Function):
     @staticmethod
     def _backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
-        in_dtype = x.dtype
+        in_dtype = torch.float32 if ctx.x_is_hi else x.dtype
         if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
             x = H.cast(x, torch.bfloat16)
         cd = torch.bfloat16 if ctx.x2 else x.dtype
+        q_x2 = ctx.x2 and not ctx.x_is_hi  # x saved as bf16x2: the transposed-read kernel takes its hi halves
         M, K = x.shape
         N = weight.size(0)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
@@ -107,11 +111,11 @@ class _Linear(Function):
             if split is not None and Np == N and 0 < split[0] < N and split[0] % 8 == 0:
                 ra = split[0]  # two launches over row blocks of dW; the first block is handed over before the second runs
                 dw = torch.empty((N, K), dtype=torch.float32, device=x.device)
-                H.gemm_tn(dA[:, :ra], x, out=dw[:ra], q_x2=ctx.x2)
+                H.gemm_tn(dA[:, :ra], x, out=dw[:ra], q_x2=q_x2)
                 split[1](dw[:ra])
-                H.gemm_tn(dA[:, ra:], x, out=dw[ra:], q_x2=ctx.x2)
+                H.gemm_tn(dA[:, ra:], x, out=dw[ra:], q_x2=q_x2)
             else:
-                dw = H.gemm_tn(dA, x, q_x2=ctx.x2) if need_dw else None  # (Np, K)
+                dw = H.gemm_tn(dA, x, q_x2=q_x2) if need_dw else None  # (Np, K)
                 if dw is not None and Np != N:
                     dw = dw[:N]
         elif need_dw:
@@ -222,12 +226,16 @@ def linear_group(x, heads):
     return _LinearGroup.apply(x, meta, *wb)
 
 
+_WANT_HI = [False]  # set by the ROI heads while training under the "parity" precision (the pooled tensor feeds a dW)
+
+
 class _RoIPool(Function):
     @staticmethod
     def forward(ctx, feat, rois, output_size, spatial_scale, roi_scale, out_dtype):
         need_grad = feat.requires_grad
         out, argmax = H.roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=roi_scale,
-                                         out_dtype=out_dtype, need_argmax=need_grad)
+                                         out_dtype=out_dtype, need_argmax=need_grad,
+                                         want_hi=out_dtype == H.X2 and _WANT_HI[0])
         ctx.shape = tuple(feat.shape)
         ctx.cl = not feat.is_contiguous()
         ctx.in_dtype = feat.dtype
@@ -276,7 +284,7 @@ class _RoIAlign(Function):
     @staticmethod
     def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned, roi_scale, out_dtype):
         out = H.roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned,
-                                  roi_scale=roi_scale, out_dtype=out_dtype)
+                                  roi_scale=roi_scale, out_dtype=out_dtype, want_hi=out_dtype == H.X2 and _WANT_HI[0])
         ctx.cfg = (tuple(feat.shape), not feat.is_contiguous(), spatial_scale, sampling_ratio, aligned, feat.dtype)
         ctx.save_for_backward(rois, roi_scale)
         return out

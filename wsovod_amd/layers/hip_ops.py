@@ -123,8 +123,28 @@ def format_rois(boxes, seg_offsets, objectness=None):
     return rois, scale
 
 
-def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out_dtype=None, need_argmax=True):
-    """RoI max pool -> (out (R,C,ph,pw), argmax int32 or None)."""
+_X2_HI = {}  # data_ptr of a bf16x2 pooler output -> its plain bf16 copy (consumed by the first Linear that reads it)
+
+
+def x2_hi_pop(x):
+    """The plain bf16 rounding the pooler wrote next to the bf16x2 tensor `x` (or None): the first FC layer keeps it for
+    its weight-gradient contraction, which would otherwise fetch half lines out of the bf16x2 rows."""
+    hi = _X2_HI.pop(x.data_ptr(), None)
+    return hi if (hi is not None and hi.numel() == x.numel()) else None
+
+
+def _x2_hi_alloc(out):
+    if len(_X2_HI) >= 4:  # never consumed (eval mode): do not pile up
+        _X2_HI.clear()
+    hi = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
+    _X2_HI[out.data_ptr()] = hi
+    return hi
+
+
+def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out_dtype=None, need_argmax=True,
+                     want_hi=False):
+    """RoI max pool -> (out (R,C,ph,pw), argmax int32 or None).  want_hi (bf16x2 output only): also write the plain
+    bf16 rounding, fetched later with x2_hi_pop(out)."""
     require_gpu(feat, rois, roi_scale)
     layout, N, Cc, H, W = feature_layout(feat)
     rois = _rois_f32(rois)
@@ -135,9 +155,10 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     argmax = torch.empty((R, Cc, ph, pw), dtype=torch.int32, device=feat.device) if need_argmax else None
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
-    check(lib().wsovod_roi_pool_forward(
+    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
+    check(lib().wsovod_roi_pool_forward_x2hi(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), ptr(out), fmt_code(out_dtype), ptr(argmax), stream()), "roi_pool_forward")
+        C.c_float(spatial_scale), ptr(out), fmt_code(out_dtype), ptr(argmax), ptr(hi), stream()), "roi_pool_forward")
     return out, argmax
 
 
@@ -171,7 +192,7 @@ def roi_pool_backward(grad_out, rois, argmax, input_shape, channels_last=False, 
 
 
 def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned, roi_scale=None,
-                      out_dtype=None):
+                      out_dtype=None, want_hi=False):
     require_gpu(feat, rois, roi_scale)
     layout, N, Cc, H, W = feature_layout(feat)
     rois = _rois_f32(rois)
@@ -181,9 +202,10 @@ def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, al
     out = torch.empty((R, Cc, ph, pw), dtype=storage_dtype(out_dtype), device=feat.device)
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
-    check(lib().wsovod_roi_align_forward(
+    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
+    check(lib().wsovod_roi_align_forward_x2hi(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out), fmt_code(out_dtype),
+        C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out), fmt_code(out_dtype), ptr(hi),
         stream()), "roi_align_forward")
     return out
 
