@@ -1005,7 +1005,7 @@ int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const 
       if (obf) {
         auto k = roi_pool_fwd_nhwc_rows<bf16_t, false, 7, 4, true>;
         hipLaunchKernelGGL(k, dim3(grid7), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, out, out_dtype, argmax, cgroups);
+                           spatial_scale, out, out_dtype, argmax, cgroups, (void*)nullptr);
       } else if (wide) {
         LAUNCH_ROWS(bf16_t, false, 4);
       } else if (widef) {
@@ -1123,7 +1123,7 @@ int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 8, true>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups);
+                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, (void*)nullptr);
       } else if (dtype == WSOVOD_BF16) {
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
         if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
