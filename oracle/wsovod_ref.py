@@ -290,15 +290,26 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, n
 @torch.no_grad()
 def eval_forward(sd, batch, *, depth=18, classifier=None, pooler_type="ROIPool", temperature=50.0,
                  pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True, refine_K=1,
-                 sampling_ratio=0):
+                 sampling_ratio=0, rpn=None):
     """Per image: (scores (R, K+1) = mean over the refinement heads of softmax(logits), boxes (R, 4) =
-    apply_deltas(mean deltas, proposals)) -- the `all_scores` / `all_boxes` the detection tail consumes."""
+    apply_deltas(mean deltas, proposals)) -- the `all_scores` / `all_boxes` the detection tail consumes.
+    rpn: None, or a dict of find_top_rpn_proposals keyword arguments (rcnn_wsovod.py:267-283: the RPN's boxes, with
+    sigmoid objectness, ahead of the loaded ones); the per-image RPN proposals are then left in rpn["proposals"]."""
     x = preprocess_image([b["image"] for b in batch], pixel_mean, pixel_std)
     res5 = backbone_forward(sd, x, depth)["res5"]
     boxes_list = [b["boxes"] for b in batch]
+    obj_list = [b["objectness"] for b in batch]
+    if rpn is not None:
+        anchors = anchor_grid(res5.shape[-2], res5.shape[-1])
+        lo, de = rpn_head_forward(sd, res5)
+        kw = {k: v for k, v in rpn.items() if k != "proposals"}
+        props = find_top_rpn_proposals(anchors, lo, de, [tuple(b["image"].shape[-2:]) for b in batch], **kw)
+        rpn["proposals"] = props
+        boxes_list = [torch.cat([pb, b]) for (pb, _), b in zip(props, boxes_list)]
+        obj_list = [torch.cat([torch.sigmoid(ps), o]) for (_, ps), o in zip(props, obj_list)]
     nums = [len(b) for b in boxes_list]
     pooled = roi_pooler(res5, boxes_list, pooler_type, 7, 0.125, sampling_ratio)
-    pooled = pooled * torch.cat([b["objectness"] + 1 for b in batch]).view(-1, 1, 1, 1)
+    pooled = pooled * torch.cat([o + 1 for o in obj_list]).view(-1, 1, 1, 1)
     feat = neck_forward(sd, pooled)
     if data_aware:
         daf = data_aware_forward(sd, res5)
@@ -335,6 +346,33 @@ def tta_avg_merge(view_boxes, view_scores, inverse_apply_box, shape_hw, score_th
     scores = torch.stack(list(view_scores)).mean(dim=0)
     return (boxes, scores) + tuple(fast_rcnn_inference_single_image(boxes, scores, shape_hw, score_thresh, nms_thresh,
                                                                      topk_per_image))
+
+
+def tta_union_view_proposals(boxes, objectness, apply_box, image_shape, proposal_topk, min_box_size=0):
+    """test_time_augmentation_union.py:25-63 (`transform_proposals` of the UNION mapper, proposal_topk > 0): the loaded
+    boxes follow the view's transforms (`apply_box`: (n,4) numpy -> numpy), are clipped to the view, boxes with a side
+    <= min_box_size are dropped, the first proposal_topk stay."""
+    b = torch.from_numpy(apply_box(boxes.numpy())).to(boxes.dtype)
+    h, w = image_shape
+    b[:, 0::2] = b[:, 0::2].clamp(min=0, max=w)
+    b[:, 1::2] = b[:, 1::2].clamp(min=0, max=h)
+    keep = ((b[:, 2] - b[:, 0]) > min_box_size) & ((b[:, 3] - b[:, 1]) > min_box_size)
+    return b[keep][:proposal_topk], objectness[keep][:proposal_topk]
+
+
+def tta_union_merge(view_dets, inverse_apply_box, shape_hw, num_classes, nms_thresh, topk_per_image):
+    """test_time_augmentation_union.py:273-309: every view's DETECTIONS (boxes, scores, classes) go back to the original
+    frame through the inverse of that view's transforms and are pooled; a (n, K+1) score matrix holds each detection's
+    score in its class column; one more detection tail pass at score threshold 1e-8.
+    -> (pooled boxes, boxes, scores, classes)."""
+    back = [torch.from_numpy(inv(b.numpy())).to(b.dtype) for (b, _, _), inv in zip(view_dets, inverse_apply_box)]
+    boxes = torch.cat(back)
+    scores = torch.cat([s for _, s, _ in view_dets])
+    classes = torch.cat([c for _, _, c in view_dets])
+    sc2d = torch.zeros(len(boxes), num_classes + 1)
+    sc2d[torch.arange(len(boxes)), classes] = scores
+    rb, rs, rc, _ = fast_rcnn_inference_single_image(boxes, sc2d, shape_hw, 1e-8, nms_thresh, topk_per_image)
+    return boxes, rb, rs, rc
 
 
 def refinement_losses(logits, deltas, gt_classes, gt_weights, proposal_boxes, gt_boxes, num_classes,

@@ -389,12 +389,10 @@ class RefStandardRPNHead(nn.Module):
         return lo, de
 
 
-def golden_rpn(r):
-    """G12: the REFERENCE's WSOVODRPN_V2 + find_top_rpn_proposals + the meta-arch / ROI-heads RPN branches on one
-    training step (RPN boxes + loaded boxes, pseudo-GT from the refinement head, RPN losses).  detectron2's
-    anchor generator / matcher / box transform / RPN head are the restated stand-ins, batched_nms is the oracle's;
-    subsample_labels is replaced by the deterministic first-k rule of tests/golden/gen.py on both sides."""
-    from oracle import wsovod_ref as R
+def _install_rpn(r):
+    """Stand-ins the reference's RPN files need (detectron2's anchor generator / matcher / box transform / RPN head are
+    the restated ones; batched_nms is the INDEPENDENT brute-force NMS below, not the oracle's) and the reference's own
+    proposal_utils.py / rpn.py loaded on top of them.  Returns a builder of the reference model with the RPN branch."""
     from wsovod_amd.modeling import anchor_generator as AG
     from wsovod_amd.testing import hot_path_cfg
 
@@ -403,7 +401,7 @@ def golden_rpn(r):
     C.RPN_HEAD_REGISTRY_REF._obj_map["StandardRPNHead"] = RefStandardRPNHead
     L = sys.modules["detectron2.layers"]
     L.CycleBatchNormList = _Unsupported
-    L.batched_nms = R.batched_nms
+    L.batched_nms = brute_force_batched_nms
     L.move_device_like = lambda src, dst: src.to(dst.device)
     _mod("detectron2.modeling.anchor_generator", build_anchor_generator=AG.build_anchor_generator,
          DefaultAnchorGenerator=AG.DefaultAnchorGenerator)
@@ -430,23 +428,36 @@ def golden_rpn(r):
         cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shape)
     _Storage.iter = 1000
 
-    import pickle
-    import tempfile
-    K, D = 20, 512
-    emb = os.path.join(tempfile.mkdtemp(prefix="golden_"), "emb.pkl")
-    with open(emb, "wb") as f:
-        pickle.dump(torch.randn(K, D), f)
-    cfg = hot_path_cfg(depth=18, K=K, D=D, device="cpu", weight_path=emb, rpn=True)
-    cfg.MODEL.PIXEL_STD = list(gen.PIXEL_STD)
-    cfg.MODEL.ROI_HEADS.NAME = "WSOVODROIHeads"
-    cfg.DATASETS.TRAIN = ("synthetic",)
-    cfg.SOLVER.MAX_ITER = 4000
-    torch.manual_seed(0)
-    model = r.meta.GeneralizedRCNN_WSOVOD(cfg)
-    assert type(model.proposal_generator).__name__ == "WSOVODRPN_V2" and model.roi_heads.rpn_on
-    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    sd = gen.seeded_state(shapes, seed=41)
-    model.load_state_dict(sd, strict=True)
+    def build(K=20, D=512):
+        import pickle
+        import tempfile
+        emb = os.path.join(tempfile.mkdtemp(prefix="golden_"), "emb.pkl")
+        with open(emb, "wb") as f:
+            pickle.dump(torch.randn(K, D), f)
+        cfg = hot_path_cfg(depth=18, K=K, D=D, device="cpu", weight_path=emb, rpn=True)
+        cfg.MODEL.PIXEL_STD = list(gen.PIXEL_STD)
+        cfg.MODEL.ROI_HEADS.NAME = "WSOVODROIHeads"
+        cfg.DATASETS.TRAIN = ("synthetic",)
+        cfg.SOLVER.MAX_ITER = 4000
+        torch.manual_seed(0)
+        model = r.meta.GeneralizedRCNN_WSOVOD(cfg)
+        assert type(model.proposal_generator).__name__ == "WSOVODRPN_V2" and model.roi_heads.rpn_on
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        sd = gen.seeded_state(shapes, seed=41)
+        model.load_state_dict(sd, strict=True)
+        return cfg, model, shapes
+
+    return build
+
+
+def golden_rpn(r):
+    """G12: the REFERENCE's WSOVODRPN_V2 + find_top_rpn_proposals + the meta-arch / ROI-heads RPN branches on one
+    training step (RPN boxes + loaded boxes, pseudo-GT from the refinement head, RPN losses).  detectron2's
+    anchor generator / matcher / box transform / RPN head are the restated stand-ins, batched_nms is the brute-force
+    NMS of this file (independent of the oracle and of the HIP kernel); subsample_labels is replaced by the
+    deterministic first-k rule of tests/golden/gen.py on both sides."""
+    K = 20
+    cfg, model, shapes = _install_rpn(r)()
     model.train()
     for m in model.modules():
         if isinstance(m, nn.Dropout):
@@ -570,13 +581,11 @@ def golden_eval_tail(r):
     save("g14_eval_tail", **arrays)
 
 
-def golden_tta(r):
-    """G15: the REFERENCE's DatasetMapperTTAAVG + GeneralizedRCNNWithTTAAVG (test_time_augmentation_avg.py:67-334)
-    around the reference model: 2 short-edge sizes x flip = 4 views of one image, per-view inference, boxes mapped back
-    through the inverse transforms, mean over views, one tail pass.  detectron2's ResizeShortestEdge / RandomFlip /
-    apply_augmentations / fvcore transforms are un-vendored: the stand-ins below wrap the restatements in
-    wsovod_amd/data/proposals.py (image resampling = PIL bilinear).  detectron2's own `fast_rcnn_inference_single_image`
-    (imported by the TTA file, un-vendored) is the reference's superset of it cut to its 2-tuple return."""
+def _install_tta(r):
+    """Stand-ins the reference's TTA files import: detectron2's ResizeShortestEdge / RandomFlip / apply_augmentations /
+    fvcore transforms are un-vendored and wrap the restatements in wsovod_amd/data/proposals.py (image resampling = PIL
+    bilinear); detectron2's own `fast_rcnn_inference_single_image` (un-vendored) is the reference's superset of it cut to
+    its 2-tuple return."""
     from wsovod_amd.data import proposals as P
     from wsovod_amd.modeling import test_time_augmentation as T
 
@@ -612,7 +621,6 @@ def golden_tta(r):
                 image = image[:, ::-1]
         return image, TL(tf)
 
-    cfg, model, post = _eval_reference_model(r)
     sys.modules["detectron2.data.detection_utils"].read_image = None  # (extend the shim module; later generators read others)
     _mod("detectron2.data.transforms", RandomFlip=RandomFlip, ResizeShortestEdge=ResizeShortestEdge,
          ResizeTransform=lambda h, w, nh, nw: TL([P.ResizeTransform(h, w, nh, nw)]),
@@ -621,6 +629,14 @@ def golden_tta(r):
     _mod("detectron2.modeling.roi_heads.fast_rcnn",
          fast_rcnn_inference_single_image=lambda *a: r.frcnn.fast_rcnn_inference_single_image(*a)[:2])
     _mod("fvcore.transforms", HFlipTransform=P.HFlipTransform, NoOpTransform=NoOp)
+
+
+def golden_tta(r):
+    """G15: the REFERENCE's DatasetMapperTTAAVG + GeneralizedRCNNWithTTAAVG (test_time_augmentation_avg.py:67-334)
+    around the reference model: 2 short-edge sizes x flip = 4 views of one image, per-view inference, boxes mapped back
+    through the inverse transforms, mean over views, one tail pass (stand-ins: _install_tta)."""
+    cfg, model, post = _eval_reference_model(r)
+    _install_tta(r)
     tta_mod = load_ref("wsovod.modeling.test_time_augmentation_avg", "wsovod/modeling/test_time_augmentation_avg.py")
     model.classifier = torch.randn(20, 512, generator=torch.Generator().manual_seed(77))
     cfg.TEST.DETECTIONS_PER_IMAGE = 100
@@ -664,6 +680,71 @@ def golden_tta(r):
         arrays[f"view{i}/image_checksum"] = img.double().sum()
         arrays[f"view{i}/proposal_boxes"] = bx
     save("g15_tta_avg", **arrays)
+
+
+def golden_tta_union(r):
+    """G17: the REFERENCE's DatasetMapperTTAUNION + GeneralizedRCNNWithTTAUNION (test_time_augmentation_union.py:66-330;
+    the wrapper the reference picks when the model has an RPN) around the reference model WITH its RPN branch in eval
+    mode: 2 short-edge sizes x flip = 4 views, the mapper's own `transform_proposals` (proposal_topk > 0) moves the loaded
+    boxes with each view, per-view inference (RPN boxes + loaded boxes -> heads -> detection tail), the views' detections
+    mapped back through the inverse transforms and pooled, one more tail pass at threshold 1e-8.  Stored: every view's
+    image checksum / proposals / detections, the pooled boxes and the merged result."""
+    cfg, model, shapes = _install_rpn(r)()
+    _eval_patch = _eval_reference_model  # (its stand-ins: postprocessing.py + brute-force NMS in the detection tail)
+    sys.modules["detectron2.structures"].ROIMasks = _Unsupported
+    post = load_ref("wsovod.modeling.postprocessing", "wsovod/modeling/postprocessing.py")
+    r.meta.detector_postprocess = post.detector_postprocess
+    r.frcnn.batched_nms = brute_force_batched_nms
+    _install_tta(r)
+    tta_mod = load_ref("wsovod.modeling.test_time_augmentation_union", "wsovod/modeling/test_time_augmentation_union.py")
+    model.eval()
+    model.classifier = torch.randn(20, 512, generator=torch.Generator().manual_seed(79))
+    cfg.TEST.DETECTIONS_PER_IMAGE = 100
+    cfg.MODEL.KEYPOINT_ON = False
+    cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.3
+    mapper = tta_mod.DatasetMapperTTAUNION([192, 256], 4000, True, 4000)
+    tta = tta_mod.GeneralizedRCNNWithTTAUNION(cfg, model, mapper)
+    inp = to_inputs(gen.seeded_batch(1, 60, 20, 256, 352, seed=23))[0]
+    captured = {}
+    orig_batch = tta._batch_inference
+
+    def cap_batch(aug, det=None):
+        captured["views"] = [(a["image"].clone(), a["proposals"].proposal_boxes.tensor.clone(),
+                              a["proposals"].objectness_logits.clone()) for a in aug]
+        outs = orig_batch(aug, det)
+        captured["dets"] = [(o.pred_boxes.tensor.clone(), o.scores.clone(), o.pred_classes.clone()) for o in outs]
+        return outs
+
+    tta._batch_inference = cap_batch
+    orig_get = tta._get_augmented_boxes
+
+    def cap_get(aug, tfms):
+        o = orig_get(aug, tfms)
+        captured["pooled"] = (o[0].clone(), torch.stack(list(o[1])), torch.stack(list(o[2])))
+        return o
+
+    tta._get_augmented_boxes = cap_get
+    rpn_props = []
+    orig_pred = model.proposal_generator.predict_proposals
+
+    def cap_props(*a, **k):
+        o = orig_pred(*a, **k)
+        rpn_props.append([(p.proposal_boxes.tensor.clone(), p.objectness_logits.clone()) for p in o])
+        return o
+
+    model.proposal_generator.predict_proposals = cap_props
+    with torch.no_grad():
+        out = tta([inp])[0]["instances"]
+    arrays = {"classifier": model.classifier, "pooled_boxes": captured["pooled"][0], "pooled_scores": captured["pooled"][1],
+              "pooled_classes": captured["pooled"][2], "boxes": out.pred_boxes.tensor, "scores": out.scores,
+              "classes": out.pred_classes}
+    for i, ((img, bx, ol), (db, ds, dc)) in enumerate(zip(captured["views"], captured["dets"])):
+        arrays[f"view{i}/shape"] = np.array(img.shape)
+        arrays[f"view{i}/image_checksum"] = img.double().sum()
+        arrays[f"view{i}/proposal_boxes"], arrays[f"view{i}/objectness"] = bx, ol
+        arrays[f"view{i}/det_boxes"], arrays[f"view{i}/det_scores"], arrays[f"view{i}/det_classes"] = db, ds, dc
+        arrays[f"view{i}/rpn_boxes"], arrays[f"view{i}/rpn_logits"] = rpn_props[i][0]
+    save("g17_tta_union", **arrays)
 
 
 def golden_subsample(r):
@@ -805,6 +886,8 @@ def main():
         return golden_mixed(r)
     if "--only-rpn" in sys.argv:
         return golden_rpn(r)
+    if "--only-union" in sys.argv:
+        return golden_tta_union(r)
     if "--only-eval" in sys.argv:
         golden_eval_tail(r)
         golden_subsample(r)

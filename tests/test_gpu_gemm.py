@@ -221,9 +221,22 @@ def test_staggered_tiles_race_screen(gpu):
                 junk.mul_(1.0001)
             out = H.gemm_nt(A, B, out_dtype=torch.float32, tile_hint=8256256)
             assert torch.equal(out, ref), (M, N, K, rep, "8-phase")
+            out = H.gemm_nt(A, B, out_dtype=torch.float32, tile_hint=2256256)  # its two-phase form (round 3)
+            assert torch.equal(out, ref), (M, N, K, rep, "2-phase")
             if M % 8 == 0 and N % 8 == 0:
-                tn = H.gemm_tn(At, Bt)
+                tn = H.gemm_tn(At, Bt, split_tail=False)  # (fixed summation order: no K slices meeting by atomics)
                 assert torch.equal(tn, ref), (M, N, K, rep, "tn")
+    # the bf16x2 (three-MFMA) forms of the two schedules: same products in the same order
+    for (M, N, K) in [(512, 768, 128), (777, 1333, 2048), (2048, 512, 4096), (256, 4096, 8192)]:
+        K32 = (K + 31) // 32 * 32
+        A = H.x2_encode(torch.rand(M, K32, device=gpu, generator=g) - 0.5)
+        B = H.x2_encode(torch.rand(N, K32, device=gpu, generator=g) - 0.5)
+        ref = H.gemm_nt(A, B, x2=True, out_dtype=torch.float32, tile_hint=256256)  # 16 wavefronts, plain __syncthreads
+        for rep in range(6):
+            with torch.cuda.stream(side):
+                junk.mul_(1.0001)
+            assert torch.equal(H.gemm_nt(A, B, x2=True, out_dtype=torch.float32, tile_hint=2256256), ref), (M, N, K, rep, "x3 2-phase")
+            assert torch.equal(H.gemm_nt(A, B, x2=True, out_dtype=torch.float32, tile_hint=8256256), ref), (M, N, K, rep, "x3 8-phase")
     torch.cuda.synchronize()
 
 

@@ -261,3 +261,63 @@ def test_bf16x3_rpn_step_matches_reference_golden(gpu, monkeypatch):
             ref = float(g["gradnorm/" + k])
             got = float(q.grad.double().norm())
             assert abs(got - ref) <= 2e-2 * ref + 1e-6, (k, got, ref)
+
+
+def test_tta_union_matches_reference_golden(gpu):
+    """G17 (the reference's DatasetMapperTTAUNION + GeneralizedRCNNWithTTAUNION around the reference model with its RPN
+    branch, 4 views): the HIP model under the product's TTA-UNION wrapper.  Views (images, moved loaded boxes) exact;
+    each view's RPN proposals and detections against the reference's (fp32 mode: same classes in the same order, boxes
+    1e-2 px, scores 1e-4); the merge of the reference's own per-view detections through the HIP tail is exact; the end
+    to end result has the reference's detections."""
+    from wsovod_amd.modeling import GeneralizedRCNNWithTTAUNION
+    from wsovod_amd.modeling.test_time_augmentation import DatasetMapperTTAUNION
+
+    g = load_golden("g17_tta_union")
+    cfg, model, sd, _ = build_rpn_model("fp32")
+    model.eval()
+    model.classifier = g["classifier"].to(gpu)
+    cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.3
+    cfg.TEST.DETECTIONS_PER_IMAGE = 100
+    tta = GeneralizedRCNNWithTTAUNION(cfg, model, DatasetMapperTTAUNION([192, 256], 4000, True, 4000))
+    inp = to_inputs(gen.seeded_batch(1, 60, 20, 256, 352, seed=23))[0]
+    seen = {}
+    orig_run = tta._run_model
+
+    def run(aug):
+        for i, a in enumerate(aug):
+            assert float(a["image"].double().sum()) == float(g[f"view{i}/image_checksum"])
+            assert torch.equal(a["proposals"].proposal_boxes.tensor.cpu(), g[f"view{i}/proposal_boxes"])
+            assert torch.equal(a["proposals"].objectness_logits.cpu(), g[f"view{i}/objectness"])
+        out = orig_run(aug)
+        seen["dets"] = out[0]
+        return out
+
+    tta._run_model = run
+    orig_get = tta._get_augmented_boxes
+
+    def get(aug, tfms):
+        o = orig_get(aug, tfms)
+        seen["tfms"] = tfms
+        return o
+
+    tta._get_augmented_boxes = get
+    out = tta([inp])[0]["instances"]
+    assert len(seen["dets"]) == 4
+    for i, det in enumerate(seen["dets"]):
+        n = len(g[f"view{i}/det_scores"])
+        assert len(det) == n
+        same = det.pred_classes.cpu() == g[f"view{i}/det_classes"]
+        assert float(same.float().mean()) > 0.97, i  # (near-tied scores may swap neighbours between fp32 implementations)
+        torch.testing.assert_close(det.scores.cpu(), g[f"view{i}/det_scores"], rtol=1e-3, atol=1e-4)
+        assert float((det.pred_boxes.tensor.cpu()[same] - g[f"view{i}/det_boxes"][same]).abs().max()) < 5e-2
+    # the merge itself, fed the reference's per-view detections: exact (boxes, scores, classes, order)
+    back = [torch.from_numpy(t.inverse().apply_box(g[f"view{i}/det_boxes"].numpy())) for i, t in enumerate(seen["tfms"])]
+    pooled = torch.cat(back).to(gpu)
+    assert torch.equal(pooled.cpu(), g["pooled_boxes"])
+    merged = tta._merge_detections(pooled, list(g["pooled_scores"].to(gpu)), list(g["pooled_classes"].to(gpu)), (256, 352))
+    assert torch.equal(merged.pred_boxes.tensor.cpu(), g["boxes"]) and torch.equal(merged.scores.cpu(), g["scores"])
+    assert torch.equal(merged.pred_classes.cpu(), g["classes"])
+    # end to end
+    assert len(out) == len(g["scores"]) == 100
+    torch.testing.assert_close(out.scores.cpu(), g["scores"], rtol=1e-3, atol=1e-4)
+    assert float((out.pred_classes.cpu() == g["classes"]).float().mean()) > 0.95

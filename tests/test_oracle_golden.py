@@ -239,6 +239,48 @@ def test_tta_avg_matches_reference():
     assert len(rc) == 100
 
 
+def test_tta_union_matches_reference():
+    """G17: the reference's DatasetMapperTTAUNION + GeneralizedRCNNWithTTAUNION (test_time_augmentation_union.py:66-330)
+    around the reference model WITH its RPN branch, 4 views.  The product's mapper reproduces the views (images and the
+    loaded boxes moved by the mapper's own transform_proposals) exactly; the oracle's eval forward (RPN boxes + loaded
+    boxes -> heads -> tail) reproduces every view's detections; the merge of the reference's own per-view detections
+    is exact."""
+    from tests.helpers import to_inputs
+    from wsovod_amd.modeling.test_time_augmentation import DatasetMapperTTAUNION
+
+    g = load("g17_tta_union")
+    d = np.load(os.path.join(G, "shapes_rpn_r18.npz"))
+    sd = gen.seeded_state({str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}, 41)
+    inp = to_inputs(gen.seeded_batch(1, 60, 20, 256, 352, seed=23))[0]
+    views = DatasetMapperTTAUNION([192, 256], 4000, True, 4000)(inp)
+    assert len(views) == 4
+    dets, inv = [], []
+    for i, v in enumerate(views):
+        assert tuple(v["image"].shape) == tuple(int(x) for x in g[f"view{i}/shape"])
+        assert float(v["image"].double().sum()) == float(g[f"view{i}/image_checksum"])
+        assert torch.equal(v["proposals"].proposal_boxes.tensor, g[f"view{i}/proposal_boxes"])
+        assert torch.equal(v["proposals"].objectness_logits, g[f"view{i}/objectness"])
+        # the oracle's statement of the mapper's transform_proposals agrees with the product's mapper
+        ob, oo = R.tta_union_view_proposals(inp["proposals"].proposal_boxes.tensor, inp["proposals"].objectness_logits,
+                                            v["transforms"].apply_box, tuple(v["image"].shape[1:]), 4000)
+        assert torch.equal(ob, g[f"view{i}/proposal_boxes"]) and torch.equal(oo, g[f"view{i}/objectness"])
+        b = dict(image=v["image"], boxes=ob, objectness=oo)
+        rpn = dict(nms_thresh=0.7, pre_nms_topk=2048, post_nms_topk=1024, min_box_size=40.0)
+        (scores, boxes), = R.eval_forward(sd, [b], depth=18, classifier=g["classifier"], pixel_std=gen.PIXEL_STD, rpn=rpn)
+        pb, pl = rpn["proposals"][0]
+        assert torch.equal(pb, g[f"view{i}/rpn_boxes"]) and torch.equal(pl, g[f"view{i}/rpn_logits"])
+        rb, rs, rc, _ = R.fast_rcnn_inference_single_image(boxes, scores, tuple(v["image"].shape[1:]), 1e-5, 0.3, 100)
+        assert torch.equal(rc, g[f"view{i}/det_classes"])
+        torch.testing.assert_close(rb, g[f"view{i}/det_boxes"], rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(rs, g[f"view{i}/det_scores"], rtol=1e-4, atol=1e-6)
+        dets.append((g[f"view{i}/det_boxes"], g[f"view{i}/det_scores"], g[f"view{i}/det_classes"]))
+        inv.append(v["transforms"].inverse().apply_box)
+    pooled, rb, rs, rc = R.tta_union_merge(dets, inv, (256, 352), 20, 0.3, 100)
+    assert torch.equal(pooled, g["pooled_boxes"])
+    assert torch.equal(rb, g["boxes"]) and torch.equal(rs, g["scores"]) and torch.equal(rc, g["classes"])
+    assert len(rc) == 100 and len(pooled) == 400
+
+
 def test_subsample_matches_reference():
     """G16: the reference's _sample_proposals_wsl beyond BATCH_SIZE_PER_IMAGE / below POSITIVE_FRACTION 1 with the
     deterministic first-k stand-in for subsample_labels; the oracle's keyed form with keys = row index is that rule."""

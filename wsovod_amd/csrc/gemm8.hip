@@ -219,11 +219,12 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const unsigned ldsA = 0, ldsB = 0;
 #endif
 
-  // bf16: k-halves (0,0), (1,1).  X3: (b_hi, a_hi), (b_lo, a_hi), (b_hi, a_lo) -- the lo*lo term (2^-16 of a product) is dropped
+  // bf16: k-halves (0,0), (1,1).  X3: (b_lo, a_hi), (b_hi, a_hi), (b_hi, a_lo) -- the order of gemm.hip's X3 tiles (bit-
+  // identical results); the lo*lo term (2^-16 of a product) is dropped
 #define WS_MFMA_QUAD(I0, BREG, J0)                                                                                   \
   _Pragma("unroll") for (int ks = 0; ks < (X3 ? 3 : 2); ++ks) _Pragma("unroll") for (int i = 0; i < 4; ++i)           \
       _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
-          __builtin_bit_cast(bf16x8, BREG[j][X3 ? (ks == 1) : ks]), __builtin_bit_cast(bf16x8, af[i][X3 ? (ks == 2) : ks]), \
+          __builtin_bit_cast(bf16x8, BREG[j][X3 ? (ks == 0) : ks]), __builtin_bit_cast(bf16x8, af[i][X3 ? (ks == 2) : ks]), \
           acc[(I0) + i][(J0) + j], 0, 0, 0)
 
   // ---- DMA schedule (two instructions per phase; the LDS rows a pass overwrites were last read >= 2 phases ago):

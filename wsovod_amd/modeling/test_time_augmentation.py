@@ -94,15 +94,40 @@ class DatasetMapperTTAAVG:
         return ret
 
 
-DatasetMapperTTAUNION = DatasetMapperTTAAVG
+class DatasetMapperTTAUNION(DatasetMapperTTAAVG):
+    """test_time_augmentation_union.py:66-145: the same views; with `proposal_topk` > 0 the already-mapped `proposals` of
+    the input follow each view through the mapper's own `transform_proposals` (:25-63): view transforms (without the
+    pre-transform), clip to the view, boxes with an empty side dropped, the first proposal_topk kept."""
+
+    def __call__(self, dataset_dict):
+        views = super().__call__(dataset_dict)
+        if not self.proposal_topk or "proposals" not in dataset_dict:
+            return views
+        src = dataset_dict["proposals"]
+        shape = tuple(dataset_dict["image"].shape[1:])
+        orig_shape = (dataset_dict["height"], dataset_dict["width"])
+        n_pre = 1 if shape != orig_shape else 0
+        for v in views:
+            view_tf = _InvertibleList(list(v["transforms"].transforms)[n_pre:])
+            hw = tuple(v["image"].shape[1:])
+            boxes = Boxes(torch.from_numpy(view_tf.apply_box(src.proposal_boxes.tensor.cpu().numpy())).float())
+            boxes.clip(hw)
+            keep = boxes.nonempty(threshold=0)
+            q = Instances(hw)
+            q.proposal_boxes = boxes[keep][:self.proposal_topk]
+            q.objectness_logits = src.objectness_logits[keep][:self.proposal_topk]
+            v["proposals"] = q
+        return views
 
 
 class _TTABase(nn.Module):
+    _mapper_cls = DatasetMapperTTAAVG
+
     def __init__(self, cfg, model, tta_mapper=None, batch_size=1):
         super().__init__()
         self.cfg = cfg.clone()
         self.model = model
-        self.tta_mapper = tta_mapper if tta_mapper is not None else DatasetMapperTTAAVG(cfg)
+        self.tta_mapper = tta_mapper if tta_mapper is not None else self._mapper_cls(cfg)
         self.batch_size = batch_size
 
     def _run_model(self, batched_inputs):
@@ -151,6 +176,7 @@ class GeneralizedRCNNWithTTAAVG(_TTABase):
 
 class GeneralizedRCNNWithTTAUNION(_TTABase):
     """Pool the detections of every view (mapped back to the original frame) and let the NMS choose."""
+    _mapper_cls = DatasetMapperTTAUNION
 
     def _get_augmented_boxes(self, augmented, tfms):
         outputs, _, _ = self._run_model(augmented)
