@@ -218,45 +218,61 @@ def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher around it: start the N ranks here, one process per GPU, as
     the reference's `launch(main, num_gpus)` does (/root/reference/tools/train_net.py:80-90).  The parent never
     touches the GPU (no HIP call, no exec after one): it only spawns children, relays rank 0's JSON line and
-    returns non-zero if any rank fails."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WSOVOD_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    rc, line = 0, b""
-    try:
-        pending = set(range(args.gpus))
-        while pending:
-            for r in sorted(pending):
-                code = procs[r].poll()
-                if code is None:
-                    continue
-                pending.discard(r)
-                if r == 0:
-                    line = procs[0].stdout.read()
-                if code != 0:
-                    rc = rc or code
-                    print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
-            if rc:  # a dead rank leaves the others waiting in a collective: stop exactly the children started here
-                for r in pending:
-                    procs[r].terminate()
-                for r in pending:
-                    try:
-                        procs[r].wait(timeout=20)
-                    except subprocess.TimeoutExpired:
-                        procs[r].kill()
-                break
-            time.sleep(0.05)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+    returns non-zero if any rank fails.  Every child gets its share of the host threads (OMP_NUM_THREADS = cores // N);
+    rank 0's stdout is drained by a reader thread (a line longer than the pipe buffer must not block it); a launch that
+    dies within its first seconds (the rendezvous port was taken between probing and binding) is retried on a new port."""
+    import threading
+
+    cores = os.cpu_count() or 1
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        t_start = time.time()
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WSOVOD_BENCH_CHILD="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+            env.setdefault("OMP_NUM_THREADS", str(max(1, cores // args.gpus)))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr))
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        rc = 0
+        try:
+            pending = set(range(args.gpus))
+            while pending:
+                for r in sorted(pending):
+                    code = procs[r].poll()
+                    if code is None:
+                        continue
+                    pending.discard(r)
+                    if code != 0:
+                        rc = rc or code
+                        print(f"bench.py: rank {r} exited with code {code}", file=sys.stderr)
+                if rc:  # a dead rank leaves the others waiting in a collective: stop exactly the children started here
+                    for r in pending:
+                        procs[r].terminate()
+                    for r in pending:
+                        try:
+                            procs[r].wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            procs[r].kill()
+                    break
+                time.sleep(0.05)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        reader.join(timeout=30)
+        line = b"".join(chunks)
+        if rc and time.time() - t_start < 15 and attempt < 2 and not os.environ.get("WSOVOD_BENCH_FAIL_RANK"):
+            print(f"bench.py: launch attempt {attempt + 1} died within {time.time() - t_start:.0f} s: retrying on a new port",
+                  file=sys.stderr)
+            continue
+        break
     lines = [x for x in line.decode().splitlines() if x.strip()]
     if rc == 0 and (len(lines) != 1 or json.loads(lines[0]).get("n_gpus") != args.gpus):
         print(f"bench.py: expected one JSON line with n_gpus={args.gpus} from rank 0, got {lines!r}", file=sys.stderr)
@@ -339,6 +355,51 @@ class H2DStager:
         return batch
 
 
+def _agree(flag, dev, op):
+    """All ranks learn the MIN / MAX of a per-rank number (one tiny all-reduce on the bench's own process group)."""
+    t = torch.tensor([float(flag)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
+
+
+def pick_exchange(trainer, step, sync, dev, algos=("ring", "direct"), warm=2, steps=4):
+    """N > 1, bf16 wire: time BOTH gradient exchanges in this run, in this process (`trainer.set_exchange`), a few steps
+    each after a short warm-up, and leave the trainer on the faster one.  An algorithm that raises or produces a
+    non-finite loss on ANY rank is dropped on EVERY rank (the ranks agree through an all-reduce of an ok flag) and its
+    half-finished exchange is aborted -- never a re-exec, never a second process on a GPU that was touched.  Returns
+    {"ms": {algo: ms_per_step | None}, "errors": {algo: text}, "chosen": algo}."""
+    ms, errors = {}, {}
+    for algo in algos:
+        ok, err = 1.0, None
+        try:
+            trainer.set_exchange(algo)
+            for _ in range(warm):
+                last = step()
+            trainer.flush()
+            if not all(bool(torch.isfinite(v.detach()).all()) for v in last.values()):
+                ok, err = 0.0, "non-finite loss during warm-up"
+        except Exception as e:  # noqa: BLE001 -- whatever the collective raised: fall back, in process
+            ok, err = 0.0, f"{type(e).__name__}: {e}"[:300]
+        if _agree(ok, dev, dist.ReduceOp.MIN) < 1.0:
+            errors[algo] = err or "failed on another rank"
+            ms[algo] = None
+            trainer.abort_pending()
+            continue
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        trainer.flush()
+        sync()
+        ms[algo] = _agree((time.perf_counter() - t0) / steps * 1e3, dev, dist.ReduceOp.MAX)  # the slowest rank's time
+    good = [a for a in algos if ms.get(a) is not None]
+    if not good:
+        raise RuntimeError(f"no gradient exchange worked: {errors}")
+    chosen = min(good, key=lambda a: ms[a])
+    trainer.set_exchange(chosen)
+    return {"ms": ms, "errors": errors, "chosen": chosen}
+
+
 def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, warmup, h2d=False, rpn=False,
                want_roofline=False, keep=False, depth=None, proposals=None, classes=None, embed_dim=None):
     """Build the model, run `warmup` + `steps` training steps, return the timing record (and the live objects if keep)."""
@@ -359,9 +420,12 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     # the reported final losses stay meaningful: tests/test_gpu_model_parity.py::test_training_on_a_fixed_batch_...)
     cfg.SOLVER.BASE_LR = 1e-3
     optimizer = build_optimizer(cfg, model)
-    wire = ("bf16" if precision == "bf16" else "fp32") if args.grad_wire == "auto" else args.grad_wire
-    # asynchronous gradient exchange behind the next step's frozen forward
-    trainer = HotPathTrainer(model, optimizer, grad_wire=wire, exchange=args.exchange if wire == "bf16" else "ring")
+    wire = ("bf16" if precision in ("bf16", "parity", "bf16x3f") else "fp32") if args.grad_wire == "auto" else args.grad_wire
+    # asynchronous gradient exchange behind the next step's frozen forward.  At N > 1 with --exchange auto both forms are
+    # timed below and the faster one carries the headline: the trainer starts on the ring (RCCL's own all-reduce)
+    ab = world > 1 and wire == "bf16" and args.exchange == "auto"
+    trainer = HotPathTrainer(model, optimizer, grad_wire=wire,
+                             exchange=("ring" if ab else args.exchange) if wire == "bf16" else "ring")
     trainer.broadcast_parameters()
     cpu_state = None
     if keep and rank == 0 and world == 1 and not args.no_cpu_baseline:  # untrained weights for the CPU leg
@@ -381,6 +445,12 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     for _ in range(warmup):
         step()
     sync()
+    exchange_ab = None
+    if ab:
+        exchange_ab = pick_exchange(trainer, step, sync, dev, steps=max(3, min(6, steps)))
+        for _ in range(2):  # settle on the chosen form before the timed region
+            step()
+        sync()
     events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     events[0].record()
@@ -395,7 +465,7 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     if not all(v == v and abs(v) != float("inf") for v in final_losses.values()):
         raise RuntimeError(f"training diverged during the benchmark: {final_losses}")
     rec = {"elapsed": elapsed, "per_step_ms": per_step, "final_losses": final_losses, "wire": wire,
-           "exchange": trainer.exchange_algo}
+           "exchange": trainer.exchange_algo, "exchange_ab": exchange_ab}
 
     if want_roofline:
         # second pass over the same K steps with every launch bracketed by hipEvents on its stream
@@ -523,6 +593,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and "OMP_NUM_THREADS" not in os.environ:  # (an external launcher: N ranks share the host's cores)
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     if args.launch_check:
         return launch_check(args, world, rank, result_fd)
     if not torch.cuda.is_available():
@@ -616,6 +688,8 @@ def main():
                        "per_step_percentiles": "hipEvent time between consecutive steps on rank 0's stream",
                        "per_step_ms": [round(v, 3) for v in ms],
                        "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms), "all": rank_ms},
+                       "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                       "exchange_ab": rec.get("exchange_ab"),
                        "final_losses": rec["final_losses"]},
         }
         if roofline is not None:

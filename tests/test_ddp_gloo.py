@@ -4,6 +4,8 @@ The HIP model itself needs a GPU, so this drives the same engine code (wrap_mode
 CPU stand-in module that has the path's loss-dict interface."""
 import os
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -613,3 +615,75 @@ def test_three_rank_direct_exchange_with_unused_tensors_and_iter_size():
                 buf[n].mul_(0.9).add_(gsum.float() / world + 0.05 * p)
                 p.sub_(0.1 * buf[n])
     torch.testing.assert_close(torch.tensor(res[0][1]), model.fc.weight.detach(), rtol=0, atol=1e-6)
+
+
+def _worker_pick_exchange(rank, world, port, q, break_direct):
+    """bench.py's same-run A/B of the two bf16-wire exchanges (`pick_exchange`) on three gloo ranks with the torch
+    stand-ins of the HIP kernels: both forms are timed in one process and the faster one is kept; with a direct path
+    that raises (simulated RCCL failure inside the all-to-all) every rank falls back to the ring IN THIS PROCESS and
+    training goes on with identical replicas."""
+    import sys
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from wsovod_amd.engine import HotPathTrainer
+    from wsovod_amd.engine.trainer import HipSGD
+    from wsovod_amd.layers import hip_ops as H
+
+    def pack(pairs):
+        for src, dst in pairs:
+            dst.copy_(src.reshape(-1))
+
+    def sgd(entries, momentum, grad_scale=1.0):
+        for p, g, buf, shadow, lr, wd, used in entries:
+            buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
+            p.sub_(lr * buf)
+
+    def sum_shards(src, n, dst):
+        dst.copy_(src.view(n, -1).float().sum(0))
+        return dst
+
+    H.pack_bf16_multi, H.sgd_momentum_multi, H.sum_shards_bf16 = pack, sgd, sum_shards
+    HotPathTrainer.split_on_cpu = True
+    HotPathTrainer.split_rows = staticmethod(lambda n_rows, n_cols, cus=256, tile=256: 8)
+    if break_direct:
+        def broken(*a, **k):
+            raise RuntimeError("simulated RCCL failure in all_to_all_single")
+        dist.all_to_all_single = broken
+    model = _SplitModel(cols=48)
+    opt = HipSGD([{"params": [p], "lr": 0.01, "weight_decay": 0.0} for p in model.parameters()], 0.01, momentum=0.9)
+    tr = HotPathTrainer(model, opt, overlap=True, grad_wire="bf16", exchange="ring")
+    tr.broadcast_parameters()
+    g = torch.Generator().manual_seed(7 + rank)
+    batch = [{"x": torch.randn(48, generator=g)} for _ in range(4)]
+    res = bench.pick_exchange(tr, lambda: tr.run_step(batch), dist.barrier, torch.device("cpu"), warm=2, steps=3)
+    for _ in range(2):
+        tr.run_step(batch)
+    tr.flush()
+    q.put((rank, res["chosen"], sorted(res["errors"]), {k: v is not None for k, v in res["ms"].items()}, tr.exchange_algo,
+           model.big.detach().tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("break_direct", [False, True])
+def test_bench_times_both_exchanges_and_falls_back_in_process(break_direct):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + os.getpid() % 2000 + (7 if break_direct else 0)
+    world = 3
+    procs = [ctx.Process(target=_worker_pick_exchange, args=(r, world, port, q, break_direct)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len({r[1] for r in res}) == 1 and all(r[4] == r[1] for r in res)  # every rank chose (and runs) the same form
+    assert all(r[5] == res[0][5] for r in res), "replicas diverged"
+    if break_direct:
+        assert res[0][1] == "ring" and res[0][2] == ["direct"] and res[0][3] == {"ring": True, "direct": False}
+    else:
+        assert res[0][1] in ("ring", "direct") and res[0][2] == [] and res[0][3] == {"ring": True, "direct": True}

@@ -190,6 +190,42 @@ class HotPathTrainer:
         if self.exchange:
             for t in list(self.model.parameters()) + list(self.model.buffers()):
                 dist.broadcast(t.data, src)
+                # the broadcast wrote through `.data`: bump the version counter so that caches keyed on it (bf16 / bf16x2
+                # shadows, folded conv weights, class matrices) are rebuilt from the received values
+                torch.autograd.graph.increment_version(t)
+
+    def set_exchange(self, algo):
+        """Switch the bf16-wire exchange algorithm ("ring" / "direct") between steps, in this process: applies the pending
+        update first, then rebuilds the wire buffer (the direct form pads it to whole shards) and the early block."""
+        if algo not in ("ring", "direct"):
+            raise ValueError(f"exchange must be 'ring' or 'direct', got {algo!r}")
+        if algo == "direct" and self.grad_wire != "bf16":
+            raise ValueError("exchange='direct' is defined on the bf16 wire buffer (grad_wire='bf16')")
+        self.flush()
+        if not self.exchange or algo == self.exchange_algo:
+            return
+        self.exchange_algo = algo
+        self._reset_wire()
+
+    def _reset_wire(self):
+        self._wire = self._direct = self._early = None
+        if self._split is not None:
+            self._split[0]._dw_split = None
+            self._split = None
+        for p in self.params:
+            p._wire_grad = None
+        if self.exchange and self.grad_wire == "bf16" and self.params and self.iter_size == 1:
+            self._setup_early_exchange()
+
+    def abort_pending(self):
+        """Drop an exchange that failed half way (an exception out of a collective): the step's gradients are discarded,
+        no update is applied, the wire state is rebuilt.  Every rank must call it for the same step."""
+        self._pending = self._used = None
+        for p in self.params:
+            p.grad = None
+            p._wire_grad = None
+            p._used_flag = None
+        self._reset_wire()
 
     def _finish_pending(self):
         if self._pending is None:
