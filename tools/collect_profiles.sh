@@ -2,17 +2,24 @@
 # Runs ON THE GPU BOX (via gpurun): the round's bench line, the rocprofv3 kernel-trace summary of the same command and
 # the PMC passes behind roofline.traffic and the MFMA-utilisation table.  Counters are collected in their own runs with
 # --kernel-trace only (no sys/hip/hsa trace domains).  Everything lands under gpurun_out/final/ (copy to profiles/).
-#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh'
+#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh'                       (the bf16 headline, 32 images / step)
+#   gpurun --timeout 1800 -- 'PREC=parity BATCH=48 bash tools/collect_profiles.sh'  (the tolerance-meeting mode)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+PREC=${PREC:-bf16}
+BATCH=${BATCH:-32}
+TAG=b${BATCH}_${PREC}
 OUT=$ROOT/gpurun_out/final
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-SHORT="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-side --no-parity"
-python3 "$ROOT/bench.py" --steps 20 --warmup 5 > "$OUT/bench_b32_bf16.json" 2> "$OUT/bench_b32_bf16.err"
+COMMON="--precision $PREC --batch $BATCH"
+SHORT="$COMMON --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-side --no-parity"
+FULL=""
+if [ "$PREC" != "bf16" ]; then FULL="--no-side --no-parity --no-cpu-baseline"; fi
+python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 5 $FULL > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- \
-    python3 "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-side --no-parity > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.err"
-cp /tmp/prof_kt/*kernel_stats.csv "$OUT/kernel_stats.csv"
+    python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 5 --no-cpu-baseline --no-side --no-parity > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/rocprof_$TAG.err"
+cp /tmp/prof_kt/*kernel_stats.csv "$OUT/kernel_stats_$TAG.csv"
 declare -A PASS
 PASS[FETCH_SIZE]="FETCH_SIZE"
 PASS[WRITE_SIZE]="WRITE_SIZE"
@@ -24,6 +31,6 @@ for C in FETCH_SIZE WRITE_SIZE SQ LDS; do
       python3 "$ROOT/bench.py" $SHORT > "$OUT/pmc_$C.log" 2>&1
   cp /tmp/prof_$C/*counter_collection.csv "$OUT/pmc_$C.csv" 2>/dev/null && ARGS="$ARGS $C=$OUT/pmc_$C.csv"
 done
-python3 "$ROOT/tools/pmc_aggregate.py" "$OUT/pmc_b32_bf16.json" $ARGS
+python3 "$ROOT/tools/pmc_aggregate.py" "$OUT/pmc_$TAG.json" $ARGS
 rm -f "$OUT"/pmc_*.csv
 ls -la "$OUT"
