@@ -76,3 +76,11 @@ if __name__ == "__main__":
     r = bench({str(t): (lambda t=t: H.gemm_nt(x, w, conv=geom, relu=True, out_dtype=torch.bfloat16, tile_hint=t))
                for t in (256256, 8256256, 2256256)})
     print("res5 bf16", {t: f"{ms:.3f} ms {2.0 * n * 7500 * 512 * 4608 / ms / 1e9:.0f} TF" for t, ms in r.items()}, flush=True)
+    # res3 (128 -> 128, K = 1152) and res4 (256 -> 256, K = 2304) in bf16: short-K convs, tile choice
+    for name, C, dil, tiles in (("res3 bf16", 128, 1, (256128, 1128128, 128128, 256256, 3128128, 4128128)),
+                                ("res4 bf16", 256, 2, (256256, 256128, 1128128, 8256256, 3256128))):
+        x = torch.randn(n, 75, 100, C, device=dev).to(torch.bfloat16)
+        w = (torch.randn(C, 9 * C, device=dev) * 0.02).to(torch.bfloat16)
+        geom = dict(n_img=n, H=75, W=100, Cin=C, Ho=75, Wo=100, KH=3, KW=3, stride=1, pad=dil, dil=dil)
+        r = bench({str(t): (lambda t=t: H.gemm_nt(x, w, conv=geom, relu=True, out_dtype=torch.bfloat16, tile_hint=t)) for t in tiles})
+        print(name, {t: f"{ms:.3f} ms {2.0 * n * 7500 * C * 9 * C / ms / 1e9:.0f} TF" for t, ms in r.items()}, flush=True)

@@ -986,21 +986,33 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 // The epilogue adds bias and the (bf16x2) residual, applies ReLU, optionally the 2x2 / stride-2 max pool (pool = 2),
 // and stores bf16x2.
 // ---------------------------------------------------------------------------------
-constexpr int C64X_NPIX_PAD = (C64_NPIX + 15) / 16 * 16;  // whole 16-pixel DMA passes (4 wavefronts x 4 pixels)
-constexpr int C64X_PATCH_BYTES = C64X_NPIX_PAD * 256;
-constexpr int C64X_W_BYTES = 64 * 256;
-constexpr int C64X_LDS_BYTES = C64X_PATCH_BYTES + 2 * C64X_W_BYTES;
+// Tile width TW = 16 (default): 8 x 16 output pixels per workgroup, 80 KiB of LDS -> TWO workgroups per CU: one's patch
+// staging and per-tap barriers hide behind the other's MFMAs (two wavefronts per SIMD).  TW = 32: the bf16 kernel's
+// 8 x 32 tile, 120 KiB, one workgroup per CU (3 MFMAs per fragment read instead of 2, but nothing to overlap the
+// prologue with): measured slower (WSOVOD_C64X_TW=32 selects it for A/B runs).
+template <int TW>
+struct C64X {
+  static constexpr int XG = TW / 16, NI = 2 * XG;       // 16-pixel groups per image row / per wavefront (2 rows)
+  static constexpr int PW = TW + 2, NPIX = PW * C64_PH;
+  static constexpr int NPIX_PAD = (NPIX + 15) / 16 * 16;  // whole 16-pixel DMA passes (4 wavefronts x 4 pixels)
+  static constexpr int PATCH_BYTES = NPIX_PAD * 256;
+  static constexpr int W_BYTES = 64 * 256;
+  static constexpr int LDS_BYTES = PATCH_BYTES + 2 * W_BYTES;
+};
 
+template <int TW>
 __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, int tiles_x, int tiles_y) {
+  using G = C64X<TW>;
+  constexpr int XG = G::XG, NI = G::NI, PW = G::PW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sP = smem;                     // halo patch [pixel][256 B]
-  char* sW = smem + C64X_PATCH_BYTES;  // 2 x [64 cout][256 B] weight slices
+  char* sP = smem;                    // halo patch [pixel][256 B]
+  char* sW = smem + G::PATCH_BYTES;   // 2 x [64 cout][256 B] weight slices
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tpi = tiles_x * tiles_y;
   const int img = blockIdx.x / tpi;
   const int t = blockIdx.x - img * tpi;
   const int ty = t / tiles_x, tx = t - ty * tiles_x;
-  const int y0 = ty * C64_TH, x0 = tx * C64_TW;
+  const int y0 = ty * C64_TH, x0 = tx * TW;
   typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcA =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
@@ -1018,17 +1030,17 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
       const int chunk = (lane & 15) ^ (row & 15);          // swizzle on the source
       const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);  // a lane ends up with 16 consecutive channels
       const int off = (int)((cout * p.ldb + tap * 128 + chunk * 8) * 2);    // (p.ldb, in bf16 slots = 2 x 9 x 64)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + buf * C64X_W_BYTES + (i * 16 + wave_u * 4) * 256), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + buf * G::W_BYTES + (i * 16 + wave_u * 4) * 256), 16,
                                                off, 0, 0, 0);
     }
 #endif
   };
 #if defined(__HIP_DEVICE_COMPILE__)
-  for (int base = 0; base < C64X_NPIX_PAD; base += 16) {
+  for (int base = 0; base < G::NPIX_PAD; base += 16) {
     const int q = base + wave_u * 4 + (lane >> 4);
-    const int py = q / C64_PW, px = q - py * C64_PW;
+    const int py = q / PW, px = q - py * PW;
     const int y = y0 - 1 + py, x = x0 - 1 + px;
-    const bool ok = q < C64_NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const bool ok = q < G::NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
     const int chunk = (lane & 15) ^ (q & 15);
     const int off = (((img * p.H + y) * p.W + x) * 128 + chunk * 8) * 2;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sP + (base + wave_u * 4) * 256), 16, ok ? off : -1, 0, 0, 0);
@@ -1040,9 +1052,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
   const int frow = lane & 15, fq = lane >> 4;
   f32x4 bias4[4];
   c64_load_bias(p, fq, bias4);
-  f32x4 acc[4][4];
+  f32x4 acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -1050,13 +1062,13 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
     const int cur = tap & 1;
     if (tap + 1 < 9) stage_weights(tap + 1, cur ^ 1);
     const int r = tap / 3, s3 = tap - r * 3;
-    const char* cW = sW + cur * C64X_W_BYTES;
+    const char* cW = sW + cur * G::W_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {  // 32-value group of the 64 input channels: chunks 8 kk + (0-3 hi | 4-7 lo)
-      u32x4 ah[4], al[4], bh[4], bl[4];
+      u32x4 ah[NI], al[NI], bh[4], bl[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = (wave * 2 + (i >> 1) + r) * C64_PW + (i & 1) * 16 + frow + s3;
+      for (int i = 0; i < NI; ++i) {
+        const int q = (wave * 2 + (i / XG) + r) * PW + (i % XG) * 16 + frow + s3;
         const char* row = sP + q * 256;
         ah[i] = *(const u32x4*)(row + (((8 * kk + fq) ^ (q & 15)) << 4));
         al[i] = *(const u32x4*)(row + (((8 * kk + 4 + fq) ^ (q & 15)) << 4));
@@ -1068,19 +1080,19 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
         bl[j] = *(const u32x4*)(cW + row * 256 + (((8 * kk + 4 + fq) ^ (row & 15)) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
                                                               __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]),
                                                               __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
@@ -1117,13 +1129,13 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
   if (p.pool) {  // MaxPool2d(2, 2): the wavefront's two image rows are one pooled row, the horizontal partner is lane frow ^ 1
     const int Hp = p.H >> 1, Wp = p.W >> 1;
 #pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
+    for (int ih = 0; ih < XG; ++ih) {
       float best[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
 #pragma unroll
       for (int iv = 0; iv < 2; ++iv) {
-        const int i = ih + 2 * iv;
+        const int i = ih + XG * iv;
         const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
         const long long m = ((long long)img * p.H + y) * p.W + x;
         float v[16];
@@ -1149,9 +1161,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
     return;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int y = y0 + wave * 2 + (i >> 1);
-    const int x = x0 + (i & 1) * 16 + frow;
+  for (int i = 0; i < NI; ++i) {
+    const int y = y0 + wave * 2 + (i / XG);
+    const int x = x0 + (i % XG) * 16 + frow;
     if (y >= p.H || x >= p.W) continue;
     const long long m = ((long long)img * p.H + y) * p.W + x;
     float v[16];
@@ -1451,13 +1463,19 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     static int slot = wsovod::prof_slot("conv3x3_c64_halo_bf16x2");
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64X_LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<16>::LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<32>::LDS_BYTES);
       attr = true;
     }
-    const int tiles_x = ceil_div(a.W, C64_TW), tiles_y = ceil_div(a.H, C64_TH);
+    const char* tw = getenv("WSOVOD_C64X_TW");
+    const bool wide = tw && tw[0] == '3';
+    const int tiles_x = ceil_div(a.W, wide ? 32 : 16), tiles_y = ceil_div(a.H, C64_TH);
     const int n_tiles = d->geom.n_img * tiles_x * tiles_y;
     wsovod::ProfScope prof(slot, s, flops, bytes);
-    hipLaunchKernelGGL(conv3x3_c64_x3_kernel, dim3(n_tiles), dim3(256), C64X_LDS_BYTES, s, a, tiles_x, tiles_y);
+    if (wide)
+      hipLaunchKernelGGL(conv3x3_c64_x3_kernel<32>, dim3(n_tiles), dim3(256), C64X<32>::LDS_BYTES, s, a, tiles_x, tiles_y);
+    else
+      hipLaunchKernelGGL(conv3x3_c64_x3_kernel<16>, dim3(n_tiles), dim3(256), C64X<16>::LDS_BYTES, s, a, tiles_x, tiles_y);
     WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64 bf16x2)");
     return WSOVOD_OK;
   }

@@ -114,7 +114,7 @@ class HotPathTrainer:
     split_on_cpu = False  # tests: let the early-exchange logic run on a CPU stand-in model
 
     def __init__(self, model, optimizer, overlap=True, reduce_unused=False, grad_wire="fp32", iter_size=1,
-                 exchange="ring"):
+                 exchange="ring", start_iter=0):
         """reduce_unused: parameters that received no gradient this step (mixed-dataset mode: the other
         datasets' object miners) still take part in the exchange with zeros, so that every rank issues the same
         collectives -- the job `find_unused_parameters=True` does in the reference (engine/defaults.py:146-148).
@@ -171,7 +171,7 @@ class HotPathTrainer:
             exchange = "direct" if grad_wire == "bf16" and self.world > 2 else "ring"
         self.exchange_algo = exchange if self.exchange else "none"
         self.iter_size = int(iter_size)
-        self.iter = 0
+        self.iter = int(start_iter)  # the reference's global iteration (engine/trainer.py:72-84): pass it when resuming
         if self.iter_size < 1:
             raise ValueError(f"iter_size must be >= 1, got {iter_size}")
         for p in self.params:
@@ -185,6 +185,21 @@ class HotPathTrainer:
             self._hooks.append(optimizer.register_state_dict_pre_hook(lambda *_a, **_k: self.synchronize()))
         if isinstance(optimizer, HipSGD):
             optimizer.grad_scale = 1.0 / self.world
+        # model.inference() between steps (EvalHook, TTA wrappers call it directly, past any forward hook) applies the
+        # pending update first
+        try:
+            model._pre_inference = self.synchronize
+        except Exception:  # noqa: BLE001 -- a stand-in model without attribute assignment
+            pass
+
+    def close(self):
+        """Apply the pending update and detach from the model / optimizer (state-dict hooks, inference hook)."""
+        self.flush()
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if getattr(self.model, "_pre_inference", None) == self.synchronize:
+            self.model._pre_inference = None
 
     def broadcast_parameters(self, src=0):
         if self.exchange:

@@ -296,8 +296,15 @@ def stem_conv1_x2(images_u8, sizes, mean, std, w32_x2, bias):
 # bf16x3 mode (MODEL.HIP.PRECISION = "bf16x3"): fp32 tensors everywhere, every contraction evaluated on the bf16 MFMA
 # kernels as sum ah*bh + ah*bl + al*bh over operands split by wsovod_split3_bf16 (include/wsovod_hip.h).
 # ---------------------------------------------------------------------------------------
-class _X3State:
+import threading
+
+
+class _X3StateT(threading.local):
+    """Per-thread: a TTA / data-loader thread must neither see nor clobber the mode of the autograd thread."""
     active = False
+
+
+_X3State = _X3StateT()
 
 
 class x3_mode:

@@ -127,6 +127,8 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None, out
     # the kernels address the NHWC input through one buffer resource (< 2 GiB): larger batches (> 139 images of
     # 800x600 at the 64-channel stem maps) go through in image blocks -- images are independent
     per_image = max(Hh * Ww * Cin, Ho * Wo * conv.out_channels) * x.element_size()
+    if H.x3_active() in ("full", "fwd") and x.dtype == torch.float32:
+        per_image = max(per_image, Hh * Ww * 3 * Cin * 2)  # the operand the kernel addresses is the [hi | hi | lo] bf16 split
     max_n = max(1, CONV_MAX_OPERAND_BYTES // max(per_image, 1))
     if N > max_n:
         parts = []

@@ -171,6 +171,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
 
     @torch.no_grad()
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, classifier=None):
+        pre = getattr(self, "_pre_inference", None)  # an overlapped trainer applies its pending update first (eval / TTA
+        if pre is not None:                          # hooks between steps must see the weights after optimizer.step())
+            pre()
         with H.x3_mode(self.x3):
             return self._inference(batched_inputs, detected_instances, do_postprocess, classifier)
 
