@@ -498,8 +498,9 @@ def side_measurements(args, dev):
         ("bf16x3 parity-grade mode", dict(precision="bf16x3", steps=max(3, args.side_steps // 2), warmup=2)),
         ("bf16x3f: fp32-grade forward (logit bound met), bf16 backward", dict(precision="bf16x3f",
                                                                               steps=max(3, args.side_steps // 2), warmup=2)),
-        ("parity: the fast tolerance-meeting mode (split forward on its own activation format, bf16 backward)",
-         dict(precision="parity", steps=args.side_steps, warmup=3)),
+        ("parity: the tolerance-meeting mode (bf16x2 activations, three-MFMA forward products, bf16 backward), 48 images/step",
+         dict(precision="parity", batch_size=48, steps=args.side_steps, warmup=3)),
+        ("parity at the headline's 32 images/step", dict(precision="parity", steps=args.side_steps, warmup=3)),
         ("H2D-inclusive (uint8 images + boxes copied from pinned host memory every step)", dict(h2d=True)),
         ("BASELINE config 2 shapes: K = 80 classes, D = 768 (CLIP ViT-L/14)", dict(classes=80, embed_dim=768)),
         ("BASELINE config 3 shapes: WSR_50, 1024 proposals, K = 80, 8 images/step", dict(depth=50, proposals=1024, classes=80,
@@ -705,10 +706,12 @@ def main():
                 # throughput of the mode that MEETS the north star's 1e-3 logit bound (measured against the oracle in the
                 # parity block above), next to the bf16 headline
                 pm = (out.get("parity") or {}).get("modes", {}).get("parity", {})
-                for line in out["side"]:
-                    if line.get("precision") == "parity" and "images_per_sec" in line:
-                        out["parity_grade_value"] = line["images_per_sec"]
-                        out["parity_grade_meets_bound"] = pm.get("meets_1e-3_logit_bound")
+                best = max((ln for ln in out["side"] if ln.get("precision") == "parity" and "images_per_sec" in ln),
+                           key=lambda ln: ln["images_per_sec"], default=None)
+                if best is not None:
+                    out["parity_grade_value"] = best["images_per_sec"]
+                    out["parity_grade_images_per_step"] = best["images_per_step"]
+                    out["parity_grade_meets_bound"] = pm.get("meets_1e-3_logit_bound")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, cpu_state, host_batch, args)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
