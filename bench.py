@@ -87,24 +87,28 @@ def pmc_traffic(kernel_name, args):
     import re
 
     path = None
-    for rnd in ("r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
-        cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{args.batch}_bf16.json")
+    prec = args.precision
+    for rnd in ("r03", "r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
+        cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{args.batch}_{prec}.json")
         if os.path.exists(cand):
             path = cand
             break
-    if not (path and args.precision == "bf16" and args.depth == 18 and args.proposals == 512):
+    if not (path and prec in ("bf16", "parity") and args.depth == 18 and args.proposals == 512):
         return None, None
     if getattr(args, "rpn", False) or args.pooler != "ROIPool" or args.h2d:
         return None, None
-    m = re.match(r"(gemm_nt|conv_igemm)_(bf16|f32)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
+    m = re.match(r"(gemm_nt|conv_igemm)_(bf16x2|bf16|f32)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
     if not m:
         return None, None
-    conv = m.group(1) == "conv_igemm"
-    if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled
-        tags = ("gemm256_8ph_kernelILb%d" % conv, "gemm256_8ph_kernel<%s>" % ("true" if conv else "false"))
+    conv, x3 = m.group(1) == "conv_igemm", m.group(2) == "bf16x2"
+    if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled: gemm256_8ph_kernel<CONV, X3, PH>
+        c, x = ("true" if conv else "false"), ("true" if x3 else "false")
+        tags = (f"gemm256_8ph_kernel<{c}, {x},", f"gemm256_8ph_kernel<{c}>") if not x3 else (f"gemm256_8ph_kernel<{c}, {x},",)
     else:
-        tags = ("gemm_nt_kernelI%sLi%sELi%sELb%d" % ("DF16b" if m.group(2) == "bf16" else "f", m.group(3), m.group(4),
-                                                    conv),)
+        tags = ("gemm_nt_kernelI%sLi%sELi%sELb%dELi4ELi4ELb1ELi2ELb%dE" % ("f" if m.group(2) == "f32" else "DF16b", m.group(3),
+                                                                          m.group(4), conv, x3),
+                "gemm_nt_kernelI%sLi%sELi%sELb%dELi4ELi4ELb1ELi2EEE" % ("f" if m.group(2) == "f32" else "DF16b", m.group(3),
+                                                                       m.group(4), conv))
     with open(path) as f:
         table = json.load(f)["kernels"]
     hits = [v for k, v in table.items() if any(t in k for t in tags)]
