@@ -41,3 +41,12 @@ ms = timeit(lambda: H.roi_pool_forward(feat, rois, 0.125, (7, 7), roi_scale=scal
 print(f"roi_pool  + argmax    : {ms:.3f} ms")
 ms = timeit(lambda: H.roi_align_forward(feat, rois, 0.125, (7, 7), 0, True, roi_scale=scale, out_dtype=torch.bfloat16))
 print(f"roi_align aligned     : {ms:.3f} ms")
+
+# the "parity" precision's pooler: fp32 map in, bf16x2 (+ plain bf16 copy) out
+feat32 = torch.randn(N, 75, 100, Cc, device=dev).permute(0, 3, 1, 2)
+ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=H.X2, need_argmax=False))
+print(f"roi_pool  fp32 -> bf16x2        : {ms:.3f} ms  (WSOVOD_ROIPOOL_F32_CPL={os.environ.get('WSOVOD_ROIPOOL_F32_CPL', '4')})")
+ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=H.X2, need_argmax=False, want_hi=True))
+print(f"roi_pool  fp32 -> bf16x2 + bf16 : {ms:.3f} ms")
+ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=torch.float32, need_argmax=False))
+print(f"roi_pool  fp32 -> fp32          : {ms:.3f} ms")

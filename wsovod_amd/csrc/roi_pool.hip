@@ -987,9 +987,13 @@ int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const 
       // (4 bf16 / 2 fp32 channels); bf16 maps whose channel count is not a multiple of 4 keep 2 channels per lane
       const bool wide = dtype == WSOVOD_BF16 && (C & 3) == 0 && !argmax;  // measured: 4 channels per lane pay off only without argmax registers (C = 2048: 1.83 -> 1.66 ms; with argmax 0.70 -> 1.07)
       // fp32 maps (the "parity" precision's res5): 4 channels = one 16-byte load per lane and cell (WSOVOD_ROIPOOL_F32_WIDE=0: 2)
-      const char* wf = getenv("WSOVOD_ROIPOOL_F32_WIDE");
-      const bool widef = dtype == WSOVOD_F32 && (C & 3) == 0 && !argmax && (((uintptr_t)feat) & 15) == 0 && !(wf && wf[0] == '0');
-      const int cg = (wide || widef) ? 256 : 128;
+      // (WSOVOD_ROIPOOL_F32_CPL = 1 / 2 / 4 selects the channels per lane for A/B runs: 64 / 128 / 256 channels per workgroup)
+      const char* wf = getenv("WSOVOD_ROIPOOL_F32_CPL");
+      const int fcpl = wf ? atoi(wf) : 4;
+      const bool f32na = dtype == WSOVOD_F32 && !argmax;
+      const bool widef = f32na && fcpl == 4 && (C & 3) == 0 && (((uintptr_t)feat) & 15) == 0;
+      const bool narrowf = f32na && fcpl == 1;  // one XCD per 64-channel group: its slice of an fp32 map (1.9 MB) stays in L2
+      const int cg = (wide || widef) ? 256 : narrowf ? 64 : 128;
       const int cgroups = ceil_div(C, cg);
       const bool obf = wide && out_dtype == WSOVOD_BF16;  // bf16 transpose tile: 25 instead of 50 KiB per workgroup (0.833 -> 0.817 ms)
       const int lds7 = obf ? cg * ph * pw * 2 : cg * ph * pw * 4 * (argmax ? 2 : 1);
@@ -1010,6 +1014,8 @@ int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const 
         LAUNCH_ROWS(bf16_t, false, 4);
       } else if (widef) {
         LAUNCH_ROWS(float, false, 4);
+      } else if (narrowf) {
+        LAUNCH_ROWS(float, false, 1);
       } else if (dtype == WSOVOD_BF16) {
         if (argmax) LAUNCH_ROWS(bf16_t, true, 2); else LAUNCH_ROWS(bf16_t, false, 2);
       } else {

@@ -7,7 +7,6 @@ ONE launch (epilogue fused); the backward is the mask/transpose prologue + two c
 """
 from typing import List
 
-import numpy as np
 import torch
 from torch import nn
 
@@ -24,24 +23,25 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
     @configurable
     def __init__(self, input_shape: ShapeSpec, *, conv_dims: List[int], fc_dims: List[int], conv_norm="", seed: int = -1):
         super().__init__()
-        assert len(conv_dims) + len(fc_dims) > 0
-        if len(conv_dims):
+        if len(conv_dims) + len(fc_dims) == 0:
+            raise ValueError("DiscriminativeAdaptationNeck needs at least one layer")
+        if conv_dims:
             raise NotImplementedError("NUM_CONV > 0 is not used by any WSOVOD config (hot path: FC neck only)")
+        # Child names and order are the checkpoint contract of the reference (box_head.py:60-71): flatten, then per
+        # layer k = 1.. `fc{k}` (N(0, 0.005) weights, bias 0.1), `fc_relu{k}`, `fc_dropout{k}` (p = 0.5).
+        self.conv_norm_relus, self.fcs = [], []
+        width = input_shape.channels * (input_shape.height or 1) * (input_shape.width or 1)
         self._output_size = (input_shape.channels, input_shape.height, input_shape.width)
-        self.conv_norm_relus = []
-        self.fcs = []
-        for k, fc_dim in enumerate(fc_dims):
-            if k == 0:
-                self.add_module("flatten", nn.Flatten())
-            fc = nn.Linear(int(np.prod(self._output_size)), fc_dim)
-            self.add_module("fc{}".format(k + 1), fc)
-            self.add_module("fc_relu{}".format(k + 1), nn.ReLU(inplace=True))
-            self.add_module("fc_dropout{}".format(k + 1), nn.Dropout(p=0.5, inplace=False))
-            self.fcs.append(fc)
-            self._output_size = fc_dim
-        for layer in self.fcs:
-            torch.nn.init.normal_(layer.weight, std=0.005)
-            torch.nn.init.constant_(layer.bias, 0.1)
+        self.add_module("flatten", nn.Flatten())
+        for k, out_width in enumerate(fc_dims, start=1):
+            layer = nn.Linear(width, out_width)
+            nn.init.normal_(layer.weight, std=0.005)
+            nn.init.constant_(layer.bias, 0.1)
+            for name, child in ((f"fc{k}", layer), (f"fc_relu{k}", nn.ReLU(inplace=True)),
+                                (f"fc_dropout{k}", nn.Dropout(p=0.5, inplace=False))):
+                self.add_module(name, child)
+            self.fcs.append(layer)
+            width = self._output_size = out_width
         # Counter-based dropout (mask = hash(seed, step, layer, row, unit)); the reference draws from per-process
         # torch RNG streams seeded `cfg.SEED + rank` (detectron2 seed_all_rng): the base seed mixes cfg.SEED and the
         # data-parallel rank (read at the first training forward, the process group may not exist yet), the step
