@@ -989,3 +989,72 @@ def test_backbone_in_image_blocks_equals_the_single_launch(gpu, depth, monkeypat
     monkeypatch.setattr(B, "CONV_MAX_OPERAND_BYTES", 2 * 48 * 64 * 64 * 2 + 1)
     got = model.backbone.forward_uint8(canvas, sizes_t, model._mean, model._std)["res5"]
     assert got.shape == want.shape and torch.equal(got, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# MODEL.HIP.PRECISION = "parity" (bf16x2 activations, three-MFMA forward products) on the paths beside the headline step
+# ---------------------------------------------------------------------------------------------------------------
+def test_parity_mode_step_matches_reference_golden(gpu):
+    """The reference's golden step (g8) in the parity precision: forward quantities inside the north star's bound, labels
+    and pseudo-GT exact, losses 1e-3, gradients of the bf16 grade (the backward is plain bf16)."""
+    g = load_golden("g8_train_step_r18_k20")
+    cfg, model, sd = build_seeded_hip_model("parity")
+    batch = gen.seeded_batch(4, 64, 20, 320, 416, seed=2)
+    losses, cap, pgt = _run(model, batch)
+    scores, logits = cap["miner"][0].detach().cpu(), cap["refine"][0].detach().cpu()
+    assert float((logits - g["refine_logits"]).abs().max()) < 1e-3
+    assert float((scores - g["mining_scores"]).abs().max()) < 1e-3
+    torch.testing.assert_close(cap["refine"][1].detach().cpu(), g["refine_deltas"], rtol=1e-3, atol=1e-4)
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+        torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=1e-3, atol=1e-5)
+    assert torch.equal(pgt["gt_classes"].cpu(), g["label/gt_classes"])
+    assert torch.equal(pgt["gt_boxes"].cpu(), g["label/gt_boxes"])
+    assert torch.equal(pgt["pgt_boxes"].cpu(), g["pgt/gt_boxes"])
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            ref = float(g["gradnorm/" + k])
+            assert abs(float(p.grad.double().norm()) - ref) <= 0.15 * ref + 1e-6, k
+
+
+def test_parity_mode_inference_matches_reference_golden(gpu):
+    """G14's per-proposal scores / boxes from the HIP model in the parity precision (eval branch: the per-module Linear
+    calls instead of the grouped heads, per-call class embeddings)."""
+    g = load_golden("g14_eval_tail")
+    cfg, model, sd = build_seeded_hip_model("parity")
+    model.eval()
+    batch = gen.seeded_batch(3, 200, 20, 256, 352, seed=15)
+    inputs = to_inputs(batch)
+    res, all_scores, all_boxes = model.inference(inputs, do_postprocess=False, classifier=g["classifier"].to(gpu))
+    for i in range(3):
+        assert (all_scores[i][0].cpu() - g[f"img{i}/all_scores"]).abs().max() < 1e-4
+        assert (all_boxes[i][0].cpu() - g[f"img{i}/all_boxes"]).abs().max() < 2e-2
+
+
+def test_parity_mode_mixed_datasets_step_matches_reference_golden(gpu):
+    """G10 (the reference's mixed-dataset model) in the parity precision: per-dataset miners and per-call embeddings."""
+    from wsovod_amd.modeling import build_model
+    from wsovod_amd.testing import mixed_datasets_cfg
+
+    g = load_golden("g10_mixed_datasets_step")
+    Ks = (20, 20, 80)
+    cfg = mixed_datasets_cfg(Ks=Ks, precision="parity", device="cuda:0")
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    model._std = [float(v) for v in gen.PIXEL_STD]
+    sd = gen.mixed_seeded_state({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=17)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    for source_id in (2, 0):
+        K, p = Ks[source_id], f"s{source_id}/"
+        batch = gen.seeded_batch(2, 40, K, 256, 352, seed=19 + source_id)
+        for b in batch:
+            b["dataset_id"] = source_id
+        model.zero_grad(set_to_none=True)
+        model.roi_heads.select_source(source_id)
+        losses, cap, pgt = _run(model, batch)
+        assert float((cap["refine"][0].detach().cpu() - g[p + "refine_logits"]).abs().max()) < 1e-3
+        assert float((cap["miner"][0].detach().cpu() - g[p + "mining_scores"]).abs().max()) < 1e-3
+        assert torch.equal(pgt["gt_classes"].cpu(), g[p + "label/gt_classes"])

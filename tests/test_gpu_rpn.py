@@ -321,3 +321,24 @@ def test_tta_union_matches_reference_golden(gpu):
     assert len(out) == len(g["scores"]) == 100
     torch.testing.assert_close(out.scores.cpu(), g["scores"], rtol=1e-3, atol=1e-4)
     assert float((out.pred_classes.cpu() == g["classes"]).float().mean()) > 0.95
+
+
+def test_parity_mode_rpn_step_matches_reference_golden(gpu, monkeypatch):
+    """The shipped form (RPN branch on, g12) in the parity precision: the trunk runs on bf16x2 maps, the RPN head on the
+    fp32 res5 map through the hi/lo operand split, pooling moves behind the RPN; losses against the reference's."""
+    g = load_golden("g12_rpn_train_step")
+    cfg, model, sd, sampling = build_rpn_model("parity")
+    first_k_keys(model, monkeypatch)
+    batch = gen.seeded_batch(2, 40, 20, 256, 352, seed=43)
+    losses = model(to_inputs(batch))
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(model.proposal_generator.pred_objectness_logits[0].detach().cpu(), g["rpn_logits"], rtol=1e-3,
+                               atol=1e-3)
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0", "loss_rpn_cls", "loss_rpn_loc"):
+        torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=1e-2, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    for i, t in enumerate(model.roi_heads.proposal_targets):
+        assert torch.equal(t.gt_classes.cpu(), g[f"target{i}/gt_classes"])
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None and bool(torch.isfinite(q.grad).all()), k
