@@ -45,7 +45,11 @@ class _RPNHeadFn(Function):
     def forward(ctx, x_nhwc, conv, w_conv, b_conv, w_obj, b_obj, w_del, b_del, max_active):  # conv: module (folded cache)
         with torch.no_grad():
             cd = x_nhwc.dtype
-            h = hip_conv(x_nhwc, conv, relu=True)  # (N,H,W,C)
+            if H.x3_active() == "x2":  # "parity": res5 leaves the backbone as real fp32; the conv kernel reads bf16x2
+                xe = H.x2_encode(x_nhwc.view(-1, x_nhwc.shape[-1])).view(x_nhwc.shape)
+                h = hip_conv(xe, conv, relu=True, out_fp32=True)
+            else:
+                h = hip_conv(x_nhwc, conv, relu=True)  # (N,H,W,C)
             Cc = h.shape[-1]
             h2 = h.view(-1, Cc)
             A = w_obj.shape[0]
