@@ -119,9 +119,14 @@ def pmc_traffic(kernel_name, args):
 
 
 def to_device_batch(batch, dev):
+    """The resident form of one batch: the images as per-image views of ONE collated device tensor (what a collate
+    function that batches before the copy hands over), the reference's list-of-dicts format otherwise unchanged."""
+    import torch
     out = []
-    for x in batch:
-        out.append({"image": x["image"].to(dev), "proposals": x["proposals"].to(dev),
+    shapes = {tuple(x["image"].shape) for x in batch}
+    images = torch.stack([x["image"] for x in batch]).to(dev) if len(shapes) == 1 else None
+    for i, x in enumerate(batch):
+        out.append({"image": images[i] if images is not None else x["image"].to(dev), "proposals": x["proposals"].to(dev),
                     "instances": x["instances"],  # image-level labels stay on the host (no sync to read them)
                     "height": x["height"], "width": x["width"]})
     return out

@@ -8,7 +8,10 @@ if os.environ.get("WSOVOD_LIB"):
 from wsovod_amd.layers import hip_ops
 n=32
 torch.manual_seed(0)
-for (H,W,pool) in ((300,400,0),(300,400,2),(150,200,0),(150,200,2)):
+SHAPES = ((300,400,0),(300,400,2),(150,200,0),(150,200,2))
+if os.environ.get("C64_ONLY"):  # e.g. C64_ONLY=300,400,0 : one shape (counter passes)
+    SHAPES = (tuple(int(v) for v in os.environ["C64_ONLY"].split(",")),)
+for (H,W,pool) in SHAPES:
     x = (torch.rand(n, H, W, 64, device="cuda") * 2 - 1).to(torch.bfloat16)
     w = ((torch.rand(64, 9*64, device="cuda") * 2 - 1) * 0.05).to(torch.bfloat16)
     bias = torch.randn(64, device="cuda")

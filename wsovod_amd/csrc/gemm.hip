@@ -776,6 +776,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
 constexpr int C64P_W_BYTES = 9 * 8192;
 constexpr int C64P_LDS_BYTES = C64P_W_BYTES + 2 * C64_PATCH_BYTES;
 
+// WREG (the product form): the 72 weight fragments of a lane (9 taps x 2 k-halves x 4 channel tiles = 288 VGPRs) are read
+// from the LDS image ONCE and stay in registers for every tile of the workgroup (one wavefront per SIMD: the 512-entry
+// register file is all its own).  A (tap, k-half) step then reads only its 4 pixel fragments for 16 MFMAs -- 4 MFMAs per
+// ds_read_b128 instead of 2, i.e. half of the LDS array's bandwidth at the full MFMA rate instead of all of it (the
+// LDS-weights form saturates the array: profiles/r02_c64_persistent.md).  Same products in the same order.
+template <bool WREG>
 __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int tiles_x, int tiles_y, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;                  // 9 x [64 cout][128 B]
@@ -914,10 +920,308 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
   C64P_WAIT1(1, fa[S][2]); C64P_MF(S, 8); C64P_MF(S, 9); C64P_MF(S, 10); C64P_MF(S, 11); C64P_SB;                  \
   C64P_WAIT1(0, fa[S][3]); C64P_MF(S, 12); C64P_MF(S, 13); C64P_MF(S, 14); C64P_MF(S, 15); C64P_SB
 
+// WREG form: the weights come from registers -- taps 0-7 from AGPRs (all 256 of them; the MFMA reads its B operand
+// there directly), tap 8 from VGPRs -- and a step reads the NEXT step's four A fragments one behind every fourth MFMA; at
+// each wait exactly three younger reads are in flight.  The MFMAs are inline asm (the compiler's own selection copies
+// AGPR-resident operands to VGPRs first): the accumulators live in VGPRs, the first product of a tile writes them with
+// srcC = 0, an accumulator is touched again 16 MFMAs later (no back-to-back dependency), and the epilogue's first VALU
+// read of them sits behind an explicit 32-wait-state gap (XDL write -> VALU read needs 11 for an 8-pass MFMA).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C64R_MFMA(ACC, W, A, CLS)                                                                  \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(ACC) : CLS(W), "v"(A))
+#define C64R_MFMA0(ACC, W, A, CLS)                                                                 \
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(ACC) : CLS(W), "v"(A))
+#else
+#define C64R_MFMA(ACC, W, A, CLS) (void)0
+#define C64R_MFMA0(ACC, W, A, CLS) (void)0
+#endif
+#define C64R_MF(S, M, TAP, KS)                                                                                          \
+  do {                                                                                                                  \
+    if ((TAP) == 0 && (KS) == 0) C64R_MFMA0(acc[(M) >> 2][(M) & 3], wa[0][0][(M) & 3], fa[S][(M) >> 2], "a");           \
+    else if ((TAP) < 8) C64R_MFMA(acc[(M) >> 2][(M) & 3], wa[(TAP) < 8 ? (TAP) : 0][KS][(M) & 3], fa[S][(M) >> 2], "a"); \
+    else C64R_MFMA(acc[(M) >> 2][(M) & 3], wv[KS][(M) & 3], fa[S][(M) >> 2], "v");                                      \
+  } while (0)
+#define C64R_QUAD(S, I, TAP, KS, RD)                                                                                   \
+  C64P_WAIT1(3, fa[S][I]); C64R_MF(S, 4 * (I), TAP, KS); RD; C64R_MF(S, 4 * (I) + 1, TAP, KS);                          \
+  C64R_MF(S, 4 * (I) + 2, TAP, KS); C64R_MF(S, 4 * (I) + 3, TAP, KS)
+#define C64R_STEP(S, N, TAP, KS, NTAP, NKS)                                                                            \
+  C64R_QUAD(S, 0, TAP, KS, C64R_RD_A(N, 0, NTAP, NKS)); C64R_QUAD(S, 1, TAP, KS, C64R_RD_A(N, 1, NTAP, NKS));           \
+  C64R_QUAD(S, 2, TAP, KS, C64R_RD_A(N, 2, NTAP, NKS)); C64R_QUAD(S, 3, TAP, KS, C64R_RD_A(N, 3, NTAP, NKS))
+#define C64R_TAIL(S, I, W, TAP, KS)                                                                                    \
+  C64P_WAIT1(W, fa[S][I]); C64R_MF(S, 4 * (I), TAP, KS); C64R_MF(S, 4 * (I) + 1, TAP, KS);                              \
+  C64R_MF(S, 4 * (I) + 2, TAP, KS); C64R_MF(S, 4 * (I) + 3, TAP, KS)
+#define C64R_LAST_STEP(S, TAP, KS)                                                                                     \
+  C64R_TAIL(S, 0, 3, TAP, KS); C64R_TAIL(S, 1, 2, TAP, KS); C64R_TAIL(S, 2, 1, TAP, KS); C64R_TAIL(S, 3, 0, TAP, KS)
+// A fragment i of tap (r, s3): patch row wave*2 + (i>>1) + r (4 distinct rows), column (i&1)*16 + frow + s3 -- the second
+// 16-pixel half is the first + 2048 bytes exactly (the swizzle key (q>>1)&7 repeats every 16 pixels): 12 address
+// registers + an immediate instead of a 36-entry table.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C64R_RD_A(S, I, TAP, KS)                                                                                       \
+  do {                                                                                                                  \
+    const unsigned ad_ = (pbase + aoff12[((I) >> 1) + (TAP) / 3][(TAP) % 3]) ^ ((KS) ? 64u : 0u);                       \
+    if ((I) & 1) asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(fa[S][I]) : "v"(ad_));                           \
+    else asm volatile("ds_read_b128 %0, %1" : "=v"(fa[S][I]) : "v"(ad_));                                               \
+  } while (0)
+#else
+#define C64R_RD_A(S, I, TAP, KS) (void)0
+#endif
+
   f32x4 bias4[4];
-  c64_load_bias(p, fq, bias4);
+  if constexpr (!WREG) c64_load_bias(p, fq, bias4);
   const bool res_pre = c64_residual_preloadable(p);
   __syncthreads();  // weights and the first patch have landed (hipcc drains vmcnt(0) in front of the barrier)
+  u32x4 wa[WREG ? 8 : 1][2][4], wv[2][4];  // WREG: this lane's weight fragments, taps 0-7 (AGPRs) and tap 8 (VGPRs)
+  unsigned aoff12[4][3];
+  if constexpr (WREG) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned ad = (ldsW + tap * 8192 + boff[j]) ^ (ks ? 64u : 0u);
+          if (tap < 8) asm volatile("ds_read_b128 %0, %1" : "=a"(wa[tap < 8 ? tap : 0][ks][j]) : "v"(ad));
+          else asm volatile("ds_read_b128 %0, %1" : "=v"(wv[ks][j]) : "v"(ad));
+        }
+#pragma unroll
+    for (int tap = 0; tap < 8; ++tap)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+a"(wa[tap][ks][j]));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[ks][j]));
+#endif
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int s3 = 0; s3 < 3; ++s3) {
+        const int q = (wave * 2 + rr) * C64_PW + frow + s3;
+        aoff12[rr][s3] = (unsigned)(q * 128 + ((fq ^ ((q >> 1) & 7)) << 4));
+      }
+  }
+  if constexpr (WREG) {
+    // ---- lean per-tile staging and epilogue of the WREG form (one wavefront per SIMD: every VALU instruction outside the
+    // MFMA loop is exposed, so the per-tile address work is hoisted: per-lane offsets relative to the tile origin are
+    // computed once, the tile origin is scalar, loads and stores go through buffer resources whose range check drops the
+    // lanes outside the image) ----
+    constexpr int INVALID = (int)0x80000000;  // buffer offset past any < 2 GiB resource (also after a +16 immediate)
+    // tile index -> (image, tile origin) with multiply-high by precomputed reciprocals (exact while n_tiles * tiles per
+    // image < 2^32, checked by the launcher): scalar instructions, no division sequence in the tile loop
+    const unsigned m_tpi = (unsigned)(((1ull << 32) + (unsigned)tpi - 1) / (unsigned)tpi);
+    const unsigned m_tx = (unsigned)(((1ull << 32) + (unsigned)tiles_x - 1) / (unsigned)tiles_x);
+    struct TileAt { int img, y0, x0; };
+    auto tile_at = [&](int tl) {
+      const int img = (int)__umulhi((unsigned)tl, m_tpi);
+      const int t = tl - img * tpi;
+      const int ty = (int)__umulhi((unsigned)t, m_tx);
+      return TileAt{img, ty * C64_TH, (t - ty * tiles_x) * C64_TW};
+    };
+    // One 16-byte request of a halo patch: request k of this thread is patch pixel q = 32 k + tid/8 (row q / 34 by a
+    // multiply-shift, exact below 384), chunk tid%8, swizzled as the fragment reads expect; outside the image (or with
+    // `on` false) the offset is out of range and the DMA writes zeros.  About ten VALU instructions: issued one at a time
+    // between the MFMA steps they hide in the matrix pipe's shadow, and the request never meets a full address FIFO
+    // (44 requests of a workgroup in one burst cost each wavefront ~1.2 k cycles of issue stalls: profiles/r03_c64_wreg.md).
+    const int rq = tid >> 3, rc = tid & 7;
+    auto stage_one = [&](const TileAt at, unsigned lds_base, int k, bool on) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const int q = k * 32 + rq;
+      const int py = (q * 241) >> 13, px = q - py * C64_PW;
+      const int y = at.y0 - 1 + py, x = at.x0 - 1 + px;
+      const bool ok = on && q < C64_NPIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const int off = ((at.img * p.H + y) * p.W + x) * 128 + ((rc ^ ((q >> 1) & 7)) << 4);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(size_t)(lds_base + wave_u * 1024 + k * 4096), 16,
+                                               ok ? off : -1, 0, 0, 0);
+#endif
+    };
+    auto stage_patch_r = [&](const TileAt at, unsigned lds_base) {
+#pragma unroll
+      for (int k = 0; k < C64P_NLOAD; ++k) stage_one(at, lds_base, k, true);
+    };
+    const int n_img = p.M / (p.H * p.W);
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    const int ldc2 = (int)p.ldc * 2, ldr2 = (int)p.ldr * 2;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcC = __builtin_amdgcn_make_buffer_rsrc(
+        p.C, 0, (p.pool ? n_img * Hp * Wp : p.M) * ldc2, 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.residual, 0, p.residual ? p.M * ldr2 : 0, 0x00020000);
+    // this lane's pixel group i: tile row wave*2 + (i>>1), tile column (i&1)*16 + frow; its 16 channels 16*fq ..
+    int ooff[4], roff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 2 + (i >> 1), col = (i & 1) * 16 + frow;
+      roff[i] = (row * p.W + col) * ldr2 + 32 * fq;
+      ooff[i] = p.pool ? (wave * Wp + (((i & 1) * 16 + frow) >> 1)) * ldc2 + 32 * fq : (row * p.W + col) * ldc2 + 32 * fq;
+    }
+    const float lo = p.relu ? 0.f : -__builtin_inff();
+    // Three patch buffers (the third is the weights' LDS image, dead once the fragments sit in registers): the 11 requests
+    // of patch t+2 are issued one by one inside tile t's MFMA loop, into the buffer tile t-1 was read from, so a request
+    // has more than a whole tile period to land.
+    // Vector-memory order per tile:  ... stores(t-1) | residual(t) | patch(t+2) ;  the wait in front of tile t's epilogue
+    // leaves exactly the 11 patch(t+2) requests in flight (vmcnt counts in order; past the last tile they are issued
+    // out of range): it covers patch(t+1), the stores of tile t-1 and residual(t) without waiting for the youngest.
+    __builtin_amdgcn_s_barrier();  // every wavefront has its weight fragments: the weights' LDS image is free
+    // the bias moves from 16 registers to the free tail of that image (the epilogue reads its 16 values back per tile)
+    float* sBias = (float*)(sW + C64_PATCH_BYTES);
+    if (tid < 64) sBias[tid] = p.bias ? p.bias[tid] : 0.f;
+    __syncthreads();
+    const int stride = (int)gridDim.x;
+    unsigned pb0 = ldsP, pb1 = ldsP + C64_PATCH_BYTES, pb2 = ldsW;  // LDS byte addresses of patch t, t+1, t+2
+    u32x4 rres[4][2];
+    auto load_residual = [&](const TileAt at) {
+      const int img = at.img, y0 = at.y0, x0 = at.x0;
+      const int rbase = ((img * p.H + y0) * p.W + x0) * ldr2;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool in = wave * 2 + (i >> 1) < p.H - y0 && (i & 1) * 16 + frow < p.W - x0;
+        const int ro = in ? rbase + roff[i] : INVALID;  // (a lane outside the image reads zeros)
+        rres[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, ro, 0, 0);
+        rres[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrcR, ro + 16, 0, 0);
+      }
+    };
+    TileAt at0 = tile_at(tile), at1 = tile_at(tile + stride), at2 = tile_at(tile + 2 * stride);  // tiles t, t+1, t+2
+    if (tile + stride < n_tiles) stage_patch_r(at1, pb1);
+    if (p.residual) load_residual(at0);
+    u32x4 fa[2][4];
+    unsigned pbase = pb0;
+    C64R_RD_A(0, 0, 0, 0); C64R_RD_A(0, 1, 0, 0); C64R_RD_A(0, 2, 0, 0); C64R_RD_A(0, 3, 0, 0);
+#if (C64P_ABL & 64)
+    long long tph[5] = {0, 0, 0, 0, 0}, tmark = (long long)__builtin_amdgcn_s_memtime();
+#define C64R_MARK(K) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); tph[K] += n_ - tmark; tmark = n_; } while (0)
+#else
+#define C64R_MARK(K) (void)0
+#endif
+    for (;;) {
+      C64R_MARK(4);
+      const int next = tile + stride;
+      const int img = at0.img, y0 = at0.y0, x0 = at0.x0;
+      const int rows_left = p.H - y0, cols_left = p.W - x0;
+      f32x4 acc[4][4];
+      __builtin_amdgcn_sched_barrier(0);
+      if (!((C64P_ABL & 1) && p.alpha != 12345.f)) {
+      const bool on2 = tile + 2 * stride < n_tiles && !((C64P_ABL & 4) && p.alpha != 12345.f);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        C64R_STEP(0, 1, tap, 0, tap, 1);
+        if (2 * tap < C64P_NLOAD) stage_one(at2, pb2, 2 * tap, on2);
+        if (tap < 8) {
+          C64R_STEP(1, 0, tap, 1, tap + 1 < 9 ? tap + 1 : 8, 0);
+        } else {
+          C64R_LAST_STEP(1, 8, 1);
+        }
+        if (2 * tap + 1 < C64P_NLOAD) stage_one(at2, pb2, 2 * tap + 1, on2);
+      }
+      }
+      C64R_MARK(0);
+#if defined(__HIP_DEVICE_COMPILE__)
+      // the last MFMAs' results reach the VGPRs before the epilogue reads them (XDL write -> VALU read: 11 wait states for
+      // an 8-pass MFMA); the next patch (this wavefront's share) and this tile's residual rows have landed
+      if (!((C64P_ABL & 32) && p.alpha != 12345.f)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt vmcnt(11)" ::: "memory");
+#endif
+      C64R_MARK(1);
+      if (next < n_tiles) {
+        __builtin_amdgcn_s_barrier();  // every wavefront is done reading patch t and has seen its share of patch t+1 land
+        C64R_MARK(2);
+        pbase = pb1;                   // the first fragments of tile t+1 travel under this tile's epilogue
+        C64R_RD_A(0, 0, 0, 0); C64R_RD_A(0, 1, 0, 0); C64R_RD_A(0, 2, 0, 0); C64R_RD_A(0, 3, 0, 0);
+      }
+      // epilogue: bias + residual + ReLU (+ the 2x2 max pool), the same arithmetic as c64_epilogue's bf16 path
+      if (!((C64P_ABL & 2) && p.alpha != 12345.f)) {
+      f32x4 bias4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bias4[j] = *(const f32x4*)(sBias + 16 * fq + 4 * j);
+      if (p.pool) {
+        const int obase = ((img * Hp + (y0 >> 1)) * Wp + (x0 >> 1)) * ldc2;
+        const int py = (y0 >> 1) + wave;
+#pragma unroll
+        for (int ih = 0; ih < 2; ++ih) {
+          float best[16];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
+#pragma unroll
+          for (int iv = 0; iv < 2; ++iv) {
+            const int i = ih + 2 * iv;
+            float v[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+            if (p.residual) {
+              const bf16x8 r0 = __builtin_bit_cast(bf16x8, rres[i][0]), r1 = __builtin_bit_cast(bf16x8, rres[i][1]);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                v[e] += (float)r0[e];
+                v[8 + e] += (float)r1[e];
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], (float)(bf16_t)fmaxf(v[e], lo));
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
+          const int px = (x0 + ih * 16 + frow) >> 1;
+          const bool st = (frow & 1) == 0 && py < Hp && px < Wp;
+          bf16x8 o0, o1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o0[e] = (bf16_t)best[e];
+            o1[e] = (bf16_t)best[8 + e];
+          }
+          const int oo = st ? obase + ooff[ih] : INVALID;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsrcC, oo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsrcC, oo + 16, 0, 0);
+        }
+      } else {
+        const int obase = ((img * p.H + y0) * p.W + x0) * ldc2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v[16];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+          if (p.residual) {
+            const bf16x8 r0 = __builtin_bit_cast(bf16x8, rres[i][0]), r1 = __builtin_bit_cast(bf16x8, rres[i][1]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              v[e] += (float)r0[e];
+              v[8 + e] += (float)r1[e];
+            }
+          }
+          bf16x8 o0, o1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o0[e] = (bf16_t)fmaxf(v[e], lo);
+            o1[e] = (bf16_t)fmaxf(v[8 + e], lo);
+          }
+          const bool in = wave * 2 + (i >> 1) < rows_left && (i & 1) * 16 + frow < cols_left;
+          const int oo = in ? obase + ooff[i] : INVALID;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rsrcC, oo, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rsrcC, oo + 16, 0, 0);
+        }
+      }
+      }
+      C64R_MARK(3);
+      if (next >= n_tiles) break;
+      if (p.residual) load_residual(at1);
+      at0 = at1; at1 = at2; at2 = tile_at(tile + 3 * stride);
+      {
+        const unsigned tp = pb0;  // the buffer tile t was read from (free since the barrier) takes patch t+3 next
+        pb0 = pb1; pb1 = pb2; pb2 = tp;
+      }
+      tile = next;
+    }
+#if (C64P_ABL & 64)
+    // per-phase cycle sums of wavefront 0: [MFMA loop, vmcnt wait, barrier, first reads + epilogue, residual + staging]
+    if (p.partial && lane == 0 && wave == 0)
+      for (int k = 0; k < 5; ++k) p.partial[blockIdx.x * 8 + k] = (float)tph[k];
+#endif
+#undef C64R_MARK
+    return;
+  }
   for (int cur = 0;; cur ^= 1) {
     const int next = tile + (int)gridDim.x;
     if (next < n_tiles && !((C64P_ABL & 4) && p.alpha != 12345.f)) stage_patch(next, cur ^ 1);  // lands behind this tile's MFMAs and epilogue
@@ -972,6 +1276,14 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 #undef C64P_SB
 #undef C64P_STEP
 #undef C64P_LAST_STEP
+#undef C64R_MF
+#undef C64R_MFMA
+#undef C64R_MFMA0
+#undef C64R_RD_A
+#undef C64R_QUAD
+#undef C64R_STEP
+#undef C64R_TAIL
+#undef C64R_LAST_STEP
 }
 
 // ---------------------------------------------------------------------------------
@@ -1443,10 +1755,24 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (persist && n_tiles >= 512) {  // enough tiles for two per CU: resident weights + double-buffered patches
       static bool attr = false;
       if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)conv3x3_c64p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES);
         attr = true;
       }
-      hipLaunchKernelGGL(conv3x3_c64p_kernel, dim3(256), dim3(256), C64P_LDS_BYTES, s, a, tiles_x, tiles_y, n_tiles);
+      const char* wr = getenv("WSOVOD_C64_WREG");  // "0": weights read from LDS at every step (the round-2 form; A/B runs)
+      // the register-weights form: bf16 output, 16-byte aligned rows, buffer-addressable output / residual
+      const bool lean = d->dtype_c == WSOVOD_BF16 && (d->ldc & 7) == 0 && ((uintptr_t)d->C & 15) == 0 &&
+                        (!d->bias || ((uintptr_t)d->bias & 3) == 0) && (double)d->M * d->ldc * 2 < 2147483648.0 &&
+                        (!d->residual || (d->dtype_r == WSOVOD_BF16 && (d->ldr & 7) == 0 && ((uintptr_t)d->residual & 15) == 0 &&
+                                          (double)d->M * d->ldr * 2 < 2147483648.0)) &&
+                        (double)(n_tiles + 3 * 256) * (tiles_x * tiles_y) < 4294967296.0;
+#if (C64P_ABL & 64)
+      if (const char* dp = getenv("WSOVOD_C64_DEBUG_PTR")) a.partial = (float*)strtoull(dp, nullptr, 16);
+#endif
+      if ((wr && wr[0] == '0') || !lean)
+        hipLaunchKernelGGL(conv3x3_c64p_kernel<false>, dim3(256), dim3(256), C64P_LDS_BYTES, s, a, tiles_x, tiles_y, n_tiles);
+      else
+        hipLaunchKernelGGL(conv3x3_c64p_kernel<true>, dim3(256), dim3(256), C64P_LDS_BYTES, s, a, tiles_x, tiles_y, n_tiles);
       WS_CHECK_LAUNCH("wsovod_gemm_nt(conv3x3_c64 persistent)");
       return WSOVOD_OK;
     }

@@ -171,9 +171,14 @@ class HotPathTrainer:
             exchange = "direct" if grad_wire == "bf16" and self.world > 2 else "ring"
         self.exchange_algo = exchange if self.exchange else "none"
         self.iter_size = int(iter_size)
+        self._seed = None
         self.iter = int(start_iter)  # the reference's global iteration (engine/trainer.py:72-84): pass it when resuming
         if self.iter_size < 1:
             raise ValueError(f"iter_size must be >= 1, got {iter_size}")
+        if self.iter:  # resume: the neck's dropout stream is a function of the iteration (box_head.set_step)
+            for m in model.modules():
+                if hasattr(m, "set_step"):
+                    m.set_step(self.iter)
         for p in self.params:
             p._wire_grad = None
         if self.exchange and grad_wire == "bf16" and self.params and self.iter_size == 1:
@@ -391,10 +396,13 @@ class HotPathTrainer:
         st = self.model.forward_frozen(data)
         self._finish_pending()
         loss_dict = self.model.forward_trainable(st)
-        losses = sum(loss_dict.values())
-        if self.iter_size > 1:
-            losses = losses / self.iter_size
-        losses.backward()
+        # d(sum of the loss dict / iter_size): one backward pass from the loss tensors themselves with a cached seed --
+        # the same gradients as `sum(loss_dict.values()).backward()` without the adds, the division and the ones_like
+        roots = list(loss_dict.values())
+        seed = self._seed
+        if seed is None or seed.device != roots[0].device or seed.dtype != roots[0].dtype:
+            seed = self._seed = torch.full((), 1.0 / self.iter_size, dtype=roots[0].dtype, device=roots[0].device)
+        torch.autograd.backward(roots, [seed.expand_as(r) for r in roots])
         step_now = self.iter % self.iter_size == 0
         self.iter += 1
         if not step_now:  # gradients keep accumulating in p.grad; nothing goes on the wire

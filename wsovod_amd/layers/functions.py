@@ -19,6 +19,15 @@ def _pad(n, m):
     return (n + m - 1) // m * m
 
 
+def scale_losses(losses, loss_weight):
+    """{name: loss * loss_weight.get(name, 1)}; a weight of exactly 1 (every shipped config) launches nothing."""
+    out = {}
+    for k, v in losses.items():
+        w = loss_weight.get(k, 1.0) if isinstance(loss_weight, dict) else loss_weight
+        out[k] = v if w == 1.0 else v * w
+    return out
+
+
 def _contig2d(t):
     return t if (t.dim() == 2 and t.stride(1) == 1) else t.contiguous()
 

@@ -17,6 +17,7 @@ from torch.nn import functional as F
 from ..config import configurable
 from ..layers import functions as Fn
 from ..layers import hip_ops as H
+from ..layers.functions import scale_losses
 from ..structures import Boxes, Instances, ShapeSpec
 from .box_regression import Box2BoxTransform
 
@@ -269,7 +270,7 @@ class ObjectMiningOutputLayers(nn.Module):
         loss, img = Fn.image_bce(scores, seg, gt_classes_img_oh, norm)
         self._pred_class_img_logits = img
         losses = {"loss_cls_object_mining": loss}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+        return scale_losses(losses, self.loss_weight)
 
     def predict_boxes(self, predictions, proposals):
         return [p.proposal_boxes.tensor for p in proposals]
@@ -385,7 +386,7 @@ class InstanceRefinementOutputLayers(nn.Module):
                 proposal_deltas, proposal_boxes, gt_boxes, gt_classes, weights,
                 num_classes if num_classes is not None else self.num_classes, self.box2box_transform.weights,
                 self.smooth_l1_beta, weighted=weighted_box)
-        return {k_: v * self.loss_weight.get(k_, 1.0) for k_, v in losses.items()}
+        return scale_losses(losses, self.loss_weight)
 
     # ---- eval tail ("next" row n2): plain torch ops on the device ----
     def inference(self, predictions, proposals):

@@ -90,7 +90,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
         Hp, Wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
         if all(im.device == self.device for im in images) and all(s == sizes[0] for s in sizes):
-            canvas = torch.stack(images)  # already resident: one gather pass
+            canvas = self._adjacent(images)  # already resident as consecutive slices of one batch tensor: no pass at all
+            if canvas is None:
+                canvas = torch.stack(images)  # already resident: one gather pass
         elif all(s == sizes[0] for s in sizes):
             # host images (the DatasetMapper's format): each one is copied straight into its slot of the batch tensor --
             # no per-image device temporary and no second (stack) pass over the batch
@@ -105,6 +107,23 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             raise RuntimeError("GeneralizedRCNN_WSOVOD expects uint8 CHW images (DatasetMapper format)")
         sizes_t = H.const_tensor([v for s in sizes for v in s], torch.int32, self.device).view(-1, 2)
         return canvas.contiguous(), sizes_t, sizes
+
+    @staticmethod
+    def _adjacent(images):
+        """The (N,3,H,W) view over `images` when they are contiguous, equally shaped slices i = 0..N-1 of one allocation
+        (a collated batch handed over as per-image views, the reference's list-of-dicts format), else None."""
+        im0 = images[0]
+        n = im0.numel()
+        if not im0.is_contiguous() or n == 0:
+            return None
+        base, esz, st = im0.data_ptr(), im0.element_size(), im0.untyped_storage()
+        for i, im in enumerate(images):
+            if im.shape != im0.shape or not im.is_contiguous() or im.dtype != im0.dtype \
+                    or im.data_ptr() != base + i * n * esz or im.untyped_storage().data_ptr() != st.data_ptr():
+                return None
+        if im0.storage_offset() + len(images) * n > st.nbytes() // esz:
+            return None
+        return im0.as_strided((len(images),) + tuple(im0.shape), (n,) + tuple(im0.stride()), im0.storage_offset())
 
     def preprocess_image(self, batched_inputs):
         """rcnn_wsovod.py:321-328: normalise, pad and batch -> ImageList (fp32 NCHW)."""

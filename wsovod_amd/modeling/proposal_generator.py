@@ -22,6 +22,7 @@ from torch.autograd import Function
 
 from ..config import Registry, configurable
 from ..layers import hip_ops as H
+from ..layers.functions import scale_losses
 from ..structures import Boxes, ImageList, Instances, ShapeSpec
 from .anchor_generator import build_anchor_generator
 from .backbone import Conv2d, hip_conv
@@ -365,7 +366,7 @@ class WSOVODRPN_V2(nn.Module):
               (F.binary_cross_entropy_with_logits(ln, torch.zeros_like(ln), reduction="none") * neg_valid).sum()
         normalizer = self.batch_size_per_image * B
         losses = {"loss_rpn_cls": obj / normalizer, "loss_rpn_loc": loc / normalizer}
-        return {k: v * self.loss_weight.get(k, 1.0) for k, v in losses.items()}
+        return scale_losses(losses, self.loss_weight)
 
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor],
                 gt_instances: Optional[List[Instances]] = None):
