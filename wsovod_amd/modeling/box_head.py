@@ -35,13 +35,14 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
         self.add_module("flatten", nn.Flatten())
         for k, out_width in enumerate(fc_dims, start=1):
             layer = nn.Linear(width, out_width)
-            nn.init.normal_(layer.weight, std=0.005)
-            nn.init.constant_(layer.bias, 0.1)
             for name, child in ((f"fc{k}", layer), (f"fc_relu{k}", nn.ReLU(inplace=True)),
                                 (f"fc_dropout{k}", nn.Dropout(p=0.5, inplace=False))):
                 self.add_module(name, child)
             self.fcs.append(layer)
             width = self._output_size = out_width
+        for layer in self.fcs:  # (after all layers exist: the same draws from the generator as the reference's constructor)
+            nn.init.normal_(layer.weight, std=0.005)
+            nn.init.constant_(layer.bias, 0.1)
         # Counter-based dropout (mask = hash(seed, step, layer, row, unit)); the reference draws from per-process
         # torch RNG streams seeded `cfg.SEED + rank` (detectron2 seed_all_rng): the base seed mixes cfg.SEED and the
         # data-parallel rank (read at the first training forward, the process group may not exist yet), the step
