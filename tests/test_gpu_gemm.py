@@ -353,18 +353,22 @@ def test_conv3x3_c64_fused_maxpool_equals_conv_then_pool(gpu, shape, with_res):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 300, 400), (8, 121, 163)])
+@pytest.mark.parametrize("shape", [(2, 300, 400), (8, 121, 163), (8, 128, 128), (24, 150, 200), (2, 300, 400, "lds")])
 @pytest.mark.parametrize("with_res", [False, True])
 @pytest.mark.parametrize("pool", [0, 2])
 def test_conv3x3_c64_persistent_kernel_equals_one_tile_kernel(gpu, shape, with_res, pool, monkeypatch):
-    """From 512 tiles up the 64-channel 3x3 conv runs as one persistent workgroup per CU (weights resident in LDS,
-    double-buffered halo patches, residual rows fetched ahead of the MFMAs).  Same products in the same order as the
-    one-tile kernel: the outputs are bit-identical, ragged image edges, residual and fused pool included; and both agree
-    with an fp64 convolution."""
+    """From 512 tiles up the 64-channel 3x3 conv runs as one persistent workgroup per CU: the weight fragments in
+    registers (AGPR operands of hand-issued MFMAs), three halo-patch buffers whose requests are issued inside the MFMA
+    loop two tiles ahead, residual rows fetched ahead of the MFMAs, buffer-addressed stores.  Same products in the same
+    order as the one-tile kernel: the outputs are bit-identical -- ragged image edges, residual and fused pool included,
+    at exactly two tiles per workgroup (8 x 128 x 128: the look-ahead runs past the last tile from the start), at three
+    and at seventeen; the round-2 form (weights read from LDS at every step, "lds") as well -- and all agree with an fp64
+    convolution."""
     from wsovod_amd.layers import hip_ops
 
     torch.manual_seed(13)
-    n, H, W = shape
+    monkeypatch.setenv("WSOVOD_C64_WREG", "0" if len(shape) == 4 else "1")
+    n, H, W = shape[:3]
     x = torch.randn(n, H, W, 64, device=gpu).to(torch.bfloat16)
     w = (torch.randn(64, 9 * 64, device=gpu) * 0.05).to(torch.bfloat16)
     bias = torch.randn(64, device=gpu)
@@ -375,6 +379,9 @@ def test_conv3x3_c64_persistent_kernel_equals_one_tile_kernel(gpu, shape, with_r
     monkeypatch.setenv("WSOVOD_C64_PERSIST", "1")
     per = hip_ops.gemm_nt(x, w, conv=geom, bias=bias, relu=True, residual=res, out_dtype=torch.bfloat16)
     assert torch.equal(one, per)
+    for _ in range(8):  # counted LDS / vector-memory waits: a stale fragment or patch would differ from run to run
+        again = hip_ops.gemm_nt(x, w, conv=geom, bias=bias, relu=True, residual=res, out_dtype=torch.bfloat16)
+        assert torch.equal(again, per)
     if not pool:
         img = 1
         ref = F.conv2d(x[img].permute(2, 0, 1)[None].double(), w.view(64, 3, 3, 64).permute(0, 3, 1, 2).double(),
