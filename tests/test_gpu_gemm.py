@@ -148,35 +148,53 @@ def test_gemm_tn_transposed_reads(gpu, shape):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_linear_group_equals_separate_linears(gpu, dtype):
-    """Heads sharing one input: grouped autograd node (one dX GEMM, one dW contraction) vs one Linear per head."""
+    """Heads sharing one input: grouped autograd node (one dX GEMM, one dW contraction) vs one Linear per head; and the
+    joined form the ROI heads use -- [cls | det] given as two row blocks of one head, joined with the box regression into
+    ONE forward GEMM (N = 44), outputs = column blocks of its result."""
     from wsovod_amd.layers import functions as Fn
 
     torch.manual_seed(5)
     M, K = 1000, 512
     x0 = torch.randn(M, K, device=gpu).to(dtype)
-    specs = [(40, False, torch.float32), (1024, True, None), (4, False, torch.float32)]
+    specs = [(40, False, torch.float32), (4, False, torch.float32), (1024, True, None)]
     params = [(torch.randn(n, K, device=gpu) * 0.05, torch.randn(n, device=gpu) * 0.1) for n, _, _ in specs]
     gys = None
     res = {}
-    for mode in ("separate", "group"):
+    for mode in ("separate", "group", "joined"):
         x = x0.clone().requires_grad_(True)
         ws = [(w.clone().requires_grad_(True), b.clone().requires_grad_(True)) for w, b in params]
         if mode == "separate":
             ys = [Fn.linear(x, w, b, relu=r, out_dtype=od) for (w, b), (_, r, od) in zip(ws, specs)]
-        else:
+        elif mode == "group":
             ys = Fn.linear_group(x, [(w, b, r, od) for (w, b), (_, r, od) in zip(ws, specs)])
+        else:  # the 40-row head as two leaf blocks of 20 rows
+            w0 = [params[0][0][:20].clone().requires_grad_(True), params[0][0][20:].clone().requires_grad_(True)]
+            b0 = [params[0][1][:20].clone().requires_grad_(True), params[0][1][20:].clone().requires_grad_(True)]
+            heads = [(w0, b0, False, torch.float32)] + [(w, b, r, od) for (w, b), (_, r, od) in zip(ws[1:], specs[1:])]
+            ys = Fn.linear_group(x, heads, joins=[[0, 1]])
+            assert ys[0].data_ptr() + 40 * 4 == ys[1].data_ptr() and ys[0].stride(0) == 44  # one (M, 44) result
         if gys is None:
             gys = [torch.randn_like(y) for y in ys]
         torch.autograd.backward(list(ys), gys)
-        res[mode] = ([y.detach() for y in ys], x.grad, [(w.grad, b.grad) for w, b in ws])
+        if mode == "joined":
+            ws[0] = (torch.cat([w.grad for w in w0]), torch.cat([b.grad for b in b0]))
+            res[mode] = ([y.detach() for y in ys], x.grad, [ws[0]] + [(w.grad, b.grad) for w, b in ws[1:]])
+        else:
+            res[mode] = ([y.detach() for y in ys], x.grad, [(w.grad, b.grad) for w, b in ws])
     for a, b in zip(res["separate"][0], res["group"][0]):
         assert torch.equal(a, b)  # same forward GEMMs
     tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-4, atol=1e-4)
-    # dx: one K = sum N_h contraction vs a bf16-rounded sum of per-head products
-    torch.testing.assert_close(res["group"][1].float(), res["separate"][1].float(), **tol)
-    for (wa, ba), (wb, bb) in zip(res["separate"][2], res["group"][2]):
-        torch.testing.assert_close(wb, wa, rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(bb, ba, rtol=1e-4, atol=1e-4)
+    for a, b in zip(res["separate"][0], res["joined"][0]):  # same products per output, another tile shape
+        torch.testing.assert_close(b.float(), a.float(), rtol=1e-5, atol=1e-5)
+    for mode in ("group", "joined"):
+        # dx: one K = sum N_h contraction vs a bf16-rounded sum of per-head products
+        torch.testing.assert_close(res[mode][1].float(), res["separate"][1].float(), **tol)
+        for (wa, ba), (wb, bb) in zip(res["separate"][2], res[mode][2]):
+            torch.testing.assert_close(wb, wa, rtol=1e-4, atol=1e-4)
+            torch.testing.assert_close(bb, ba, rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError, match="join"):
+        Fn.linear_group(x0, [(params[0][0], params[0][1], False, torch.float32),
+                             (params[2][0], params[2][1], True, None)], joins=[[0, 1]])
 
 
 def test_fused_stem_conv1_is_bit_identical_to_im2col_gemm(gpu):

@@ -143,26 +143,43 @@ def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=No
 
 class _LinearGroup(Function):
     """Several Linear(+ReLU) heads on ONE input (object mining, box regression and the classifier projection all
-    read the same box features).  Forward: one GEMM per head (own output dtype / activation).  Backward: the heads'
-    masked output gradients are written side by side into one (M, sum N_h) matrix, so that the input gradient is ONE
-    GEMM against the stacked weights (instead of one skinny GEMM per head plus adds), the weight gradients ONE
-    contraction (one pass over x, no per-head x^T), the bias gradients one column sum."""
+    read the same box features).  A head's weight may be given in row blocks (object mining: [cls | det] are two
+    modules, one (2K, F) contraction) and consecutive heads with the same epilogue can be JOINED: one forward GEMM on the
+    stacked rows (the input is streamed once), the heads' outputs are column blocks of its result.  Backward: the heads'
+    masked output gradients are written side by side into one (M, sum N_h) matrix, so that the input gradient is ONE GEMM
+    against the stacked weights (instead of one skinny GEMM per head plus adds), the weight gradients ONE contraction
+    (one pass over x, no per-head x^T), the bias gradients one column sum."""
 
     @staticmethod
     def forward(ctx, x, meta, *wb):
         cd = x.dtype
-        heads = len(meta)
+        heads, joins = meta  # heads[h] = (relu, out_dtype, number of row blocks); joins = runs of head indices
         ws, bs = wb[0::2], wb[1::2]
-        ys = []
+        first = [0]
+        for h in heads:
+            first.append(first[-1] + h[2])
         ctx.x2 = _x2_mode()
-        for h in range(heads):
-            relu, out_dtype = meta[h]
-            if ctx.x2:  # bf16x2 input, three-MFMA products; a head's output is bf16x2 where the caller asks (hip_ops.X2)
-                ys.append(H.gemm_nt(x, H.x2_cached(ws[h]), x2=True, bias=bs[h], relu=relu, out_dtype=out_dtype or cd))
-            else:
-                ys.append(H.gemm_nt(x, weight_shadow(ws[h], cd), bias=bs[h], relu=relu, out_dtype=out_dtype or cd))
-        ctx.meta = meta
-        ctx.save_for_backward(x, *ws, *[y if meta[h][0] else None for h, y in enumerate(ys)])
+
+        def operand(w):
+            return H.x2_cached(w) if ctx.x2 else weight_shadow(w, cd)
+
+        ys = [None] * len(heads)
+        for run in joins:
+            relu, out_dtype, _ = heads[run[0]]
+            blocks = [i for h in run for i in range(first[h], first[h + 1])]
+            wq = operand(ws[blocks[0]]) if len(blocks) == 1 else torch.cat([operand(ws[i]) for i in blocks])
+            bias = bs[blocks[0]] if len(blocks) == 1 else \
+                (torch.cat([bs[i] for i in blocks]) if all(bs[i] is not None for i in blocks) else None)
+            if bias is None and any(bs[i] is not None for i in blocks):
+                raise RuntimeError("linear_group: the row blocks of a joined contraction must all have a bias or none")
+            y = H.gemm_nt(x, wq, x2=ctx.x2, bias=bias, relu=relu, out_dtype=out_dtype or cd)
+            col = 0
+            for h in run:
+                n = sum(ws[i].size(0) for i in range(first[h], first[h + 1]))
+                ys[h] = y if len(run) == 1 else y[:, col:col + n]
+                col += n
+        ctx.heads, ctx.first = heads, first
+        ctx.save_for_backward(x, *ws, *[y if heads[h][0] else None for h, y in enumerate(ys)])
         ctx.has_bias = [b is not None for b in bs]
         ctx.x3 = H.x3_active()
         return tuple(ys)
@@ -175,37 +192,44 @@ class _LinearGroup(Function):
 
     @staticmethod
     def _backward(ctx, *dys):
-        heads = len(ctx.meta)
+        heads, first = ctx.heads, ctx.first
+        nh, nb = len(heads), first[-1]
         saved = ctx.saved_tensors
-        x, ws, ys = saved[0], saved[1:1 + heads], saved[1 + heads:]
+        x, ws, ys = saved[0], saved[1:1 + nb], saved[1 + nb:]
         in_dtype = x.dtype
         if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
             x = H.cast(x, torch.bfloat16)
         cd = torch.bfloat16 if ctx.x2 else x.dtype
         M, K = x.shape
-        Ns = [w.size(0) for w in ws]
+        Ns = [sum(ws[i].size(0) for i in range(first[h], first[h + 1])) for h in range(nh)]
         offs = [0]
         for n in Ns:
             offs.append(offs[-1] + _pad(n, 8))
         Nt = offs[-1]
         dA = torch.zeros((M, Nt), dtype=cd, device=x.device)
-        want_db = any(ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h] for h in range(heads))
+        want_db = any(ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i] for i in range(nb))
         dbcat = torch.zeros((Nt,), dtype=torch.float32, device=x.device) if want_db else None
-        for h in range(heads):
+        for h in range(nh):
             if dys[h] is not None:
                 H.mask_transpose(_contig2d(dys[h]), ys[h], 1.0, cd, want_t=False,
                                  out_plain=dA[:, offs[h]:offs[h] + Ns[h]],
                                  colsum=dbcat[offs[h]:offs[h] + Ns[h]] if want_db else None,
-                                 y_x2=ctx.x2 and ctx.meta[h][1] == H.X2)
+                                 y_x2=ctx.x2 and heads[h][1] == H.X2)
         need_dx = ctx.needs_input_grad[0]
-        need_dw = any(ctx.needs_input_grad[2 + 2 * h] for h in range(heads))
-        wcat = torch.zeros((Nt, K), dtype=cd, device=x.device)
-        for h in range(heads):
-            wcat[offs[h]:offs[h] + Ns[h]] = ws[h]
+        need_dw = any(ctx.needs_input_grad[2 + 2 * i] for i in range(nb))
+        rows = []  # (row block i, first row in the stacked layout)
+        for h in range(nh):
+            r = offs[h]
+            for i in range(first[h], first[h + 1]):
+                rows.append((i, r))
+                r += ws[i].size(0)
         dx = None
         if need_dx:
+            wcat = torch.zeros((Nt, K), dtype=cd, device=x.device)
+            for i, r in rows:
+                wcat[r:r + ws[i].size(0)] = ws[i]
             dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=in_dtype)  # (M,K) = dA_cat @ W_cat
-        grads = [None] * (2 * heads)
+        grads = [None] * (2 * nb)
         if need_dw:
             if ctx.x2:
                 dwcat = H.gemm_tn(dA, x, q_x2=True)
@@ -216,23 +240,43 @@ class _LinearGroup(Function):
                 Mp = _pad(M, 64)
                 dwcat = H.gemm_nt(H.transpose_cast(dA, cd, ld_dst=Mp), H.transpose_cast(x, cd, ld_dst=Mp),
                                   out_dtype=torch.float32)
-            for h in range(heads):
-                if ctx.needs_input_grad[2 + 2 * h]:
-                    grads[2 * h] = dwcat[offs[h]:offs[h] + Ns[h]]
+            for i, r in rows:
+                if ctx.needs_input_grad[2 + 2 * i]:
+                    grads[2 * i] = dwcat[r:r + ws[i].size(0)]
         if want_db:
-            for h in range(heads):
-                if ctx.has_bias[h] and ctx.needs_input_grad[3 + 2 * h]:
-                    grads[2 * h + 1] = dbcat[offs[h]:offs[h] + Ns[h]]
+            for i, r in rows:
+                if ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i]:
+                    grads[2 * i + 1] = dbcat[r:r + ws[i].size(0)]
         return (dx, None, *grads)
 
 
-def linear_group(x, heads):
-    """heads: list of (weight (N_h,K) fp32 master, bias or None, relu, out_dtype or None) -> tuple of outputs."""
-    meta = tuple((bool(h[2]), h[3]) for h in heads)
-    wb = []
+def linear_group(x, heads, joins=None):
+    """heads: list of (weight (N_h,K) fp32 master -- or a list of row blocks --, bias (list of biases) or None, relu,
+    out_dtype or None); joins: optional list of runs of consecutive head indices computed by ONE forward GEMM each (same
+    relu / out_dtype; no bf16x2 output) -- heads not named are contractions of their own.  -> tuple of outputs, one per
+    head (the outputs of a joined run are column blocks of one matrix)."""
+    meta_heads, wb = [], []
     for h in heads:
-        wb += [h[0], h[1]]
-    return _LinearGroup.apply(x, meta, *wb)
+        blocks = list(h[0]) if isinstance(h[0], (list, tuple)) else [h[0]]
+        biases = list(h[1]) if isinstance(h[1], (list, tuple)) else [h[1]] * len(blocks)
+        if len(biases) != len(blocks) or (len(blocks) > 1 and h[1] is not None and not isinstance(h[1], (list, tuple))):
+            raise RuntimeError("linear_group: one bias per row block expected")
+        meta_heads.append((bool(h[2]), h[3], len(blocks)))
+        for w, b in zip(blocks, biases):
+            wb += [w, b]
+    named = set()
+    runs = []
+    for run in (joins or []):
+        run = list(run)
+        if run != list(range(run[0], run[0] + len(run))) or named & set(run) or \
+                any(meta_heads[h][:2] != meta_heads[run[0]][:2] for h in run) or \
+                (len(run) > 1 and (meta_heads[run[0]][0] or meta_heads[run[0]][1] == H.X2)):
+            raise RuntimeError("linear_group: a join is a run of consecutive heads with the same (ReLU-free) epilogue")
+        named |= set(run)
+        runs.append(tuple(run))
+    runs += [(h,) for h in range(len(heads)) if h not in named]
+    runs.sort()
+    return _LinearGroup.apply(x, (tuple(meta_heads), tuple(runs)), *wb)
 
 
 _WANT_HI = [False]  # set by the ROI heads while training under the "parity" precision (the pooled tensor feeds a dW)

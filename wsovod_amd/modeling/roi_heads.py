@@ -352,21 +352,27 @@ class WSOVODROIHeads(ROIHeads):
         Returns (mining logits, [(hidden_k, deltas_k)])."""
         if self.object_miner.num_classes == 1 or os.environ.get("WSOVOD_DISABLE_GROUP", "0") == "1":
             return None  # the K == 1 padding path keeps the per-module form (env switch: A/B measurements)
-        w, b = self.object_miner.stacked_params()
-        heads = [(w, b, False, torch.float32)]
-        slots = []
+        om = self.object_miner
+        # fp32 heads first: [cls | det] (two modules, one head of 2K rows) and every box regression ride in ONE forward
+        # GEMM (the box features are streamed once for them); then the ReLU projections
+        heads = [([om.cls.weight, om.det.weight], [om.cls.bias, om.det.bias], False, torch.float32)]
+        regs = []
         for k in range(self.refine_K):
             r = self.box_refinery[k]
-            l1 = r.cls.projection[0]
-            heads.append((l1.weight, l1.bias, True, H.X2 if H.x3_active() == "x2" else None))  # feeds the 2nd projection
-            hid = len(heads) - 1
-            reg = None
+            regs.append(None)
             if r.refine_reg[r.refine_k]:
                 heads.append((r.bbox_pred.weight, r.bbox_pred.bias, False, torch.float32))
-                reg = len(heads) - 1
-            slots.append((hid, reg))
-        outs = Fn.linear_group(box_features, heads)
-        return [outs[0]] + [(outs[hid], outs[reg] if reg is not None else None) for hid, reg in slots]
+                regs[-1] = len(heads) - 1
+        join = list(range(len(heads)))
+        biased = [h[1] is not None and all(b is not None for b in (h[1] if isinstance(h[1], list) else [h[1]])) for h in heads]
+        joins = [join] if all(biased) and os.environ.get("WSOVOD_JOIN_HEADS", "1") != "0" else []  # (env: A/B runs)
+        hids = []
+        for k in range(self.refine_K):
+            l1 = self.box_refinery[k].cls.projection[0]
+            heads.append((l1.weight, l1.bias, True, H.X2 if H.x3_active() == "x2" else None))  # feeds the 2nd projection
+            hids.append(len(heads) - 1)
+        outs = Fn.linear_group(box_features, heads, joins=joins)
+        return [outs[0]] + [(outs[hid], outs[reg] if reg is not None else None) for hid, reg in zip(hids, regs)]
 
     @torch.no_grad()
     def rpn_targets(self, prev_pred_scores, prev_pred_boxes, proposals, seg):
