@@ -186,7 +186,11 @@ def require_gpu(*tensors):
             )
 
 
+PROFILING = [False]  # per-launch hipEvent brackets are on: captured graphs are bypassed (a replay launches nothing here)
+
+
 def profile_enable(on=True):
+    PROFILING[0] = bool(on)
     return lib().wsovod_profile_enable(1 if on else 0)
 
 

@@ -6,6 +6,8 @@ backward, optimizer step every ITER_SIZE) and engine/defaults.py:135-153,274-318
 parameter update itself is the fused HIP kernel `wsovod_sgd_momentum`; gradient exchange is
 torch DistributedDataParallel over RCCL ("nccl" backend on ROCm) -- the only collective on the path.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -172,6 +174,11 @@ class HotPathTrainer:
         self.exchange_algo = exchange if self.exchange else "none"
         self.iter_size = int(iter_size)
         self._seed = None
+        # small batches are host-bound: the frozen backbone runs as one captured HIP graph per input shape
+        # (modeling/backbone.py; WSOVOD_BACKBONE_GRAPH=0 keeps the eager launches)
+        bb = getattr(model, "backbone", None)
+        if bb is not None and hasattr(bb, "graph_max_batch") and os.environ.get("WSOVOD_BACKBONE_GRAPH", "1") != "0":
+            bb.graph_max_batch = 8
         self.iter = int(start_iter)  # the reference's global iteration (engine/trainer.py:72-84): pass it when resuming
         if self.iter_size < 1:
             raise ValueError(f"iter_size must be >= 1, got {iter_size}")
@@ -203,6 +210,10 @@ class HotPathTrainer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        bb = getattr(self.model, "backbone", None)
+        if bb is not None and hasattr(bb, "graph_max_batch"):
+            bb.graph_max_batch = 0
+            bb.__dict__.pop("_graphs", None)
         if getattr(self.model, "_pre_inference", None) == self.synchronize:
             self.model._pre_inference = None
 

@@ -418,7 +418,40 @@ class ResNet(nn.Module):
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
         with H.x3_mode({"bf16x3": "full", "bf16x3f": "fwd", "parity": "x2"}.get(self.precision, False)):
+            if self.graph_max_batch and images_u8.is_cuda and images_u8.size(0) <= self.graph_max_batch:
+                g = self._graph_for(images_u8, sizes, pixel_mean, pixel_std)
+                if g is not None:
+                    return g(images_u8)
             return self._forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
+
+    # ---- the frozen forward as a HIP graph (small batches: the ~25 launches of the backbone cost more host time than
+    # device time; one replay instead).  Opt-in (`graph_max_batch`, set by the overlapped trainer): the returned maps
+    # are the graph's static buffers, valid until the next call with the same input shape ----
+    graph_max_batch = 0
+    GRAPH_CACHE = 4
+
+    def _graph_fingerprint(self):
+        ps = getattr(self, "_graph_tensors", None)
+        if ps is None:
+            ps = self._graph_tensors = list(self.parameters()) + list(self.buffers())
+        return sum(t._version for t in ps), ps[0].data_ptr() if ps else 0
+
+    def _graph_for(self, images_u8, sizes, pixel_mean, pixel_std):
+        from .._lib import PROFILING
+
+        if PROFILING[0] or torch.cuda.is_current_stream_capturing():
+            return None
+        fp = self._graph_fingerprint()
+        cache = self.__dict__.setdefault("_graphs", {})
+        if cache and next(iter(cache.values())).fingerprint != fp:
+            cache.clear()  # a weight changed (load_state_dict, broadcast): the folded copies the graphs point at are stale
+        key = (tuple(images_u8.shape), sizes.data_ptr(), tuple(pixel_mean), tuple(pixel_std), H.x3_active())
+        g = cache.get(key)
+        if g is None:
+            if len(cache) >= self.GRAPH_CACHE:
+                cache.pop(next(iter(cache)))
+            g = cache[key] = _BackboneGraph(self, images_u8, sizes, pixel_mean, pixel_std, fp)
+        return g
 
     def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         self._check_frozen()
@@ -455,6 +488,32 @@ class ResNet(nn.Module):
             blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, **curr_kwargs))
             in_channels = out_channels
         return blocks
+
+
+class _BackboneGraph:
+    """One captured frozen forward for one input shape: static input / output buffers, replayed per call."""
+
+    def __init__(self, net, images_u8, sizes, pixel_mean, pixel_std, fingerprint):
+        self.fingerprint = fingerprint
+        self.sizes = sizes  # (kept alive: the kernels of the graph read it)
+        self.static_in = torch.empty_like(images_u8)
+        self.static_in.copy_(images_u8)
+        main = torch.cuda.current_stream(images_u8.device)
+        side = torch.cuda.Stream(device=images_u8.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):  # warm-up outside the capture: weight folds, function attributes, allocator
+            for _ in range(2):
+                net._forward_uint8(self.static_in, sizes, pixel_mean, pixel_std)
+        main.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = net._forward_uint8(self.static_in, sizes, pixel_mean, pixel_std)
+
+    def __call__(self, images_u8):
+        if images_u8.data_ptr() != self.static_in.data_ptr():
+            self.static_in.copy_(images_u8)
+        self.graph.replay()
+        return self.out
 
 
 def make_stage(*args, **kwargs):
