@@ -33,6 +33,8 @@ def test_backbone_graph_replay_equals_eager(gpu, precision):
     eager = [run(b).clone() for b in batches]
     bb.graph_max_batch = 8
     try:
+        for _ in range(bb.GRAPH_AFTER - 1):  # a shape is captured on its third call
+            assert torch.equal(run(batches[0]), eager[0]) and not bb.__dict__.get("_graphs")
         got = [run(b).clone() for b in batches]
         again = run(batches[0])
         assert len(bb._graphs) == 1  # one shape, one graph; the second batch replayed it
@@ -42,12 +44,15 @@ def test_backbone_graph_replay_equals_eager(gpu, precision):
         with torch.no_grad():
             bb.stem.conv1.weight.mul_(1.25)
         changed = run(batches[0]).clone()
+        assert len(bb._graphs) == 1  # (the shape had been seen: recaptured at once)
         bb.graph_max_batch = 0
         assert torch.equal(changed, run(batches[0])) and not torch.equal(changed, eager[0])
         # another shape -> another graph; a batch above the limit stays eager
         bb.graph_max_batch = 2
         other = _inputs(1, 128, 192, 3, gpu)
-        a = run(other).clone()
+        for _ in range(bb.GRAPH_AFTER):
+            a = run(other).clone()
+        assert len(bb._graphs) == 2
         big = _inputs(3, 128, 192, 4, gpu)
         n_graphs = len(bb._graphs)
         b3 = run(big).clone()

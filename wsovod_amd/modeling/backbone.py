@@ -428,7 +428,8 @@ class ResNet(nn.Module):
     # device time; one replay instead).  Opt-in (`graph_max_batch`, set by the overlapped trainer): the returned maps
     # are the graph's static buffers, valid until the next call with the same input shape ----
     graph_max_batch = 0
-    GRAPH_CACHE = 4
+    GRAPH_CACHE = 4  # graphs kept (each holds the backbone's activations of its shape)
+    GRAPH_AFTER = 3  # calls with a shape before it is captured
 
     def _graph_fingerprint(self):
         ps = getattr(self, "_graph_tensors", None)
@@ -448,6 +449,14 @@ class ResNet(nn.Module):
         key = (tuple(images_u8.shape), sizes.data_ptr(), tuple(pixel_mean), tuple(pixel_std), H.x3_active())
         g = cache.get(key)
         if g is None:
+            # capture on the third call with a shape: with multi-scale inputs most shapes never repeat, and a capture
+            # costs three forwards
+            seen = self.__dict__.setdefault("_graph_seen", {})
+            if len(seen) > 64:
+                seen.clear()
+            seen[key] = seen.get(key, 0) + 1
+            if seen[key] < self.GRAPH_AFTER:
+                return None
             if len(cache) >= self.GRAPH_CACHE:
                 cache.pop(next(iter(cache)))
             g = cache[key] = _BackboneGraph(self, images_u8, sizes, pixel_mean, pixel_std, fp)
