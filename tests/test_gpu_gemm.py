@@ -409,6 +409,38 @@ def test_conv3x3_c64_persistent_kernel_equals_one_tile_kernel(gpu, shape, with_r
         torch.testing.assert_close(per.view(n, H, W, 64)[img].permute(2, 0, 1).double(), F.relu(ref), rtol=1e-2, atol=2e-2)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool", [0, 2])
+def test_conv3x3_c64_persistent_kernel_epilogue_options(gpu, pool, monkeypatch):
+    """The register-weights form with the epilogue options the backbone does not use: no bias, no ReLU, alpha != 1, output
+    rows inside a wider buffer, residual rows with another pitch; an fp32 output goes to round 2's form (still
+    bit-identical to the one-tile kernel)."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(21)
+    n, H, W = 6, 122, 130
+    x = torch.randn(n, H, W, 64, device=gpu).to(torch.bfloat16)
+    w = (torch.randn(64, 9 * 64, device=gpu) * 0.05).to(torch.bfloat16)
+    geom = dict(n_img=n, H=H, W=W, Cin=64, Ho=H, Wo=W, KH=3, KW=3, stride=1, pad=1, dil=1, pool=pool)
+    rows = n * (H // 2) * (W // 2) if pool else n * H * W
+    res_wide = torch.randn(n * H * W, 96, device=gpu).to(torch.bfloat16)
+    for kw in (dict(), dict(alpha=0.5), dict(residual=res_wide[:, 16:80])):
+        outs = []
+        for persist in ("0", "1"):
+            monkeypatch.setenv("WSOVOD_C64_PERSIST", persist)
+            buf = torch.full((rows, 128), 7.0, device=gpu, dtype=torch.bfloat16)
+            hip_ops.gemm_nt(x, w, conv=geom, relu=False, out=buf[:, 32:96], **kw)
+            outs.append(buf)
+        assert torch.equal(outs[0], outs[1])
+        assert bool((outs[1][:, :32] == 7).all()) and bool((outs[1][:, 96:] == 7).all())  # nothing outside the view
+        assert float(outs[1][:, 32:96].float().min()) < 0  # no ReLU
+    if not pool:
+        monkeypatch.setenv("WSOVOD_C64_PERSIST", "0")
+        a = hip_ops.gemm_nt(x, w, conv=geom, out_dtype=torch.float32)
+        monkeypatch.setenv("WSOVOD_C64_PERSIST", "1")
+        assert torch.equal(a, hip_ops.gemm_nt(x, w, conv=geom, out_dtype=torch.float32))
+
+
 def test_gemm_tn_reduction_longer_than_one_buffer_resource(gpu, monkeypatch):
     """Operands past the 2 GiB a buffer resource addresses (96 images x 512 proposals x 25088 features) are reduced in
     row blocks that accumulate: same result as the single launch up to fp32 summation order, `accumulate` and `alpha`
