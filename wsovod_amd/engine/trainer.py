@@ -409,7 +409,7 @@ class HotPathTrainer:
         loss_dict = self.model.forward_trainable(st)
         # d(sum of the loss dict / iter_size): one backward pass from the loss tensors themselves with a cached seed --
         # the same gradients as `sum(loss_dict.values()).backward()` without the adds, the division and the ones_like
-        roots = list(loss_dict.values())
+        roots = [v for v in loss_dict.values() if v.requires_grad]  # (a constant term has nothing to differentiate)
         seed = self._seed
         if seed is None or seed.device != roots[0].device or seed.dtype != roots[0].dtype:
             seed = self._seed = torch.full((), 1.0 / self.iter_size, dtype=roots[0].dtype, device=roots[0].device)
