@@ -766,10 +766,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const GemmArgs p, int 
 // 160 KiB of LDS = 72 KiB weights + 2 x 43 KiB patches: one workgroup (4 wavefronts, one per SIMD) per CU.
 // Same products in the same order as the one-tile kernel: bit-identical outputs.
 // ---------------------------------------------------------------------------------
-// Ablation build switch (tools/c64_ablate.sh; results in profiles/r02_c64_persistent.md), never set in the product
-// build: bit 0 drops the fragment-read + MFMA loop, 1 the epilogue, 2 the patch staging of every tile but the first,
-// 3 the fragment reads and their waits (MFMAs on stale registers), 4 only the waits.  The `alpha` comparisons keep
-// the dropped code reachable for the compiler, so the rest of the kernel compiles as in the product build.
+// Ablation build switch (tools/c64_ablate.sh; results in profiles/r02_c64_persistent.md, profiles/r03_c64_wreg.md),
+// never set in the product build: bit 0 drops the fragment-read + MFMA loop, 1 the epilogue, 2 the patch staging of
+// every tile but the first, 3 the fragment reads and their waits (MFMAs on stale registers; LDS-weights form only), 4
+// only the waits (the same), 5 the vector-memory wait in front of the epilogue (register-weights form), 6 = per-phase
+// s_memtime sums written to GemmArgs.partial (tools/c64_phases.py).  The `alpha` comparisons keep the dropped code
+// reachable for the compiler, so the rest of the kernel compiles as in the product build.
 #ifndef C64P_ABL
 #define C64P_ABL 0
 #endif
