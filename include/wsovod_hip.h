@@ -99,10 +99,24 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
 int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale,
                                  int R, int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,
                                  int out_dtype, int* argmax, void* out_hi, wsovod_stream_t stream);
+/* The general form.  `workspace` (may be NULL) is caller-owned scratch of wsovod_roi_pool_workspace_bytes(...) bytes: when
+ * that function returns > 0 (NHWC map, 7 bins wide, values only, enough rois to re-read the map many times over) the
+ * launcher first writes the map's stride-1 2x2 maxima there and the pooling kernel covers every bin of >= 2 x 2 cells
+ * with windows of THAT map -- a quarter of the gather's requests; max is order-free, so the values are the same bit for
+ * bit.  With workspace = NULL (or argmax wanted: the first maximum in scan order needs the cells themselves) the cell
+ * scan runs. */
+long long wsovod_roi_pool_workspace_bytes(int dtype, int layout, int R, int N, int C, int H, int W, int ph, int pw,
+                                          int want_argmax);
+int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                               int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
+                               int* argmax, void* out_hi, void* workspace, long long workspace_bytes,
+                               wsovod_stream_t stream);
 /* ROILoopPool in the 3-output form of the reference's CUDA op (wsovod/layers/ROILoopPool/ROILoopPool_cuda.cu:9-204,
  * bound as `_C.roi_loop_pool_forward`, wsovod/layers/roi_loop_pool.py:9-22; context_ratio is 1.8 there): out and
  * argmax are (3R, C, ph, pw) = [region | frame | context] fp32 / int32 (NCHW order).  The matching backward is
- * wsovod_roi_pool_backward over the 3R outputs with the rois repeated three times (ROILoopPool_cuda.cu:207-243). */
+ * wsovod_roi_pool_backward over the 3R outputs with the rois repeated three times (ROILoopPool_cuda.cu:207-243).
+ * The map must be NHWC (wavefront per pooled row, channels per lane; WSOVOD_ERR_UNSUPPORTED otherwise): the Python
+ * fronts bring the reference's NCHW tensors into channels_last first. */
 int wsovod_roi_loop_pool_forward(const void* feat, int dtype, int layout, const float* rois, int R, int N, int C, int H,
                                  int W, int ph, int pw, float spatial_scale, float context_ratio, float* out,
                                  int* argmax, wsovod_stream_t stream);
@@ -279,9 +293,26 @@ typedef struct wsovod_sgd_tensor {
   const float* used_flag; /* optional DEVICE scalar: 0 = no data-parallel rank produced a gradient for this tensor in
                            * this step -> parameter and momentum stay untouched, as torch.optim.SGD skips `grad is None`
                            * under DDP(find_unused_parameters=True) (engine/defaults.py:146-148); NULL = always update */
+  const float* grad_coef; /* optional DEVICE scalar multiplied into grad_scale: the norm-clipping coefficient of the
+                           * wsovod_grad_clip_coef pass below (engine/defaults.py:292-318).  NULL = 1 */
+  float clip_value;       /* > 0: grad * grad_scale is clamped to [-clip_value, clip_value] (detectron2's
+                           * SOLVER.CLIP_GRADIENTS.CLIP_TYPE "value" = clip_grad_value_ per parameter); 0 = off */
 } wsovod_sgd_tensor;
 int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
                               wsovod_stream_t stream);
+
+/* Gradient-norm clipping coefficients on the device (no host read of the norm).  Replaces
+ * torch.nn.utils.clip_grad_norm_(params, max_norm) (L2) as the reference applies it: over ALL parameters at once for
+ * SOLVER.CLIP_GRADIENTS.CLIP_TYPE "full_model" (FullModelGradientClippingOptimizer, engine/defaults.py:292-318;
+ * per_tensor = 0) or parameter by parameter for detectron2's CLIP_TYPE "norm" (per_tensor = 1).  The norm is taken of
+ * grad * grad_scale (the gradient the optimizer sees after the data-parallel average); tensors whose used_flag reads 0
+ * do not count (their grad is None in the reference).  coef[k] = min(1, max_norm / (norm + 1e-6)) for tensor k: pass
+ * coef + k as that tensor's grad_coef to wsovod_sgd_momentum_multi.  Fixed summation order (run-to-run bit-identical).
+ * workspace: wsovod_grad_clip_workspace_floats(tensors, count) fp32 elements; `tensors` is a HOST array (grad, numel,
+ * grad_is_bf16 and used_flag are read). */
+long long wsovod_grad_clip_workspace_floats(const wsovod_sgd_tensor* tensors, int count);
+int wsovod_grad_clip_coef(const wsovod_sgd_tensor* tensors, int count, float grad_scale, float max_norm, int per_tensor,
+                          float* workspace, float* coef, wsovod_stream_t stream);
 
 /* bf16 gradient wire format (the reference's counterpart is DDP's fp16 compression hook, engine/defaults.py:149-152):
  * every tensor's fp32 gradient is rounded to bf16 into its slice of one flat buffer, the operand of ONE RCCL

@@ -264,7 +264,7 @@ def _worker_bf16_wire(rank, world, port, q):
             assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and dst.data_ptr() % 16 == 0
             dst.copy_(src.reshape(-1))
 
-    def sgd(entries, momentum, grad_scale=1.0):
+    def sgd(entries, momentum, grad_scale=1.0, clip=None):
         for p, g, buf, shadow, lr, wd, used in entries:
             assert g.dtype == torch.bfloat16 and used is not None
             if float(used) == 0.0:  # no rank produced a gradient: the kernel leaves parameter and momentum alone
@@ -379,7 +379,7 @@ def _worker_early_block(rank, world, port, q):
             assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
             dst.copy_(src.reshape(-1))
 
-    def sgd(entries, momentum, grad_scale=1.0):
+    def sgd(entries, momentum, grad_scale=1.0, clip=None):
         for p, g, buf, shadow, lr, wd, used in entries:
             assert g.dtype == torch.bfloat16 and g.numel() == p.numel() and used is None  # (no reduce_unused here)
             buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
@@ -459,7 +459,7 @@ def _worker_direct(rank, world, port, q):
         for src, dst in pairs:
             dst.copy_(src.reshape(-1))
 
-    def sgd(entries, momentum, grad_scale=1.0):
+    def sgd(entries, momentum, grad_scale=1.0, clip=None):
         for p, g, buf, shadow, lr, wd, used in entries:
             assert g.dtype == torch.bfloat16 and g.numel() == p.numel()
             buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
@@ -543,7 +543,7 @@ def _worker_direct_unused_iter(rank, world, port, q):
         for src, dst in pairs:
             dst.copy_(src.reshape(-1))
 
-    def sgd(entries, momentum, grad_scale=1.0):
+    def sgd(entries, momentum, grad_scale=1.0, clip=None):
         for p, g, buf, shadow, lr, wd, used in entries:
             assert used is not None
             if float(used) == 0.0:
@@ -636,7 +636,7 @@ def _worker_pick_exchange(rank, world, port, q, break_direct):
         for src, dst in pairs:
             dst.copy_(src.reshape(-1))
 
-    def sgd(entries, momentum, grad_scale=1.0):
+    def sgd(entries, momentum, grad_scale=1.0, clip=None):
         for p, g, buf, shadow, lr, wd, used in entries:
             buf.mul_(momentum).add_(g.float().view_as(p) * grad_scale + wd * p)
             p.sub_(lr * buf)

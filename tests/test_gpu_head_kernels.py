@@ -344,3 +344,70 @@ def test_column_sums_are_run_to_run_bit_identical(gpu):
     torch.testing.assert_close(H.segment_colsum(rows_bf, seg).double().cpu(),
                                torch.stack([rows_bf[a:b].double().sum(0) for a, b in zip(bounds[:-1], bounds[1:])]).cpu(),
                                rtol=2e-6, atol=0.0)
+
+
+@pytest.mark.parametrize("kind", ["full_model", "norm", "value"])
+@pytest.mark.parametrize("wire", [False, True])
+def test_hip_sgd_gradient_clipping_matches_torch(gpu, kind, wire):
+    """SOLVER.CLIP_GRADIENTS on the fused optimizer (engine/defaults.py:292-323): "full_model" = clip_grad_norm_ over all
+    parameters at once (the reference's FullModelGradientClippingOptimizer), "norm" / "value" = detectron2's per-parameter
+    forms.  Norms and coefficients stay on the device; compared with torch's clip + SGD over three steps (fp32 gradients
+    and the bf16 wire slices), a clip value that bites on some tensors and not on others, one tensor with grad None."""
+    from wsovod_amd.engine.trainer import HipSGD
+
+    torch.manual_seed(3)
+    shapes = [(300, 70), (4097,), (64, 64), (5,)]
+    ps = [torch.nn.Parameter(torch.randn(s, device=gpu)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    value = {"full_model": 3.0, "norm": 20.0, "value": 0.05}[kind]
+    hip = HipSGD([{"params": [p], "lr": 0.1, "weight_decay": 1e-3} for p in ps], 0.1, momentum=0.9, clip=(kind, value))
+    hip.grad_scale = 0.5
+    ref = torch.optim.SGD([{"params": [q], "lr": 0.1, "weight_decay": 1e-3} for q in qs], 0.1, momentum=0.9)
+    for step in range(3):
+        grads = [torch.randn(s, device=gpu) * (0.02 if i == 2 else 0.3) for i, s in enumerate(shapes)]
+        if wire:
+            grads = [g.to(torch.bfloat16).float() for g in grads]
+        for i, (p, q, g) in enumerate(zip(ps, qs, grads)):
+            if i == 3 and step == 1:  # no gradient this step: skipped by both, and not part of the norm
+                p.grad = q.grad = None
+                p._wire_grad = None
+                continue
+            q.grad = g * 0.5
+            if wire:
+                p.grad, p._wire_grad = None, g.to(torch.bfloat16).reshape(-1)
+            else:
+                p.grad, p._wire_grad = g.clone(), None
+        live = [q for q in qs if q.grad is not None]
+        if kind == "full_model":
+            torch.nn.utils.clip_grad_norm_(live, value)
+        elif kind == "norm":
+            for q in live:
+                torch.nn.utils.clip_grad_norm_(q, value)
+        else:
+            for q in live:
+                torch.nn.utils.clip_grad_value_(q, value)
+        ref.step()
+        hip.step()
+        for p, q in zip(ps, qs):
+            torch.testing.assert_close(p.detach(), q.detach(), rtol=2e-6, atol=2e-6)
+    if kind != "value":
+        c = hip.last_clip_coef.cpu()
+        assert bool((c <= 1.0).all()) and bool((c < 1.0).any())
+        if kind == "norm":
+            assert float(c[2]) == 1.0  # the small tensor's norm is under the bound: left alone
+
+
+def test_build_optimizer_reads_clip_gradients(gpu):
+    from wsovod_amd.engine import build_optimizer
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(device="cpu")
+    assert build_optimizer(cfg, model).clip is None
+    cfg.SOLVER.CLIP_GRADIENTS.ENABLED = True
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "full_model"
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE = 1.5
+    assert build_optimizer(cfg, model).clip == ("full_model", 1.5)
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "norm"
+    cfg.SOLVER.CLIP_GRADIENTS.NORM_TYPE = 1.0
+    with pytest.raises(NotImplementedError):
+        build_optimizer(cfg, model)

@@ -178,3 +178,80 @@ def test_roi_pool_512_channel_bf16_form(gpu, C):
     assert arg is None and torch.equal(out.cpu(), (ref * sc.view(-1, 1, 1, 1)).to(torch.bfloat16))
     plain, _ = hip_ops.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), out_dtype=torch.bfloat16, need_argmax=False)
     assert torch.equal(plain.cpu(), ref.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype,C,out_fmt", [(torch.bfloat16, 512, "bf16"), (torch.bfloat16, 1024, "bf16"),
+                                             (torch.bfloat16, 264, "bf16"), (torch.bfloat16, 512, "f32"),
+                                             (torch.float32, 256, "x2"), (torch.float32, 512, "x2hi"),
+                                             (torch.float32, 260, "f32")])
+def test_roi_pool_through_the_2x2_max_map_is_bit_identical(gpu, monkeypatch, dtype, C, out_fmt):
+    """Values-only pooling of an NHWC map with many rois goes through the map's stride-1 2x2 maxima
+    (`wsovod_roi_pool_forward_ws`): a quarter of the gather's requests.  max() is order-free and the windows cover exactly
+    the bin's cells, so the result equals the cell scan (`WSOVOD_ROIPOOL_M2=0`) and the oracle bit for bit -- with NaN and
+    +-Inf cells (the reference's `v > maxval` skips NaN and never lets -Inf replace -FLT_MAX), bins one cell wide or
+    high (those rows of bins keep the cell scan), boxes outside the map, every output format."""
+    from wsovod_amd._lib import lib
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(77)
+    feat = torch.randn(3, C, 38, 50, generator=g).to(dtype)
+    feat[torch.rand(feat.shape, generator=g) < 0.02] = float("nan")
+    feat[torch.rand(feat.shape, generator=g) < 0.02] = float("-inf")
+    feat[torch.rand(feat.shape, generator=g) < 0.01] = float("inf")
+    feat[0, :, 5:9, 7:12] = float("nan")   # whole bins of NaN
+    feat[1, :, 20:30, 10:30] = float("-inf")
+    rois = random_rois(400, 3, 304, 400, seed=41)
+    small = random_rois(60, 3, 304, 400, seed=42, edge_cases=False)
+    small[:, 3] = small[:, 1] + torch.rand(60, generator=g) * 70  # 1 .. 9 cells wide: bins of one and two columns mixed
+    small[:, 4] = small[:, 2] + torch.rand(60, generator=g) * 70
+    rois = torch.cat([rois, small])
+    sc = torch.rand(len(rois), generator=g) + 1.0
+    f = feat.to(gpu).contiguous(memory_format=torch.channels_last)
+    need = lib().wsovod_roi_pool_workspace_bytes(1 if dtype == torch.bfloat16 else 0, 1, len(rois), 3, C, 38, 50, 7, 7, 0)
+    assert need == 3 * 38 * 50 * C * (2 if dtype == torch.bfloat16 else 4)  # this shape takes the 2x2-max path
+    assert lib().wsovod_roi_pool_workspace_bytes(1, 1, len(rois), 3, C, 38, 50, 7, 7, 1) == 0  # argmax: the cell scan
+    od = {"bf16": torch.bfloat16, "f32": torch.float32, "x2": H.X2, "x2hi": H.X2}[out_fmt]
+
+    def run():
+        out, arg = H.roi_pool_forward(f, rois.to(gpu), 0.125, (7, 7), roi_scale=sc.to(gpu), out_dtype=od,
+                                      need_argmax=False, want_hi=out_fmt == "x2hi")
+        assert arg is None
+        hi = H.x2_hi_pop(out) if out_fmt == "x2hi" else None
+        if od == H.X2:
+            out = H.x2_decode(out.view(len(rois), -1)).view(out.shape)
+        return out, hi
+
+    got, hi = run()
+    monkeypatch.setenv("WSOVOD_ROIPOOL_M2", "0")
+    want, hi0 = run()
+    monkeypatch.delenv("WSOVOD_ROIPOOL_M2")
+    eq = lambda a, b: torch.equal(torch.nan_to_num(a.float(), nan=12345.0), torch.nan_to_num(b.float(), nan=12345.0))
+    assert eq(got, want)
+    if hi is not None:
+        assert eq(hi, hi0)
+    ref, _ = O.roi_pool_forward(feat.float(), rois, 0.125, (7, 7))
+    ref = ref * sc.view(-1, 1, 1, 1)
+    if out_fmt == "bf16":
+        ref = ref.to(torch.bfloat16)
+    if od == H.X2:  # hi + lo of an fp32 value: exact up to 2^-17
+        torch.testing.assert_close(torch.nan_to_num(got.cpu(), nan=0.0, posinf=1e30, neginf=-1e30),
+                                   torch.nan_to_num(ref, nan=0.0, posinf=1e30, neginf=-1e30), rtol=2e-5, atol=0)
+    else:
+        assert eq(got.cpu(), ref)
+
+
+@pytest.mark.parametrize("size,C", [((3, 5), 70), ((14, 14), 16), ((1, 1), 130), ((7, 7), 256), ((9, 8), 64)])
+def test_roi_loop_pool_generic_sizes_bit_exact(gpu, size, C):
+    """The wavefront-per-pooled-row NHWC form of the 3-output op at pooled sizes other than 7 x 7 (columns in chunks of
+    7, pooled rows strided over the wavefronts; 14 x 14: one LDS tile, region and frame from two scans), odd channel
+    counts, two channels per lane (C = 256), bf16 and fp32 maps: values and argmax equal to the C restatement."""
+    from wsovod_amd.layers import hip_ops as H
+
+    g = torch.Generator().manual_seed(5)
+    for dtype in (torch.float32, torch.bfloat16):
+        feat = torch.relu(torch.randn(2, C, 30, 41, generator=g)).to(dtype)
+        rois = random_rois(50, 2, 240, 328, seed=9)
+        ref, ref_arg = O.roi_loop_pool_forward(feat.float(), rois, 0.125, size)
+        out, arg = H.roi_loop_pool_forward(feat.to(gpu), rois.to(gpu), 0.125, size)
+        assert out.shape == (150, C) + size
+        assert torch.equal(out.cpu(), ref) and torch.equal(arg.cpu(), ref_arg), (size, C, dtype)

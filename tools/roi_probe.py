@@ -50,3 +50,23 @@ ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=sc
 print(f"roi_pool  fp32 -> bf16x2 + bf16 : {ms:.3f} ms")
 ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=torch.float32, need_argmax=False))
 print(f"roi_pool  fp32 -> fp32          : {ms:.3f} ms")
+
+
+# round 4: the 2x2-max-map path against the cell scan (switches are read per call)
+print("--- 2x2-max map (WSOVOD_ROIPOOL_M2) / channels per lane / XCD-aware order ---")
+def env(**kw):
+    for k, v in kw.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+
+for m2, cpl, xcd in [(0, None, None), (1, 8, None), (1, 4, None), (1, 4, 1)]:
+    env(WSOVOD_ROIPOOL_M2=m2, WSOVOD_ROIPOOL_BF16_CPL=cpl, WSOVOD_ROIPOOL_XCD=xcd)
+    ms = timeit(lambda: H.roi_pool_forward(feat, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=torch.bfloat16, need_argmax=False))
+    print(f"bf16 -> bf16        M2={m2} CPL={cpl} XCD={xcd}: {ms:.3f} ms  ({N*R*Cc*49*2/ms/1e9 + N*Cc*7500*2/ms/1e9:.2f} TB/s algorithmic)")
+for m2, cpl, xcd in [(0, None, None), (1, 4, None), (1, 2, None), (1, 2, 1), (1, 1, 1)]:
+    env(WSOVOD_ROIPOOL_M2=m2, WSOVOD_ROIPOOL_F32_CPL=cpl, WSOVOD_ROIPOOL_XCD=xcd)
+    ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=H.X2, need_argmax=False, want_hi=True))
+    print(f"fp32 -> bf16x2+bf16 M2={m2} CPL={cpl} XCD={xcd}: {ms:.3f} ms")
+env(WSOVOD_ROIPOOL_M2=None, WSOVOD_ROIPOOL_F32_CPL=None, WSOVOD_ROIPOOL_XCD=None, WSOVOD_ROIPOOL_BF16_CPL=None)

@@ -50,7 +50,7 @@ class ProfEntry(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
-ABI_VERSION = 4  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
+ABI_VERSION = 5  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
 
 # name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
 SIGNATURES = {
@@ -96,6 +96,10 @@ SIGNATURES = {
     "wsovod_split3_bf16": [_P, _L, _I, _I, _P, _L, _L, _I, _P],
     "wsovod_subsample_labels": [_P, _P, _P, _I, _I, _I, _I, _L, _P, _P],
     "wsovod_sgd_momentum_multi": [_P, _I, _F, _F, _P],
+    "wsovod_grad_clip_workspace_floats": [_P, _I],
+    "wsovod_grad_clip_coef": [_P, _I, _F, _F, _I, _P, _P, _P],
+    "wsovod_roi_pool_workspace_bytes": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
+    "wsovod_roi_pool_forward_ws": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _L, _P],
     "wsovod_pack_bf16_multi": [_P, _I, _P],
     "wsovod_sum_shards_bf16": [_P, _I, _L, _P, _P],
     "wsovod_format_rois": [_P, _P, _I, _I, _P, _P, _P, _P],
@@ -115,7 +119,8 @@ class SgdTensor(C.Structure):
     """wsovod_sgd_tensor (include/wsovod_hip.h)."""
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
                 ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
-                ("shadow_is_bf16x2", C.c_int), ("used_flag", C.c_void_p)]
+                ("shadow_is_bf16x2", C.c_int), ("used_flag", C.c_void_p), ("grad_coef", C.c_void_p),
+                ("clip_value", C.c_float)]
 
 
 class PackTensor(C.Structure):
@@ -142,7 +147,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = C.c_int
         _lib.wsovod_last_error.restype = C.c_char_p
-        _lib.wsovod_colsum_workspace_floats.restype = C.c_longlong
+        for name in ("wsovod_colsum_workspace_floats", "wsovod_grad_clip_workspace_floats", "wsovod_roi_pool_workspace_bytes"):
+            getattr(_lib, name).restype = C.c_longlong
         got = _lib.wsovod_abi_version()
         if got != ABI_VERSION:  # the structs of include/wsovod_hip.h (gemm desc, sgd tensor) changed size across versions
             raise RuntimeError(f"wsovod_amd: {LIB_PATH} has ABI version {got}, this package needs {ABI_VERSION}: rebuild "

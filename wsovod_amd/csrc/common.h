@@ -51,6 +51,18 @@ int x2_add_group_rows(const void* x, long long ldx, const int* row_group, const 
     }                                                                             \
   } while (0)
 
+// A HIP runtime call whose status must not be lost (hipFuncSetAttribute for > 64 KiB of LDS, ...): a refusal is reported
+// through the library's error convention at the call site instead of surfacing later as an unexplained launch failure.
+#define WS_CHECK_HIP(expr, what)                                                             \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (void)hipGetLastError();                                                               \
+      wsovod::set_error("%s: %s failed: %s", what, #expr, hipGetErrorString(e_));            \
+      return WSOVOD_ERR_HIP;                                                                 \
+    }                                                                                        \
+  } while (0)
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;

@@ -465,9 +465,11 @@ struct SgdTable {
   unsigned g_bf16;  // bit k: g[k] points at bf16 values (gradients that travelled in the bf16 wire format)
   unsigned x2_shadow;  // bit k: shadow[k] is a bf16x2 copy of the parameter (include/wsovod_hip.h), n[k] a multiple of 32
   const float* used[kSgdMax];  // optional device flag: 0 = no rank produced a gradient for the tensor -> left untouched
+  const float* coef[kSgdMax];  // optional device scalar multiplied into the gradient scale (norm clipping coefficient)
+  float clip[kSgdMax];         // > 0: the scaled gradient is clamped to [-clip, clip] (clip_grad_value_)
 };
 
-__global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable t, float mu, float gscale) {
+__global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable t, float mu, float gscale0) {
   int k = 0;
   while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
   const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * kSgdChunk;
@@ -481,6 +483,8 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
   const bool sx2 = (t.x2_shadow >> k) & 1u;
   const bf16_t* __restrict__ g16 = (const bf16_t*)t.g[k];
   if (t.used[k] && *t.used[k] == 0.f) return;  // torch.optim.SGD skips parameters whose grad is None
+  const float gscale = t.coef[k] ? gscale0 * *t.coef[k] : gscale0;
+  const float cv = t.clip[k];
   const bool vec = ((((uintptr_t)p | (uintptr_t)buf) & 15) == 0) && (((uintptr_t)shadow & 7) == 0) &&
                    (((uintptr_t)g & (gb ? 7 : 15)) == 0);
   for (int e = threadIdx.x * 4; e < kSgdChunk; e += 256 * 4) {
@@ -496,7 +500,12 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
         gv = __builtin_nontemporal_load((const f32x4*)(g + i));
       }
       f32x4 bv = __builtin_nontemporal_load((const f32x4*)(buf + i));
-      bv = mu * bv + (gv * gscale + wd * pv);
+      gv = gv * gscale;
+      if (cv > 0.f) {
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) gv[e4] = fminf(fmaxf(gv[e4], -cv), cv);
+      }
+      bv = mu * bv + (gv + wd * pv);
       pv -= lr * bv;
       __builtin_nontemporal_store(bv, (f32x4*)(buf + i));
       __builtin_nontemporal_store(pv, (f32x4*)(p + i));
@@ -513,7 +522,9 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
       }
     } else {
       for (long long q = i; q < min(i + 4, n); ++q) {
-        const float b = mu * buf[q] + ((gb ? (float)g16[q] : g[q]) * gscale + wd * p[q]);
+        float gq = (gb ? (float)g16[q] : g[q]) * gscale;
+        if (cv > 0.f) gq = fminf(fmaxf(gq, -cv), cv);
+        const float b = mu * buf[q] + (gq + wd * p[q]);
         buf[q] = b;
         const float pv = p[q] - lr * b;
         p[q] = pv;
@@ -527,6 +538,74 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
       }
     }
   }
+}
+
+// Gradient-norm clipping (torch.nn.utils.clip_grad_norm_, L2) without a host read: a fixed-order two-stage sum of
+// squares -- one fp32 partial per 4096-element chunk (lanes stride the chunk, a tree over the workgroup), then per tensor
+// the chunk partials added in chunk order in fp64 -- and one tiny pass that turns the sums into the coefficients
+// min(1, max_norm / (norm + 1e-6)) the SGD kernel multiplies into its gradient scale.
+struct SumsqTable {
+  const void* g[kSgdMax];
+  long long n[kSgdMax];
+  int first_block[kSgdMax + 1];
+  int count;
+  unsigned g_bf16;
+  const float* used[kSgdMax];
+};
+
+__global__ __launch_bounds__(256) void grad_sumsq_partial_kernel(const SumsqTable t, float* __restrict__ partials) {
+  __shared__ float red[256];
+  int k = 0;
+  while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+  const long long base = (long long)((int)blockIdx.x - t.first_block[k]) * kSgdChunk;
+  const long long n = t.n[k];
+  const bool gb = (t.g_bf16 >> k) & 1u;
+  const float* g = (const float*)t.g[k];
+  const bf16_t* g16 = (const bf16_t*)t.g[k];
+  float acc = 0.f;
+  for (int e = threadIdx.x; e < kSgdChunk; e += 256) {
+    const long long i = base + e;
+    if (i < n) {
+      const float v = gb ? (float)g16[i] : g[i];
+      acc += v * v;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+// one wavefront per tensor: its chunk partials in chunk order (lane-strided, then a fixed shuffle tree), fp64
+__global__ __launch_bounds__(64) void grad_sumsq_tensor_kernel(const SumsqTable t, const float* __restrict__ partials,
+                                                                float* __restrict__ sumsq) {
+  const int k = blockIdx.x;
+  double acc = 0.0;
+  for (int b = t.first_block[k] + (int)threadIdx.x; b < t.first_block[k + 1]; b += 64) acc += (double)partials[b];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (threadIdx.x == 0) sumsq[k] = (t.used[k] && *t.used[k] == 0.f) ? 0.f : (float)acc;
+}
+
+__global__ __launch_bounds__(64) void grad_clip_coef_kernel(const float* __restrict__ sumsq, int count, float grad_scale,
+                                                             float max_norm, int per_tensor, float* __restrict__ coef) {
+  if (per_tensor) {
+    for (int k = threadIdx.x; k < count; k += 64) {
+      const float norm = grad_scale * sqrtf(sumsq[k]);
+      coef[k] = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    }
+    return;
+  }
+  double acc = 0.0;
+  for (int k = threadIdx.x; k < count; k += 64) acc += (double)sumsq[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  const float norm = grad_scale * (float)sqrt(acc);
+  const float c = fminf(max_norm / (norm + 1e-6f), 1.0f);
+  for (int k = threadIdx.x; k < count; k += 64) coef[k] = c;
 }
 
 // Gradient wire format: every trainable tensor's fp32 gradient rounded to bf16 into its slice of ONE flat buffer (the
@@ -1046,6 +1125,8 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
         t.x2_shadow |= 1u << k;
       }
       t.used[k] = d.used_flag;
+      t.coef[k] = d.grad_coef;
+      t.clip[k] = d.clip_value;
       t.n[k] = d.numel;
       t.lr[k] = d.lr;
       t.wd[k] = d.weight_decay;
@@ -1060,6 +1141,54 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
     hipLaunchKernelGGL(sgd_momentum_multi_kernel, dim3(blocks), dim3(256), 0, s, t, momentum, grad_scale);
     WS_CHECK_LAUNCH("wsovod_sgd_momentum_multi");
   }
+  return WSOVOD_OK;
+}
+
+long long wsovod_grad_clip_workspace_floats(const wsovod_sgd_tensor* tensors, int count) {
+  long long blocks = 0;
+  for (int k = 0; k < count; ++k) blocks += ceil_div_ll(tensors[k].numel, kSgdChunk);
+  return blocks + count;
+}
+
+int wsovod_grad_clip_coef(const wsovod_sgd_tensor* tensors, int count, float grad_scale, float max_norm, int per_tensor,
+                          float* workspace, float* coef, wsovod_stream_t stream) {
+  WS_CHECK_ARG(count >= 0 && (count == 0 || (tensors && workspace && coef)), "wsovod_grad_clip_coef: bad arguments");
+  WS_CHECK_ARG(max_norm > 0.f, "wsovod_grad_clip_coef: max_norm must be positive");
+  if (count == 0) return WSOVOD_OK;
+  static int slot = wsovod::prof_slot("grad_clip_coef");
+  hipStream_t s = (hipStream_t)stream;
+  long long total = 0, all_blocks = 0;
+  for (int k = 0; k < count; ++k) all_blocks += ceil_div_ll(tensors[k].numel, kSgdChunk);
+  float* sumsq = workspace + all_blocks;
+  long long block0 = 0;
+  for (int k = 0; k < count; ++k) total += tensors[k].numel;
+  wsovod::ProfScope prof(slot, s, 2.0 * total, (double)total * 4.0);
+  for (int start = 0; start < count; start += kSgdMax) {
+    SumsqTable t;
+    memset(&t, 0, sizeof(t));
+    int blocks = 0;
+    for (int k = 0; k < kSgdMax && start + k < count; ++k) {
+      const wsovod_sgd_tensor& d = tensors[start + k];
+      WS_CHECK_ARG(d.numel >= 0 && (d.numel == 0 || d.grad), "wsovod_grad_clip_coef: null gradient in entry %d", start + k);
+      t.g[k] = d.grad;
+      t.n[k] = d.numel;
+      t.used[k] = d.used_flag;
+      if (d.grad_is_bf16) t.g_bf16 |= 1u << k;
+      t.first_block[k] = blocks;
+      blocks += (int)ceil_div_ll(d.numel, kSgdChunk);
+      t.count = k + 1;
+    }
+    t.first_block[t.count] = blocks;
+    if (blocks > 0) {
+      hipLaunchKernelGGL(grad_sumsq_partial_kernel, dim3(blocks), dim3(256), 0, s, t, workspace + block0);
+      WS_CHECK_LAUNCH("wsovod_grad_clip_coef (partials)");
+    }
+    hipLaunchKernelGGL(grad_sumsq_tensor_kernel, dim3(t.count), dim3(64), 0, s, t, workspace + block0, sumsq + start);
+    WS_CHECK_LAUNCH("wsovod_grad_clip_coef (tensors)");
+    block0 += blocks;
+  }
+  hipLaunchKernelGGL(grad_clip_coef_kernel, dim3(1), dim3(64), 0, s, sumsq, count, grad_scale, max_norm, per_tensor, coef);
+  WS_CHECK_LAUNCH("wsovod_grad_clip_coef");
   return WSOVOD_OK;
 }
 

@@ -1504,7 +1504,7 @@ int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops
   constexpr int lds_bytes = STAGES * (BM + BN) * 128;
   auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA, STAGES, X3>;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt: LDS opt-in");
     attr_set = true;
   }
   GemmArgs args = a;
@@ -1757,8 +1757,8 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (persist && n_tiles >= 512) {  // enough tiles for two per CU: resident weights + double-buffered patches
       static bool attr = false;
       if (!attr) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv3x3_c64p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES);
+        WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
+        WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C64P_LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
         attr = true;
       }
       const char* wr = getenv("WSOVOD_C64_WREG");  // "0": weights read from LDS at every step (the round-2 form; A/B runs)
@@ -1791,8 +1791,8 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     static int slot = wsovod::prof_slot("conv3x3_c64_halo_bf16x2");
     static bool attr = false;
     if (!attr) {
-      (void)hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<16>::LDS_BYTES);
-      (void)hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<32>::LDS_BYTES);
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<16>::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<32>::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
       attr = true;
     }
     const char* tw = getenv("WSOVOD_C64X_TW");

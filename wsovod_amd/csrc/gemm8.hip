@@ -551,14 +551,14 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   static bool attr_set = false;
   constexpr int lds_bytes = 2 * (256 + 256) * 128;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    (void)hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
     attr_set = true;
   }
   GemmArgs args = a;

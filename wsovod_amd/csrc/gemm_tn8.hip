@@ -331,7 +331,7 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
   static bool attr_set = false;
   constexpr int lds_bytes = 2 * 2 * 2 * 64 * 256;  // 2 K-steps x (P, Q) x 2 sub-images x 64 rows x 256 B = 128 KiB
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;

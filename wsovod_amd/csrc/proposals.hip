@@ -322,7 +322,7 @@ int wsovod_nms_segments(const float* boxes, const int* seg_offsets, const unsign
   {
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)nms_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024), "wsovod_nms_segments: LDS opt-in");
       attr_set = true;
     }
     wsovod::ProfScope prof(slot_s, s, 0.0, (double)N * W * 8);

@@ -137,6 +137,36 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nhwc(const T* __restrict__ f
 }
 
 // ---------------------------------------------------------------------------------
+// Stride-1 2x2 max of an NHWC map: m2[n][h][w][c] = max over rows {h, min(h+1, H-1)} x columns {w, min(w+1, W-1)},
+// NaN cells skipped (fmaxf).  The first level of a range-max hierarchy: the RoIPool rows kernel below covers a bin of
+// >= 2 x 2 cells with ceil(nh/2) x ceil(nw/2) windows of this map instead of nh x nw cells.  With 512 rois on a 75 x 100
+// map every cell lies in ~30 rois, so one pass over the map (16 bytes per lane) replaces most of the gather's requests.
+// ---------------------------------------------------------------------------------
+template <typename T, int V>
+__global__ __launch_bounds__(256) void max2x2_s1_nhwc(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C,
+                                                      long long total_vec) {
+  typedef T vec __attribute__((ext_vector_type(V)));
+  const int cv = C / V;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * V;
+    const long long px = idx / cv;
+    const int w = (int)(px % W);
+    const int h = (int)((px / W) % H);
+    const long long n = px / ((long long)W * H);
+    const int h1 = min(h + 1, H - 1), w1 = min(w + 1, W - 1);
+    const T* pl = in + n * H * W * C + c;
+    const vec a = *(const vec*)(pl + ((long long)h * W + w) * C), b = *(const vec*)(pl + ((long long)h * W + w1) * C);
+    const vec d = *(const vec*)(pl + ((long long)h1 * W + w) * C), e = *(const vec*)(pl + ((long long)h1 * W + w1) * C);
+    vec o;
+#pragma unroll
+    for (int q = 0; q < V; ++q)
+      o[q] = from_f32<T>(fmaxf(fmaxf(to_f32(a[q]), to_f32(b[q])), fmaxf(to_f32(d[q]), to_f32(e[q]))));
+    *(vec*)(out + px * C + c) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // RoIPool forward, NHWC, pooled width PWT (7 on every shipped config): one WORKGROUP per
 // (roi, 64-channel group), one wavefront per pooled row ph.  The PWT bins of the row are
 // scanned together: each inner iteration issues PWT independent coalesced loads (one per
@@ -144,28 +174,55 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nhwc(const T* __restrict__ f
 // scan order inside every bin is still (h ascending, w ascending) with a strict '>' --
 // the reference's first-maximum argmax semantics (ROILoopPool_cpu.cpp:63-71).
 // ---------------------------------------------------------------------------------
+// v_max_f32 as the hardware does it: a NaN operand yields the other one (the reference's `v > maxval` never takes a NaN
+// cell either).  fmaxf() means the same but makes hipcc re-canonicalise the loop-carried accumulators every round.
+__device__ __forceinline__ float hw_max(float a, float b) {
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float hw_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 template <typename T, bool ARGMAX, int PWT, int CPL, bool OBF = false>
 __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
                                        const float* __restrict__ roi_scale, int C, int H, int W, int PH,
                                        float spatial_scale, void* out, int out_dtype, int* __restrict__ argmax,
-                                       int cgroups, void* out_hi = nullptr) {
-  // lane = CPL adjacent channels (one 8-byte load: 4 bf16 / 2 fp32), workgroup = 64*CPL channels of one roi
+                                       int cgroups, void* out_hi = nullptr, const T* __restrict__ m2 = nullptr,
+                                       int R = 0, int xcd_per_group = 0) {
+  // lane = CPL adjacent channels (one 8- or 16-byte load), workgroup = 64*CPL channels of one roi
   typedef T vec2 __attribute__((ext_vector_type(CPL)));
   constexpr int CG = 64 * CPL;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  // the pooled row is the same for all lanes of a wavefront: said so explicitly, every window bound, loop count and row
+  // address below lives in scalar registers and the loads take (scalar base, lane offset) addresses
+  const int lane = threadIdx.x & 63, ph = uni(threadIdx.x >> 6);
   const int nbins = PH * PWT;
   // output transpose tile [channel][bin]: fp32, or (OBF: bf16 output, no argmax) the output bits themselves: half the
   // LDS per workgroup, twice the workgroups (wavefronts with loads in flight) per CU
   typedef typename std::conditional<OBF, bf16_t, float>::type sval_t;
   sval_t* sval = (sval_t*)smem;
   int* sarg = (int*)(smem + (size_t)CG * nbins * sizeof(sval_t));
-  const int r = blockIdx.x / cgroups;
-  const int c0 = (blockIdx.x - r * cgroups) * CG;
+  int r = blockIdx.x / cgroups;
+  int c0 = (blockIdx.x - r * cgroups) * CG;
+  if (xcd_per_group) {
+    // XCD-aware order (workgroups go round-robin over the 8 XCDs): channel group g is served by `xcd_per_group`
+    // XCDs only, so the slice of the map an XCD's private 4-MB L2 sees is 1 / cgroups of every image
+    const int xcd = blockIdx.x & 7, blk = blockIdx.x >> 3;
+    c0 = (xcd / xcd_per_group) * CG;
+    r = blk * xcd_per_group + xcd % xcd_per_group;
+    if (r >= R) return;  // (whole workgroup)
+  }
   const int c = c0 + lane * CPL;
   const RoiBox b = decode_roi(rois + (long long)r * 5, spatial_scale, PH, PWT);
   const float scale = roi_scale ? roi_scale[r] : 1.0f;
-  const T* base = feat + (long long)b.batch * H * W * C + (c < C ? c : 0);
+  const unsigned lane_off = (unsigned)(c < C ? c : 0) * (unsigned)sizeof(T);  // bytes: (scalar row address) + (lane offset)
+  const long long img_off = (long long)b.batch * H * W * C;  // (scalar)
+  const T* base = feat + img_off;
   int hs, he, ws[PWT], we[PWT];
   float maxv[PWT][CPL];
   int maxi[PWT][CPL];
@@ -173,6 +230,13 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
 #pragma unroll
   for (int pw = 0; pw < PWT; ++pw) {
     bin_window(b, ph, pw, H, W, hs, he, ws[pw], we[pw]);
+    ws[pw] = uni(ws[pw]);
+    we[pw] = uni(we[pw]);
+  }
+  hs = uni(hs);
+  he = uni(he);
+#pragma unroll
+  for (int pw = 0; pw < PWT; ++pw) {
     const bool empty = (he <= hs) || (we[pw] <= ws[pw]);
 #pragma unroll
     for (int q = 0; q < CPL; ++q) {
@@ -181,6 +245,71 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
     }
     bw = max(bw, we[pw] - ws[pw]);
   }
+  // Values only, every bin of this pooled row at least 2 x 2 cells: the bin is covered by windows of the stride-1
+  // 2x2-max map `m2` (max2x2_s1_nhwc) anchored every second row / column, the last anchor clamped to the bin's end --
+  // a quarter of the loads of the cell scan, no per-load predicate.  max() is order-free and the windows cover exactly
+  // the bin's cells, NaN cells are skipped at both levels as `v > maxval` skips them: the same values bit for bit.
+  bool use_m2 = false;
+  constexpr int VB = CPL * (int)sizeof(T);  // bytes per lane and load
+  constexpr bool M2OK = !ARGMAX && (VB == 8 || VB == 16);
+  if constexpr (M2OK) {
+    if (m2 != nullptr && he - hs >= 2) {
+      int nwmin = we[0] - ws[0];
+#pragma unroll
+      for (int pw = 1; pw < PWT; ++pw) nwmin = min(nwmin, we[pw] - ws[pw]);
+      use_m2 = nwmin >= 2;
+    }
+  }
+  if constexpr (M2OK) if (use_m2) {
+    // U windows per bin in flight (U * PWT independent loads per wavefront before the first compare).
+    // Buffer loads: (resource of the image's map, lane offset in a VGPR, window offset in an SGPR) -- no per-load
+    // address registers, so the kernel stays within the 64 VGPRs that let 8 wavefronts share a SIMD (a 7-wavefront
+    // workgroup is resident 4 times per CU instead of twice: the launch is bound by latency, not by bandwidth).
+    constexpr int U = VB == 8 ? 2 : 1;
+    typedef int ivec __attribute__((ext_vector_type(VB / 4)));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(m2 + img_off), 0, H * W * C * (int)sizeof(T), 0x00020000);
+    const int nh2 = (he - hs + 1) >> 1, nw2 = (bw + 1) >> 1, nit = nh2 * nw2;
+    const int cb = C * (int)sizeof(T), wcb = W * cb;  // byte offsets inside the image's map (< 2^31: launcher), scalar
+    int colo[PWT], cmax[PWT];
+#pragma unroll
+    for (int pw = 0; pw < PWT; ++pw) colo[pw] = ws[pw] * cb, cmax[pw] = (we[pw] - 2) * cb;
+    int i = 0, j = 0;
+    for (int it = 0; it < nit; it += U) {
+      ivec raw[U][PWT];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rowo = min(hs + 2 * i, he - 2) * wcb, jo = 2 * j * cb;
+#pragma unroll
+        for (int pw = 0; pw < PWT; ++pw) {
+          const int so = rowo + min(colo[pw] + jo, cmax[pw]);
+          if constexpr (VB == 8)
+            raw[u][pw] = __builtin_bit_cast(ivec, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)lane_off, so, 0));
+          else
+            raw[u][pw] = __builtin_bit_cast(ivec, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane_off, so, 0));
+        }
+        if (U > 1 && it + u + 1 < nit) {  // (scalar) next window position, the last one repeated (max is idempotent)
+          if (++j == nw2) j = 0, ++i;
+        }
+      }
+      if (U == 1) {
+        if (++j == nw2) j = 0, ++i;
+      }
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        vec2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_bit_cast(vec2, raw[u][pw]);
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          if constexpr (U == 2)
+            maxv[pw][q] = hw_max3(maxv[pw][q], to_f32(v[0][q]), to_f32(v[1][q]));
+          else
+            maxv[pw][q] = hw_max(maxv[pw][q], to_f32(v[0][q]));
+        }
+      }
+    }
+  }
+  if (!use_m2)
   for (int h = hs; h < he; ++h) {
     const T* row = base + (long long)h * W * C;
     for (int j = 0; j < bw; ++j) {
@@ -188,7 +317,7 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
         const int w = min(ws[pw] + j, W - 1);  // clamped: lanes past the bin load a valid cell and ignore it
-        v[pw] = *(const vec2*)(row + (long long)w * C);
+        v[pw] = *(const vec2*)((const char*)(row + (long long)w * C) + lane_off);
       }
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
@@ -328,83 +457,182 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_nchw(const T* __restrict__ f
 //   region : max over the bin (as RoIPool, but with the accumulator starting at 0: inputs are post-ReLU)
 //   frame  : the same bin without the cells STRICTLY inside the roi shrunk by context_ratio about its centre
 //   context: the bin of the roi GROWN by context_ratio, without the cells strictly inside the roi itself
-// out / argmax: (3R, C, PH, PW) = [region | frame | context].  One thread per (roi, channel, bin), as the reference;
-// this op is selected by the MRRP / contextlocnet configs only, not by the WSR hot path.
+// out / argmax: (3R, C, PH, PW) = [region | frame | context].
+//
+// NHWC form of the plain RoIPool rows kernel above (the reference runs one thread per output bin over an NCHW map):
+// workgroup = (roi, 64 * CPL channels), wavefront = pooled row, lane = CPL adjacent channels, so every cell is one
+// coalesced wave access; the PWT bins of a row advance together (PWT independent loads in flight); region and frame
+// share the bins and therefore every cell load -- one scan feeds both accumulators, the frame's hole is a wave-uniform
+// test; the context ring is a second scan over the grown roi's bins.  The three (CG, PH, PW) result tiles go through
+// one LDS transpose tile each and leave as contiguous runs of the reference's (3R, C, PH, PW) layout.  Scan order per
+// bin is (h ascending, w ascending) with a strict '>' from 0: first-maximum argmax, -1 for an empty / all-zero bin.
 // ---------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void roi_loop_pool_fwd(const T* __restrict__ feat, const float* __restrict__ rois,
-                                                         long long total, int R, int C, int H, int W, int PH, int PW,
-                                                         float spatial_scale, float context_ratio, int nhwc,
-                                                         float* __restrict__ out, int* __restrict__ argmax) {
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int pw = (int)(idx % PW);
-    const int ph = (int)((idx / PW) % PH);
-    const int c = (int)((idx / ((long long)PW * PH)) % C);
-    const int r = (int)(idx / ((long long)PW * PH * C));
-    const float* roi = rois + (long long)r * 5;
-    const int batch = (int)roi[0];
-    const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
-    const float rw = x2 - x1, rh = y2 - y1;
-    const float in_rw = rw - rw / context_ratio, in_rh = rh - rh / context_ratio;    // inner residuals
-    const float out_rw = rw * context_ratio - rw, out_rh = rh * context_ratio - rh;  // outer residuals
-    const float xmax = (float)(1.0 * W / spatial_scale), ymax = (float)(1.0 * H / spatial_scale);
-    const float x1i = fminf(fmaxf(x1 + in_rw / 2, 0.f), xmax), y1i = fminf(fmaxf(y1 + in_rh / 2, 0.f), ymax);
-    const float x2i = fminf(fmaxf(x2 - in_rw / 2, 0.f), xmax), y2i = fminf(fmaxf(y2 - in_rh / 2, 0.f), ymax);
-    const float x1o = fminf(fmaxf(x1 - out_rw / 2, 0.f), xmax), y1o = fminf(fmaxf(y1 - out_rh / 2, 0.f), ymax);
-    const float x2o = fminf(fmaxf(x2 + out_rw / 2, 0.f), xmax), y2o = fminf(fmaxf(y2 + out_rh / 2, 0.f), ymax);
-    const T* plane = nhwc ? feat + (long long)batch * H * W * C + c : feat + ((long long)batch * C + c) * H * W;
-    const long long es = nhwc ? C : 1;
-    const long long part = (long long)R * C * PH * PW;
-    // the roi's own rounded rectangle: bins of region/frame, hole of context
-    const int sw = (int)roundf(x1 * spatial_scale), sh = (int)roundf(y1 * spatial_scale);
-    const int ew = (int)roundf(x2 * spatial_scale), eh = (int)roundf(y2 * spatial_scale);
-    {
-      const int swi = (int)roundf(x1i * spatial_scale), shi = (int)roundf(y1i * spatial_scale);
-      const int ewi = (int)roundf(x2i * spatial_scale), ehi = (int)roundf(y2i * spatial_scale);
-      const int roi_w = max(ew - sw + 1, 1), roi_h = max(eh - sh + 1, 1);
-      const float bin_h = (float)roi_h / (float)PH, bin_w = (float)roi_w / (float)PW;
-      const int hs = min(max((int)floorf((float)ph * bin_h) + sh, 0), H);
-      const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + sh, 0), H);
-      const int ws = min(max((int)floorf((float)pw * bin_w) + sw, 0), W);
-      const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + sw, 0), W);
-      float mv = 0.f, mvf = 0.f;
-      int mi = -1, mif = -1;
-      for (int h = hs; h < he; ++h)
-        for (int w = ws; w < we; ++w) {
-          const float v = to_f32(plane[(long long)(h * W + w) * es]);
-          if (v > mv) { mv = v; mi = h * W + w; }
-          if (h > shi && h < ehi && w > swi && w < ewi) continue;  // strictly inside the inner rectangle
-          if (v > mvf) { mvf = v; mif = h * W + w; }
-        }
-      out[idx] = mv;
-      argmax[idx] = mi;
-      out[idx + part] = mvf;
-      argmax[idx + part] = mif;
-    }
-    {
-      const int swo = (int)roundf(x1o * spatial_scale), sho = (int)roundf(y1o * spatial_scale);
-      const int ewo = (int)roundf(x2o * spatial_scale), eho = (int)roundf(y2o * spatial_scale);
-      const int roi_w = max(ewo - swo + 1, 1), roi_h = max(eho - sho + 1, 1);
-      const float bin_h = (float)roi_h / (float)PH, bin_w = (float)roi_w / (float)PW;
-      const int hs = min(max((int)floorf((float)ph * bin_h) + sho, 0), H);
-      const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + sho, 0), H);
-      const int ws = min(max((int)floorf((float)pw * bin_w) + swo, 0), W);
-      const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + swo, 0), W);
-      float mv = 0.f;
-      int mi = -1;
-      for (int h = hs; h < he; ++h) {
-        const bool in_h = h > sh && h < eh;
-        for (int w = ws; w < we; ++w) {
-          if (in_h && w > sw && w < ew) continue;
-          const float v = to_f32(plane[(long long)(h * W + w) * es]);
-          if (v > mv) { mv = v; mi = h * W + w; }
-        }
-      }
-      out[idx + 2 * part] = mv;
-      argmax[idx + 2 * part] = mi;
+struct LoopRects {
+  int batch;
+  int sw, sh, ew, eh;      // the roi itself, rounded: bins of region / frame, hole of context
+  int swi, shi, ewi, ehi;  // shrunk: hole of frame
+  int swo, sho, ewo, eho;  // grown: bins of context
+};
+
+__device__ __forceinline__ LoopRects loop_rects(const float* roi, float spatial_scale, float context_ratio, int H, int W) {
+  LoopRects q;
+  q.batch = (int)roi[0];
+  const float x1 = roi[1], y1 = roi[2], x2 = roi[3], y2 = roi[4];
+  const float rw = x2 - x1, rh = y2 - y1;
+  const float in_rw = rw - rw / context_ratio, in_rh = rh - rh / context_ratio;    // inner residuals
+  const float out_rw = rw * context_ratio - rw, out_rh = rh * context_ratio - rh;  // outer residuals
+  const float xmax = (float)(1.0 * W / spatial_scale), ymax = (float)(1.0 * H / spatial_scale);
+  const float x1i = fminf(fmaxf(x1 + in_rw / 2, 0.f), xmax), y1i = fminf(fmaxf(y1 + in_rh / 2, 0.f), ymax);
+  const float x2i = fminf(fmaxf(x2 - in_rw / 2, 0.f), xmax), y2i = fminf(fmaxf(y2 - in_rh / 2, 0.f), ymax);
+  const float x1o = fminf(fmaxf(x1 - out_rw / 2, 0.f), xmax), y1o = fminf(fmaxf(y1 - out_rh / 2, 0.f), ymax);
+  const float x2o = fminf(fmaxf(x2 + out_rw / 2, 0.f), xmax), y2o = fminf(fmaxf(y2 + out_rh / 2, 0.f), ymax);
+  q.sw = (int)roundf(x1 * spatial_scale), q.sh = (int)roundf(y1 * spatial_scale);
+  q.ew = (int)roundf(x2 * spatial_scale), q.eh = (int)roundf(y2 * spatial_scale);
+  q.swi = (int)roundf(x1i * spatial_scale), q.shi = (int)roundf(y1i * spatial_scale);
+  q.ewi = (int)roundf(x2i * spatial_scale), q.ehi = (int)roundf(y2i * spatial_scale);
+  q.swo = (int)roundf(x1o * spatial_scale), q.sho = (int)roundf(y1o * spatial_scale);
+  q.ewo = (int)roundf(x2o * spatial_scale), q.eho = (int)roundf(y2o * spatial_scale);
+  return q;
+}
+
+// One pooled row `ph` of the bins of the rectangle (sw, sh, ew, eh), pooled columns [pw0, pw0 + npw): the cells of a bin
+// strictly inside (hw0, hh0, hw1, hh1) are skipped by accumulator B (and by accumulator A too when SKIP_A); results go to
+// the [channel][bin] LDS tiles.  TWO = both accumulators wanted (region + frame), else only B (context).
+template <typename T, int PWT, int CPL, bool TWO>
+__device__ __forceinline__ void loop_pool_row(const T* __restrict__ base, int C, int H, int W, int PH, int PW, int ph,
+                                              int pw0, int npw, int sw, int sh, int ew, int eh, int hw0, int hh0, int hw1,
+                                              int hh1, int lane, float* svalA, int* sargA, float* svalB, int* sargB) {
+  typedef T vecc __attribute__((ext_vector_type(CPL)));
+  const int roi_w = max(ew - sw + 1, 1), roi_h = max(eh - sh + 1, 1);
+  const float bin_h = (float)roi_h / (float)PH, bin_w = (float)roi_w / (float)PW;
+  const int hs = min(max((int)floorf((float)ph * bin_h) + sh, 0), H);
+  const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + sh, 0), H);
+  int ws[PWT], we[PWT], bw = 0;
+  float mvA[PWT][CPL], mvB[PWT][CPL];
+  int miA[PWT][CPL], miB[PWT][CPL];
+#pragma unroll
+  for (int k = 0; k < PWT; ++k) {
+    const int pw = min(pw0 + k, PW - 1);
+    ws[k] = min(max((int)floorf((float)pw * bin_w) + sw, 0), W);
+    we[k] = k < npw ? min(max((int)ceilf((float)(pw + 1) * bin_w) + sw, 0), W) : ws[k];  // (past the chunk: empty)
+    bw = max(bw, we[k] - ws[k]);
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      mvA[k][q] = mvB[k][q] = 0.f;
+      miA[k][q] = miB[k][q] = -1;
     }
   }
+  for (int h = hs; h < he; ++h) {
+    const T* row = base + (long long)h * W * C;
+    const bool in_h = h > hh0 && h < hh1;
+    for (int j = 0; j < bw; ++j) {
+      vecc v[PWT];
+#pragma unroll
+      for (int k = 0; k < PWT; ++k) v[k] = *(const vecc*)(row + (long long)min(ws[k] + j, W - 1) * C);
+#pragma unroll
+      for (int k = 0; k < PWT; ++k) {
+        const int w = ws[k] + j;
+        if (w < we[k]) {
+          const bool hole = in_h && w > hw0 && w < hw1;
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            const float vq = to_f32(v[k][q]);
+            if (TWO && vq > mvA[k][q]) {
+              mvA[k][q] = vq;
+              miA[k][q] = h * W + w;
+            }
+            if (!hole && vq > mvB[k][q]) {
+              mvB[k][q] = vq;
+              miB[k][q] = h * W + w;
+            }
+          }
+        }
+      }
+    }
+  }
+  const int nbins = PH * PW;
+#pragma unroll
+  for (int k = 0; k < PWT; ++k)
+    if (k < npw) {
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const int o = (lane * CPL + q) * nbins + ph * PW + pw0 + k;
+        if (TWO && svalA) {
+          svalA[o] = mvA[k][q];
+          sargA[o] = miA[k][q];
+        }
+        if (svalB) {
+          svalB[o] = mvB[k][q];
+          sargB[o] = miB[k][q];
+        }
+      }
+    }
+}
+
+template <typename T, int CPL>
+__global__ void roi_loop_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois, int R, int C,
+                                            int H, int W, int PH, int PW, float spatial_scale, float context_ratio,
+                                            float* __restrict__ out, int* __restrict__ argmax, int cgroups, int share) {
+  constexpr int PWT = 7, CG = 64 * CPL;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int nbins = PH * PW;
+  float* svalA = (float*)smem;  // tile A: region, later context; tile B: frame
+  int* sargA = (int*)(svalA + CG * nbins);
+  float* svalB = (float*)(sargA + CG * nbins);
+  int* sargB = (int*)(svalB + CG * nbins);
+  const int r = blockIdx.x / cgroups;
+  const int c0 = (blockIdx.x - r * cgroups) * CG;
+  const int c = c0 + lane * CPL;
+  const LoopRects q = loop_rects(rois + (long long)r * 5, spatial_scale, context_ratio, H, W);
+  const T* base = feat + (long long)q.batch * H * W * C + (c + CPL <= C ? c : 0);  // (lanes past C read channel 0, never stored)
+  const long long part = (long long)R * C * nbins;
+  const int nvalid = min(CG, C - c0) * nbins;
+  const long long obase = ((long long)r * C + c0) * nbins;
+  const bool vec = (nvalid & 3) == 0 && (obase & 3) == 0;
+  auto flush = [&](const float* sv, const int* sa, long long off) {
+    float* o = out + off + obase;
+    int* oa = argmax + off + obase;
+    if (vec) {
+      for (int i = threadIdx.x * 4; i < nvalid; i += blockDim.x * 4) {
+        *(float4*)(o + i) = *(const float4*)(sv + i);
+        *(int4*)(oa + i) = *(const int4*)(sa + i);
+      }
+    } else {
+      for (int i = threadIdx.x; i < nvalid; i += blockDim.x) {
+        o[i] = sv[i];
+        oa[i] = sa[i];
+      }
+    }
+  };
+  // region + frame: one scan of the roi's own bins feeds both (frame skips the cells strictly inside the shrunk roi).
+  // share = 0 (a pooled tile too large for two LDS tiles): one tile, the two outputs in two scans
+  if (!share) svalB = nullptr, sargB = nullptr;
+  for (int ph = wave; ph < PH; ph += nwaves)
+    for (int pw0 = 0; pw0 < PW; pw0 += PWT)
+      loop_pool_row<T, PWT, CPL, true>(base, C, H, W, PH, PW, ph, pw0, min(PWT, PW - pw0), q.sw, q.sh, q.ew, q.eh, q.swi,
+                                       q.shi, q.ewi, q.ehi, lane, svalA, sargA, svalB, sargB);
+  __syncthreads();
+  flush(svalA, sargA, 0);
+  if (share) {
+    flush(svalB, sargB, part);
+  } else {
+    __syncthreads();
+    for (int ph = wave; ph < PH; ph += nwaves)
+      for (int pw0 = 0; pw0 < PW; pw0 += PWT)
+        loop_pool_row<T, PWT, CPL, false>(base, C, H, W, PH, PW, ph, pw0, min(PWT, PW - pw0), q.sw, q.sh, q.ew, q.eh, q.swi,
+                                          q.shi, q.ewi, q.ehi, lane, nullptr, nullptr, svalA, sargA);
+    __syncthreads();
+    flush(svalA, sargA, part);
+  }
+  __syncthreads();
+  // context: the bins of the grown roi without the cells strictly inside the roi itself
+  for (int ph = wave; ph < PH; ph += nwaves)
+    for (int pw0 = 0; pw0 < PW; pw0 += PWT)
+      loop_pool_row<T, PWT, CPL, false>(base, C, H, W, PH, PW, ph, pw0, min(PWT, PW - pw0), q.swo, q.sho, q.ewo, q.eho,
+                                        q.sw, q.sh, q.ew, q.eh, lane, nullptr, nullptr, svalA, sargA);
+  __syncthreads();
+  flush(svalA, sargA, 2 * part);
 }
 
 // RoIPool backward: scatter-add through argmax (ROILoopPool_cpu.cpp:82-123).
@@ -938,6 +1166,26 @@ int wsovod_roi_pool_forward(const void* feat, int dtype, int layout, const float
 int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
                                  int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out,
                                  int out_dtype, int* argmax, void* out_hi, wsovod_stream_t stream) {
+  return wsovod_roi_pool_forward_ws(feat, dtype, layout, rois, roi_scale, R, N, C, H, W, ph, pw, spatial_scale, out, out_dtype,
+                                    argmax, out_hi, nullptr, 0, stream);
+}
+
+long long wsovod_roi_pool_workspace_bytes(int dtype, int layout, int R, int N, int C, int H, int W, int ph, int pw,
+                                          int want_argmax) {
+  // the 2x2-max map pays when the rois re-read the map many times over (512 boxes on 75 x 100 cells: ~30x); a handful of
+  // boxes keeps the direct scan.  Values only: argmax needs the first maximum in scan order, i.e. the cells themselves.
+  const int v = dtype == WSOVOD_BF16 ? 8 : 4;
+  if (want_argmax || layout != WSOVOD_NHWC || pw != 7 || ph > 16 || (dtype != WSOVOD_BF16 && dtype != WSOVOD_F32)) return 0;
+  if (C % v != 0 || H < 2 || W < 2 || N <= 0 || (long long)R * 49 < (long long)N * H * W / 2) return 0;
+  const char* e = getenv("WSOVOD_ROIPOOL_M2");
+  if (e && atoi(e) == 0) return 0;
+  return (long long)N * H * W * C * (dtype == WSOVOD_BF16 ? 2 : 4);
+}
+
+int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                               int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
+                               int* argmax, void* out_hi, void* workspace, long long workspace_bytes,
+                               wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_pool_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
   WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
                "wsovod_roi_pool_forward_x2hi: the bf16 copy goes with a bf16x2 output");
@@ -978,48 +1226,74 @@ int wsovod_roi_pool_forward_x2hi(const void* feat, int dtype, int layout, const 
 #define LAUNCH_POOL(T, AM)                                                                                        \
   do {                                                                                                            \
     auto k = roi_pool_fwd_nhwc<T, AM>;                                                                            \
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+    if (lds > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds), \
+                                      "wsovod_roi_pool_forward: LDS opt-in");                                      \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const T*)feat, rois, roi_scale, R, C, H, W, ph, pw,      \
                        spatial_scale, out, out_dtype, argmax, cgroups);                                           \
   } while (0)
     if (pw == 7 && ph <= 16 && (C & 1) == 0 && (((uintptr_t)feat) & 7) == 0) {
-      // fast path: workgroup per (roi, 64*CPL-channel group), wavefront per pooled row, one 8-byte load per lane and cell
-      // (4 bf16 / 2 fp32 channels); bf16 maps whose channel count is not a multiple of 4 keep 2 channels per lane
+      // fast path: workgroup per (roi, 64*CPL-channel group), wavefront per pooled row, one 8- or 16-byte load per lane
+      // and cell; bf16 maps whose channel count is not a multiple of 4 keep 2 channels per lane
+      const long long need = wsovod_roi_pool_workspace_bytes(dtype, layout, R, N, C, H, W, ph, pw, argmax != nullptr);
+      const bool use_m2 = workspace && need > 0 && workspace_bytes >= need && (((uintptr_t)feat | (uintptr_t)workspace) & 15) == 0;
+      if (use_m2) {  // one pass over the map: its stride-1 2x2 maxima (the rows kernel then reads a quarter of the cells)
+        static int slot2 = wsovod::prof_slot("roi_pool_max2x2_map");
+        const int v = dtype == WSOVOD_BF16 ? 8 : 4;
+        const long long total_vec = (long long)N * H * W * (C / v);
+        const int g2 = (int)std::min<long long>(ceil_div_ll(total_vec, 256), 256 * 64);
+        wsovod::ProfScope prof2(slot2, s, 0.0, 2.0 * (double)N * C * H * W * esz);
+        if (dtype == WSOVOD_BF16)
+          hipLaunchKernelGGL((max2x2_s1_nhwc<bf16_t, 8>), dim3(g2), dim3(256), 0, s, (const bf16_t*)feat, (bf16_t*)workspace,
+                             H, W, C, total_vec);
+        else
+          hipLaunchKernelGGL((max2x2_s1_nhwc<float, 4>), dim3(g2), dim3(256), 0, s, (const float*)feat, (float*)workspace, H,
+                             W, C, total_vec);
+        WS_CHECK_LAUNCH("wsovod_roi_pool_forward (2x2-max map)");
+      }
       const bool wide = dtype == WSOVOD_BF16 && (C & 3) == 0 && !argmax;  // measured: 4 channels per lane pay off only without argmax registers (C = 2048: 1.83 -> 1.66 ms; with argmax 0.70 -> 1.07)
       // fp32 maps (the "parity" precision's res5): 4 channels = one 16-byte load per lane and cell (WSOVOD_ROIPOOL_F32_WIDE=0: 2)
       // (WSOVOD_ROIPOOL_F32_CPL = 1 / 2 / 4 selects the channels per lane for A/B runs: 64 / 128 / 256 channels per workgroup)
       const char* wf = getenv("WSOVOD_ROIPOOL_F32_CPL");
-      const int fcpl = wf ? atoi(wf) : 2;  // measured at 32 x 512 boxes, bf16x2 + bf16 out: 4 -> 1.665, 2 -> 1.530, 1 -> 1.673 ms
+      const int fcpl = wf ? atoi(wf) : (use_m2 ? 4 : 2);  // cell scan, 32 x 512 boxes, bf16x2 + bf16 out: 4 -> 1.665, 2 -> 1.530, 1 -> 1.673 ms
       const bool f32na = dtype == WSOVOD_F32 && !argmax;
       const bool widef = f32na && fcpl == 4 && (C & 3) == 0 && (((uintptr_t)feat) & 15) == 0;
       const bool narrowf = f32na && fcpl == 1;  // one XCD per 64-channel group: its slice of an fp32 map (1.9 MB) stays in L2
-      const int cg = (wide || widef) ? 256 : narrowf ? 64 : 128;
+      // bf16 maps through the 2x2-max map: WSOVOD_ROIPOOL_BF16_CPL = 8 selects 8 channels = one 16-byte load per lane
+      // (A/B runs: 0.560 vs 0.575 ms at 32 x 512 boxes, but 123 VGPRs against 68: the 4-channel form stays the default)
+      const char* wb = getenv("WSOVOD_ROIPOOL_BF16_CPL");
+      const bool wide8 = wide && use_m2 && out_dtype == WSOVOD_BF16 && (C & 7) == 0 && wb && atoi(wb) == 8;
+      const int cg = wide8 ? 512 : (wide || widef) ? 256 : narrowf ? 64 : 128;
       const int cgroups = ceil_div(C, cg);
       const bool obf = wide && out_dtype == WSOVOD_BF16;  // bf16 transpose tile: 25 instead of 50 KiB per workgroup (0.833 -> 0.817 ms)
       const int lds7 = obf ? cg * ph * pw * 2 : cg * ph * pw * 4 * (argmax ? 2 : 1);
-      const int grid7 = R * cgroups;
+      // WSOVOD_ROIPOOL_XCD=1: channel group g on 8 / cgroups XCDs only (A/B switch; see the kernel)
+      const char* wx = getenv("WSOVOD_ROIPOOL_XCD");
+      const int xpg = (wx && atoi(wx) == 1 && (cgroups == 2 || cgroups == 4 || cgroups == 8)) ? 8 / cgroups : 0;
+      const int grid7 = xpg ? ceil_div(R, xpg) * 8 : R * cgroups;
+      const void* m2p = use_m2 ? workspace : nullptr;
       WS_CHECK_ARG(lds7 <= 160 * 1024, "wsovod_roi_pool_forward: pooled tile too large for LDS");
-#define LAUNCH_ROWS(T, AM, CPL)                                                                                    \
+#define LAUNCH_ROWS(T, AM, CPL, OBF)                                                                               \
   do {                                                                                                             \
-    auto k = roi_pool_fwd_nhwc_rows<T, AM, 7, CPL>;                                                                \
-    if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7); \
+    auto k = roi_pool_fwd_nhwc_rows<T, AM, 7, CPL, OBF>;                                                           \
+    if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), \
+                                       "wsovod_roi_pool_forward: LDS opt-in");                                     \
     hipLaunchKernelGGL(k, dim3(grid7), dim3(64 * ph), lds7, s, (const T*)feat, rois, roi_scale, C, H, W, ph,        \
-                       spatial_scale, out, out_dtype, argmax, cgroups, out_hi);                                    \
+                       spatial_scale, out, out_dtype, argmax, cgroups, out_hi, (const T*)m2p, R, xpg);             \
   } while (0)
-      if (obf) {
-        auto k = roi_pool_fwd_nhwc_rows<bf16_t, false, 7, 4, true>;
-        hipLaunchKernelGGL(k, dim3(grid7), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, out, out_dtype, argmax, cgroups, (void*)nullptr);
+      if (wide8) {
+        LAUNCH_ROWS(bf16_t, false, 8, true);
+      } else if (obf) {
+        LAUNCH_ROWS(bf16_t, false, 4, true);
       } else if (wide) {
-        LAUNCH_ROWS(bf16_t, false, 4);
+        LAUNCH_ROWS(bf16_t, false, 4, false);
       } else if (widef) {
-        LAUNCH_ROWS(float, false, 4);
+        LAUNCH_ROWS(float, false, 4, false);
       } else if (narrowf) {
-        LAUNCH_ROWS(float, false, 1);
+        LAUNCH_ROWS(float, false, 1, false);
       } else if (dtype == WSOVOD_BF16) {
-        if (argmax) LAUNCH_ROWS(bf16_t, true, 2); else LAUNCH_ROWS(bf16_t, false, 2);
+        if (argmax) LAUNCH_ROWS(bf16_t, true, 2, false); else LAUNCH_ROWS(bf16_t, false, 2, false);
       } else {
-        if (argmax) LAUNCH_ROWS(float, true, 2); else LAUNCH_ROWS(float, false, 2);
+        if (argmax) LAUNCH_ROWS(float, true, 2, false); else LAUNCH_ROWS(float, false, 2, false);
       }
 #undef LAUNCH_ROWS
     } else if (dtype == WSOVOD_BF16) {
@@ -1051,19 +1325,45 @@ int wsovod_roi_loop_pool_forward(const void* feat, int dtype, int layout, const 
   WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16, "wsovod_roi_loop_pool_forward: bad dtype");
   WS_CHECK_ARG(R >= 0 && N >= 0 && C > 0 && H > 0 && W > 0 && ph > 0 && pw > 0 && context_ratio > 0.f,
                "wsovod_roi_loop_pool_forward: bad shape");
+  WS_CHECK_ARG((long long)H * W < (1ll << 31), "wsovod_roi_loop_pool_forward: H*W overflows int32 argmax");
   if (R == 0) return WSOVOD_OK;
   WS_CHECK_ARG(feat && rois && out && argmax, "wsovod_roi_loop_pool_forward: null pointer");
+  if (layout != WSOVOD_NHWC) {
+    // channels per lane need the channels innermost: the HIP backbone's layout.  The reference's NCHW tensors go through
+    // `.contiguous(memory_format=torch.channels_last)` in the Python fronts (wsovod_amd/_C.py, layers/hip_ops.py).
+    wsovod::set_error("wsovod_roi_loop_pool_forward: the feature map must be NHWC (channels_last)");
+    return WSOVOD_ERR_UNSUPPORTED;
+  }
   static int slot = wsovod::prof_slot("roi_loop_pool_fwd");
   hipStream_t s = (hipStream_t)stream;
-  const long long total = (long long)R * C * ph * pw;
-  const int grid = (int)std::min<long long>(ceil_div_ll(total, 256), 256 * 32);
-  wsovod::ProfScope prof(slot, s, 0.0, (double)total * 24.0);
-  if (dtype == WSOVOD_BF16)
-    hipLaunchKernelGGL(roi_loop_pool_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)feat, rois, total, R, C, H,
-                       W, ph, pw, spatial_scale, context_ratio, layout == WSOVOD_NHWC ? 1 : 0, out, argmax);
-  else
-    hipLaunchKernelGGL(roi_loop_pool_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)feat, rois, total, R, C, H, W,
-                       ph, pw, spatial_scale, context_ratio, layout == WSOVOD_NHWC ? 1 : 0, out, argmax);
+  const int nbins = ph * pw;
+  // two (channels, bins) value + argmax tiles per workgroup; 2 channels per lane when both fit next to a second workgroup
+  const bool two = (C & 1) == 0 && (((uintptr_t)feat) & 7) == 0 && C >= 128 && 2 * 128 * nbins * 8 <= 80 * 1024;
+  const int cpl = two ? 2 : 1, cg = 64 * cpl;
+  const int share = 2 * cg * nbins * 8 <= 160 * 1024 ? 1 : 0;  // region and frame from one scan (two tiles) or from two
+  const int lds = (share ? 2 : 1) * cg * nbins * 8;
+  if (lds > 160 * 1024) {
+    wsovod::set_error("wsovod_roi_loop_pool_forward: a %d x %d pooled tile of 64 channels does not fit the LDS", ph, pw);
+    return WSOVOD_ERR_UNSUPPORTED;
+  }
+  const int cgroups = ceil_div(C, cg);
+  const int nwaves = std::min(ph, 8);
+  const double cells = (double)R * C * nbins;
+  wsovod::ProfScope prof(slot, s, 0.0, cells * 24.0 + (double)N * C * H * W * (dtype == WSOVOD_BF16 ? 2 : 4));
+#define LAUNCH_LOOP(T, CPL)                                                                                          \
+  do {                                                                                                               \
+    auto k = roi_loop_pool_fwd_nhwc_rows<T, CPL>;                                                                    \
+    if (lds > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds), \
+                                      "wsovod_roi_loop_pool_forward: LDS opt-in");                                   \
+    hipLaunchKernelGGL(k, dim3(R * cgroups), dim3(64 * nwaves), lds, s, (const T*)feat, rois, R, C, H, W, ph, pw,      \
+                       spatial_scale, context_ratio, out, argmax, cgroups, share);                                   \
+  } while (0)
+  if (dtype == WSOVOD_BF16) {
+    if (two) LAUNCH_LOOP(bf16_t, 2); else LAUNCH_LOOP(bf16_t, 1);
+  } else {
+    if (two) LAUNCH_LOOP(float, 2); else LAUNCH_LOOP(float, 1);
+  }
+#undef LAUNCH_LOOP
   WS_CHECK_LAUNCH("wsovod_roi_loop_pool_forward");
   return WSOVOD_OK;
 }
@@ -1127,28 +1427,28 @@ int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const
       const int lds7 = ((cg * ph * pw * (wide ? 2 : 4) + 15) & ~15) + kAlignTabBytes;
       if (wide) {
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 8, true>;
-        if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), "wsovod_roi_align_forward: LDS opt-in");
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
                            spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, (void*)nullptr);
       } else if (dtype == WSOVOD_BF16) {
         auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
-        if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), "wsovod_roi_align_forward: LDS opt-in");
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
                            spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, out_hi);
       } else {
         auto k = roi_align_fwd_nhwc_rows<float, 7, 2>;
-        if (lds7 > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7);
+        if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), "wsovod_roi_align_forward: LDS opt-in");
         hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const float*)feat, rois, roi_scale, C, H, W, ph,
                            spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, out_hi);
       }
     } else if (dtype == WSOVOD_BF16) {
       auto k = roi_align_fwd_nhwc<bf16_t>;
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (lds > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "wsovod_roi_align_forward: LDS opt-in");
       hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const bf16_t*)feat, rois, roi_scale, R, C, H, W, ph, pw,
                          spatial_scale, sampling_ratio, aligned, out, out_dtype, cgroups);
     } else {
       auto k = roi_align_fwd_nhwc<float>;
-      if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (lds > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "wsovod_roi_align_forward: LDS opt-in");
       hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, s, (const float*)feat, rois, roi_scale, R, C, H, W, ph, pw,
                          spatial_scale, sampling_ratio, aligned, out, out_dtype, cgroups);
     }

@@ -17,9 +17,17 @@ from ..layers import hip_ops as H
 class HipSGD(torch.optim.Optimizer):
     """torch.optim.SGD semantics (momentum, weight decay, dampening 0) on wsovod_sgd_momentum."""
 
-    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0):
+    def __init__(self, params, lr, momentum=0.0, weight_decay=0.0, clip=None):
+        """clip: None or (kind, value) -- "full_model" (the reference's FullModelGradientClippingOptimizer,
+        engine/defaults.py:292-318: clip_grad_norm_ over every parameter at once), "norm" / "value" (detectron2's
+        per-parameter clip_grad_norm_ / clip_grad_value_, maybe_add_gradient_clipping).  The norm is taken of the gradient
+        the optimizer sees (after the data-parallel average); it stays on the device."""
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.grad_scale = 1.0  # 1/world_size when gradients arrive as a SUM over ranks
+        if clip is not None and (clip[0] not in ("full_model", "norm", "value") or not clip[1] > 0.0):
+            raise ValueError(f"HipSGD: clip must be (full_model | norm | value, positive value), got {clip!r}")
+        self.clip = clip
+        self.last_clip_coef = None  # device tensor of the coefficients applied by the last step (norm kinds; tests, logging)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -42,8 +50,11 @@ class HipSGD(torch.optim.Optimizer):
                 by_momentum.setdefault(group["momentum"], []).append(
                     (p.data, g, state["momentum_buffer"], shadow, group["lr"], group["weight_decay"],
                      getattr(p, "_used_flag", None), p))
+        if self.clip is not None and self.clip[0] == "full_model" and len(by_momentum) > 1:
+            raise NotImplementedError("HipSGD: full-model clipping needs one momentum value for all parameter groups")
         for mu, entries in by_momentum.items():  # every tensor of the model in one launch
-            H.sgd_momentum_multi([e[:7] for e in entries], mu, grad_scale=self.grad_scale)
+            self.last_clip_coef = H.sgd_momentum_multi([e[:7] for e in entries], mu, grad_scale=self.grad_scale,
+                                                       clip=self.clip)
             for e in entries:
                 # the kernel wrote through raw pointers: advance the version counter so that caches keyed on it (folded
                 # conv weights, class matrices) are rebuilt, and re-stamp the bf16 shadow the kernel refreshed itself
@@ -66,7 +77,26 @@ def build_optimizer(cfg, model):
         params.append({"params": [value], "lr": lr, "weight_decay": cfg.SOLVER.WEIGHT_DECAY})
     if cfg.SOLVER.OPTIMIZER != "SGD":
         raise NotImplementedError("hot path optimizer is SGD (every WSR config)")
-    return HipSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
+    return HipSGD(params, cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM, clip=gradient_clipping(cfg))
+
+
+def gradient_clipping(cfg):
+    """SOLVER.CLIP_GRADIENTS -> HipSGD's `clip` (engine/defaults.py:292-323).  "full_model" is the reference's own
+    FullModelGradientClippingOptimizer (L2 norm over all parameters, enabled only for CLIP_VALUE > 0); every other
+    CLIP_TYPE goes to detectron2's maybe_add_gradient_clipping: "value" / "norm" per parameter (NORM_TYPE 2 only)."""
+    cg = cfg.SOLVER.CLIP_GRADIENTS
+    if not cg.ENABLED:
+        return None
+    kind, value = str(cg.CLIP_TYPE).lower(), float(cg.CLIP_VALUE)
+    if kind == "full_model":
+        return ("full_model", value) if value > 0.0 else None
+    if kind == "value":
+        return ("value", value)
+    if kind == "norm":
+        if float(cg.NORM_TYPE) != 2.0:
+            raise NotImplementedError(f"SOLVER.CLIP_GRADIENTS.NORM_TYPE {cg.NORM_TYPE}: the HIP optimizer clips L2 norms")
+        return ("norm", value)
+    raise NotImplementedError(f"SOLVER.CLIP_GRADIENTS.CLIP_TYPE {cg.CLIP_TYPE!r} (full_model | value | norm)")
 
 
 def wrap_model_with_ddp(model, local_rank, find_unused_parameters=False, bucket_cap_mb=128):

@@ -4,6 +4,7 @@
 C-ABI kernels; torch only carries tensors, streams and the autograd graph.
 """
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -279,7 +280,13 @@ def linear_group(x, heads, joins=None):
     return _LinearGroup.apply(x, (tuple(meta_heads), tuple(runs)), *wb)
 
 
-_WANT_HI = [False]  # set by the ROI heads while training under the "parity" precision (the pooled tensor feeds a dW)
+class _WantHi(threading.local):
+    """Per-thread (as the x3 state): set by the ROI heads while training under the "parity" precision, when the pooled
+    tensor feeds a weight-gradient contraction."""
+    on = False
+
+
+_WANT_HI = _WantHi()
 
 
 class _RoIPool(Function):
@@ -288,7 +295,7 @@ class _RoIPool(Function):
         need_grad = feat.requires_grad
         out, argmax = H.roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=roi_scale,
                                          out_dtype=out_dtype, need_argmax=need_grad,
-                                         want_hi=out_dtype == H.X2 and _WANT_HI[0])
+                                         want_hi=out_dtype == H.X2 and _WANT_HI.on)
         ctx.shape = tuple(feat.shape)
         ctx.cl = not feat.is_contiguous()
         ctx.in_dtype = feat.dtype
@@ -337,7 +344,7 @@ class _RoIAlign(Function):
     @staticmethod
     def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned, roi_scale, out_dtype):
         out = H.roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned,
-                                  roi_scale=roi_scale, out_dtype=out_dtype, want_hi=out_dtype == H.X2 and _WANT_HI[0])
+                                  roi_scale=roi_scale, out_dtype=out_dtype, want_hi=out_dtype == H.X2 and _WANT_HI.on)
         ctx.cfg = (tuple(feat.shape), not feat.is_contiguous(), spatial_scale, sampling_ratio, aligned, feat.dtype)
         ctx.save_for_backward(rois, roi_scale)
         return out

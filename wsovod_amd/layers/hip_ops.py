@@ -123,21 +123,26 @@ def format_rois(boxes, seg_offsets, objectness=None):
     return rois, scale
 
 
-_X2_HI = {}  # data_ptr of a bf16x2 pooler output -> its plain bf16 copy (consumed by the first Linear that reads it)
-
-
 def x2_hi_pop(x):
     """The plain bf16 rounding the pooler wrote next to the bf16x2 tensor `x` (or None): the first FC layer keeps it for
-    its weight-gradient contraction, which would otherwise fetch half lines out of the bf16x2 rows."""
-    hi = _X2_HI.pop(x.data_ptr(), None)
+    its weight-gradient contraction, which would otherwise fetch half lines out of the bf16x2 rows.  The copy rides on
+    the pooled tensor OBJECT (and on the views the box head makes of it: `x2_hi_of`), never on a pointer-keyed table."""
+    hi = x2_hi_of(x)
     return hi if (hi is not None and hi.numel() == x.numel()) else None
 
 
+def x2_hi_of(x):
+    """The bf16 copy attached to `x` or to the tensor `x` is a view of (flatten / view keep `_base`)."""
+    hi = getattr(x, "_x2_hi", None)
+    if hi is None and getattr(x, "_base", None) is not None and x._base.data_ptr() == x.data_ptr() \
+            and x._base.numel() == x.numel():
+        hi = getattr(x._base, "_x2_hi", None)
+    return hi
+
+
 def _x2_hi_alloc(out):
-    if len(_X2_HI) >= 4:  # never consumed (eval mode): do not pile up
-        _X2_HI.clear()
     hi = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
-    _X2_HI[out.data_ptr()] = hi
+    out._x2_hi = hi
     return hi
 
 
@@ -156,21 +161,32 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
-    check(lib().wsovod_roi_pool_forward_x2hi(
+    # scratch for the map's 2x2 maxima (0 bytes: this shape keeps the cell scan; include/wsovod_hip.h)
+    ws_bytes = int(lib().wsovod_roi_pool_workspace_bytes(dtype_code(feat.dtype), layout, R, N, Cc, H, W, ph, pw,
+                                                         int(need_argmax))) if R > 0 else 0
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=feat.device) if ws_bytes > 0 else None
+    check(lib().wsovod_roi_pool_forward_ws(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), ptr(out), fmt_code(out_dtype), ptr(argmax), ptr(hi), stream()), "roi_pool_forward")
+        C.c_float(spatial_scale), ptr(out), fmt_code(out_dtype), ptr(argmax), ptr(hi), ptr(ws), ws_bytes, stream()),
+        "roi_pool_forward")
     return out, argmax
 
 
 def roi_loop_pool_forward(feat, rois, spatial_scale, output_size, context_ratio=1.8):
     """The reference's 3-output ROILoopPool: -> (out (3R,C,ph,pw) fp32 = [region | frame | context], argmax int32)."""
     require_gpu(feat, rois)
+    if feat.dim() == 4 and not feat.is_contiguous(memory_format=torch.channels_last):
+        # the kernel runs channels-per-lane on NHWC maps (the HIP backbone's layout); the reference's NCHW tensors are
+        # brought into it first, as its own op makes its input `.contiguous()` (ROILoopPool_cuda.cu:293)
+        feat = feat.contiguous(memory_format=torch.channels_last)
     layout, N, Cc, Hh, Ww = feature_layout(feat)
+    if layout != NHWC:  # (a 1 x 1 map or one channel is both NCHW- and NHWC-contiguous)
+        layout = NHWC
     rois = _rois_f32(rois)
     ph, pw = output_size
     R = rois.shape[0]
-    out = torch.zeros((3 * R, Cc, ph, pw), dtype=torch.float32, device=feat.device)
-    arg = torch.full((3 * R, Cc, ph, pw), -1, dtype=torch.int32, device=feat.device)
+    out = torch.empty((3 * R, Cc, ph, pw), dtype=torch.float32, device=feat.device)
+    arg = torch.empty((3 * R, Cc, ph, pw), dtype=torch.int32, device=feat.device)
     check(lib().wsovod_roi_loop_pool_forward(ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), R, N, Cc, Hh, Ww, ph,
                                              pw, C.c_float(spatial_scale), C.c_float(context_ratio), ptr(out), ptr(arg),
                                              stream()), "roi_loop_pool_forward")
@@ -907,15 +923,19 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=F
     return out
 
 
-def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
+def sgd_momentum_multi(entries, momentum, grad_scale=1.0, clip=None):
     """entries: list of (param, grad fp32 or bf16, momentum_buf, bf16_shadow or None, lr, weight_decay[, used_flag]);
     one launch per 32.  used_flag: optional 1-element fp32 device tensor, 0 = leave the tensor untouched.
-    A float32-typed shadow is a bf16x2 copy of the parameter (X2 carrier): refreshed as (hi, lo) pairs."""
+    A float32-typed shadow is a bf16x2 copy of the parameter (X2 carrier): refreshed as (hi, lo) pairs.
+    clip: None, or (kind, value) with kind "full_model" (one L2 norm over all entries, engine/defaults.py:292-318),
+    "norm" (detectron2's per-parameter clip_grad_norm_) or "value" (per-parameter clip_grad_value_): the norms and the
+    coefficients min(1, value / (norm + 1e-6)) are computed on the device, nothing is read back."""
     from .._lib import SgdTensor
 
     if not entries:
         return
     arr = (SgdTensor * len(entries))()
+    coef = None
     for d, e in zip(arr, entries):
         p, g, b, sh, lr, wd = e[:6]
         used = e[6] if len(e) > 6 else None
@@ -928,8 +948,24 @@ def sgd_momentum_multi(entries, momentum, grad_scale=1.0):
         d.shadow_is_bf16x2 = 1 if (sh is not None and sh.dtype == torch.float32) else 0
         d.numel, d.lr, d.weight_decay = p.numel(), lr, wd
         d.grad_is_bf16 = 1 if g.dtype == torch.bfloat16 else 0
+    if clip is not None:
+        kind, value = clip
+        if kind == "value":
+            for d in arr:
+                d.clip_value = float(value)
+        elif kind in ("full_model", "norm"):
+            dev = entries[0][0].device
+            ws = torch.empty((int(lib().wsovod_grad_clip_workspace_floats(arr, len(entries))),), dtype=torch.float32, device=dev)
+            coef = torch.empty((len(entries),), dtype=torch.float32, device=dev)
+            check(lib().wsovod_grad_clip_coef(arr, len(entries), C.c_float(grad_scale), C.c_float(value),
+                                              1 if kind == "norm" else 0, ptr(ws), ptr(coef), stream()), "grad_clip_coef")
+            for k, d in enumerate(arr):
+                d.grad_coef = coef.data_ptr() + 4 * k
+        else:
+            raise ValueError(f"sgd_momentum_multi: unknown clip kind {kind!r}")
     check(lib().wsovod_sgd_momentum_multi(arr, len(entries), C.c_float(momentum), C.c_float(grad_scale), stream()),
           "sgd_momentum_multi")
+    return coef
 
 
 def pack_bf16_multi(pairs):

@@ -264,12 +264,12 @@ class WSOVODROIHeads(ROIHeads):
         if self.pooler_type == "ROILoopPool":  # (3R, C, 7, 7) = [region | frame | context], roi_heads.py:727-739
             out = self.box_pooler(feats, [x.proposal_boxes for x in proposals], out_dtype=torch.float32, rois=rois)
             return (out * roi_scale.repeat(3).view(-1, 1, 1, 1)).to(self.compute_dtype)
-        Fn._WANT_HI[0] = self.training and os.environ.get("WSOVOD_X2_HI", "1") != "0"  # (bf16x2 pooling only) a plain bf16 copy for fc1's dW
+        Fn._WANT_HI.on = self.training and os.environ.get("WSOVOD_X2_HI", "1") != "0"  # (bf16x2 pooling only) a plain bf16 copy for fc1's dW
         try:
             return self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
                                    out_dtype=self.pool_dtype, rois=rois)
         finally:
-            Fn._WANT_HI[0] = False
+            Fn._WANT_HI.on = False
 
     def boxes_cat(self, proposals):
         """(sum R, 4) boxes of all images; concatenated once per step (pooling, mining and the box loss read it)."""
