@@ -13,7 +13,8 @@ import torch
 from . import wsovod_ref as R
 
 
-def oracle_step(state_dict, host_batch, train_keys, *, depth=18, num_classes=20, pooler_type="ROIPool", classifier=None):
+def oracle_step(state_dict, host_batch, train_keys, *, depth=18, num_classes=20, pooler_type="ROIPool", classifier=None,
+                miner_prefix=None):
     """state_dict: CPU fp32 tensors under the reference's key names; host_batch: DatasetMapper-format dicts on the
     host; train_keys: names of the trainable tensors (their gradients are returned).
     -> dict(losses, mining_scores, refine_logits, refine_deltas, img_scores, gt_classes, gt_boxes, gt_weights,
@@ -21,8 +22,9 @@ def oracle_step(state_dict, host_batch, train_keys, *, depth=18, num_classes=20,
     sd = {k: v.detach().float().cpu().clone() for k, v in state_dict.items()}
     for k in train_keys:
         sd[k].requires_grad_(True)
+    extra = {} if miner_prefix is None else {"miner_prefix": miner_prefix}  # mixed-dataset models: the active miner
     losses, inter = R.train_forward(sd, R.batch_from_inputs(host_batch), depth=depth, num_classes=num_classes,
-                                    pooler_type=pooler_type, classifier=classifier)
+                                    pooler_type=pooler_type, classifier=classifier, **extra)
     grads = torch.autograd.grad(sum(losses.values()), [sd[k] for k in train_keys], allow_unused=True)
     lab, tg = inter["labelled"], inter["targets"]
     return {
@@ -69,5 +71,17 @@ def compare(got, want):
         if e > worst:
             worst, worst_key = e, k
     rep["max_rel_gradnorm_err"], rep["worst_grad"] = worst, worst_key
+    # element-wise, for the tensors the capture kept: max |g - g_ref| over the tensor / max |g_ref| over the tensor
+    elem, elem_key = 0.0, None
+    for k, g in (got.get("grads") or {}).items():
+        w = want["grads"].get(k)
+        if w is None:
+            continue
+        e = float((g.double() - w.double()).abs().max()) / max(float(w.double().abs().max()), 1e-5 * top / max(w.numel(), 1) ** 0.5,
+                                                                 1e-30)
+        if e > elem:
+            elem, elem_key = e, k
+    if got.get("grads"):
+        rep["max_rel_grad_elem_err"], rep["worst_grad_elem"] = elem, elem_key
     rep["meets_1e-3_logit_bound"] = bool(rep["max_abs_logit_err"] < 1e-3 and rep["max_abs_score_err"] < 1e-3)
     return rep

@@ -169,7 +169,11 @@ def test_full_size_precision_modes_against_the_fp32_path(gpu):
 # ---------------------------------------------------------------------------------------------------------------
 # the configs' own sizes against the oracle (reference: roi_heads.py:696-907, fast_rcnn_open_vocabulary.py:318-367,726-820)
 # ---------------------------------------------------------------------------------------------------------------
-def _oracle_vs_hip(gpu, precision, *, n_images, proposals, classes, depth=18, embed_dim=512, pooler="ROIPool", seed=4321):
+_ORACLE_CACHE = {}  # (n_images, proposals, classes, depth, pooler, seed) -> oracle step: shared by the precisions of one size
+
+
+def _oracle_vs_hip(gpu, precision, *, n_images, proposals, classes, depth=18, embed_dim=512, pooler="ROIPool", seed=4321,
+                   keep_grads_below=2_000_000):
     from oracle import compare as OC
     from wsovod_amd.data import make_batch
     from wsovod_amd.testing import build_hot_path_model, capture_full_step
@@ -185,10 +189,15 @@ def _oracle_vs_hip(gpu, precision, *, n_images, proposals, classes, depth=18, em
     train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
     batch = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
               "height": x["height"], "width": x["width"]} for x in host]
-    got = capture_full_step(model, batch)
+    got = capture_full_step(model, batch, keep_grads_below=keep_grads_below)
     del model
     torch.cuda.empty_cache()
-    want = OC.oracle_step(sd, host, train_keys, depth=depth, num_classes=classes, pooler_type=pooler)
+    key = (n_images, proposals, classes, depth, embed_dim, pooler, seed)
+    if key not in _ORACLE_CACHE:  # (the model is seeded: every precision of a size starts from the same weights)
+        if len(_ORACLE_CACHE) >= 1:
+            _ORACLE_CACHE.clear()
+        _ORACLE_CACHE[key] = OC.oracle_step(sd, host, train_keys, depth=depth, num_classes=classes, pooler_type=pooler)
+    want = _ORACLE_CACHE[key]
     rep = OC.compare(got, want)
     print(f"{precision} WSR_{depth} {n_images} x 800x600 x {proposals} proposals, K={classes}, {pooler} vs oracle:", rep)
     return rep
@@ -216,10 +225,86 @@ def test_parity_mode_matches_the_oracle_at_full_size(gpu):
     """MODEL.HIP.PRECISION = "parity" (the fast tolerance-meeting mode: split forward, bf16 backward): forward
     quantities inside the north star's bound against the oracle at the headline size; gradients of the bf16 grade."""
     rep = _oracle_vs_hip(gpu, "parity", n_images=2, proposals=512, classes=20)
+    _assert_parity_mode(rep)
+
+
+def _assert_parity_mode(rep, elem_tol=3e-2):
+    """The "parity" precision's bar: forward quantities inside the north star's bound, indices exact; the backward runs
+    in plain bf16 on the hi halves, so its gradients carry bf16's grade -- every tensor's norm within 1 % of the oracle's
+    (measured 2e-3), every element of the small tensors within 3 % of the tensor's largest element (measured 3e-3 at the
+    headline size)."""
     assert rep["max_abs_logit_err"] < 1e-3 and rep["max_abs_score_err"] < 1e-3 and rep["max_abs_delta_err"] < 1e-3, rep
-    assert rep["max_rel_loss_err"] < 1e-3, rep
+    assert rep["max_abs_img_score_err"] < 1e-3 and rep["max_rel_loss_err"] < 1e-3, rep
     assert rep["labels_exact"] and rep["label_boxes_exact"] and rep["pgt_exact"], rep
-    assert rep["max_rel_gradnorm_err"] < 0.15, rep
+    assert rep["max_rel_weight_err"] < 1e-3, rep
+    assert rep["max_rel_gradnorm_err"] < 1e-2, rep
+    assert elem_tol is None or rep["max_rel_grad_elem_err"] < elem_tol, rep
+
+
+@pytest.mark.parametrize("precision", ["parity", "fp32"])
+def test_benchmarked_batch_of_32_images_matches_the_oracle(gpu, precision):
+    """The bench's own step -- 32 x 800x600 images x 512 proposals, one training step -- against the oracle on the same
+    weights (~1 min of CPU for the oracle's step, shared by the two precisions): fc1 at M = 16384 rows (64 row tiles,
+    split-K tails of the small layers' dW at this batch), 512-row MIL segments x 32, the backbone on 32 images, the
+    transposed-read dW over 16384 proposals.  parity: the headline precision; fp32: the exact mode."""
+    rep = _oracle_vs_hip(gpu, precision, n_images=32, proposals=512, classes=20)
+    if precision == "fp32":
+        _assert_parity(rep, 2e-3)
+        assert rep["max_rel_grad_elem_err"] < 2e-3, rep
+    else:
+        _assert_parity_mode(rep)
+
+
+def test_config5_wsr50_1024_proposals_1203_classes_matches_the_oracle_at_full_size(gpu):
+    """BASELINE config 5 AT SIZE (reference: meta_arch/rcnn_wsovod_mixed_datasets.py:188-191,237-238): the mixed-dataset
+    model on WSR_50 (fc1 100352 -> 4096), one 800x600 image with 1024 proposals from the LVIS-sized source -- its own
+    object miner with K = 1203 columns, the (1203, 512) text embeddings handed to the refinement head per call, i.e. the
+    region x text GEMM at its only non-trivial size (1024 x 512 x 1204) -- against the oracle, fp32 mode AND the
+    headline precision."""
+    from oracle import compare as OC
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_mixed_model, capture_full_step
+
+    Ks, source_id = (20, 80, 1203), 2
+    host = make_batch(1, 1024, Ks[source_id], seed=555)
+    for x in host:
+        x["dataset_id"] = source_id
+    want = None
+    for precision in ("fp32", "parity"):
+        cfg, model = build_mixed_model(seed=0, names=("voc_2007_train", "coco_2017_train", "lvis_v1_train"), Ks=Ks, depth=50,
+                                       precision=precision, device="cuda:0")
+        assert type(model).__name__ == "GeneralizedRCNN_WSOVOD_MixedDatasets"
+        model.train()
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.eval()
+        model.roi_heads.select_source(source_id)
+        prefix = f"roi_heads.object_miners.{source_id}."
+        sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        train_keys = [k for k, p in model.named_parameters()
+                      if p.requires_grad and (not k.startswith("roi_heads.object_miners.") or k.startswith(prefix))]
+        batch = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
+                  "height": x["height"], "width": x["width"], "dataset_id": source_id} for x in host]
+        got = capture_full_step(model, batch, keep_grads_below=2_000_000)
+        assert got["mining_scores"].shape == (1024, 1203) and got["refine_logits"].shape == (1024, 1204)
+        # the other datasets' miners stay untouched
+        assert all(k.startswith(prefix) for k in got["grad_norms"] if k.startswith("roi_heads.object_miners."))
+        classifier = model.classifier_train[source_id].detach().float().cpu()
+        del model
+        torch.cuda.empty_cache()
+        if want is None:
+            want = OC.oracle_step(sd, host, train_keys, depth=50, num_classes=Ks[source_id], classifier=classifier,
+                                  miner_prefix=prefix)
+        rep = OC.compare(got, want)
+        print(f"config 5 at size, {precision}:", rep)
+        if precision == "fp32":
+            _assert_parity(rep, 2e-3)
+        else:
+            # one image, a 1203-way mining softmax at random initialisation: `fc2.bias.grad` is a sum over 1024 rows that
+            # cancels to ~1e-3 of its terms (the exact-fp32 mode itself is off by 2.7e-3 of the largest element there,
+            # 1000x its usual error), so bf16-grade terms move single elements by up to ~20 % of the largest one while
+            # every tensor's norm agrees to 1.3e-3: gated on the norms; the element-wise figure is printed above
+            _assert_parity_mode(rep, elem_tol=None)
 
 
 def test_config4_wsr50_1024_proposals_matches_the_oracle_at_full_size(gpu):
@@ -236,7 +321,7 @@ def test_roi_align_v2_matches_the_oracle_at_full_size(gpu):
 def test_bf16_mode_deviation_from_the_oracle_at_full_size(gpu):
     """The timed precision (bf16) against the oracle at the headline size: what it misses the bound by, kept honest."""
     rep = _oracle_vs_hip(gpu, "bf16", n_images=2, proposals=512, classes=20)
-    assert rep["max_abs_logit_err"] < 0.5 and rep["max_abs_score_err"] < 2e-2 and rep["max_rel_loss_err"] < 5e-2, rep
+    assert rep["max_abs_logit_err"] < 0.15 and rep["max_abs_score_err"] < 2e-3 and rep["max_rel_loss_err"] < 5e-2, rep
     assert rep["max_abs_logit_err"] > 1e-3  # plain bf16 does NOT meet the north star's bound: keep saying so
 
 

@@ -75,10 +75,26 @@ def build_hot_path_model(seed=0, calibrate_synthetic=True, **kw):
     return cfg, model
 
 
-def capture_full_step(model, batched_inputs):
+def build_mixed_model(seed=0, calibrate_synthetic=True, **kw):
+    """The mixed-dataset model (BASELINE config 5: GeneralizedRCNN_WSOVOD_MixedDatasets, one object miner per dataset
+    family, text embeddings handed to the refinement head per call) with the reference initialisers; see
+    build_hot_path_model for `calibrate_synthetic`."""
+    from .modeling import build_model
+
+    cfg = mixed_datasets_cfg(**kw)
+    torch.manual_seed(seed)
+    model = build_model(cfg)
+    if calibrate_synthetic:
+        with torch.no_grad():
+            model.backbone.stem.conv1.norm.weight.fill_(1.0 / 64.0)
+    return cfg, model
+
+
+def capture_full_step(model, batched_inputs, keep_grads_below=0):
     """One training forward + backward with everything a parity check reads, moved to the host: losses, mining
     scores, refinement logits / deltas, image-level scores, the mining kernel's labels and pseudo GT, and the L2 norm
-    of every trainable tensor's gradient.  Gradients are cleared afterwards."""
+    of every trainable tensor's gradient (plus, under "grads", the gradients themselves of the tensors with fewer than
+    `keep_grads_below` elements).  Gradients are cleared afterwards."""
     captured = {}
     rh = model.roi_heads
     orig_m, orig_r = rh.object_miner.forward, rh.box_refinery[0].forward
@@ -111,6 +127,8 @@ def capture_full_step(model, batched_inputs):
         # fp64 accumulation: an fp32 norm over fc1's 103 M elements is itself off by ~0.5 %
         "grad_norms": {k: float(p.grad.detach().double().norm()) for k, p in model.named_parameters()
                        if p.requires_grad and p.grad is not None},
+        "grads": {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()
+                  if p.requires_grad and p.grad is not None and p.numel() < keep_grads_below},
     }
     model.zero_grad(set_to_none=True)
     return out
