@@ -208,6 +208,10 @@ typedef struct {
    * output is never written, rounded or re-read as a residual.  NULL = off. */
   const void* A2;
   int Cin2;
+  /* optional DEVICE scalar added to dropout_seed when the kernel runs: the part of the seed that changes from step to
+   * step (box_head.py: the training-step counter) kept in memory, so that a captured HIP graph of the training step draws
+   * a new mask at every replay although its kernel arguments are frozen.  NULL = dropout_seed alone. */
+  const unsigned long long* dropout_seed_add;
 } wsovod_gemm_desc;
 
 int wsovod_gemm_nt(const wsovod_gemm_desc* desc_host, wsovod_stream_t stream);

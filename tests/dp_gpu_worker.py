@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-STEPS, LR = 3, 1e-4
+STEPS, LR = 5, 1e-4  # (the whole-step HIP graph takes over on the third step: two eager steps, a capture, two replays)
 
 
 def sample(t, n=65536):

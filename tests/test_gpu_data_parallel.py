@@ -71,9 +71,9 @@ def test_two_ranks_real_model_bf16_wire_equals_averaged_single_process(gpu):
         if not v.requires_grad:
             continue
         want = W.sample(v)
-        # one bf16 rounding per rank gradient + one of their sum: |dw| <= steps * lr * 2^-7 * |g| = 2.3e-6 |g|, and the
-        # largest gradient elements of this model are ~4 (measured 4.3e-6 on one element of fc1.weight)
-        torch.testing.assert_close(a["sample"][k], want, rtol=0, atol=1e-5, msg=lambda m: f"{k}: {m}")
+        # one bf16 rounding per rank gradient + one of their sum: |dw| <= steps * lr * 2^-7 * |g| = 3.9e-6 |g| over the
+        # five steps, and the largest gradient elements of this model are ~4
+        torch.testing.assert_close(a["sample"][k], want, rtol=0, atol=2e-5, msg=lambda m: f"{k}: {m}")
         moved += 1
     assert moved >= 15
 

@@ -1,5 +1,8 @@
-"""The frozen backbone as a captured HIP graph (small batches; opt-in, set by the overlapped trainer): replays must be
-bit-identical to the eager launches, per input, across weight changes, in both kernel precisions that have a fused stem."""
+"""Captured HIP graphs at small batches (the reference's own 1 - 2 images per GPU are host-bound): the frozen backbone
+alone (opt-in, `forward_uint8(allow_graph=True)`), and the WHOLE training step -- frozen forward, heads, backward, fused
+SGD -- through HotPathTrainer.  Replays must reproduce the eager launches: bit for bit where the eager path itself is
+bit-reproducible (the backbone, the dropout masks, every integer output), to the eager path's own run-to-run jitter
+elsewhere (a few reductions meet by float atomics)."""
 import pytest
 import torch
 
@@ -28,10 +31,14 @@ def test_backbone_graph_replay_equals_eager(gpu, precision):
 
     def run(inp):
         canvas, sizes_t, _ = model._canvas(inp)
-        return bb.forward_uint8(canvas, sizes_t, model._mean, model._std)["res5"]
+        return bb.forward_uint8(canvas, sizes_t, model._mean, model._std, allow_graph=True)["res5"]
 
     eager = [run(b).clone() for b in batches]
     bb.graph_max_batch = 8
+    canvas, sizes_t, _ = model._canvas(batches[0])  # without allow_graph (inference, TTA): always fresh eager tensors
+    for _ in range(bb.GRAPH_AFTER + 1):
+        assert torch.equal(bb.forward_uint8(canvas, sizes_t, model._mean, model._std)["res5"], eager[0])
+    assert not bb.__dict__.get("_graphs") and not bb.__dict__.get("_graph_seen")
     try:
         for _ in range(bb.GRAPH_AFTER - 1):  # a shape is captured on its third call
             assert torch.equal(run(batches[0]), eager[0]) and not bb.__dict__.get("_graphs")
@@ -73,6 +80,7 @@ def test_trainer_steps_with_backbone_graph_equal_eager_steps(gpu, monkeypatch):
     from wsovod_amd.testing import build_hot_path_model
 
     hist = {}
+    monkeypatch.setenv("WSOVOD_STEP_GRAPH", "0")  # (the whole-step graph would take over: tested below)
     for flag in ("0", "1"):
         monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", flag)
         cfg, model = build_hot_path_model(seed=0, precision="bf16", device="cuda:0")
@@ -87,3 +95,133 @@ def test_trainer_steps_with_backbone_graph_equal_eager_steps(gpu, monkeypatch):
     for a, b in zip(hist["0"], hist["1"]):  # up to the run-to-run jitter of the float atomics in the loss / gradient
         for k in a:                          # sums (two eager runs differ by the same last bits)
             assert abs(a[k] - b[k]) <= 1e-4 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "parity"])
+@pytest.mark.parametrize("shape", [(300, 256), (512, 4096)])
+def test_dropout_step_term_on_the_device_draws_the_host_seeds_mask(gpu, precision, shape):
+    """The dropout seed of a layer is base + 16 * step: with the step term in device memory (`seed_add`, what a captured
+    graph replays against) the kernels draw exactly the mask of the host-computed seed -- both GEMM tiles, both modes."""
+    from wsovod_amd.layers import functions as Fn
+    from wsovod_amd.layers import hip_ops as H
+
+    M, N = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, 512, generator=g).to(gpu)
+    w = (torch.randn(N, 512, generator=g) * 0.05).to(gpu)
+    b = torch.randn(N, generator=g).to(gpu)
+    step = torch.tensor([16 * 7], dtype=torch.int64, device=gpu)
+    base = 0x1234567 * 1000003 + 1
+    with H.x3_mode("x2" if precision == "parity" else False):
+        xin = H.x2_encode(x) if precision == "parity" else x.to(torch.bfloat16)
+        od = H.X2 if precision == "parity" else None
+        a = Fn.linear(xin, w, b, relu=True, dropout_p=0.5, seed=base + 16 * 7, out_dtype=od)
+        c = Fn.linear(xin, w, b, relu=True, dropout_p=0.5, seed=base, out_dtype=od, seed_add=step)
+        other = Fn.linear(xin, w, b, relu=True, dropout_p=0.5, seed=base + 16 * 8, out_dtype=od)
+    assert torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a, c.view(torch.int32) if c.dtype == torch.float32 else c)
+    assert not torch.equal(a, other)
+    step.add_(16)
+    with H.x3_mode("x2" if precision == "parity" else False):
+        d = Fn.linear(xin, w, b, relu=True, dropout_p=0.5, seed=base, out_dtype=od, seed_add=step)
+    assert torch.equal(d, other)
+
+
+def _varying_batches(n_steps, nums_list, K=20, H=320, W=416):
+    """One batch per step, every step other images / boxes / labels; the per-image proposal counts follow `nums_list`
+    (same total: the layout a step graph is keyed on)."""
+    from wsovod_amd.data import make_batch
+
+    out = []
+    for s in range(n_steps):
+        nums = nums_list[s % len(nums_list)]
+        big = make_batch(len(nums), max(nums), K, H=H, W=W, seed=100 + s)
+        for x, n in zip(big, nums):
+            x["proposals"] = x["proposals"][:n]
+        out.append(big)
+    return out
+
+
+@pytest.mark.parametrize("precision", ["bf16", "parity"])
+def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision):
+    """HotPathTrainer at 2 images per step, dropout ON, eight steps on eight different batches whose per-image proposal
+    counts change from step to step (same total): with the whole-step HIP graph (captured on the third step, replayed
+    from then on) against WSOVOD_STEP_GRAPH=0.  Every integer output -- per-proposal labels, pseudo-GT indices -- is
+    equal step by step, the losses agree to the eager path's own jitter (float atomics in a few reductions; weight-gradient
+    tails kept in fixed order here), and so do the trained parameters: same dropout masks, same updates, same data."""
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.engine.trainer import _StepGraph
+    from wsovod_amd.layers import hip_ops as H
+    from wsovod_amd.testing import build_hot_path_model
+
+    monkeypatch.setattr(H, "DETERMINISTIC", True)
+    monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", "0")
+    batches = _varying_batches(8, [(64, 64), (60, 68), (70, 58), (33, 95)])
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WSOVOD_STEP_GRAPH", flag)
+        cfg, model = build_hot_path_model(seed=0, precision=precision, device="cuda:0")
+        model.train()
+        cfg.SOLVER.BASE_LR = 1e-3
+        tr = HotPathTrainer(model, build_optimizer(cfg, model))
+        hist = []
+        for b in batches:
+            losses = tr.run_step(b)
+            pgt = model.roi_heads._last_pgt
+            t = int(sum(len(torch.unique(x["instances"].gt_classes)) for x in b))
+            hist.append(({k: float(v.detach()) for k, v in losses.items()}, pgt["gt_classes"].cpu().clone(),
+                         pgt["pgt_index"][:t].cpu().clone(), pgt["pgt_classes"][:t].cpu().clone()))
+        if flag == "1":
+            assert [type(g) for g in tr._graphs.values()] == [_StepGraph]  # one layout, one graph, five replays
+            assert model.roi_heads.box_head._step == len(batches) and tr.iter == len(batches)
+            assert int(model.roi_heads.box_head._step_dev) == 16 * len(batches)
+        else:
+            assert not tr._graphs
+        tr.flush()
+        runs[flag] = (hist, {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
+        tr.close()
+    for s, (e, g) in enumerate(zip(runs["0"][0], runs["1"][0])):
+        assert torch.equal(e[1], g[1]) and torch.equal(e[2], g[2]) and torch.equal(e[3], g[3]), s
+        for k in e[0]:
+            assert abs(e[0][k] - g[0][k]) <= 2e-5 * max(abs(e[0][k]), 1e-3), (s, k, e[0][k], g[0][k])
+    for k, v in runs["0"][1].items():
+        torch.testing.assert_close(runs["1"][1][k], v, rtol=1e-5, atol=2e-6 * float(v.abs().max()) + 1e-9, msg=lambda m: f"{k}: {m}")
+
+
+def test_step_graph_falls_back_and_respects_its_limits(gpu, monkeypatch):
+    """A layout is captured on its third sighting; another total proposal count is another graph; nine images stay
+    eager; state_dict() between replays sees the applied update; a failing capture leaves the layout on the eager path
+    (remembered, not retried) with the step still executed."""
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.engine import trainer as T
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, precision="bf16", device="cuda:0")
+    model.train()
+    cfg.SOLVER.BASE_LR = 1e-3
+    tr = HotPathTrainer(model, build_optimizer(cfg, model))
+    a = _varying_batches(5, [(48, 48)], H=256, W=320)
+    for i, b in enumerate(a):
+        tr.run_step(b)
+        assert len(tr._graphs) == (1 if i >= 2 else 0)
+    before = model.state_dict()["roi_heads.box_head.fc2.bias"].clone()
+    tr.run_step(a[0])
+    assert not torch.equal(before, model.state_dict()["roi_heads.box_head.fc2.bias"])  # the replayed update is visible
+    for b in _varying_batches(3, [(40, 40)], H=256, W=320):
+        tr.run_step(b)
+    assert len(tr._graphs) == 2
+    nine = _varying_batches(1, [(8,) * 9], H=256, W=320)[0]
+    for _ in range(4):
+        losses = tr.run_step(nine)
+    assert len(tr._graphs) == 2 and all(torch.isfinite(v) for v in losses.values())
+
+    def boom(self, *a_, **k_):
+        raise RuntimeError("capture refused")
+
+    monkeypatch.setattr(T._StepGraph, "_capture", boom)
+    c = _varying_batches(4, [(30, 34)], H=256, W=320)
+    with pytest.warns(UserWarning, match="capture of the training step failed"):
+        for b in c[:3]:
+            losses = tr.run_step(b)
+    assert all(torch.isfinite(v) for v in losses.values()) and list(tr._graphs.values()).count(False) == 1
+    tr.run_step(c[3])  # remembered: no second attempt, no second warning
+    tr.close()

@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("conv", C.c_int), ("geom", ConvGeom),
         ("tile_hint", C.c_int), ("prof_tag", C.c_int),
         ("A2", C.c_void_p), ("Cin2", C.c_int),
+        ("dropout_seed_add", C.c_void_p),
     ]
 
 

@@ -419,6 +419,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   // staging, so lane (frow, fq) holds, for row tile i, output row m = .. + frow and the 4*TN consecutive columns
   // n = ncol + 4*j + r: row-major outputs move as 16-byte stores, 16*TN contiguous elements per row and wavefront.
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  [[maybe_unused]] const unsigned long long dseed = p.dropout_p > 0.f ? WS_DROPOUT_SEED(p) : 0ull;
   const bool vec_c = p.C && (p.dtype_c == WSOVOD_BF16X2 ? vec4_ok(p.C, p.ldc, p.dtype_c)
                                                         : (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0);
   const bool vec_r = !p.residual || (p.dtype_r == WSOVOD_BF16X2 ? vec4_ok(p.residual, p.ldr, p.dtype_r)
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
         if (drop) {
           const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[j][r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;
+          for (int r = 0; r < 4; ++r) x[j][r] = uniform01(dseed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;
         }
       }
       if (p.dtype_c == WSOVOD_BF16X2) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
           if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
           if (p.relu) x = fmaxf(x, 0.f);
           if (p.dropout_p > 0.f) {
-            const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+            const float u = uniform01(dseed, (unsigned long long)m * (unsigned long long)p.N + n);
             x = u >= p.dropout_p ? x * keep_scale : 0.f;
           }
           if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
@@ -1685,6 +1686,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   a.relu = d->relu;
   a.dropout_p = d->dropout_p;
   a.seed = d->dropout_seed;
+  a.seed_add = d->dropout_seed_add;
   a.row_group = d->row_group;
   a.group_add = d->group_add;
   a.ld_ga = d->ld_ga;
@@ -1824,6 +1826,11 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     // projection shapes: 6.63 -> 6.14, 1.12 -> 1.03, 0.274 -> 0.263 ms against the four-phase form, tools/x2_probe.py);
     // the implicit-GEMM convs stay on the 16-wavefront tile (res5: 2.32 vs 2.40 ms)
     if (!d->tile_hint && tile == 256256 && !d->conv) tile = 2256256;
+    // few rows, long K (fc1 at 1-4 images per step): the same tile with split-K, as for plain bf16 above -- a 64x64 grid
+    // re-reads the 411-MB bf16x2 weight through L2 eight times over (M = 512: 0.80 ms at 130 TFLOP/s algorithmic)
+    if (!d->tile_hint && !d->conv && d->M >= 256 && d->N >= 256 && d->K >= 8192 &&
+        (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
+      tile = 2256256;
     return d->conv ? dispatch_tile_x3<true>(a, tile, s, flops, bytes) : dispatch_tile_x3<false>(a, tile, s, flops, bytes);
   }
   if (d->dtype_in == WSOVOD_BF16)

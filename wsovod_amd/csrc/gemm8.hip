@@ -408,6 +408,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     return;
   }
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
+  [[maybe_unused]] const unsigned long long dseed = p.dropout_p > 0.f ? WS_DROPOUT_SEED(p) : 0ull;
   const bool vec_c = p.C && (p.dtype_c == WSOVOD_BF16X2 ? vec4_ok(p.C, p.ldc, p.dtype_c)
                                                         : (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0);
   const int ncol = n0 + wc * 64 + 16 * fq;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
         if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
         if (p.relu) x = fmaxf(x, 0.f);
         if (p.dropout_p > 0.f) {
-          const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+          const float u = uniform01(dseed, (unsigned long long)m * (unsigned long long)p.N + n);
           x = u >= p.dropout_p ? x * keep_scale : 0.f;
         }
         if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       if (drop) {                                                                                             \
         const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);     \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
-            x[j][r] = uniform01(p.seed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;                 \
+            x[j][r] = uniform01(dseed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;                 \
       }                                                                                                       \
     }                                                                                                         \
     if (p.dtype_c == WSOVOD_BF16X2) { /* 16 consecutive values: 32 B of hi, 32 B of lo one half-line further */  \
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) 
 
 int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops, double bytes, bool allow_split, bool x3,
                        bool merged) {
-  allow_split = (allow_split || a.ksplit == -1) && !x3;  // -1: the dispatcher chose this tile itself (no tile_hint)
+  allow_split = allow_split || a.ksplit == -1;  // -1: the dispatcher chose this tile itself (no tile_hint)
   static int slot_g = wsovod::prof_slot("gemm_nt_bf16_256x256_8ph");
   static int slot_c = wsovod::prof_slot("conv_igemm_bf16_256x256_8ph");
   static int slot_g3 = wsovod::prof_slot("gemm_nt_bf16x2_256x256_8ph");

@@ -24,6 +24,7 @@ struct GemmArgs {
   int relu;
   float dropout_p;
   unsigned long long seed;
+  const unsigned long long* seed_add;  // optional device scalar added to `seed` (a step counter kept on the device)
   const int* row_group;
   const float* group_add;
   long long ld_ga;
@@ -128,6 +129,10 @@ __device__ __forceinline__ bool vec4_ok(const void* p, long long ld, int dtype) 
   return (ld & 31) == 0 && ((uintptr_t)p & 15) == 0;  // bf16x2: whole 32-value groups per row
 }
 
+// the dropout seed of this launch: the host part plus, when given, the device-resident step term (a captured HIP graph
+// replays with the same kernel arguments: the part of the seed that changes per step lives in memory)
+#define WS_DROPOUT_SEED(p) ((p).seed_add ? (p).seed + *(p).seed_add : (p).seed)
+
 // splitmix64 finaliser: counter-based, stateless dropout mask on (seed, m, n)
 __device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long ctr) {
   unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (ctr + 1);
@@ -153,7 +158,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, int m, int nb
     if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
     if (p.relu) x = fmaxf(x, 0.f);
     if (p.dropout_p > 0.f) {
-      const float u = uniform01(p.seed, (unsigned long long)m * (unsigned long long)p.N + n);
+      const float u = uniform01(WS_DROPOUT_SEED(p), (unsigned long long)m * (unsigned long long)p.N + n);
       x = u >= p.dropout_p ? x * keep_scale : 0.f;
     }
     if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];

@@ -7,6 +7,8 @@ parameter update itself is the fused HIP kernel `wsovod_sgd_momentum`; gradient 
 torch DistributedDataParallel over RCCL ("nccl" backend on ROCm) -- the only collective on the path.
 """
 import os
+import warnings
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -126,6 +128,226 @@ def run_step(model, optimizer, data, iter_size=1, it=0):
     return loss_dict
 
 
+class _StepMeta:
+    """The per-step index data of a captured training step, as STATIC device buffers refilled before every replay:
+    per-image segment offsets of the proposals, the row -> image map, and the image-level labels of
+    get_image_level_gt (roi_heads.py:158-174) -- concatenated sorted-unique classes, their offsets, the one-hot
+    matrix.  One pinned staging buffer and one asynchronous H2D copy per step."""
+
+    MAX_CLASSES_PER_IMAGE = 128  # == kMaxPgt of the mining kernel
+
+    def __init__(self, n_img, rows, num_classes, device):
+        self.n, self.rows, self.K = n_img, rows, num_classes
+        self.t_cap = n_img * min(num_classes, self.MAX_CLASSES_PER_IMAGE)
+        lay, off = {}, 0
+        for name, count, dt in (("gt_cat", self.t_cap, torch.int64), ("onehot", n_img * num_classes, torch.float32),
+                                ("seg", n_img + 1, torch.int32), ("gt_off", n_img + 1, torch.int32),
+                                ("row_group", rows, torch.int32)):
+            lay[name] = (off, count, dt)
+            off += (count * torch.empty((), dtype=dt).element_size() + 15) // 16 * 16
+        self.nbytes = off
+        self.dev = torch.zeros((off,), dtype=torch.uint8, device=device)
+        self.host = [torch.zeros((off,), dtype=torch.uint8).pin_memory() for _ in range(4)]
+        self.events = [None] * len(self.host)
+        self.k = 0
+        self.lay = lay
+        self.seg, self.gt_off = self._view(self.dev, "seg"), self._view(self.dev, "gt_off")
+        self.row_group, self.gt_cat = self._view(self.dev, "row_group"), self._view(self.dev, "gt_cat")
+        self.onehot = self._view(self.dev, "onehot").view(n_img, num_classes)
+        self.nums = None
+
+    def _view(self, buf, name):
+        off, count, dt = self.lay[name]
+        return buf[off:off + count * torch.empty((), dtype=dt).element_size()].view(dt)
+
+    def image_level_gt(self):
+        return self.gt_cat, self.gt_off, self.onehot
+
+    def overrides(self):
+        """{(values, dtype): static tensor} for hip_ops.const_override while the step is captured (fill() came first)."""
+        offs = [0]
+        for n in self.nums:
+            offs.append(offs[-1] + n)
+        rg = tuple(i for i, n in enumerate(self.nums) for _ in range(n))
+        return {(tuple(offs), torch.int32): self.seg, (rg, torch.int32): self.row_group}
+
+    def fill(self, batched_inputs):
+        """Host side of one step: returns False when this batch does not fit the captured layout."""
+        nums = [len(x["proposals"]) for x in batched_inputs]
+        if len(nums) != self.n or sum(nums) != self.rows:
+            return False
+        cls = []
+        for x in batched_inputs:
+            gc = x["instances"].gt_classes
+            if gc.is_cuda:
+                return False
+            cls.append(torch.unique(gc, sorted=True).to(torch.int64))
+        if any(len(u) > self.MAX_CLASSES_PER_IMAGE for u in cls) or sum(len(u) for u in cls) > self.t_cap:
+            return False
+        k = self.k
+        self.k = (k + 1) % len(self.host)
+        if self.events[k] is not None:
+            self.events[k].synchronize()  # (the copy issued four steps ago)
+        h = self.host[k]
+        h.zero_()
+        seg, goff = self._view(h, "seg"), self._view(h, "gt_off")
+        rg, cat = self._view(h, "row_group"), self._view(h, "gt_cat")
+        oh = self._view(h, "onehot").view(self.n, self.K)
+        r = t = 0
+        for i, (n, u) in enumerate(zip(nums, cls)):
+            rg[r:r + n] = i
+            r += n
+            seg[i + 1] = r
+            cat[t:t + len(u)] = u
+            t += len(u)
+            goff[i + 1] = t
+            oh[i, u] = 1.0
+        self.dev.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        self.nums = nums
+        return True
+
+
+class _StepGraph:
+    """One training step of the hot path as captured HIP graph(s) for one input layout (images per step, canvas size,
+    total proposals): at the reference's own per-GPU batch (1 - 2 images, Base-RCNN-DilatedC5.yaml:61,65) the step is
+    bound by the host issuing ~150 launches, not by the device.
+
+    world == 1: ONE graph = frozen forward + heads forward + backward + fused SGD update.
+    world  > 1: TWO graphs split at the exchange wait -- G1 = the frozen forward (replayed while the previous step's
+    gradients are on the wire), then the host waits for the exchange and launches the SGD update on the reduced wire
+    slices eagerly (one kernel; `flush()` between steps keeps its meaning), G2 = heads forward + backward + gradient
+    pack; the collectives themselves are issued eagerly after G2 (never captured).
+
+    Static inputs, refilled before a replay: the uint8 image canvas, the concatenated proposal boxes / objectness, and the
+    index data of _StepMeta.  The dropout mask advances through a device-resident step term (box_head.py), the mining
+    kernel reads its segment and label ranges from memory, SGD is one launch: nothing in the step needs a host value."""
+
+    def __init__(self, trainer, batched_inputs, key):
+        self.key = key
+        self.tr = weakref.proxy(trainer)
+        model = trainer.model
+        dev = model.device
+        imgs = [x["image"] for x in batched_inputs]
+        n = len(imgs)
+        self.canvas = torch.empty((n,) + tuple(imgs[0].shape), dtype=torch.uint8, device=dev)
+        nums = [len(x["proposals"]) for x in batched_inputs]
+        rows = sum(nums)
+        self.boxes = torch.zeros((rows, 4), dtype=torch.float32, device=dev)
+        self.objectness = torch.zeros((rows,), dtype=torch.float32, device=dev)
+        self.meta = _StepMeta(n, rows, model.roi_heads.num_classes, dev)
+        self.losses = None
+        self.graphs = []
+        self.fresh = False
+        self._capture(batched_inputs, nums)
+
+    # ---- inputs ----
+    def _load(self, batched_inputs):
+        from ..modeling.meta_arch import GeneralizedRCNN_WSOVOD as M
+
+        if not self.meta.fill(batched_inputs):
+            return False
+        imgs = [x["image"] for x in batched_inputs]
+        adj = M._adjacent(imgs) if imgs[0].is_cuda else None
+        if adj is not None:
+            self.canvas.copy_(adj, non_blocking=True)
+        else:
+            for i, im in enumerate(imgs):
+                self.canvas[i].copy_(im, non_blocking=True)
+        r = 0
+        for x in batched_inputs:
+            p = x["proposals"]
+            m = len(p)
+            self.boxes[r:r + m].copy_(p.proposal_boxes.tensor, non_blocking=True)
+            self.objectness[r:r + m].copy_(p.objectness_logits, non_blocking=True)
+            r += m
+        return True
+
+    def _static_batch(self, batched_inputs, nums):
+        from ..structures import Boxes, Instances
+
+        out, r = [], 0
+        for i, (x, m) in enumerate(zip(batched_inputs, nums)):
+            props = Instances(x["proposals"].image_size, proposal_boxes=Boxes(self.boxes[r:r + m]),
+                              objectness_logits=self.objectness[r:r + m])
+            d = {"image": self.canvas[i], "proposals": props, "instances": x["instances"]}
+            for k in ("height", "width", "dataset_id"):
+                if k in x:
+                    d[k] = x[k]
+            out.append(d)
+            r += m
+        return out
+
+    # ---- capture ----
+    def _capture(self, batched_inputs, nums):
+        tr, model = self.tr, self.tr.model
+        split = tr.exchange
+        tr._finish_pending()  # the previous (eager) step's update lands first: the capture starts from clean state
+        if not self._load(batched_inputs):
+            raise RuntimeError("the batch does not fit the static input layout")
+        static = self._static_batch(batched_inputs, nums)
+        for m in model.modules():  # the device-resident step term must exist BEFORE the capture (its fill is not replayed)
+            if hasattr(m, "_step_term"):
+                m._step_term(model.device)
+        dw = [(p, getattr(p, "_dw_split", None)) for p in tr.params]
+        for p, _ in dw:  # the early weight-gradient block launches a collective from inside backward: not under capture
+            p._dw_split = None
+        model._step_meta = self.meta
+        try:
+            with H.const_override(self.meta.overrides()):
+                if split:
+                    g1 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g1, capture_error_mode="thread_local"):
+                        st = model.forward_frozen(static)
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, pool=g1.pool(), capture_error_mode="thread_local"):
+                        loss_dict = model.forward_trainable(st)
+                        tr._backward(loss_dict, capturing=True)
+                        self.blocks = tr._exchange_bf16(pack_only=True)
+                    self.wire = [(p, p._wire_grad) for p in tr.params]  # re-attached after every replay
+                    self.graphs = [g1, g2]
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        st = model.forward_frozen(static)
+                        loss_dict = model.forward_trainable(st)
+                        tr._backward(loss_dict, capturing=True)
+                        tr.optimizer.step()
+                        tr.optimizer.zero_grad(set_to_none=True)
+                    self.graphs = [g]
+        finally:
+            model._step_meta = None
+            for p, v in dw:
+                p._dw_split = v
+        self.losses = {k: v.detach() for k, v in loss_dict.items()}
+        del st, loss_dict
+        self.fresh = True  # the Python side of this step (counters, version stamps) ran during the capture
+
+    # ---- one step ----
+    def step(self, batched_inputs):
+        tr = self.tr
+        if self.fresh:
+            self.fresh = False  # inputs were loaded for the capture; the capture itself executed nothing
+        else:
+            if not self._load(batched_inputs):
+                return None
+            tr._graph_bookkeeping()
+        if len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()  # frozen forward, while the previous step's gradients are still on the wire
+            tr._finish_pending()     # wait for the exchange, SGD on the reduced wire slices (one eager launch)
+            self.graphs[1].replay()
+            for p, sl in self.wire:
+                p._wire_grad = sl
+            tr._pending = [tr._reduce_block(lo, hi) for lo, hi in self.blocks]
+            if not tr.overlap:
+                tr._wait_pending()
+        return self.losses
+
+
 class HotPathTrainer:
     """Data-parallel training loop of the hot path with the gradient exchange hidden behind compute.
 
@@ -209,6 +431,9 @@ class HotPathTrainer:
         bb = getattr(model, "backbone", None)
         if bb is not None and hasattr(bb, "graph_max_batch") and os.environ.get("WSOVOD_BACKBONE_GRAPH", "1") != "0":
             bb.graph_max_batch = 8
+        # the WHOLE step as captured HIP graph(s) at small batches (WSOVOD_STEP_GRAPH=0: eager launches + backbone graph)
+        self.graph_max_batch = 8 if os.environ.get("WSOVOD_STEP_GRAPH", "1") != "0" else 0
+        self._graphs, self._graph_seen = {}, {}
         self.iter = int(start_iter)  # the reference's global iteration (engine/trainer.py:72-84): pass it when resuming
         if self.iter_size < 1:
             raise ValueError(f"iter_size must be >= 1, got {iter_size}")
@@ -229,10 +454,20 @@ class HotPathTrainer:
             optimizer.grad_scale = 1.0 / self.world
         # model.inference() between steps (EvalHook, TTA wrappers call it directly, past any forward hook) applies the
         # pending update first
+        # (a weak reference: a deepcopy / pickle / torch.save of the model must not drag the trainer, the optimizer and the
+        # process-group handles along)
+        ref = weakref.ref(self)
+
+        def _pre_inference():
+            t = ref()
+            if t is not None:
+                t.synchronize()
+
         try:
-            model._pre_inference = self.synchronize
+            model._pre_inference = _pre_inference
+            self._pre_inference_hook = _pre_inference
         except Exception:  # noqa: BLE001 -- a stand-in model without attribute assignment
-            pass
+            self._pre_inference_hook = None
 
     def close(self):
         """Apply the pending update and detach from the model / optimizer (state-dict hooks, inference hook)."""
@@ -244,7 +479,8 @@ class HotPathTrainer:
         if bb is not None and hasattr(bb, "graph_max_batch"):
             bb.graph_max_batch = 0
             bb.__dict__.pop("_graphs", None)
-        if getattr(self.model, "_pre_inference", None) == self.synchronize:
+        self._graphs.clear()
+        if getattr(self.model, "_pre_inference", None) is getattr(self, "_pre_inference_hook", None):
             self.model._pre_inference = None
 
     def broadcast_parameters(self, src=0):
@@ -288,12 +524,21 @@ class HotPathTrainer:
             p._used_flag = None
         self._reset_wire()
 
+    def _wait_pending(self):
+        if self._pending is not None:
+            for work in self._pending:
+                if work is not None:
+                    work.wait()
+            self._pending = [None] * len(self._pending)  # waited for, update not applied yet
+
     def _finish_pending(self):
         if self._pending is None:
             return
-        for work in self._pending:
-            if work is not None:
-                work.wait()
+        self._wait_pending()
+        self._apply_update()
+
+    def _apply_update(self):
+        """The optimizer step on the exchanged gradients (everything _finish_pending does after the waits)."""
         if self._used is not None and not isinstance(self.optimizer, HipSGD):
             # a torch optimizer skips `grad is None`: restore that for tensors no rank touched (host read of a few flags;
             # the HIP optimizer reads the flags on the device instead)
@@ -404,7 +649,9 @@ class HotPathTrainer:
         H.sum_shards_bf16(recv[lo:hi], n, m)
         return dist.all_gather_into_tensor(flat[lo:hi], m, async_op=True)
 
-    def _exchange_bf16(self):
+    def _exchange_bf16(self, pack_only=False):
+        """pack_only (a captured step graph): only the gradient pack is enqueued; returns the [(lo, hi)] blocks of the
+        wire buffer whose collectives the caller issues (eagerly, after the graph's replay)."""
         flat, slices = self._wire_slices()
         pairs = []
         early, head = self._early, 0
@@ -427,27 +674,131 @@ class HotPathTrainer:
         H.pack_bf16_multi(pairs)
         for p in self.params:  # the fp32 gradients are dead once packed (stream-ordered free): the update reads the slices
             p.grad = None
+        if pack_only:
+            assert early is None
+            head = self._split[2] if self._split is not None else 0
+            return [(0, head), (head, flat.numel())] if head else [(0, flat.numel())]
         if self._split is not None and early is None:
             # the early block did not come (e.g. a non-TN contraction): keep the collective sequence of the other ranks
             head = self._split[2]
             early = self._reduce_block(0, head)
         return [early, self._reduce_block(head, flat.numel())] if head else [self._reduce_block(0, flat.numel())]
 
-    def run_step(self, data):
-        st = self.model.forward_frozen(data)
-        self._finish_pending()
-        loss_dict = self.model.forward_trainable(st)
-        # d(sum of the loss dict / iter_size): one backward pass from the loss tensors themselves with a cached seed --
-        # the same gradients as `sum(loss_dict.values()).backward()` without the adds, the division and the ones_like
+    def _backward(self, loss_dict, capturing=False):
+        """d(sum of the loss dict / iter_size): one backward pass from the loss tensors themselves with a cached seed --
+        the same gradients as `sum(loss_dict.values()).backward()` without the adds, the division and the ones_like.
+        capturing (a step graph is being recorded): the gradients are taken with autograd.grad and assigned, not
+        accumulated -- an AccumulateGrad node kept alive from an EARLIER iteration (somebody still holds that step's loss
+        tensors) belongs to the default stream and would pull work out of the capture."""
         roots = [v for v in loss_dict.values() if v.requires_grad]  # (a constant term has nothing to differentiate)
+        if not roots:
+            raise RuntimeError("HotPathTrainer: no term of the loss dict requires grad (is every parameter frozen, or was "
+                               "the forward run under no_grad?): nothing to differentiate")
         seed = self._seed
         if seed is None or seed.device != roots[0].device or seed.dtype != roots[0].dtype:
             seed = self._seed = torch.full((), 1.0 / self.iter_size, dtype=roots[0].dtype, device=roots[0].device)
+        if capturing:
+            grads = torch.autograd.grad(roots, self.params, [seed.expand_as(r) for r in roots], allow_unused=True)
+            for p, g in zip(self.params, grads):
+                p.grad = g
+            return
         torch.autograd.backward(roots, [seed.expand_as(r) for r in roots])
+
+    # ---- whole-step HIP graphs (small batches) ----
+    GRAPH_AFTER = 3  # eager steps with a layout before it is captured (the first ones fill caches and allocator pools)
+    GRAPH_CACHE = 4
+
+    def _graph_key(self, data):
+        m = self.model
+        if not (self.graph_max_batch and 0 < len(data) <= self.graph_max_batch and self.iter_size == 1
+                and not self.reduce_unused and isinstance(self.optimizer, HipSGD)
+                and getattr(m, "proposal_generator", True) is None and hasattr(m, "forward_frozen")
+                and (not self.exchange or self.grad_wire == "bf16")):
+            return None
+        x0 = data[0]
+        if "proposals" not in x0 or "instances" not in x0 or not torch.is_tensor(x0.get("image")):
+            return None
+        shape = tuple(x0["image"].shape)
+        if any(tuple(x["image"].shape) != shape or x["image"].dtype != torch.uint8 for x in data):
+            return None
+        if not m.device.type == "cuda" or H.x3_active() or torch.cuda.is_current_stream_capturing():
+            return None
+        from .._lib import PROFILING
+
+        if PROFILING[0]:  # the per-launch profiler needs the launches
+            return None
+        return (len(data), shape, sum(len(x["proposals"]) for x in data), m.roi_heads.num_classes, self.exchange_algo,
+                m.training)
+
+    def _graph_for(self, data):
+        key = self._graph_key(data)
+        if key is None or not key[-1]:
+            return None
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graph_seen) > 64:
+                self._graph_seen.clear()
+            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
+            if self._graph_seen[key] < self.GRAPH_AFTER:
+                return None
+            if len(self._graphs) >= self.GRAPH_CACHE:
+                self._graphs.pop(next(iter(self._graphs)))
+            snap = self._counters()
+            try:
+                g = _StepGraph(self, data, key)
+            except Exception as e:  # noqa: BLE001 -- out of memory in the graph's pool, an API call refused under capture
+                warnings.warn(f"wsovod_amd: HIP graph capture of the training step failed for layout {key} "
+                              f"({type(e).__name__}: {e}); this layout keeps the eager launches")
+                self._restore_counters(snap)
+                for p in self.params:
+                    p.grad = None
+                g = False
+            self._graphs[key] = g
+        return g or None
+
+    def _counters(self):
+        mods = [m for m in self.model.modules() if hasattr(m, "_step_term")]
+        return ([(m, m._step) for m in mods], self.model.roi_heads.iter)
+
+    def _restore_counters(self, snap):
+        for m, v in snap[0]:
+            m._step = v
+        self.model.roi_heads.iter = snap[1]
+
+    def _graph_bookkeeping(self):
+        """The host-side state one eager step advances, mirrored for a replay (no Python model code runs then): the
+        dropout step counters (their device terms advance inside the graph), the heads' iteration, the parameters'
+        version counters (caches keyed on them) and the stamps of the shadows the SGD kernel refreshed."""
+        rh = self.model.roi_heads
+        rh.iter += 1
+        for m in self._counters()[0]:
+            m[0]._step += 1
+        for p in self.params:
+            sh = getattr(p, "_hip_shadow", None)
+            xe = getattr(p, "_x2_enc", None)
+            stamped = sh is not None and sh[1] == p._version
+            stamped_x = xe is not None and xe[0] == (p._version, p.data_ptr(), None)
+            torch.autograd.graph.increment_version(p)
+            if stamped:
+                p._hip_shadow = (sh[0], p._version)
+            if stamped_x:
+                p._x2_enc = ((p._version, p.data_ptr(), None), xe[1])
+
+    def run_step(self, data):
+        g = self._graph_for(data)
+        if g is not None:
+            out = g.step(data)
+            if out is not None:
+                self.iter += 1
+                return out
+        st = self.model.forward_frozen(data)
+        self._finish_pending()
+        loss_dict = self.model.forward_trainable(st)
+        self._backward(loss_dict)
         step_now = self.iter % self.iter_size == 0
         self.iter += 1
         if not step_now:  # gradients keep accumulating in p.grad; nothing goes on the wire
-            return loss_dict
+            return {k: v.detach() for k, v in loss_dict.items()}
         works = []
         if self.exchange and self.reduce_unused:
             works.append(self._exchange_used_flags())
@@ -462,7 +813,8 @@ class HotPathTrainer:
         self._pending = works
         if not self.overlap:
             self._finish_pending()
-        return loss_dict
+        # (detached: the step's autograd graph dies here whatever the caller keeps)
+        return {k: v.detach() for k, v in loss_dict.items()}
 
     def flush(self):
         """Apply the update of the last run_step (waits for its gradient exchange)."""

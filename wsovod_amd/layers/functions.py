@@ -66,17 +66,18 @@ class _Linear(Function):
     kernel straight from the bf16x2 x)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype):
+    def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype, seed_add=None):
         ctx.x2 = _x2_mode()
         ctx.y_x2 = out_dtype == H.X2
         x_hi = None
         if ctx.x2:
             y = H.gemm_nt(x, H.x2_cached(weight), x2=True, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
-                          out_dtype=out_dtype)
+                          dropout_seed_add=seed_add, out_dtype=out_dtype)
             x_hi = H.x2_hi_pop(x)  # the pooler's plain bf16 copy of x, if it wrote one: the operand of dW
         else:
             wq = weight_shadow(weight, x.dtype)
-            y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, out_dtype=out_dtype)
+            y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, dropout_seed_add=seed_add,
+                          out_dtype=out_dtype)
         ctx.relu, ctx.dropout_p = relu, dropout_p
         ctx.save_for_backward(x if x_hi is None else x_hi.view(x.shape), weight, y if (relu or dropout_p > 0) else None)
         ctx.x_is_hi = x_hi is not None
@@ -134,12 +135,14 @@ class _Linear(Function):
         if need_dx:
             wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
             dx = H.gemm_nt(dA, wt, out_dtype=in_dtype)  # (M,K)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=None):
-    """out_dtype: a torch dtype, or hip_ops.X2 for a bf16x2 output ("parity" precision; the default there is fp32)."""
-    return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype)
+def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=None, seed_add=None):
+    """out_dtype: a torch dtype, or hip_ops.X2 for a bf16x2 output ("parity" precision; the default there is fp32).
+    seed_add: optional 1-element int64 DEVICE tensor added to `seed` inside the kernel (the per-step term of the dropout
+    seed kept in memory, so that a captured HIP graph draws a fresh mask at every replay)."""
+    return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype, seed_add)
 
 
 class _LinearGroup(Function):

@@ -4,6 +4,7 @@ Every function enqueues on torch's current HIP stream and never synchronises.  T
 CPU fallback: CPU tensors or a missing library raise RuntimeError.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -14,9 +15,36 @@ from .._lib import BF16, BF16X2, F32, NCHW, NHWC, GemmDesc, check, dtype_code, l
 _CONST_CACHE = {}
 
 
+class _ConstOverride(threading.local):
+    """While a training step is being CAPTURED as a HIP graph (engine/trainer.py:_StepGraph), the index tensors that
+    change from step to step (per-image segment offsets, row -> image map) must be the graph's static input buffers, not
+    value-keyed constants: the capture registers {(values, dtype): static tensor} here for its own thread."""
+    table = None
+
+
+_OVERRIDE = _ConstOverride()
+
+
+class const_override:
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        self.prev, _OVERRIDE.table = _OVERRIDE.table, self.table
+        return self
+
+    def __exit__(self, *exc):
+        _OVERRIDE.table = self.prev
+        return False
+
+
 def const_tensor(values, dtype, device):
     """Small constant index tensors (segment offsets, sizes, row->image maps) keyed by value: built and
     copied to the device once, so steady-state steps issue no tiny blocking H2D copies."""
+    if _OVERRIDE.table is not None:
+        t = _OVERRIDE.table.get((tuple(values), dtype))
+        if t is not None:
+            return t
     key = (tuple(values), dtype, str(device))
     t = _CONST_CACHE.get(key)
     if t is None:
@@ -409,7 +437,7 @@ def _ld(t):
 def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=None, bias=None, residual=None,
             relu=False, dropout_p=0.0, dropout_seed=0, row_group=None, group_add=None, mask_src=None,
             mask_scale=1.0, accumulate=False, M=None, N=None, K=None, conv=None, tile_hint=0, want_c=True, A2=None,
-            x2=False, residual_x2=False):
+            x2=False, residual_x2=False, dropout_seed_add=None):
     """C[M][N] = epilogue(sum_k A[m][k]*B[n][k]); see include/wsovod_hip.h for the epilogue order.
 
     A: (M,K) or, with `conv` (a dict of geometry), the NHWC input tensor.  B: (N,K).
@@ -428,7 +456,8 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
             raise RuntimeError("bf16x3: explicit M/N/K overrides / a fused shortcut input are not supported")
         return _gemm_nt_x3(A, B, conv=conv, out=out, out_dtype=out_dtype or torch.float32, out_t=out_t, alpha=alpha,
                            row_scale=row_scale, bias=bias, residual=residual, relu=relu, dropout_p=dropout_p,
-                           dropout_seed=dropout_seed, row_group=row_group, group_add=group_add, mask_src=mask_src,
+                           dropout_seed=dropout_seed, dropout_seed_add=dropout_seed_add, row_group=row_group,
+                           group_add=group_add, mask_src=mask_src,
                            mask_scale=mask_scale, accumulate=accumulate, tile_hint=tile_hint, want_c=want_c)
     d = GemmDesc()
     d.dtype_in = BF16X2 if x2 else dtype_code(B.dtype)
@@ -473,6 +502,10 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
         d.dtype_r = BF16X2 if residual_x2 else dtype_code(residual.dtype)
     d.relu = int(bool(relu))
     d.dropout_p, d.dropout_seed = float(dropout_p), int(dropout_seed)
+    if dropout_seed_add is not None:  # a 1-element int64 device tensor: the step term of the seed (graph-replayable)
+        require_gpu(dropout_seed_add)
+        assert dropout_seed_add.dtype == torch.int64 and dropout_seed_add.numel() == 1
+        d.dropout_seed_add = dropout_seed_add.data_ptr()
     if group_add is not None:
         d.row_group, d.group_add, d.ld_ga = row_group.data_ptr(), group_add.data_ptr(), _ld(group_add)
     if mask_src is not None:
@@ -899,6 +932,10 @@ def rpn_label_anchors(anchors, gt_boxes, gt_start, gt_count, thr_lo, thr_hi):
 
 
 GEMM_TN_MAX_OPERAND_BYTES = (1 << 31) - 1  # one buffer resource per operand (tests lower it to exercise the row blocks)
+# WSOVOD_DETERMINISTIC=1: weight-gradient tails / small grids are NOT cut along the reduction (their slices would meet by
+# fp32 atomic adds in no fixed order): every dW is then run-to-run bit-identical, at ~3 % of the step.  The default keeps
+# the split (wsovod_gemm_tn, include/wsovod_hip.h); the bias-gradient and loss sums still meet by a few float atomics.
+DETERMINISTIC = __import__("os").environ.get("WSOVOD_DETERMINISTIC", "0") == "1"
 
 
 def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=False):
@@ -906,6 +943,7 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=F
     contraction over the operands' slow index, no transposed copies (transposed LDS reads).
     split_tail=False keeps a partial last round of tiles unsplit (fixed summation order, bit-reproducible)."""
     require_gpu(P, Q, out)
+    split_tail = split_tail and not DETERMINISTIC
     # q_x2: Q is a bf16x2 matrix (fp32-typed carrier); the kernel reads the hi halves = Q rounded to bf16
     assert P.dtype == torch.bfloat16 and Q.dtype == (torch.float32 if q_x2 else torch.bfloat16) and P.shape[0] == Q.shape[0]
     Mred, NI, NJ = P.shape[0], P.shape[1], Q.shape[1]

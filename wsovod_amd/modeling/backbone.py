@@ -415,10 +415,13 @@ class ResNet(nn.Module):
             return self._run(self.stem(xn))
 
     @torch.no_grad()
-    def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
-        """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM."""
+    def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std, allow_graph=False):
+        """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM.
+        allow_graph: the caller consumes the maps before its next call with this shape (the training step's frozen
+        forward): small batches may then come from a captured HIP graph, whose outputs are that graph's STATIC buffers
+        -- overwritten by the next replay.  inference() / TTA keep the eager launches (fresh tensors)."""
         with H.x3_mode({"bf16x3": "full", "bf16x3f": "fwd", "parity": "x2"}.get(self.precision, False)):
-            if self.graph_max_batch and images_u8.is_cuda and images_u8.size(0) <= self.graph_max_batch:
+            if allow_graph and self.graph_max_batch and images_u8.is_cuda and images_u8.size(0) <= self.graph_max_batch:
                 g = self._graph_for(images_u8, sizes, pixel_mean, pixel_std)
                 if g is not None:
                     return g(images_u8)
@@ -444,7 +447,7 @@ class ResNet(nn.Module):
             return None
         fp = self._graph_fingerprint()
         cache = self.__dict__.setdefault("_graphs", {})
-        if cache and next(iter(cache.values())).fingerprint != fp:
+        if any(v and v.fingerprint != fp for v in cache.values()):
             cache.clear()  # a weight changed (load_state_dict, broadcast): the folded copies the graphs point at are stale
         key = (tuple(images_u8.shape), sizes.data_ptr(), tuple(pixel_mean), tuple(pixel_std), H.x3_active())
         g = cache.get(key)
@@ -459,8 +462,16 @@ class ResNet(nn.Module):
                 return None
             if len(cache) >= self.GRAPH_CACHE:
                 cache.pop(next(iter(cache)))
-            g = cache[key] = _BackboneGraph(self, images_u8, sizes, pixel_mean, pixel_std, fp)
-        return g
+            try:
+                g = _BackboneGraph(self, images_u8, sizes, pixel_mean, pixel_std, fp)
+            except Exception as e:  # noqa: BLE001 -- out of memory in the graph's pool, an API call refused under capture
+                import warnings
+
+                warnings.warn(f"wsovod_amd: HIP graph capture of the frozen backbone failed for input shape "
+                              f"{tuple(images_u8.shape)} ({type(e).__name__}: {e}); this shape keeps the eager launches")
+                g = False  # remembered: never retried for this key
+            cache[key] = g
+        return g or None
 
     def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         self._check_frozen()
@@ -515,7 +526,9 @@ class _BackboneGraph:
                 net._forward_uint8(self.static_in, sizes, pixel_mean, pixel_std)
         main.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: a HIP call from another thread (a DataLoader's pin-memory thread, an eval thread) during the
+        # capture -- it happens mid-training, on the third sighting of a shape -- must not abort it
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = net._forward_uint8(self.static_in, sizes, pixel_mean, pixel_std)
 
     def __call__(self, images_u8):

@@ -48,11 +48,22 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
         # data-parallel rank (read at the first training forward, the process group may not exist yet), the step
         # counter advances in training mode only and can be restored with `set_step(iteration)` on resume.
         self._step = 0
+        self._step_dev = None
         self._cfg_seed = int(seed)
         self.dropout_seed = None
 
     def set_step(self, iteration: int):
         self._step = int(iteration)
+        if self._step_dev is not None:
+            self._step_dev.fill_(16 * self._step)
+
+    def _step_term(self, device):
+        """16 x (training step) as a 1-element int64 DEVICE tensor, advanced by an in-stream add at every training
+        forward: the kernels add it to the layer's base seed, so eager launches and replays of a captured step graph
+        (frozen kernel arguments) draw the same mask for the same step."""
+        if self._step_dev is None or self._step_dev.device != device:
+            self._step_dev = torch.full((1,), 16 * self._step, dtype=torch.int64, device=device)
+        return self._step_dev
 
     def _base_seed(self):
         if self.dropout_seed is None:
@@ -72,15 +83,23 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
     def forward(self, x):
         if x.dim() > 2:
             x = torch.flatten(x, start_dim=1)
+        step_term = None
         if self.training:
+            if x.is_cuda:
+                step_term = self._step_term(x.device)  # (created, if need be, from the step count BEFORE this forward)
+                step_term.add_(16)  # in stream order: part of a captured step graph as well
             self._step += 1
         for k, fc in enumerate(self.fcs):
             drop = getattr(self, "fc_dropout{}".format(k + 1))
             p = drop.p if (self.training and drop.training) else 0.0
-            seed = (self._base_seed() * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
+            # seed = base * 1000003 + 16 * step + layer; on the device path the step term is added by the kernel
+            if step_term is not None:
+                seed = (self._base_seed() * 1000003 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
+            else:
+                seed = (self._base_seed() * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
             # "parity" precision: x arrives as bf16x2 (the pooler wrote it) and every FC hands bf16x2 on
             x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed,
-                          out_dtype=H.X2 if H.x3_active() == "x2" else None)
+                          out_dtype=H.X2 if H.x3_active() == "x2" else None, seed_add=step_term if p > 0 else None)
         return x
 
     @property

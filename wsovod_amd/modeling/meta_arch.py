@@ -151,8 +151,12 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             proposals = [Instances.cat([p1, p2]) for p1, p2 in zip(proposals, loaded)]
         return proposals
 
+    _step_meta = None  # set while a whole-step HIP graph is captured: the image-level labels are static input buffers
+
     def _image_level_gt(self, batched_inputs):
         """get_image_level_gt (roi_heads.py:158-174) on the host copies: no device sync."""
+        if self._step_meta is not None:
+            return self._step_meta.image_level_gt()
         K = self.roi_heads.num_classes
         cls_list, oh = [], torch.zeros((len(batched_inputs), K), dtype=torch.float32)
         for i, x in enumerate(batched_inputs):
@@ -211,7 +215,7 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             # would block the host until the stream drains).
             st["gt_instances"] = [x["instances"] if st["image_level_gt"] is not None else x["instances"].to(self.device)
                                   for x in batched_inputs]
-        features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std)
+        features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std, allow_graph=True)
         st["features"] = features
         st["proposals"] = self._proposals(batched_inputs) if "proposals" in batched_inputs[0] else None
         st["gaps"] = self.data_aware_head.pooled_stats(features) if self.data_aware_head is not None else None
