@@ -363,12 +363,14 @@ int wsovod_weighted_ce_forward(const float* logits, long long ld, int M, int K1,
                                float* dlogits, long long ldd, float* accum2, float* loss,
                                wsovod_stream_t stream);
 /* Weighted smooth-L1 box loss, class-agnostic deltas (fast_rcnn_open_vocabulary.py:822-892):
- * dpred receives d loss / d pred_deltas (already divided by max(M,1)). */
+ * dpred receives d loss / d pred_deltas (already divided by the row count).  rows_true: optional DEVICE scalar with the
+ * number of REAL rows when the M rows include padding (labels -1) behind the last image's proposals -- a captured step
+ * graph runs on a bucketed row count and must normalise by the step's own; NULL = M. */
 int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, const float* proposal_boxes,
                                    const float* gt_boxes, const long long* gt_classes,
                                    const float* weights, int M, int K, const float* bbox_weights_host,
                                    float beta, int weighted, float* dpred, float* accum2, float* loss,
-                                   wsovod_stream_t stream);
+                                   const int* rows_true, wsovod_stream_t stream);
 
 /* Weight-gradient contraction over the SLOW index of two row-major bf16 operands (no transposed copies):
  *   C[i][j] (+)= alpha * sum_m P[m][i] * Q[m][j],   P (Mred, NI) row stride ldp, Q (Mred, NJ) row stride ldq, C fp32.

@@ -144,7 +144,7 @@ def _varying_batches(n_steps, nums_list, K=20, H=320, W=416):
 @pytest.mark.parametrize("precision", ["bf16", "parity"])
 def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision):
     """HotPathTrainer at 2 images per step, dropout ON, eight steps on eight different batches whose per-image proposal
-    counts change from step to step (same total): with the whole-step HIP graph (captured on the third step, replayed
+    counts AND totals change from step to step (inside one row bucket): with the whole-step HIP graph (captured on the third step, replayed
     from then on) against WSOVOD_STEP_GRAPH=0.  Every integer output -- per-proposal labels, pseudo-GT indices -- is
     equal step by step, the losses agree to the eager path's own jitter (float atomics in a few reductions; weight-gradient
     tails kept in fixed order here), and so do the trained parameters: same dropout masks, same updates, same data."""
@@ -155,7 +155,9 @@ def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision
 
     monkeypatch.setattr(H, "DETERMINISTIC", True)
     monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", "0")
-    batches = _varying_batches(8, [(64, 64), (60, 68), (70, 58), (33, 95)])
+    # totals 128 / 120 / 113 / 97: one bucket of 128 rows (trainer.row_bucket) -- the graph runs the short steps with
+    # padding rows behind the last image (an empty box, label -1, zero gradient, the box loss normalised by the real count)
+    batches = _varying_batches(8, [(64, 64), (60, 60), (70, 43), (33, 64)])
     runs = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("WSOVOD_STEP_GRAPH", flag)
@@ -168,7 +170,9 @@ def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision
             losses = tr.run_step(b)
             pgt = model.roi_heads._last_pgt
             t = int(sum(len(torch.unique(x["instances"].gt_classes)) for x in b))
-            hist.append(({k: float(v.detach()) for k, v in losses.items()}, pgt["gt_classes"].cpu().clone(),
+            rows = sum(len(x["proposals"]) for x in b)
+            assert bool((pgt["gt_classes"][rows:] == -1).all()) and bool((pgt["gt_weights"][rows:] == 0).all())
+            hist.append(({k: float(v.detach()) for k, v in losses.items()}, pgt["gt_classes"][:rows].cpu().clone(),
                          pgt["pgt_index"][:t].cpu().clone(), pgt["pgt_classes"][:t].cpu().clone()))
         if flag == "1":
             assert [type(g) for g in tr._graphs.values()] == [_StepGraph]  # one layout, one graph, five replays
@@ -206,7 +210,10 @@ def test_step_graph_falls_back_and_respects_its_limits(gpu, monkeypatch):
     before = model.state_dict()["roi_heads.box_head.fc2.bias"].clone()
     tr.run_step(a[0])
     assert not torch.equal(before, model.state_dict()["roi_heads.box_head.fc2.bias"])  # the replayed update is visible
-    for b in _varying_batches(3, [(40, 40)], H=256, W=320):
+    for b in _varying_batches(3, [(40, 40)], H=256, W=320):  # 80 rows: the same 128-row bucket, the same graph
+        tr.run_step(b)
+    assert len(tr._graphs) == 1
+    for b in _varying_batches(3, [(100, 92)], H=256, W=320):  # 192 rows: another bucket, another graph
         tr.run_step(b)
     assert len(tr._graphs) == 2
     nine = _varying_batches(1, [(8,) * 9], H=256, W=320)[0]
@@ -218,7 +225,7 @@ def test_step_graph_falls_back_and_respects_its_limits(gpu, monkeypatch):
         raise RuntimeError("capture refused")
 
     monkeypatch.setattr(T._StepGraph, "_capture", boom)
-    c = _varying_batches(4, [(30, 34)], H=256, W=320)
+    c = _varying_batches(4, [(150, 150)], H=256, W=320)
     with pytest.warns(UserWarning, match="capture of the training step failed"):
         for b in c[:3]:
             losses = tr.run_step(b)

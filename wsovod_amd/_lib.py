@@ -86,7 +86,7 @@ SIGNATURES = {
     "wsovod_image_bce_forward": [_P, _P, _I, _I, _P, _F, _P, _P, _P, _P],
     "wsovod_image_bce_backward": [_P, _P, _I, _I, _P, _P, _P],
     "wsovod_weighted_ce_forward": [_P, _L, _I, _I, _P, _P, _I, _P, _L, _P, _P, _P],
-    "wsovod_weighted_l1_box_forward": [_P, _L, _P, _P, _P, _P, _I, _I, _P, _F, _I, _P, _P, _P, _P],
+    "wsovod_weighted_l1_box_forward": [_P, _L, _P, _P, _P, _P, _I, _I, _P, _F, _I, _P, _P, _P, _P, _P],
     "wsovod_mask_transpose": [_P, _L, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P],
     "wsovod_mask_transpose_colsum": [_P, _L, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P, _P],
     "wsovod_add_group_rows": [_P, _L, _I, _P, _P, _L, _I, _I, _P, _L, _P],

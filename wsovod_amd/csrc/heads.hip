@@ -275,10 +275,10 @@ __global__ void weighted_l1_kernel(const float* __restrict__ pred, long long ldp
     if (b != 0.f) atomicAdd(accum + 1, b);
   }
 }
-__global__ void l1_finalize_kernel(const float* __restrict__ accum, int M, float* __restrict__ loss,
-                                   float* __restrict__ dpred) {
+__global__ void l1_finalize_kernel(const float* __restrict__ accum, int M, const int* __restrict__ rows_true,
+                                   float* __restrict__ loss, float* __restrict__ dpred) {
   const bool bad = accum[1] > 0.f;
-  const float inv = 1.0f / (float)max(M, 1);
+  const float inv = 1.0f / (float)max(rows_true ? *rows_true : M, 1);
   if (blockIdx.x == 0 && threadIdx.x == 0) loss[0] = bad ? 0.f : accum[0] * inv;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (long long)M * 4;
        i += (long long)gridDim.x * blockDim.x)
@@ -673,7 +673,7 @@ int wsovod_weighted_ce_forward(const float* logits, long long ld, int M, int K1,
 int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, const float* proposal_boxes,
                                    const float* gt_boxes, const long long* gt_classes, const float* weights, int M,
                                    int K, const float* bbox_weights_host, float beta, int weighted, float* dpred,
-                                   float* accum2, float* loss, wsovod_stream_t stream) {
+                                   float* accum2, float* loss, const int* rows_true, wsovod_stream_t stream) {
   WS_CHECK_ARG(accum2 && loss && bbox_weights_host, "wsovod_weighted_l1_box_forward: null pointer");
   static int slot = wsovod::prof_slot("weighted_l1_box");
   hipStream_t s = (hipStream_t)stream;
@@ -686,7 +686,8 @@ int wsovod_weighted_l1_box_forward(const float* pred_deltas, long long ldp, cons
                        gt_boxes, gt_classes, weights, M, K, bbox_weights_host[0], bbox_weights_host[1],
                        bbox_weights_host[2], bbox_weights_host[3], beta, weighted, dpred, accum2);
   }
-  hipLaunchKernelGGL(l1_finalize_kernel, dim3(std::max(1, ceil_div(M * 4, 256))), dim3(256), 0, s, accum2, M, loss, dpred);
+  hipLaunchKernelGGL(l1_finalize_kernel, dim3(std::max(1, ceil_div(M * 4, 256))), dim3(256), 0, s, accum2, M, rows_true, loss,
+                     dpred);
   WS_CHECK_LAUNCH("wsovod_weighted_l1_box_forward");
   return WSOVOD_OK;
 }

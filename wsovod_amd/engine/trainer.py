@@ -163,18 +163,24 @@ class _StepMeta:
     def image_level_gt(self):
         return self.gt_cat, self.gt_off, self.onehot
 
-    def overrides(self):
-        """{(values, dtype): static tensor} for hip_ops.const_override while the step is captured (fill() came first)."""
+    def overrides(self, nums):
+        """{(values, dtype): static tensor} for hip_ops.const_override while the step is captured.  `nums`: the per-image
+        row counts the model code sees during the capture (the last image carries the padding rows up to the bucket)."""
         offs = [0]
-        for n in self.nums:
+        for n in nums:
             offs.append(offs[-1] + n)
-        rg = tuple(i for i, n in enumerate(self.nums) for _ in range(n))
+        rg = tuple(i for i, n in enumerate(nums) for _ in range(n))
         return {(tuple(offs), torch.int32): self.seg, (rg, torch.int32): self.row_group}
+
+    @property
+    def rows_true(self):
+        """1-element int32 view of seg[G] = the step's REAL row count (<= the bucket the graph runs on)."""
+        return self.seg[self.n:self.n + 1]
 
     def fill(self, batched_inputs):
         """Host side of one step: returns False when this batch does not fit the captured layout."""
         nums = [len(x["proposals"]) for x in batched_inputs]
-        if len(nums) != self.n or sum(nums) != self.rows:
+        if len(nums) != self.n or sum(nums) > self.rows or min(nums) <= 0:
             return False
         cls = []
         for x in batched_inputs:
@@ -234,7 +240,8 @@ class _StepGraph:
         n = len(imgs)
         self.canvas = torch.empty((n,) + tuple(imgs[0].shape), dtype=torch.uint8, device=dev)
         nums = [len(x["proposals"]) for x in batched_inputs]
-        rows = sum(nums)
+        rows = trainer.row_bucket(sum(nums))  # the graph runs on this many rows; the steps' own totals may be anything below
+        self.rows = rows
         self.boxes = torch.zeros((rows, 4), dtype=torch.float32, device=dev)
         self.objectness = torch.zeros((rows,), dtype=torch.float32, device=dev)
         self.meta = _StepMeta(n, rows, model.roi_heads.num_classes, dev)
@@ -263,12 +270,18 @@ class _StepGraph:
             self.boxes[r:r + m].copy_(p.proposal_boxes.tensor, non_blocking=True)
             self.objectness[r:r + m].copy_(p.objectness_logits, non_blocking=True)
             r += m
+        if r < self.rows:  # padding rows: an empty box of the last image, objectness 0 (finite features, label -1)
+            self.boxes[r:].zero_()
+            self.objectness[r:].zero_()
         return True
 
     def _static_batch(self, batched_inputs, nums):
         from ..structures import Boxes, Instances
 
         out, r = [], 0
+        nums = list(nums)
+        nums[-1] += self.rows - sum(nums)  # the model code of the capture sees the padding rows as the last image's
+        self.capture_nums = nums
         for i, (x, m) in enumerate(zip(batched_inputs, nums)):
             props = Instances(x["proposals"].image_size, proposal_boxes=Boxes(self.boxes[r:r + m]),
                               objectness_logits=self.objectness[r:r + m])
@@ -296,7 +309,7 @@ class _StepGraph:
             p._dw_split = None
         model._step_meta = self.meta
         try:
-            with H.const_override(self.meta.overrides()):
+            with H.const_override(self.meta.overrides(self.capture_nums)), H.tail_rows(self.meta.rows_true):
                 if split:
                     g1 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1, capture_error_mode="thread_local"):
@@ -727,8 +740,21 @@ class HotPathTrainer:
 
         if PROFILING[0]:  # the per-launch profiler needs the launches
             return None
-        return (len(data), shape, sum(len(x["proposals"]) for x in data), m.roi_heads.num_classes, self.exchange_algo,
-                m.training)
+        rh = m.roi_heads
+        rows = self.row_bucket(sum(len(x["proposals"]) for x in data))
+        # every row is kept by the refinement sampling (no random sub-sample inside the step): the shipped hot-path setting
+        if not getattr(rh, "sampling_on", False) or rows > min(rh.batch_size_per_images[:rh.refine_K] or [0]) \
+                or any(f < 1.0 for f in rh.positive_sample_fractions[:rh.refine_K]):
+            return None
+        return (len(data), shape, rows, rh.num_classes, self.exchange_algo, m.training)
+
+    @staticmethod
+    def row_bucket(rows):
+        """The row count a step graph runs on: the total proposal count rounded up to a bucket (1/8 of the power of two
+        below it, at least 64: <= 12 % padding rows, which ride along as an empty box with label -1)."""
+        rows = max(int(rows), 1)
+        step = max(64, (1 << (rows.bit_length() - 1)) // 8)
+        return (rows + step - 1) // step * step
 
     def _graph_for(self, data):
         key = self._graph_key(data)

@@ -420,13 +420,14 @@ class _MilScores(Function):
         scores, P, Q = H.mil_forward(logits2k, seg_offsets, K)
         ctx.save_for_backward(P, Q, seg_offsets)
         ctx.K = K
+        ctx.tail = H.tail_rows_active() is not None  # (the backward runs on autograd's thread: no thread-local there)
         return scores
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dscores):
         P, Q, seg = ctx.saved_tensors
-        return H.mil_backward(dscores, P, Q, seg, ctx.K), None, None
+        return H.mil_backward(dscores, P, Q, seg, ctx.K, tail=ctx.tail), None, None
 
 
 def mil_scores(logits2k, seg_offsets, K):
@@ -440,6 +441,7 @@ class _ImageBCE(Function):
         loss, img, dS = H.image_bce_forward(scores, seg_offsets, labels_onehot, norm)
         ctx.save_for_backward(dS, seg_offsets)
         ctx.M = scores.size(0)
+        ctx.tail = H.tail_rows_active() is not None
         ctx.mark_non_differentiable(img)
         return loss.view(()), img
 
@@ -447,7 +449,7 @@ class _ImageBCE(Function):
     @once_differentiable
     def backward(ctx, gout, _gimg):
         dS, seg = ctx.saved_tensors
-        return H.image_bce_backward(dS, seg, ctx.M, gout.reshape(1).contiguous()), None, None, None
+        return H.image_bce_backward(dS, seg, ctx.M, gout.reshape(1).contiguous(), tail=ctx.tail), None, None, None
 
 
 def image_bce(scores, seg_offsets, labels_onehot, norm):

@@ -38,6 +38,40 @@ class const_override:
         return False
 
 
+class _TailRows(threading.local):
+    """A captured step graph runs on a BUCKETED row count: behind the last image's proposals sit padding rows that belong
+    to no segment.  While this is set (to the 1-element int32 device tensor holding the step's REAL row count), the fronts
+    below allocate what the segment kernels leave untouched as zeros / ignore labels, so that a padding row carries a zero
+    gradient and label -1, and row-count normalisers read the real count from memory."""
+    rows_true = None
+
+
+_TAIL = _TailRows()
+
+
+class tail_rows:
+    def __init__(self, rows_true):
+        self.rows_true = rows_true
+
+    def __enter__(self):
+        self.prev, _TAIL.rows_true = _TAIL.rows_true, self.rows_true
+        return self
+
+    def __exit__(self, *exc):
+        _TAIL.rows_true = self.prev
+        return False
+
+
+def tail_rows_active():
+    return _TAIL.rows_true
+
+
+def _alloc(shape, dtype, device, tail=None):
+    """torch.empty, or zeros when padding rows must read as zero."""
+    return (torch.zeros if (tail if tail is not None else _TAIL.rows_true is not None) else torch.empty)(
+        shape, dtype=dtype, device=device)
+
+
 def const_tensor(values, dtype, device):
     """Small constant index tensors (segment offsets, sizes, row->image maps) keyed by value: built and
     copied to the device once, so steady-state steps issue no tiny blocking H2D copies."""
@@ -663,19 +697,19 @@ def mil_forward(logits, seg_offsets, K):
     require_gpu(logits, seg_offsets)
     M = logits.size(0)
     G = seg_offsets.numel() - 1
-    scores = torch.empty((M, K), dtype=torch.float32, device=logits.device)
-    P = torch.empty_like(scores)
-    Q = torch.empty_like(scores)
+    scores = _alloc((M, K), torch.float32, logits.device)
+    P = _alloc((M, K), torch.float32, logits.device)
+    Q = _alloc((M, K), torch.float32, logits.device)
     check(lib().wsovod_mil_forward(ptr(logits), _ld(logits), ptr(seg_offsets), G, K, ptr(scores), ptr(P), ptr(Q), M,
                                    stream()), "mil_forward")
     return scores, P, Q
 
 
-def mil_backward(dscores, P, Q, seg_offsets, K):
+def mil_backward(dscores, P, Q, seg_offsets, K, tail=False):
     require_gpu(dscores, P, Q, seg_offsets)
     M = P.size(0)
     G = seg_offsets.numel() - 1
-    dlogits = torch.empty((M, 2 * K), dtype=torch.float32, device=P.device)
+    dlogits = _alloc((M, 2 * K), torch.float32, P.device, tail)
     check(lib().wsovod_mil_backward(ptr(dscores.contiguous()), ptr(P), ptr(Q), ptr(seg_offsets), G, K, ptr(dlogits),
                                     _ld(dlogits), M, stream()), "mil_backward")
     return dlogits
@@ -692,10 +726,10 @@ def image_bce_forward(scores, seg_offsets, labels_onehot, norm):
     return loss, img, dS
 
 
-def image_bce_backward(dS_img, seg_offsets, M, grad_out):
+def image_bce_backward(dS_img, seg_offsets, M, grad_out, tail=False):
     require_gpu(dS_img, seg_offsets, grad_out)
     G, K = dS_img.shape
-    d = torch.empty((M, K), dtype=torch.float32, device=dS_img.device)
+    d = _alloc((M, K), torch.float32, dS_img.device, tail)
     check(lib().wsovod_image_bce_backward(ptr(dS_img), ptr(seg_offsets), G, K, ptr(grad_out), ptr(d), stream()),
           "image_bce_backward")
     return d
@@ -724,7 +758,7 @@ def weighted_l1_box_forward(pred, proposal_boxes, gt_boxes, gt_classes, weights,
     bw = (C.c_float * 4)(*[float(v) for v in bbox_weights])
     check(lib().wsovod_weighted_l1_box_forward(ptr(pred), _ld(pred), ptr(proposal_boxes), ptr(gt_boxes),
                                                ptr(gt_classes), ptr(weights), M, K, bw, C.c_float(beta),
-                                               int(weighted), ptr(dp), ptr(accum), ptr(loss), stream()),
+                                               int(weighted), ptr(dp), ptr(accum), ptr(loss), ptr(_TAIL.rows_true), stream()),
           "weighted_l1_box_forward")
     return loss, dp
 
@@ -744,11 +778,13 @@ def pgt_mine_and_label(scores, boxes, seg_offsets, gt_classes_img, gt_offsets, i
         pgt_weights=zero[28 * T:32 * T].view(torch.float32),
         pgt_index=torch.full((T,), -1, dtype=torch.int32, device=dev),
         pgt_count=zero[32 * T:].view(torch.int32),
-        gt_classes=torch.empty((M,), dtype=torch.int64, device=dev),
-        gt_boxes=torch.empty((M, 4), dtype=torch.float32, device=dev),
-        gt_scores=torch.empty((M,), dtype=torch.float32, device=dev),
-        gt_weights=torch.empty((M,), dtype=torch.float32, device=dev),
-        matched=torch.empty((M,), dtype=torch.int32, device=dev),
+        # (padding rows behind the last segment -- a bucketed step graph -- must read as ignored: label -1, weight 0)
+        gt_classes=torch.full((M,), -1, dtype=torch.int64, device=dev) if _TAIL.rows_true is not None
+        else torch.empty((M,), dtype=torch.int64, device=dev),
+        gt_boxes=_alloc((M, 4), torch.float32, dev),
+        gt_scores=_alloc((M,), torch.float32, dev),
+        gt_weights=_alloc((M,), torch.float32, dev),
+        matched=_alloc((M,), torch.int32, dev),
     )
     boxes = boxes.to(torch.float32).contiguous()
     check(lib().wsovod_pgt_mine_and_label(
