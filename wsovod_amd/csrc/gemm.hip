@@ -26,14 +26,9 @@ namespace wsovod_gemm {
 // X3 (T = bf16 only): the operands are bf16x2 (include/wsovod_hip.h); the launcher hands them over as bf16 matrices of
 // twice the length (K, lda, ldb, Cin doubled), every 128-byte K-step row = [hi of 32 values | lo of the same 32], and a
 // K-step computes b_hi*a_hi + b_lo*a_hi + b_hi*a_lo from the two fragment reads the bf16 form makes (see gemm8.hip).
-// SKEW (X3, LDS-direct, two stages): the third product block of a K-step (b_hi * a_lo, operands already in registers) is
-// issued AFTER the K-step's barrier, behind the next K-step's first fragment reads -- after a barrier all 16 wavefronts
-// read LDS at once (16 x 8 KB at 128 B / clk: ~1000 cycles in which no MFMA could issue: the 24 % the PMC shows idle).
-template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false,
-          bool SKEW = false>
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p) {
   static_assert(!X3 || (sizeof(T) == 2 && STAGES == 2), "X3 is a bf16, two-stage variant");
-  static_assert(!SKEW || (X3 && DMA), "SKEW is a schedule of the X3 LDS-direct kernel");
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BKE = Traits<T>::BKE;
   constexpr int NT = 64 * WM * WN;       // threads: WM x WN wavefronts
@@ -386,58 +381,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       if (kt + STAGES - 1 < nk) stage_dma(kt + STAGES - 1, (kt + STAGES - 1) % STAGES);
       compute(kt % STAGES);
     }
-  } else if constexpr (DMA && SKEW) {
-    const char* bA = sA + (wm * (BM / WM)) * 128;
-    const char* bB = sB + (wn * (BN / WN)) * 128;
-    auto rd = [&](const char* base, int t, int half) {
-      const int row = t * 16 + frow;
-      return *(const u32x4*)(base + row * 128 + (((fq + 4 * half) ^ ((row >> 1) & 7)) << 4));
-    };
-    u32x4 ca[TM], cb[TN];  // a_lo / b_hi of the K-step whose third block is still owed
-    stage_dma(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
-      if (kt + 1 < nk) stage_dma(kt + 1, cur ^ 1);
-      const char* cA = bA + cur * BM * 128;
-      const char* cB = bB + cur * BN * 128;
-      u32x4 af[TM], bfr[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = rd(cB, j, 1);  // b_lo
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = rd(cA, i, 0);   // a_hi
-      if (kt > 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)  // the owed b_hi * a_lo of K-step kt - 1
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cb[j]),
-                                                                __builtin_bit_cast(bf16x8, ca[i]), acc[i][j], 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)  // b_lo * a_hi
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
-                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) cb[j] = rd(cB, j, 0);   // b_hi
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)  // b_hi * a_hi
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cb[j]),
-                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) ca[i] = rd(cA, i, 1);   // a_lo: its block runs behind the next K-step's reads
-      __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cb[j]),
-                                                            __builtin_bit_cast(bf16x8, ca[i]), acc[i][j], 0, 0, 0);
   } else if constexpr (DMA) {
     // ---- LDS-direct pipeline: next K-step's DMA is issued before the MFMAs of the current one;
     // the barrier (with the vmcnt(0) hipcc puts in front of it) retires it.  One barrier per K-step.
@@ -1555,13 +1498,12 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
   }
 }
 
-template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false,
-          bool SKEW = false>
+template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
 int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops, double bytes) {
   static int slot = wsovod::prof_slot(slot_name);
   static bool attr_set = false;
   constexpr int lds_bytes = STAGES * (BM + BN) * 128;
-  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA, STAGES, X3, SKEW>;
+  auto kfn = gemm_nt_kernel<T, BM, BN, CONV, WM, WN, DMA, STAGES, X3>;
   if (!attr_set) {
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt: LDS opt-in");
     attr_set = true;
@@ -1656,10 +1598,6 @@ int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, d
       return launch_gemm256_8ph(a, CONV, s, flops, bytes, false, true);
     case 2256256:  // the two-phase ("merged") form of that tile
       return launch_gemm256_8ph(a, CONV, s, flops, bytes, false, true, true);
-    case 9256256:  // the skewed schedule of the 16-wavefront tile (convs; A/B against 256256)
-      if constexpr (CONV)
-        return launch<bf16_t, 256, 256, true, 4, 4, true, 2, true, true>(a, s, "conv_igemm_bf16x2_256x256_skew", flops, bytes);
-      [[fallthrough]];
     case 256256:
       return launch<bf16_t, 256, 256, CONV, 4, 4, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x256" : "gemm_nt_bf16x2_256x256",
                                                                flops, bytes);
