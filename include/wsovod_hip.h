@@ -301,6 +301,9 @@ typedef struct wsovod_sgd_tensor {
                            * wsovod_grad_clip_coef pass below (engine/defaults.py:292-318).  NULL = 1 */
   float clip_value;       /* > 0: grad * grad_scale is clamped to [-clip_value, clip_value] (detectron2's
                            * SOLVER.CLIP_GRADIENTS.CLIP_TYPE "value" = clip_grad_value_ per parameter); 0 = off */
+  const float* lr_dev;    /* optional DEVICE scalar read instead of `lr`: the learning rate of a captured step graph lives
+                           * in memory, so that a scheduler (detectron2's WarmupMultiStepLR changes it every iteration of
+                           * the warm-up, engine/defaults.py build_lr_scheduler) takes effect at the next replay */
 } wsovod_sgd_tensor;
 int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
                               wsovod_stream_t stream);

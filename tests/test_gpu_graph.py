@@ -210,6 +210,18 @@ def test_step_graph_falls_back_and_respects_its_limits(gpu, monkeypatch):
     before = model.state_dict()["roi_heads.box_head.fc2.bias"].clone()
     tr.run_step(a[0])
     assert not torch.equal(before, model.state_dict()["roi_heads.box_head.fc2.bias"])  # the replayed update is visible
+    # an LR scheduler moves the rates between steps: the captured SGD launch reads them from memory
+    lrs = [g["lr"] for g in tr.optimizer.param_groups]
+    for g in tr.optimizer.param_groups:
+        g["lr"] = 0.0
+    frozen = {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}
+    tr.run_step(a[1])
+    assert all(torch.equal(v, frozen[k]) for k, v in model.named_parameters() if v.requires_grad)
+    for g, lr in zip(tr.optimizer.param_groups, lrs):
+        g["lr"] = lr
+    tr.run_step(a[2])
+    assert not any(torch.equal(v, frozen[k]) for k, v in model.named_parameters() if v.requires_grad and v.numel() > 4)
+    assert len(tr._graphs) == 1
     for b in _varying_batches(3, [(40, 40)], H=256, W=320):  # 80 rows: the same 128-row bucket, the same graph
         tr.run_step(b)
     assert len(tr._graphs) == 1

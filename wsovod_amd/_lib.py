@@ -121,7 +121,7 @@ class SgdTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
                 ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
                 ("shadow_is_bf16x2", C.c_int), ("used_flag", C.c_void_p), ("grad_coef", C.c_void_p),
-                ("clip_value", C.c_float)]
+                ("clip_value", C.c_float), ("lr_dev", C.c_void_p)]
 
 
 class PackTensor(C.Structure):

@@ -466,6 +466,7 @@ struct SgdTable {
   unsigned x2_shadow;  // bit k: shadow[k] is a bf16x2 copy of the parameter (include/wsovod_hip.h), n[k] a multiple of 32
   const float* used[kSgdMax];  // optional device flag: 0 = no rank produced a gradient for the tensor -> left untouched
   const float* coef[kSgdMax];  // optional device scalar multiplied into the gradient scale (norm clipping coefficient)
+  const float* lr_dev[kSgdMax];  // optional device scalar that replaces lr[k] (a captured step graph under an LR schedule)
   float clip[kSgdMax];         // > 0: the scaled gradient is clamped to [-clip, clip] (clip_grad_value_)
 };
 
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
   float* __restrict__ buf = t.buf[k];
   bf16_t* __restrict__ shadow = t.shadow[k];
   const long long n = t.n[k];
-  const float lr = t.lr[k], wd = t.wd[k];
+  const float lr = t.lr_dev[k] ? *t.lr_dev[k] : t.lr[k], wd = t.wd[k];
   const bool gb = (t.g_bf16 >> k) & 1u;
   const bool sx2 = (t.x2_shadow >> k) & 1u;
   const bf16_t* __restrict__ g16 = (const bf16_t*)t.g[k];
@@ -1127,6 +1128,7 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
       t.used[k] = d.used_flag;
       t.coef[k] = d.grad_coef;
       t.clip[k] = d.clip_value;
+      t.lr_dev[k] = d.lr_dev;
       t.n[k] = d.numel;
       t.lr[k] = d.lr;
       t.wd[k] = d.weight_decay;

@@ -30,6 +30,7 @@ class HipSGD(torch.optim.Optimizer):
             raise ValueError(f"HipSGD: clip must be (full_model | norm | value, positive value), got {clip!r}")
         self.clip = clip
         self.last_clip_coef = None  # device tensor of the coefficients applied by the last step (norm kinds; tests, logging)
+        self.lr_device = None  # {param: 1-element fp32 device tensor}: set while a step graph is captured (see _StepGraph)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -49,8 +50,9 @@ class HipSGD(torch.optim.Optimizer):
                 xe = getattr(p, "_x2_enc", None)  # "parity" precision: the bf16x2 operand (hip_ops.x2_cached) instead
                 if xe is not None and xe[0] == (p._version, p.data_ptr(), None) and p.numel() % 32 == 0:
                     shadow = xe[1]
+                lr = group["lr"] if self.lr_device is None else self.lr_device[p]
                 by_momentum.setdefault(group["momentum"], []).append(
-                    (p.data, g, state["momentum_buffer"], shadow, group["lr"], group["weight_decay"],
+                    (p.data, g, state["momentum_buffer"], shadow, lr, group["weight_decay"],
                      getattr(p, "_used_flag", None), p))
         if self.clip is not None and self.clip[0] == "full_model" and len(by_momentum) > 1:
             raise NotImplementedError("HipSGD: full-model clipping needs one momentum value for all parameter groups")
@@ -136,13 +138,14 @@ class _StepMeta:
 
     MAX_CLASSES_PER_IMAGE = 128  # == kMaxPgt of the mining kernel
 
-    def __init__(self, n_img, rows, num_classes, device):
+    def __init__(self, n_img, rows, num_classes, device, n_lr=0):
         self.n, self.rows, self.K = n_img, rows, num_classes
         self.t_cap = n_img * min(num_classes, self.MAX_CLASSES_PER_IMAGE)
         lay, off = {}, 0
+        self.n_lr = int(n_lr)
         for name, count, dt in (("gt_cat", self.t_cap, torch.int64), ("onehot", n_img * num_classes, torch.float32),
                                 ("seg", n_img + 1, torch.int32), ("gt_off", n_img + 1, torch.int32),
-                                ("row_group", rows, torch.int32)):
+                                ("lr", max(self.n_lr, 1), torch.float32), ("row_group", rows, torch.int32)):
             lay[name] = (off, count, dt)
             off += (count * torch.empty((), dtype=dt).element_size() + 15) // 16 * 16
         self.nbytes = off
@@ -154,6 +157,7 @@ class _StepMeta:
         self.seg, self.gt_off = self._view(self.dev, "seg"), self._view(self.dev, "gt_off")
         self.row_group, self.gt_cat = self._view(self.dev, "row_group"), self._view(self.dev, "gt_cat")
         self.onehot = self._view(self.dev, "onehot").view(n_img, num_classes)
+        self.lr = self._view(self.dev, "lr")  # one learning rate per parameter group, refilled before every replay
         self.nums = None
 
     def _view(self, buf, name):
@@ -177,8 +181,9 @@ class _StepMeta:
         """1-element int32 view of seg[G] = the step's REAL row count (<= the bucket the graph runs on)."""
         return self.seg[self.n:self.n + 1]
 
-    def fill(self, batched_inputs):
-        """Host side of one step: returns False when this batch does not fit the captured layout."""
+    def fill(self, batched_inputs, lrs=()):
+        """Host side of one step: returns False when this batch does not fit the captured layout.  lrs: the optimizer's
+        current learning rates, one per parameter group (a scheduler may have moved them since the last step)."""
         nums = [len(x["proposals"]) for x in batched_inputs]
         if len(nums) != self.n or sum(nums) > self.rows or min(nums) <= 0:
             return False
@@ -208,6 +213,8 @@ class _StepMeta:
             t += len(u)
             goff[i + 1] = t
             oh[i, u] = 1.0
+        if self.n_lr:
+            self._view(h, "lr")[:self.n_lr] = torch.tensor([float(v) for v in lrs], dtype=torch.float32)
         self.dev.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
@@ -244,7 +251,9 @@ class _StepGraph:
         self.rows = rows
         self.boxes = torch.zeros((rows, 4), dtype=torch.float32, device=dev)
         self.objectness = torch.zeros((rows,), dtype=torch.float32, device=dev)
-        self.meta = _StepMeta(n, rows, model.roi_heads.num_classes, dev)
+        groups = trainer.optimizer.param_groups
+        self.meta = _StepMeta(n, rows, model.roi_heads.num_classes, dev, n_lr=len(groups))
+        self.hyper = [(g["weight_decay"], g["momentum"]) for g in groups]  # baked into the graph: a change drops it
         self.losses = None
         self.graphs = []
         self.fresh = False
@@ -254,7 +263,10 @@ class _StepGraph:
     def _load(self, batched_inputs):
         from ..modeling.meta_arch import GeneralizedRCNN_WSOVOD as M
 
-        if not self.meta.fill(batched_inputs):
+        groups = self.tr.optimizer.param_groups
+        if [(g["weight_decay"], g["momentum"]) for g in groups] != self.hyper:
+            return False
+        if not self.meta.fill(batched_inputs, [g["lr"] for g in groups]):
             return False
         imgs = [x["image"] for x in batched_inputs]
         adj = M._adjacent(imgs) if imgs[0].is_cuda else None
@@ -308,6 +320,9 @@ class _StepGraph:
         for p, _ in dw:  # the early weight-gradient block launches a collective from inside backward: not under capture
             p._dw_split = None
         model._step_meta = self.meta
+        # the learning rates are read from memory by the captured SGD launch (an LR scheduler moves them between replays)
+        tr.optimizer.lr_device = {p: self.meta.lr[i:i + 1] for i, g in enumerate(tr.optimizer.param_groups)
+                                  for p in g["params"]}
         try:
             with H.const_override(self.meta.overrides(self.capture_nums)), H.tail_rows(self.meta.rows_true):
                 if split:
@@ -332,6 +347,7 @@ class _StepGraph:
                     self.graphs = [g]
         finally:
             model._step_meta = None
+            tr.optimizer.lr_device = None
             for p, v in dw:
                 p._dw_split = v
         self.losses = {k: v.detach() for k, v in loss_dict.items()}

@@ -1014,6 +1014,10 @@ def sgd_momentum_multi(entries, momentum, grad_scale=1.0, clip=None):
         p, g, b, sh, lr, wd = e[:6]
         used = e[6] if len(e) > 6 else None
         require_gpu(p, g, b, sh, used)
+        if torch.is_tensor(lr):  # a 1-element fp32 DEVICE tensor: the rate is read from memory when the kernel runs
+            require_gpu(lr)
+            assert lr.dtype == torch.float32 and lr.numel() == 1
+            d.lr_dev, lr = lr.data_ptr(), 0.0
         d.used_flag = used.data_ptr() if used is not None else None
         if g.dtype not in (torch.float32, torch.bfloat16) or g.numel() != p.numel():
             raise RuntimeError("sgd_momentum_multi: gradient must be fp32 or bf16 with the parameter's element count")
