@@ -747,6 +747,8 @@ class HotPathTrainer:
         x0 = data[0]
         if "proposals" not in x0 or "instances" not in x0 or not torch.is_tensor(x0.get("image")):
             return None
+        if hasattr(m, "classifier_train") or "dataset_id" in x0:
+            return None  # mixed-dataset model: miner, class count and text embeddings change with the batch's source
         shape = tuple(x0["image"].shape)
         if any(tuple(x["image"].shape) != shape or x["image"].dtype != torch.uint8 for x in data):
             return None
