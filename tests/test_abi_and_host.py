@@ -293,3 +293,33 @@ def test_split_rows_never_adds_a_tile_round():
         assert rounds(ra, cols) + rounds(rows - ra, cols) == rounds(rows, cols), (rows, cols, ra)
     assert HotPathTrainer.split_rows(4096, 25088) == 1280  # fc1 of WSR_18: 2 + 5 = 7 rounds
     assert HotPathTrainer.split_rows(8, 8) == 0
+
+
+def test_step_graph_row_buckets_and_clip_config():
+    """Host logic of round 4 that needs no GPU: the row bucket a step graph is keyed on (padding <= 1/8, at least 64 rows,
+    monotone, idempotent) and SOLVER.CLIP_GRADIENTS -> the optimizer's clip setting (engine/defaults.py:292-323)."""
+    from wsovod_amd.config import get_cfg
+    from wsovod_amd.engine.trainer import HotPathTrainer, gradient_clipping
+
+    prev = 0
+    for rows in list(range(1, 700)) + [1000, 1024, 1025, 4000, 4096, 5024, 100000]:
+        b = HotPathTrainer.row_bucket(rows)
+        assert b >= rows and b >= 64 and b >= prev and HotPathTrainer.row_bucket(b) == b
+        assert b - rows < max(64, rows // 8 + 1), (rows, b)
+        prev = b
+    assert [HotPathTrainer.row_bucket(r) for r in (512, 513, 1024, 4000)] == [512, 576, 1024, 4096]
+    cfg = get_cfg()
+    assert gradient_clipping(cfg) is None
+    cfg.SOLVER.CLIP_GRADIENTS.ENABLED = True
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "full_model"
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE = 0.0
+    assert gradient_clipping(cfg) is None  # the reference enables full-model clipping only for a positive value
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_VALUE = 2.0
+    assert gradient_clipping(cfg) == ("full_model", 2.0)
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "value"
+    assert gradient_clipping(cfg) == ("value", 2.0)
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "norm"
+    assert gradient_clipping(cfg) == ("norm", 2.0)
+    cfg.SOLVER.CLIP_GRADIENTS.CLIP_TYPE = "bogus"
+    with pytest.raises(NotImplementedError):
+        gradient_clipping(cfg)
