@@ -244,3 +244,36 @@ def test_step_graph_falls_back_and_respects_its_limits(gpu, monkeypatch):
     assert all(torch.isfinite(v) for v in losses.values()) and list(tr._graphs.values()).count(False) == 1
     tr.run_step(c[3])  # remembered: no second attempt, no second warning
     tr.close()
+
+
+@pytest.mark.parametrize("pooler,nums_list", [("ROIAlignV2", [(96,), (81,), (70,), (96,)]), ("ROIPool", [(100,), (128,), (65,), (77,)])])
+def test_step_graph_single_image_and_roialign(gpu, monkeypatch, pooler, nums_list):
+    """The reference's own per-GPU batch -- ONE image per step -- and the north star's pooler through the step graph:
+    six steps (two eager, the capture, three replays; the proposal count changes inside its bucket) against the eager
+    trainer: labels equal, losses to the eager path's jitter."""
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.layers import hip_ops as H
+    from wsovod_amd.testing import build_hot_path_model
+
+    monkeypatch.setattr(H, "DETERMINISTIC", True)
+    monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", "0")
+    batches = _varying_batches(6, nums_list, H=256, W=352)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WSOVOD_STEP_GRAPH", flag)
+        cfg, model = build_hot_path_model(seed=0, precision="bf16", pooler=pooler, device="cuda:0")
+        model.train()
+        cfg.SOLVER.BASE_LR = 1e-3
+        tr = HotPathTrainer(model, build_optimizer(cfg, model))
+        hist = []
+        for b in batches:
+            losses = tr.run_step(b)
+            rows = len(b[0]["proposals"])
+            hist.append(({k: float(v) for k, v in losses.items()}, model.roi_heads._last_pgt["gt_classes"][:rows].cpu().clone()))
+        assert len(tr._graphs) == (1 if flag == "1" else 0)
+        tr.close()
+        runs[flag] = hist
+    for s, (e, g) in enumerate(zip(runs["0"], runs["1"])):
+        assert torch.equal(e[1], g[1]), s
+        for k in e[0]:
+            assert abs(e[0][k] - g[0][k]) <= 5e-5 * max(abs(e[0][k]), 1e-3), (s, k, e[0][k], g[0][k])
