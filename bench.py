@@ -10,6 +10,10 @@ instance refinement (cosine-similarity head) -> losses -> backward -> fused SGD 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0.  `value` = images/sec over all N GPUs (weak scaling: per-GPU batch fixed).
+The default precision is "parity" -- the mode that meets the north star's bound (MIL-head logits within 1e-3 of the
+reference path, proposal indexing bit-exact): at N = 1 the line carries that comparison, made with the oracle on the timed
+batch itself (the oracle is the checker here, never the thing measured), `roofline.frac` counts ALGORITHMIC flops (the
+executed rate of the three-MFMA products travels as `executed_frac`), and plain bf16 is a `side` line.
 """
 import argparse
 import json
