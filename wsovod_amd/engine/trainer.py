@@ -225,7 +225,7 @@ class _StepMeta:
 
 class _StepGraph:
     """One training step of the hot path as captured HIP graph(s) for one input layout (images per step, canvas size,
-    total proposals): at the reference's own per-GPU batch (1 - 2 images, Base-RCNN-DilatedC5.yaml:61,65) the step is
+    bucket of the total proposal count -- `HotPathTrainer.row_bucket`): at the reference's own per-GPU batch (1 - 2 images, Base-RCNN-DilatedC5.yaml:61,65) the step is
     bound by the host issuing ~150 launches, not by the device.
 
     world == 1: ONE graph = frozen forward + heads forward + backward + fused SGD update.
