@@ -223,13 +223,19 @@ def test_stem_conv1_x2_against_fp64(gpu):
     assert float((got - ref).abs().max()) < 3e-5 * scale
 
 
+@pytest.mark.parametrize("form", [None, "16", "32"])
 @pytest.mark.parametrize("pool", [False, True])
 @pytest.mark.parametrize("with_res", [False, True])
-def test_conv3x3_c64_halo_kernel_on_bf16x2(gpu, pool, with_res):
+def test_conv3x3_c64_halo_kernel_on_bf16x2(gpu, pool, with_res, form, monkeypatch):
     """The 64 -> 64 channel 3x3 halo-tile kernel in its bf16x2 form (stem conv2 / conv3, res2): against fp64, and against
-    the generic implicit-GEMM tile on the same operands (same products, another summation order); ragged tile edges."""
+    the generic implicit-GEMM tile on the same operands (same products, another summation order); ragged tile edges.
+    form: None = the shipped half-K 8 x 32 tile, "16" / "32" = the whole-K tiles kept for A/B runs."""
     from wsovod_amd.layers import hip_ops as H
 
+    if form is None:
+        monkeypatch.delenv("WSOVOD_C64X_TW", raising=False)
+    else:
+        monkeypatch.setenv("WSOVOD_C64X_TW", form)
     torch.manual_seed(11)
     n, Hh, Ww = 2, 22, 70  # not multiples of the 8 x 32 tile
     x = torch.randn(n, 64, Hh, Ww)

@@ -550,3 +550,43 @@ def test_conv_with_fused_projection_shortcut(gpu, dtype, tol, k, dil):
         alt = H.gemm_nt(b16(hd), b16(wcat), conv=geom, A2=b16(xd), bias=(b + bsc).to(gpu), relu=True, tile_hint=hint,
                         out_dtype=torch.float32)
         assert torch.equal(alt, ref16), hint
+
+
+@pytest.mark.parametrize("mode", ["bf16", "x2", "x2_shortcut"])
+def test_conv_tile_round_tail_launch_is_bit_identical(gpu, mode, monkeypatch):
+    """A conv whose 256x256 tile grid ends in a partly filled round of 256 tiles sends the rows behind the last full round
+    through a second launch with 256x128 tiles (gemm.hip: `m_base`): same bits as the one-launch form (WSOVOD_CONV_TAIL=0)
+    and as the 256x128 tile everywhere; residual / fused shortcut rows are addressed absolutely."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(5)
+    n, Hh, Ww, Cin, Cout = 5, 75, 100, 64, 512  # 147 x 2 tiles = 1 full round + 38 tiles
+    x = torch.randn(n * Hh * Ww, Cin, device=gpu)
+    w = torch.randn(Cout, 9 * Cin, device=gpu) * 0.05
+    b = torch.randn(Cout, device=gpu)
+    res = torch.randn(n * Hh * Ww, Cout, device=gpu)
+    geom = dict(n_img=n, H=Hh, W=Ww, Cin=Cin, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=2, dil=2)
+    if mode == "bf16":
+        xa, wa, kw = x.to(torch.bfloat16).view(n, Hh, Ww, Cin), w.to(torch.bfloat16), dict(out_dtype=torch.bfloat16, residual=res.to(torch.bfloat16))
+    elif mode == "x2":
+        xa, wa = H.x2_encode(x).view(n, Hh, Ww, Cin), H.x2_encode(w)
+        kw = dict(x2=True, out_dtype=H.X2, residual=H.x2_encode(res), residual_x2=True)
+    else:  # fused 1x1 projection shortcut: second input at the output pixel
+        x2in = torch.randn(n * Hh * Ww, 64, device=gpu)
+        w = torch.cat([w, torch.randn(Cout, 64, device=gpu) * 0.05], 1)
+        xa, wa = H.x2_encode(x).view(n, Hh, Ww, Cin), H.x2_encode(w)
+        kw = dict(x2=True, out_dtype=H.X2, A2=H.x2_encode(x2in).view(n, Hh, Ww, 64))
+
+    def run(tile=0):
+        return H.gemm_nt(xa, wa, conv=geom, bias=b, relu=True, tile_hint=tile, **kw)
+
+    monkeypatch.setenv("WSOVOD_CONV_TAIL", "0")
+    whole = run()
+    monkeypatch.delenv("WSOVOD_CONV_TAIL")
+    split = run()
+    torch.cuda.synchronize()
+    assert torch.equal(whole.view(torch.int32) if whole.dtype == torch.float32 else whole.view(torch.int16),
+                       split.view(torch.int32) if split.dtype == torch.float32 else split.view(torch.int16))
+    narrow = run(256128)
+    assert torch.equal(narrow.view(torch.int16) if narrow.dtype != torch.float32 else narrow.view(torch.int32),
+                       split.view(torch.int16) if split.dtype != torch.float32 else split.view(torch.int32))

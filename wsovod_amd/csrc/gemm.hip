@@ -20,6 +20,7 @@
 // Workgroup ids are remapped so that the 8 XCDs each get a contiguous run of tiles that
 // share the B (weight) slab in their private L2.
 #include "gemm_common.h"
+#include <type_traits>
 
 namespace wsovod_gemm {
 
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   const int in_group = wg - group_id * group_size;
   const int tile_m = first_m + in_group % gm;
   const int tile_n = in_group / gm;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -1289,6 +1290,93 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 #undef C64R_LAST_STEP
 }
 
+// Epilogue of the bf16x2 64-channel kernels: bias + (bf16x2) residual + ReLU (+ 2x2 / stride-2 max pool), bf16x2 stores.
+template <int XG, int NI>
+__device__ __forceinline__ void c64x_epilogue(const GemmArgs& p, const f32x4 (&acc)[NI][4], const f32x4 (&bias4)[4], const int img,
+                                              const int y0, const int x0, const int wave, const int frow, const int fq) {
+  // ---- epilogue: lane (frow, fq) holds, for pixel group i, channels 16 fq + 4 j + r of pixel frow: slots
+  // 64 (fq >> 1) + 16 (fq & 1) (hi) and 32 further (lo) of the pixel's 128
+  const float lo_clip = p.relu ? 0.f : -__builtin_inff();
+  const int slot = 64 * (fq >> 1) + 16 * (fq & 1);
+  auto load16 = [&](const bf16_t* q, float (&v)[16]) {  // bf16x2 residual values of this lane's 16 channels
+    const bf16x8 h0 = *(const bf16x8*)q, h1 = *(const bf16x8*)(q + 8), l0 = *(const bf16x8*)(q + 32), l1 = *(const bf16x8*)(q + 40);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[e] = (float)h0[e] + (float)l0[e];
+      v[8 + e] = (float)h1[e] + (float)l1[e];
+    }
+  };
+  auto store16 = [&](bf16_t* q, const float (&v)[16]) {
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h0[e] = (bf16_t)v[e];
+      h1[e] = (bf16_t)v[8 + e];
+      l0[e] = x2_lo(v[e], h0[e]);
+      l1[e] = x2_lo(v[8 + e], h1[e]);
+    }
+    *(bf16x8*)q = h0;
+    *(bf16x8*)(q + 8) = h1;
+    *(bf16x8*)(q + 32) = l0;
+    *(bf16x8*)(q + 40) = l1;
+  };
+  if (p.pool) {  // MaxPool2d(2, 2): the wavefront's two image rows are one pooled row, the horizontal partner is lane frow ^ 1
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+#pragma unroll
+    for (int ih = 0; ih < XG; ++ih) {
+      float best[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
+#pragma unroll
+      for (int iv = 0; iv < 2; ++iv) {
+        const int i = ih + XG * iv;
+        const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
+        const long long m = ((long long)img * p.H + y) * p.W + x;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+        if (p.residual) {
+          float rv[16];
+          load16((const bf16_t*)p.residual + 2 * m * p.ldr + slot, rv);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += rv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], fmaxf(v[e], lo_clip));
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
+      const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
+      if ((frow & 1) == 0 && py < Hp && px < Wp)
+        store16((bf16_t*)p.C + 2 * (((long long)img * Hp + py) * Wp + px) * p.ldc + slot, best);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int y = y0 + wave * 2 + (i / XG);
+    const int x = x0 + (i % XG) * 16 + frow;
+    if (y >= p.H || x >= p.W) continue;
+    const long long m = ((long long)img * p.H + y) * p.W + x;
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+    if (p.residual) {
+      float rv[16];
+      load16((const bf16_t*)p.residual + 2 * m * p.ldr + slot, rv);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] += rv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], lo_clip);
+    store16((bf16_t*)p.C + 2 * m * p.ldc + slot, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // The 64 -> 64 channel 3x3 convolution on bf16x2 maps (MODEL.HIP.PRECISION = "parity"; include/wsovod_hip.h).  Same
 // decomposition as conv3x3_c64_kernel -- a workgroup owns 8 x 32 output pixels, its 10 x 34 halo patch is DMA-staged once
@@ -1415,87 +1503,213 @@ __global__ __launch_bounds__(256) void conv3x3_c64_x3_kernel(const GemmArgs p, i
     }
     __syncthreads();
   }
-  // ---- epilogue: lane (frow, fq) holds, for pixel group i, channels 16 fq + 4 j + r of pixel frow: slots
-  // 64 (fq >> 1) + 16 (fq & 1) (hi) and 32 further (lo) of the pixel's 128
-  const float lo_clip = p.relu ? 0.f : -__builtin_inff();
-  const int slot = 64 * (fq >> 1) + 16 * (fq & 1);
-  auto load16 = [&](const bf16_t* q, float (&v)[16]) {  // bf16x2 residual values of this lane's 16 channels
-    const bf16x8 h0 = *(const bf16x8*)q, h1 = *(const bf16x8*)(q + 8), l0 = *(const bf16x8*)(q + 32), l1 = *(const bf16x8*)(q + 40);
+  c64x_epilogue<XG, NI>(p, acc, bias4, img, y0, x0, wave, frow, fq);
+}
+
+// The same convolution with the 64 input channels taken in two HALVES of 32 (the form the dispatcher uses): an 8 x 32-pixel
+// tile whose 10 x 34 halo patch is staged as 128-byte rows ([hi | lo] of 32 channels: 44 KiB) with an 8-KiB weight slice
+// per (half, tap), double buffered -- 60 KiB per workgroup, so TWO workgroups fit a CU although a wavefront now owns 4
+// pixel groups x 4 channel tiles: a K-step is 16 fragment reads for 48 MFMAs (the 8 x 16 tile above: 12 for 24, which
+// keeps the LDS pipe as busy as the matrix pipe), and the weight slices travel from L2 once per 256 pixels instead of
+// once per 128.  The patch of the second half is staged after the ninth tap of the first (the other workgroup's MFMAs
+// cover it).  Rows are swizzled like the GEMM image (chunk ^= (row >> 1) & 7, on the DMA source and on the read).
+struct C64XH {
+  static constexpr int TW = 32, XG = 2, NI = 4;
+  static constexpr int PW = TW + 2, NPIX = PW * C64_PH;
+  static constexpr int NPIX_PAD = (NPIX + 31) / 32 * 32;  // whole 32-pixel DMA passes (4 wavefronts x 8 rows of 128 B)
+  static constexpr int PATCH_BYTES = NPIX_PAD * 128;
+  static constexpr int W_BYTES = 64 * 128;
+  static constexpr int LDS_BYTES = PATCH_BYTES + 2 * W_BYTES;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_c64_x3h_kernel(const GemmArgs p, int tiles_x, int tiles_y) {
+  using G = C64XH;
+  constexpr int XG = G::XG, NI = G::NI, PW = G::PW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sP = smem;                    // halo patch of one channel half [pixel][128 B]
+  char* sW = smem + G::PATCH_BYTES;   // 2 x [64 cout][128 B] weight slices
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tpi = tiles_x * tiles_y;
+  const int img = blockIdx.x / tpi;
+  const int t = blockIdx.x - img * tpi;
+  const int ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int y0 = ty * C64_TH, x0 = tx * G::TW;
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(64 * p.ldb * 2), 0x00020000);
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+
+  // a wavefront DMA instruction lands 8 rows x 128 B: lane -> (row lane >> 3, slot lane & 7)
+  auto stage_weights = [&](int step, int buf) {  // step = 9 * half + tap
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int half = step >= 9 ? 1 : 0, tap = step - 9 * half;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[e] = (float)h0[e] + (float)l0[e];
-      v[8 + e] = (float)h1[e] + (float)l1[e];
+    for (int i = 0; i < 2; ++i) {
+      const int row = i * 32 + wave_u * 8 + (lane >> 3);   // LDS row = MFMA tile j = row >> 4, tile row f = row & 15
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);     // swizzle on the source
+      const int cout = 16 * ((row & 15) >> 2) + 4 * (row >> 4) + (row & 3);  // a lane ends up with 16 consecutive channels
+      const int off = (int)((cout * p.ldb + tap * 128 + half * 64 + chunk * 8) * 2);  // (p.ldb, in bf16 slots = 2 x 9 x 64)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sW + buf * G::W_BYTES + (i * 32 + wave_u * 8) * 128), 16,
+                                               off, 0, 0, 0);
+    }
+#endif
+  };
+  auto stage_patch = [&](int half) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (int base = 0; base < G::NPIX_PAD; base += 32) {
+      const int q = base + wave_u * 8 + (lane >> 3);
+      const int py = q / PW, px = q - py * PW;
+      const int y = y0 - 1 + py, x = x0 - 1 + px;
+      const bool ok = q < G::NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W;
+      const int chunk = (lane & 7) ^ ((q >> 1) & 7);
+      const int off = (((img * p.H + y) * p.W + x) * 128 + half * 64 + chunk * 8) * 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sP + (base + wave_u * 8) * 128), 16, ok ? off : -1, 0, 0, 0);
+    }
+#endif
+  };
+#if C64XH_PHASES  // instrumented build (tools/c64x_phases.py): s_memtime ticks per phase, wavefront 0 of every workgroup
+  long long tph[6] = {0, 0, 0, 0, 0, 0}, tmark = (long long)__builtin_amdgcn_s_memtime();
+#define C64XH_MARK(K) do { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); tph[K] += n_ - tmark; tmark = n_; } while (0)
+#else
+#define C64XH_MARK(K) (void)0
+#endif
+  stage_patch(0);
+  stage_weights(0, 0);
+  stage_weights(1, 1);
+
+  const int frow = lane & 15, fq = lane >> 4;
+  f32x4 acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int qb[NI], boff[4];  // patch pixel of this lane's fragment row with the filter at its top-left tap; weight-slice offsets
+#pragma unroll
+  for (int i = 0; i < NI; ++i) qb[i] = (wave * 2 + (i / XG)) * PW + (i % XG) * 16 + frow;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = j * 16 + frow;
+    boff[j] = row * 128 + ((fq ^ ((row >> 1) & 7)) << 4);
+  }
+  // fragments of K-step `step` (= 9 * half + tap): (a_hi, a_lo) from the patch, (b_hi, b_lo) from weight buffer step & 1;
+  // the lo chunk of a row is the hi chunk's slot ^ 4
+  auto read_a = [&](int step, u32x4 (&ah)[NI], u32x4 (&al)[NI]) {
+    const int tap = step >= 9 ? step - 9 : step;
+    const int r = tap / 3;
+    const int d = r * PW + (tap - r * 3);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = qb[i] + d;
+      const int off = q * 128 + ((fq ^ ((q >> 1) & 7)) << 4);
+      ah[i] = *(const u32x4*)(sP + off);
+      al[i] = *(const u32x4*)(sP + (off ^ 64));
     }
   };
-  auto store16 = [&](bf16_t* q, const float (&v)[16]) {
-    bf16x8 h0, h1, l0, l1;
+  auto read_b = [&](int step, u32x4 (&bh)[4], u32x4 (&bl)[4]) {
+    const char* cW = sW + (step & 1) * G::W_BYTES;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      h0[e] = (bf16_t)v[e];
-      h1[e] = (bf16_t)v[8 + e];
-      l0[e] = x2_lo(v[e], h0[e]);
-      l1[e] = x2_lo(v[8 + e], h1[e]);
+    for (int j = 0; j < 4; ++j) {
+      bh[j] = *(const u32x4*)(cW + boff[j]);
+      bl[j] = *(const u32x4*)(cW + (boff[j] ^ 64));
     }
-    *(bf16x8*)q = h0;
-    *(bf16x8*)(q + 8) = h1;
-    *(bf16x8*)(q + 32) = l0;
-    *(bf16x8*)(q + 40) = l1;
   };
-  if (p.pool) {  // MaxPool2d(2, 2): the wavefront's two image rows are one pooled row, the horizontal partner is lane frow ^ 1
-    const int Hp = p.H >> 1, Wp = p.W >> 1;
+  auto mfma = [&](const u32x4 (&ah)[NI], const u32x4 (&al)[NI], const u32x4 (&bh)[4], const u32x4 (&bl)[4]) {
 #pragma unroll
-    for (int ih = 0; ih < XG; ++ih) {
-      float best[16];
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) best[e] = -__builtin_inff();
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                            __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
 #pragma unroll
-      for (int iv = 0; iv < 2; ++iv) {
-        const int i = ih + XG * iv;
-        const int y = min(y0 + wave * 2 + iv, p.H - 1), x = min(x0 + ih * 16 + frow, p.W - 1);  // clamped: unused if outside
-        const long long m = ((long long)img * p.H + y) * p.W + x;
-        float v[16];
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bl[j]),
+                                                            __builtin_bit_cast(bf16x8, ah[i]), acc[i][j], 0, 0, 0);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
-        if (p.residual) {
-          float rv[16];
-          load16((const bf16_t*)p.residual + 2 * m * p.ldr + slot, rv);
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += rv[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], fmaxf(v[e], lo_clip));
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
-      const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
-      if ((frow & 1) == 0 && py < Hp && px < Wp)
-        store16((bf16_t*)p.C + 2 * (((long long)img * Hp + py) * Wp + px) * p.ldc + slot, best);
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                            __builtin_bit_cast(bf16x8, al[i]), acc[i][j], 0, 0, 0);
+  };
+  // Software pipeline over the 18 K-steps, two per trip (fragment sets 0 / 1): a step first requests what comes NEXT --
+  // the weight slice two steps ahead by DMA into the buffer whose fragments are already in registers, the next step's
+  // fragments from LDS into the other register set -- then issues its own 48 MFMAs, then meets the barrier (which retires
+  // both).  hipcc moves a __syncthreads() up across MFMAs (they touch registers only), which would put the DMA wait in
+  // FRONT of the products it is meant to hide behind: the scheduling barriers pin the order.
+  // Inside a step the 16 fragment reads go out one per three MFMAs: a wavefront issues in order, and sixteen reads in a
+  // row (16 KiB per wavefront, eight wavefronts on the CU's one LDS pipe) hold its MFMAs back for the whole burst.
+#define C64XH_INTERLEAVE(N)                                   \
+  do {                                                        \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {      \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      \
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);      \
+    }                                                         \
+  } while (0)
+  u32x4 ah0[NI], al0[NI], bh0[4], bl0[4], ah1[NI], al1[NI], bh1[4], bl1[4];
+  __syncthreads();
+  read_a(0, ah0, al0);
+  read_b(0, bh0, bl0);
+  __syncthreads();  // every wavefront holds the fragments of step 0: weight buffer 0 is free for step 2
+  C64XH_MARK(0);
+  // one trip = two K-steps; MODE 0: a regular trip, 1: steps 8 / 9 (the patch of the second half is staged under step 8's
+  // MFMAs and step 9's patch fragments are read behind the barrier), 2: steps 16 / 17 (nothing left to request).  The trips
+  // are branch-free inside (hipcc's group scheduling works per basic block).
+  auto trip = [&](const int step, auto mode) {
+    constexpr int MODE = decltype(mode)::value;
+    if constexpr (MODE != 2) stage_weights(step + 2, 0);
+    if constexpr (MODE == 1) stage_patch(1);  // the first half's patch is dead: step 8's fragments are in registers
+    read_b(step + 1, bh1, bl1);
+    if constexpr (MODE != 1) read_a(step + 1, ah1, al1);
+    mfma(ah0, al0, bh0, bl0);
+    if constexpr (MODE != 1) C64XH_INTERLEAVE(16);
+    else C64XH_INTERLEAVE(8);
+    __builtin_amdgcn_sched_barrier(0);
+    C64XH_MARK(2);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    C64XH_MARK(3);
+    if constexpr (MODE == 1) {  // the second half's patch landed at the barrier
+      read_a(9, ah1, al1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int y = y0 + wave * 2 + (i / XG);
-    const int x = x0 + (i % XG) * 16 + frow;
-    if (y >= p.H || x >= p.W) continue;
-    const long long m = ((long long)img * p.H + y) * p.W + x;
-    float v[16];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
-    if (p.residual) {
-      float rv[16];
-      load16((const bf16_t*)p.residual + 2 * m * p.ldr + slot, rv);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) v[e] += rv[e];
+    if constexpr (MODE != 2) {
+      stage_weights(step + 3, 1);
+      read_b(step + 2, bh0, bl0);
+      read_a(step + 2, ah0, al0);
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], lo_clip);
-    store16((bf16_t*)p.C + 2 * m * p.ldc + slot, v);
+    mfma(ah1, al1, bh1, bl1);
+    if constexpr (MODE != 2) C64XH_INTERLEAVE(16);
+    __builtin_amdgcn_sched_barrier(0);
+    C64XH_MARK(2);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    C64XH_MARK(3);
+  };
+#pragma unroll 1
+  for (int step = 0; step < 8; step += 2) trip(step, std::integral_constant<int, 0>{});
+  trip(8, std::integral_constant<int, 1>{});
+#pragma unroll 1
+  for (int step = 10; step < 16; step += 2) trip(step, std::integral_constant<int, 0>{});
+  trip(16, std::integral_constant<int, 2>{});
+  f32x4 bias4[4];  // (loaded here: 16 registers the loop's two fragment sets leave no room for)
+  c64_load_bias(p, fq, bias4);
+  c64x_epilogue<XG, NI>(p, acc, bias4, img, y0, x0, wave, frow, fq);
+#if C64XH_PHASES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  C64XH_MARK(5);
+  if (p.partial && tid == 0) {
+    float* dst = p.partial + (blockIdx.x & 511) * 8;
+    for (int k = 0; k < 6; ++k) atomicAdd(dst + k, (float)tph[k]);
+    atomicAdd(dst + 7, 1.f);
   }
+#endif
+#undef C64XH_MARK
+#undef C64XH_INTERLEAVE
 }
 
 template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
@@ -1509,7 +1723,7 @@ int launch(const GemmArgs& a, hipStream_t s, const char* slot_name, double flops
     attr_set = true;
   }
   GemmArgs args = a;
-  args.tiles_m = ceil_div(a.M, BM);
+  args.tiles_m = ceil_div(a.M - a.m_base, BM);
   args.tiles_n = ceil_div(a.N, BN);
   {
     const int run = std::max(1, args.tiles_m * args.tiles_n / 8);  // tiles per XCD
@@ -1795,14 +2009,20 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!attr) {
       WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<16>::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
       WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<32>::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64XH::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
       attr = true;
     }
-    const char* tw = getenv("WSOVOD_C64X_TW");
-    const bool wide = tw && tw[0] == '3';
-    const int tiles_x = ceil_div(a.W, wide ? 32 : 16), tiles_y = ceil_div(a.H, C64_TH);
+    const char* tw = getenv("WSOVOD_C64X_TW");  // "16" / "32": the whole-K forms (A/B runs); default: the half-K 8 x 32 tile
+    const bool wide = tw && tw[0] == '3', halfk = !tw || (tw[0] != '3' && tw[0] != '1');
+    const int tiles_x = ceil_div(a.W, wide || halfk ? 32 : 16), tiles_y = ceil_div(a.H, C64_TH);
     const int n_tiles = d->geom.n_img * tiles_x * tiles_y;
+#if C64XH_PHASES
+    if (const char* dp = getenv("WSOVOD_C64_DEBUG_PTR")) a.partial = (float*)strtoull(dp, nullptr, 16);
+#endif
     wsovod::ProfScope prof(slot, s, flops, bytes);
-    if (wide)
+    if (halfk)
+      hipLaunchKernelGGL(conv3x3_c64_x3h_kernel, dim3(n_tiles), dim3(256), C64XH::LDS_BYTES, s, a, tiles_x, tiles_y);
+    else if (wide)
       hipLaunchKernelGGL(conv3x3_c64_x3_kernel<32>, dim3(n_tiles), dim3(256), C64X<32>::LDS_BYTES, s, a, tiles_x, tiles_y);
     else
       hipLaunchKernelGGL(conv3x3_c64_x3_kernel<16>, dim3(n_tiles), dim3(256), C64X<16>::LDS_BYTES, s, a, tiles_x, tiles_y);
@@ -1821,6 +2041,30 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
     tile = 8256256;
   a.ksplit = d->tile_hint == 0 ? -1 : 0;  // split-K may only change the summation order when the caller named no tile
+  // Tile-round tail of the one-workgroup-per-CU 256x256 conv tile: the last, partly filled round of 256 tiles costs a whole
+  // tile time (32 images of 75x100, 512 channels: 1876 tiles = 7.33 rounds -> 8).  When the leftover tiles, cut in halves
+  // along N (256x128, still one workgroup per CU), fit ONE round, the rows behind the last full round go through a second
+  // launch with that tile: ~0.6 of a tile time instead of 1.  Same products in the same order per output element.
+  if (d->conv && !d->tile_hint && tile == 256256 && d->dtype_in != WSOVOD_F32 &&
+      !(getenv("WSOVOD_CONV_TAIL") && getenv("WSOVOD_CONV_TAIL")[0] == '0')) {
+    const int tm = ceil_div(d->M, 256), tn = ceil_div(d->N, 256);
+    const long long tiles = (long long)tm * tn;
+    const int rounds = (int)(tiles / 256);
+    const int main_tm = (int)((long long)rounds * 256 / tn);
+    const long long tail_rows = (long long)d->M - (long long)main_tm * 256;
+    const long long tail_tiles = ceil_div((int)tail_rows, 256) * (long long)ceil_div(d->N, 128);
+    if (rounds >= 1 && tail_rows > 0 && tail_tiles <= 256 && tiles - (long long)main_tm * tn > 0) {
+      const double fmain = (double)main_tm * 256 / d->M;
+      GemmArgs am = a, at = a;
+      am.M = main_tm * 256;
+      at.m_base = main_tm * 256;
+      int rc = x2 ? dispatch_tile_x3<true>(am, 256256, s, flops * fmain, bytes * fmain)
+                  : dispatch_tile<bf16_t, true>(am, 256256, s, flops * fmain, bytes * fmain);
+      if (rc != WSOVOD_OK) return rc;
+      return x2 ? dispatch_tile_x3<true>(at, 256128, s, flops * (1.0 - fmain), bytes * (1.0 - fmain))
+                : dispatch_tile<bf16_t, true>(at, 256128, s, flops * (1.0 - fmain), bytes * (1.0 - fmain));
+    }
+  }
   if (x2) {
     // plain contractions: the 8-wavefront tile in its two-phase form (48 MFMAs per phase; measured on the fc1 / fc2 /
     // projection shapes: 6.63 -> 6.14, 1.12 -> 1.03, 0.274 -> 0.263 ms against the four-phase form, tools/x2_probe.py);

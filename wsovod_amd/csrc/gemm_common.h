@@ -44,6 +44,7 @@ struct GemmArgs {
   long long partial_ld;
   long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
   int tiles_m, tiles_n;
+  int m_base;  // gemm_nt_kernel: first output row of this launch (a launch may cover rows [m_base, M) only: tail launches)
   int group_m;  // tile-order group height (see the XCD remap in the kernel)
   // conv: optional second input contracted 1x1 / stride 1 after the KH*KW*Cin main K range (fused projection shortcut)
   const char* A2;
