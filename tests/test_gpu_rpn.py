@@ -335,10 +335,28 @@ def test_parity_mode_rpn_step_matches_reference_golden(gpu, monkeypatch):
     torch.cuda.synchronize()
     torch.testing.assert_close(model.proposal_generator.pred_objectness_logits[0].detach().cpu(), g["rpn_logits"], rtol=1e-3,
                                atol=1e-3)
-    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0", "loss_rpn_cls", "loss_rpn_loc"):
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
         torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=1e-2, atol=1e-5, msg=lambda m: f"{k}: {m}")
-    for i, t in enumerate(model.roi_heads.proposal_targets):
+    targets = model.roi_heads.proposal_targets
+    for i, t in enumerate(targets):  # the pseudo ground truth the RPN is trained on: same proposals picked, boxes to 0.1 px
         assert torch.equal(t.gt_classes.cpu(), g[f"target{i}/gt_classes"])
+        torch.testing.assert_close(t.gt_boxes.tensor.cpu(), g[f"target{i}/gt_boxes"], rtol=0, atol=0.1)
+    pg = model.proposal_generator
+    if torch.equal(pg.sampled_labels.cpu(), g["anchor_labels"]):
+        for k in ("loss_rpn_cls", "loss_rpn_loc"):
+            torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=1e-2, atol=1e-5, msg=lambda m: f"{k}: {m}")
+    else:
+        # Matcher(allow_low_quality_matches=True) makes EVERY anchor that ties for a pseudo-GT box's best IoU positive: a
+        # small box lies inside dozens of equal-area anchors, and whether that tie set or one partly overlapping anchor is
+        # "best" flips with a 0.02-px change of the box (this batch: 44 vs 77 positives).  The labels are then compared with
+        # the oracle's matcher on the model's OWN pseudo-GT boxes (exact) and the losses with the oracle's on those labels.
+        ref, ref_labels = R.rpn_losses(pg.anchors[0].tensor.cpu(), pg.pred_objectness_logits[0].detach().float().cpu(),
+                                       pg.pred_anchor_deltas[0].detach().float().cpu(),
+                                       [dict(gt_boxes=t.gt_boxes.tensor.cpu()) for t in targets], gen.first_k_subsample,
+                                       thresholds=(0.2, 0.6))
+        assert torch.equal(pg.sampled_labels.cpu(), ref_labels)
+        for k in ("loss_rpn_cls", "loss_rpn_loc"):
+            torch.testing.assert_close(losses[k].detach().cpu(), ref[k], rtol=1e-4, atol=1e-6, msg=lambda m: f"{k}: {m}")
     for k, q in model.named_parameters():
         if q.requires_grad:
             assert q.grad is not None and bool(torch.isfinite(q.grad).all()), k
