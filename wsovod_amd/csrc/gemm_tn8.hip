@@ -359,7 +359,8 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
       grid = ntiles * S;
       if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(ntiles), dim3(256), 0, s, a);
     }
-  } else if (!(accumulate & 2) && ntiles > cus && tail > 0 && tail <= cus / 2) {
+  } else if (!(accumulate & 2) && ntiles > cus && tail > 0 && tail <= cus / 2 &&
+             !(getenv("WSOVOD_TN_TAIL") && getenv("WSOVOD_TN_TAIL")[0] == '0')) {
     const int S = std::min(8, cus / tail);
     if (nk >= 8 * S) {
       a.full_tiles = ntiles - tail;
