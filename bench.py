@@ -550,6 +550,10 @@ def side_measurements(args, dev):
         cfgv = dict(precision=args.precision, batch_size=args.batch, pooler=args.pooler, steps=args.side_steps,
                     warmup=5, h2d=False)
         cfgv.update(kw)
+        if cfgv["batch_size"] <= 8 and "warmup" not in kw:
+            # whole-step HIP graphs: captured on the layout's fourth step, and the first few replays run 5 - 10 % slow
+            # (measured at 8 images: 8.7 / 8.1 / 8.9 / 9.0 ms, then 7.95 +- 0.03) -- the timed region starts behind them
+            cfgv["warmup"] = 12
         try:
             r = run_config(args, dev, 0, 1, **cfgv)
         except Exception as e:  # a side line must never take the headline down
@@ -557,6 +561,7 @@ def side_measurements(args, dev):
             continue
         ms = r["per_step_ms"]
         out.append({"name": name, "precision": cfgv["precision"], "images_per_step": cfgv["batch_size"],
+                    "warmup": cfgv["warmup"],
                     "meets_1e-3_logit_bound": cfgv["precision"] in ("parity", "fp32", "bf16x3", "bf16x3f"),
                     "pooler": cfgv["pooler"], "steps": cfgv["steps"], "depth": cfgv.get("depth") or args.depth,
                     "proposals": cfgv.get("proposals") or args.proposals,
