@@ -50,6 +50,10 @@ ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=sc
 print(f"roi_pool  fp32 -> bf16x2 + bf16 : {ms:.3f} ms")
 ms = timeit(lambda: H.roi_pool_forward(feat32, rois, 0.125, (7, 7), roi_scale=scale, out_dtype=torch.float32, need_argmax=False))
 print(f"roi_pool  fp32 -> fp32          : {ms:.3f} ms")
+ms = timeit(lambda: H.roi_align_forward(feat32, rois, 0.125, (7, 7), 0, True, roi_scale=scale, out_dtype=H.X2, want_hi=True))
+print(f"roi_align fp32 -> bf16x2 + bf16 : {ms:.3f} ms")
+if os.environ.get("ROI_PROBE_ALIGN_ONLY"):
+    sys.exit(0)
 
 
 # round 4: the 2x2-max-map path against the cell scan (switches are read per call)

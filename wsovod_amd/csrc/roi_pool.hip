@@ -801,8 +801,9 @@ constexpr int kAlignMaxGrid = 64;  // sample columns per bin the row kernel keep
 constexpr int kSepMax = 24;        // cells per bin and axis of the separable form (rois up to ~150 cells wide / high)
 constexpr int kAlignTabBytes = 7 * kAlignMaxGrid * 16 + (7 + 16) * kSepMax * 4 + (2 * 7 + 2 * 16 + 1) * 4 + 12;
 
-template <typename T, int PWT, int CPL, bool OBF = false>
-__global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
+// U = columns of every bin per loop iteration; WPE = wavefronts per SIMD the register allocation has to leave room for.
+template <typename T, int PWT, int CPL, bool OBF = false, int U = 1, int WPE = 4>
+__global__ __launch_bounds__(512, WPE) void roi_align_fwd_nhwc_rows(const T* __restrict__ feat, const float* __restrict__ rois,
                                                                const float* __restrict__ roi_scale, int C, int H, int W,
                                                                int PH, float spatial_scale, int sampling_ratio,
                                                                int aligned, void* out, int out_dtype, int cgroups,
@@ -909,20 +910,20 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
     if (*fits) {
       int x0[PWT], nc[PWT], ncmax = 0;
 #pragma unroll
-      for (int pw = 0; pw < PWT; ++pw) {
-        x0[pw] = max(meta[pw], 0);
-        nc[pw] = meta[PWT + pw];
+      for (int pw = 0; pw < PWT; ++pw) {  // (the same for every lane: kept in scalar registers)
+        x0[pw] = __builtin_amdgcn_readfirstlane(max(meta[pw], 0));
+        nc[pw] = __builtin_amdgcn_readfirstlane(meta[PWT + pw]);
         ncmax = max(ncmax, nc[pw]);
       }
-      const int y0 = meta[2 * PWT + ph], nr = meta[2 * PWT + 16 + ph];
+      const int y0 = __builtin_amdgcn_readfirstlane(meta[2 * PWT + ph]), nr = __builtin_amdgcn_readfirstlane(meta[2 * PWT + 16 + ph]);
       for (int ri = 0; ri < nr; ++ri) {
         const float wyv = wy[ph * kSepMax + ri];
         const T* row = base + (long long)(y0 + ri) * W * C;
-        for (int ci = 0; ci < ncmax; ci += 2) {  // two columns of every bin per iteration: 14 loads in flight
-          vecc v[2][PWT];
-          float w[2][PWT];
+        for (int ci = 0; ci < ncmax; ci += U) {  // U columns of every bin per iteration: 7 U loads in flight per wavefront
+          vecc v[U][PWT];
+          float w[U][PWT];
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int pw = 0; pw < PWT; ++pw) {
               const bool in = ci + u < nc[pw];
@@ -930,7 +931,7 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
               w[u][pw] = in ? wyv * wx[pw * kSepMax + min(ci + u, kSepMax - 1)] : 0.f;
             }
 #pragma unroll
-          for (int u = 0; u < 2; ++u)
+          for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int pw = 0; pw < PWT; ++pw)
 #pragma unroll
@@ -946,27 +947,20 @@ __global__ __launch_bounds__(512) void roi_align_fwd_nhwc_rows(const T* __restri
     if (!ay.valid) continue;  // uniform over the wavefront (one roi, one pooled row)
     const T* r0 = base + (long long)ay.lo * W * C;
     const T* r1 = base + (long long)ay.hi * W * C;
+    // (rois wider than kSepMax cells per bin: rare, so one bin at a time -- four loads in flight -- and the register
+    // count of the kernel is set by the separable loop above)
     for (int ix = 0; ix < a.grid_w; ++ix) {
-      int4 rec[PWT];
-      vecc v1[PWT], v2[PWT], v3[PWT], v4[PWT];
 #pragma unroll
       for (int pw = 0; pw < PWT; ++pw) {
-        rec[pw] = tabled ? xtab[pw * a.grid_w + ix] : x_record(pw, ix);
-        const int lo = max(rec[pw].x, 0);  // an invalid sample still loads a valid cell and is skipped below
-        v1[pw] = *(const vecc*)(r0 + lo);
-        v2[pw] = *(const vecc*)(r0 + rec[pw].y);
-        v3[pw] = *(const vecc*)(r1 + lo);
-        v4[pw] = *(const vecc*)(r1 + rec[pw].y);
-      }
-#pragma unroll
-      for (int pw = 0; pw < PWT; ++pw) {
-        if (rec[pw].x < 0) continue;
-        const float xl = __int_as_float(rec[pw].z), xh = __int_as_float(rec[pw].w);
+        const int4 rec = tabled ? xtab[pw * a.grid_w + ix] : x_record(pw, ix);
+        if (rec.x < 0) continue;  // (uniform over the wavefront)
+        const vecc v1 = *(const vecc*)(r0 + rec.x), v2 = *(const vecc*)(r0 + rec.y);
+        const vecc v3 = *(const vecc*)(r1 + rec.x), v4 = *(const vecc*)(r1 + rec.y);
+        const float xl = __int_as_float(rec.z), xh = __int_as_float(rec.w);
         const float w1 = ay.h * xh, w2 = ay.h * xl, w3 = ay.l * xh, w4 = ay.l * xl;
 #pragma unroll
         for (int q = 0; q < CPL; ++q)
-          acc[pw][q] += w1 * to_f32(v1[pw][q]) + w2 * to_f32(v2[pw][q]) + w3 * to_f32(v3[pw][q]) +
-                        w4 * to_f32(v4[pw][q]);
+          acc[pw][q] += w1 * to_f32(v1[q]) + w2 * to_f32(v2[q]) + w3 * to_f32(v3[q]) + w4 * to_f32(v4[q]);
       }
     }
   }
@@ -1421,26 +1415,28 @@ int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const
       // bf16 maps of 512 channels and more (res5 of both depths) with bf16 output: 8 channels = 16 bytes per lane and
       // load, half the load instructions and L2 requests of the 4-channel form (2.15 -> 1.39 ms at the bench shape)
       const bool wide = dtype == WSOVOD_BF16 && out_dtype == WSOVOD_BF16 && C % 512 == 0 && ((uintptr_t)feat & 15) == 0;
-      const int cg = dtype == WSOVOD_BF16 ? (wide ? 512 : 256) : 128;
-      const int groups = ceil_div(C, cg);
-      // output transpose tile + sample-column table + separable weights
-      const int lds7 = ((cg * ph * pw * (wide ? 2 : 4) + 15) & ~15) + kAlignTabBytes;
-      if (wide) {
-        auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 8, true>;
-        if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), "wsovod_roi_align_forward: LDS opt-in");
-        hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, (void*)nullptr);
-      } else if (dtype == WSOVOD_BF16) {
-        auto k = roi_align_fwd_nhwc_rows<bf16_t, 7, 4>;
-        if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), "wsovod_roi_align_forward: LDS opt-in");
-        hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const bf16_t*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, out_hi);
-      } else {
-        auto k = roi_align_fwd_nhwc_rows<float, 7, 2>;
-        if (lds7 > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds7), "wsovod_roi_align_forward: LDS opt-in");
-        hipLaunchKernelGGL(k, dim3(R * groups), dim3(64 * ph), lds7, s, (const float*)feat, rois, roi_scale, C, H, W, ph,
-                           spatial_scale, sampling_ratio, aligned, out, out_dtype, groups, out_hi);
-      }
+      // (LDS of a workgroup: output transpose tile + sample-column table + separable weights)
+      // Occupancy decides this kernel (it waits on L2 gathers): ONE column of every bin per iteration (7 loads in flight
+      // per wavefront) and at most 128 registers, so that two 7-wavefront workgroups share a CU -- measured at the bench
+      // shape against two columns per iteration at 136 - 230 registers (one workgroup per CU): bf16 1.39 -> 0.91 ms, fp32
+      // map -> bf16x2 + bf16 3.71 -> 1.69 ms (with 4 instead of 2 fp32 channels per lane: 16-byte loads, two channel
+      // groups per roi instead of four).
+#define WS_ALIGN_ROWS(TV, CPLV, OBFV, HI)                                                                              \
+  {                                                                                                                    \
+    auto k = roi_align_fwd_nhwc_rows<TV, 7, CPLV, OBFV, 1, 4>;                                                         \
+    const int cgv = 64 * CPLV, groupsv = ceil_div(C, cgv);                                                             \
+    const int ldsv = ((cgv * ph * pw * (OBFV ? 2 : 4) + 15) & ~15) + kAlignTabBytes;                                   \
+    if (ldsv > 64 * 1024)                                                                                              \
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, ldsv),              \
+                   "wsovod_roi_align_forward: LDS opt-in");                                                            \
+    hipLaunchKernelGGL(k, dim3(R * groupsv), dim3(64 * ph), ldsv, s, (const TV*)feat, rois, roi_scale, C, H, W, ph,    \
+                       spatial_scale, sampling_ratio, aligned, out, out_dtype, groupsv, HI);                           \
+  }
+      if (wide) WS_ALIGN_ROWS(bf16_t, 8, true, (void*)nullptr)
+      else if (dtype == WSOVOD_BF16) WS_ALIGN_ROWS(bf16_t, 4, false, out_hi)
+      else if (C % 256 == 0 && ((uintptr_t)feat & 15) == 0) WS_ALIGN_ROWS(float, 4, false, out_hi)
+      else WS_ALIGN_ROWS(float, 2, false, out_hi)
+#undef WS_ALIGN_ROWS
     } else if (dtype == WSOVOD_BF16) {
       auto k = roi_align_fwd_nhwc<bf16_t>;
       if (lds > 64 * 1024) WS_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds), "wsovod_roi_align_forward: LDS opt-in");
