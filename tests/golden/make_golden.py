@@ -874,6 +874,226 @@ def golden_sampler():
     save("g11_multi_dataset_sampler", **arrays)
 
 
+def edge_batch(K=20, seed=7):
+    """The batch of G18's whole step (shared with the tests): 3 ragged images ~160x208, 24 proposals each; EVERY proposal
+    of image 1 has area <= 20 px^2 (the pseudo-GT miner filters them all: roi_heads.py:1090-1111 -> the empty-result
+    fallbacks :1181-1207), image 2's best-scoring candidates include filtered boxes next to normal ones."""
+    batch = gen.seeded_batch(3, 24, K, 160, 208, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    b = batch[1]
+    r = len(b["boxes"])
+    h, w = b["image"].shape[-2:]
+    x0 = torch.rand(r, generator=g) * (w - 8)
+    y0 = torch.rand(r, generator=g) * (h - 8)
+    wh = 2.0 + 2.4 * torch.rand(r, 2, generator=g)  # area <= 19.4
+    b["boxes"] = torch.stack([x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], dim=1)
+    b2 = batch[2]
+    b2["boxes"][2::3, 2:] = b2["boxes"][2::3, :2] + torch.tensor([4.0, 4.5])  # a third of image 2's boxes: area 18
+    return batch
+
+
+def golden_edges(r):
+    """G18: the branches of the reference that the happy-path vectors never reach, each run through the reference's own
+    code: (a) the MIL head at num_classes == 1 (fast_rcnn_open_vocabulary.py:338-357), directly and as a whole step;
+    (b) get_pgt_top_k on images whose candidate boxes are all <= 20 px^2 (roi_heads.py:1090-1111,1181-1207) followed by
+    the labelling, directly and as a whole step with gradients; (c) the refinement losses with -1 ignores, zero weights
+    and an all-background batch (fast_rcnn_open_vocabulary.py:813-820,864-878); (d) OpenVocabularyClassifier with
+    use_bias != 0, at K = 80 / D = 768, with and without norm_weight (open_vocabulary_classifier.py:35-37,79-105)."""
+    import pickle
+    import tempfile
+
+    arrays = {}
+    K, D = 20, 512
+    cfg, model, sd, shapes = build_ref_model(r, 18, K, D, seed=1)  # the state of g8 (shapes_r18_k20, seed 1)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 1e-12
+    rh = model.roi_heads
+
+    # ---- (b1) whole step on the edge batch ----
+    batch = edge_batch(K)
+    captured = {}
+
+    def cap(name, fn):
+        def wrapped(*a, **k):
+            o = fn(*a, **k)
+            captured[name] = o
+            return o
+        return wrapped
+
+    orig = (rh.object_miner.forward, rh.box_refinery[0].forward, rh.label_and_sample_proposals_wsl, rh.get_pgt_top_k)
+    rh.object_miner.forward = cap("miner", orig[0])
+    rh.box_refinery[0].forward = cap("refine", orig[1])
+    rh.label_and_sample_proposals_wsl = cap("proposals_k", orig[2])
+    rh.get_pgt_top_k = cap("targets", orig[3])
+    loss_dict = model(to_inputs(batch))
+    sum(loss_dict.values()).backward()
+    rh.object_miner.forward, rh.box_refinery[0].forward, rh.label_and_sample_proposals_wsl, rh.get_pgt_top_k = orig
+    p = "step/"
+    for k, v in loss_dict.items():
+        arrays[p + "loss/" + k] = v
+    arrays[p + "mining_scores"] = captured["miner"][0]
+    arrays[p + "refine_logits"] = captured["refine"][0]
+    arrays[p + "refine_deltas"] = captured["refine"][1]
+    arrays[p + "pred_class_img_logits"] = rh.pred_class_img_logits
+    for f in ("gt_classes", "gt_weights", "gt_scores"):
+        arrays[p + "label/" + f] = torch.cat([getattr(q, f) for q in captured["proposals_k"]])
+    arrays[p + "label/gt_boxes"] = torch.cat([q.gt_boxes.tensor for q in captured["proposals_k"]])
+    arrays[p + "pgt/num"] = np.array([len(t) for t in captured["targets"]])
+    arrays[p + "pgt/gt_boxes"] = torch.cat([t.gt_boxes.tensor for t in captured["targets"]])
+    for f in ("gt_classes", "gt_weights", "gt_scores"):
+        arrays[p + "pgt/" + f] = torch.cat([getattr(t, f) for t in captured["targets"]])
+    for k, q in model.named_parameters():
+        if q.requires_grad and q.grad is not None:
+            arrays[p + "gradnorm/" + k] = q.grad.norm()
+            arrays[p + "gradsample/" + k] = gen.strided_sample(q.grad, 1024)
+    model.zero_grad(set_to_none=True)
+    assert arrays[p + "pgt/num"].tolist()[1] == 1 and float(arrays[p + "pgt/gt_boxes"][arrays[p + "pgt/num"][0]][0]) == -10000.0
+
+    # ---- (b2) get_pgt_top_k + labelling called directly on crafted candidates ----
+    g = torch.Generator().manual_seed(41)
+    sizes = [(120, 160), (120, 160), (96, 128), (96, 128)]
+    nums = [12, 9, 7, 5]
+    boxes, scores = [], []
+    for i, (n, (h, w)) in enumerate(zip(nums, sizes)):
+        x0 = torch.rand(n, generator=g) * (w - 40)
+        y0 = torch.rand(n, generator=g) * (h - 40)
+        wh = 8 + torch.rand(n, 2, generator=g) * 30
+        boxes.append(torch.stack([x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], 1))
+        scores.append(torch.rand(n, K, generator=g) / n)
+    boxes[1][:, 2:] = boxes[1][:, :2] + torch.tensor([5.0, 4.0])      # image 1: every box has area exactly 20 (not > 20)
+    gt_int = [torch.tensor([3, 11]), torch.tensor([0, 7, 19]), torch.tensor([5]), torch.tensor([2, 4])]
+    top = int(scores[2][:, 5].argmax())                               # image 2: its best box for class 5 is filtered
+    boxes[2][top, 2:] = boxes[2][top, :2] + torch.tensor([4.0, 4.0])
+    boxes[3][:, 2:] = boxes[3][:, :2] + torch.tensor([3.0, 3.0])      # image 3: all filtered but one
+    boxes[3][4] = torch.tensor([10.0, 10.0, 60.0, 50.0])
+    img_logits = torch.rand(4, K, generator=g).clamp(1e-6, 1 - 1e-6)
+    props = [S.Instances(sz, proposal_boxes=S.Boxes(b.clone()), objectness_logits=torch.zeros(len(b)))
+             for sz, b in zip(sizes, boxes)]
+    rh.gt_classes_img_int = gt_int
+    rh.pred_class_img_logits = img_logits
+    rh.images = [torch.zeros(3, *sz) for sz in sizes]
+    targets = rh.get_pgt_top_k([b.clone() for b in boxes], [s_.clone() for s_ in scores], props)
+    labelled = rh.label_and_sample_proposals_wsl(0, props, targets)
+    p = "direct/"
+    arrays[p + "nums"] = np.array(nums)
+    arrays[p + "boxes"] = torch.cat(boxes)
+    arrays[p + "scores"] = torch.cat(scores)
+    arrays[p + "gt_int"] = torch.cat(gt_int)
+    arrays[p + "gt_int_num"] = np.array([len(t) for t in gt_int])
+    arrays[p + "img_logits"] = img_logits
+    arrays[p + "pgt/num"] = np.array([len(t) for t in targets])
+    arrays[p + "pgt/gt_boxes"] = torch.cat([t.gt_boxes.tensor for t in targets])
+    for f in ("gt_classes", "gt_weights", "gt_scores"):
+        arrays[p + "pgt/" + f] = torch.cat([getattr(t, f) for t in targets])
+        arrays[p + "label/" + f] = torch.cat([getattr(q, f) for q in labelled])
+    arrays[p + "label/gt_boxes"] = torch.cat([q.gt_boxes.tensor for q in labelled])
+    assert arrays[p + "pgt/num"].tolist() == [2, 1, 1, 2], arrays[p + "pgt/num"]
+
+    # ---- (c) refinement losses on crafted labels ----
+    ref0 = rh.box_refinery[0]
+    n = 40
+    logits = torch.randn(n, K + 1, generator=g) * 3
+    deltas = torch.randn(n, 4, generator=g) * 0.1
+    pb = torch.cat([boxes[0], boxes[0], boxes[0], boxes[0][:4]])[:n].clone()
+    gb = pb + torch.randn(n, 4, generator=g) * 2
+    gb[:, 2:] = torch.maximum(gb[:, 2:], gb[:, :2] + 1)
+    wts = torch.rand(n, generator=g)
+    cases = {
+        "ignores": torch.randint(0, K + 1, (n,), generator=g),
+        "all_background": torch.full((n,), K, dtype=torch.int64),
+        "zero_weights": torch.randint(0, K + 1, (n,), generator=g),
+        "one_foreground": torch.full((n,), K, dtype=torch.int64),
+    }
+    cases["ignores"][::3] = -1
+    cases["one_foreground"][17] = 4
+    arrays["loss/logits"], arrays["loss/deltas"], arrays["loss/proposal_boxes"], arrays["loss/gt_boxes"] = logits, deltas, pb, gb
+    for name, gc in cases.items():
+        w = wts.clone()
+        if name == "zero_weights":
+            w[1::2] = 0.0
+            w[4] = 1e-13  # below the 1e-12 validity threshold: contributes to the sum, not to the count
+        q = S.Instances((120, 160), proposal_boxes=S.Boxes(pb.clone()), gt_boxes=S.Boxes(gb.clone()), gt_classes=gc.clone(),
+                        gt_weights=w.clone())
+        lg, dl = logits.clone().requires_grad_(True), deltas.clone().requires_grad_(True)
+        out = ref0.losses((lg, dl), [q])
+        tot = out["loss_cls_r0"] + out["loss_box_reg_r0"]
+        if tot.requires_grad:
+            tot.backward()
+        arrays[f"loss/{name}/gt_classes"], arrays[f"loss/{name}/gt_weights"] = gc, w
+        arrays[f"loss/{name}/loss_cls"], arrays[f"loss/{name}/loss_box"] = out["loss_cls_r0"], out["loss_box_reg_r0"]
+        arrays[f"loss/{name}/dlogits"] = lg.grad if lg.grad is not None else torch.zeros_like(logits)
+        arrays[f"loss/{name}/ddeltas"] = dl.grad if dl.grad is not None else torch.zeros_like(deltas)
+
+    # ---- (a) MIL head at num_classes == 1 ----
+    cfg1, model1, sd1, shapes1 = build_ref_model(r, 18, 1, D, seed=5)
+    model1.train()
+    for m in model1.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 1e-12
+    om = model1.roi_heads.object_miner
+    x = torch.randn(40, 4096, generator=g) * 0.5
+    arrays["k1/x"] = x
+    arrays["k1/cls_w"], arrays["k1/cls_b"] = om.cls.weight, om.cls.bias
+    arrays["k1/det_w"], arrays["k1/det_b"] = om.det.weight, om.det.bias
+    pl = [S.Instances((96, 128), proposal_boxes=S.Boxes(torch.zeros(k_, 4))) for k_ in (25, 15)]
+    with torch.no_grad():
+        s2, _ = om(x, pl)
+        s1, _ = om(x[:25], pl[:1])
+        s0, _ = om(x, None)
+    arrays["k1/scores_two_images"], arrays["k1/scores_one_image"], arrays["k1/scores_no_proposals"] = s2, s1, s0
+    oh = torch.tensor([[1.0], [0.0]])
+    xs = x.clone().requires_grad_(True)
+    pred = om(xs, pl)
+    lm = om.losses(pred, pl, oh)["loss_cls_object_mining"]
+    lm.backward()
+    arrays["k1/gt_oh"], arrays["k1/loss"], arrays["k1/dx_sample"] = oh, lm, gen.strided_sample(xs.grad, 2048)
+    arrays["k1/dcls_w"], arrays["k1/ddet_w"] = om.cls.weight.grad, om.det.weight.grad
+    model1.zero_grad(set_to_none=True)
+    # the whole step at K = 1 (refinement over 2 columns: class 0 + background)
+    save("shapes_r18_k1", keys=np.array(list(shapes1.keys())), shapes=np.array([str(v) for v in shapes1.values()]))
+    b1 = gen.seeded_batch(2, 20, 1, 128, 160, seed=9)
+    ld = model1(to_inputs(b1))
+    sum(ld.values()).backward()
+    for k, v in ld.items():
+        arrays["k1/step/loss/" + k] = v
+    arrays["k1/step/pred_class_img_logits"] = model1.roi_heads.pred_class_img_logits
+    for k, q in model1.named_parameters():
+        if q.requires_grad and q.grad is not None:
+            arrays["k1/step/gradnorm/" + k] = q.grad.norm()
+
+    # ---- (d) OpenVocabularyClassifier: use_bias != 0, K = 80 / D = 768, norm_weight on / off ----
+    Kc, Dc = 80, 768
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    emb_path = os.path.join(tmp, "emb.pkl")
+    emb = torch.randn(Kc, Dc, generator=torch.Generator().manual_seed(61))
+    with open(emb_path, "wb") as f:
+        pickle.dump(emb.numpy(), f)
+    xin = torch.randn(33, 4096, generator=torch.Generator().manual_seed(62)) * 0.5
+    clsf = torch.randn(17, Dc, generator=torch.Generator().manual_seed(63))
+    arrays["ovc/x"], arrays["ovc/emb"], arrays["ovc/classifier"] = xin, emb, clsf
+    for tag, kw in (("bias", dict(use_bias=-2.0, norm_weight=True)), ("nobias", dict(use_bias=0.0, norm_weight=True)),
+                    ("bias_nonorm", dict(use_bias=0.75, norm_weight=False))):
+        head = r.ovc.OpenVocabularyClassifier(S.ShapeSpec(channels=4096), num_classes=Kc, weight_path=emb_path,
+                                              weight_dim=Dc, norm_temperature=50.0, **kw)
+        shp = {"projection." + k: tuple(v.shape) for k, v in head.projection.state_dict().items()}
+        st = gen.seeded_state(shp, 23)  # the tests rebuild the projection from (shapes, seed 23)
+        head.projection.load_state_dict({k[len("projection."):]: v for k, v in st.items()})
+        xg = xin.clone().requires_grad_(True)
+        out = head(xg, None, append_background=True)
+        out.square().mean().backward()
+        arrays[f"ovc/{tag}/logits_bg"] = out
+        arrays[f"ovc/{tag}/dx_sample"] = gen.strided_sample(xg.grad, 2048)
+        if head.use_bias:
+            arrays[f"ovc/{tag}/dcls_bias"] = head.cls_bias.grad
+        with torch.no_grad():
+            arrays[f"ovc/{tag}/logits_nobg"] = head(xin, None, append_background=False)
+            arrays[f"ovc/{tag}/logits_classifier"] = head(xin, clsf, append_background=True)
+    save("g18_edge_branches", **arrays)
+
+
+
 def main():
     if "--only-sampler" in sys.argv:
         return golden_sampler()
@@ -888,6 +1108,8 @@ def main():
         return golden_rpn(r)
     if "--only-union" in sys.argv:
         return golden_tta_union(r)
+    if "--only-edges" in sys.argv:
+        return golden_edges(r)
     if "--only-eval" in sys.argv:
         golden_eval_tail(r)
         golden_subsample(r)
@@ -997,6 +1219,7 @@ def main():
     golden_sampler()
     golden_rpn(r)
     golden_formats()
+    golden_edges(r)
 
 
 if __name__ == "__main__":

@@ -277,3 +277,88 @@ def test_step_graph_single_image_and_roialign(gpu, monkeypatch, pooler, nums_lis
         assert torch.equal(e[1], g[1]), s
         for k in e[0]:
             assert abs(e[0][k] - g[0][k]) <= 5e-5 * max(abs(e[0][k]), 1e-3), (s, k, e[0][k], g[0][k])
+
+
+def test_eager_and_replayed_layouts_interleave_in_update_order(gpu, monkeypatch):
+    """Two row buckets in rotation: X (128 rows) is captured and replayed, Y (192 rows) is still on the eager path when it
+    comes between two replays of X.  The eager step leaves its SGD update deferred (overlap=True): the next replay must
+    apply it BEFORE the graph reads the weights and runs its own update, or the update order drifts from the eager
+    trainer's (and the reference's).  Step for step against WSOVOD_STEP_GRAPH=0."""
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.layers import hip_ops as H
+    from wsovod_amd.testing import build_hot_path_model
+
+    monkeypatch.setattr(H, "DETERMINISTIC", True)
+    monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", "0")
+    X = _varying_batches(7, [(64, 64), (60, 57)], H=256, W=320)
+    Y = _varying_batches(3, [(100, 92)], H=256, W=320)
+    order = [X[0], X[1], X[2], X[3], Y[0], X[4], Y[1], X[5], X[6], Y[2]]  # X captured at its 3rd sighting; Y never (2 eager + capture at the end)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WSOVOD_STEP_GRAPH", flag)
+        cfg, model = build_hot_path_model(seed=0, precision="bf16", device="cuda:0")
+        model.train()
+        cfg.SOLVER.BASE_LR = 2e-2  # large steps: a missed / reordered update moves the next step's losses visibly
+        tr = HotPathTrainer(model, build_optimizer(cfg, model))
+        hist, kept = [], []
+        for b in order:
+            out = tr.run_step(b)
+            kept.append(out)  # held across steps: must not alias the graph's static loss buffers
+            hist.append({k: float(v) for k, v in out.items()})
+        for h, o in zip(hist, kept):
+            assert {k: float(v) for k, v in o.items()} == h
+        tr.flush()
+        runs[flag] = (hist, {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
+        tr.close()
+    for s, (e, g) in enumerate(zip(runs["0"][0], runs["1"][0])):
+        for k in e:
+            assert abs(e[k] - g[k]) <= 5e-5 * max(abs(e[k]), 1e-3), (s, k, e[k], g[k])
+    for k, v in runs["0"][1].items():
+        torch.testing.assert_close(runs["1"][1][k], v, rtol=1e-4, atol=1e-5 * float(v.abs().max()) + 1e-9, msg=lambda m: f"{k}: {m}")
+
+
+def test_step_graph_cache_is_lru_and_stops_capturing_when_it_thrashes(gpu, monkeypatch):
+    """The cache keeps the most recently REPLAYED layouts; an evicted layout has to be sighted again (twice as often)
+    before it is recaptured, and once recaptures exceed the budget no further layout is captured: multi-scale training with
+    more hot layouts than the cache holds runs eager instead of re-tracing a graph per step."""
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, precision="bf16", device="cuda:0")
+    model.train()
+    tr = HotPathTrainer(model, build_optimizer(cfg, model))
+    monkeypatch.setattr(tr, "GRAPH_CACHE", 2, raising=False)
+    monkeypatch.setattr(tr, "GRAPH_RECAPTURES", 1, raising=False)
+    shapes = [(128, 160), (128, 192), (160, 160)]
+    data = {s: _varying_batches(1, [(32,)], H=s[0], W=s[1])[0] for s in shapes}
+
+    def key(s):
+        return tr._graph_key(data[s])
+
+    A, B, C = shapes
+    for _ in range(3):
+        tr.run_step(data[A])
+    for _ in range(3):
+        tr.run_step(data[B])
+    assert list(tr._graphs) == [key(A), key(B)]
+    tr.run_step(data[A])  # a replay refreshes A: B is now the least recently used
+    assert list(tr._graphs) == [key(B), key(A)]
+    for _ in range(3):
+        tr.run_step(data[C])
+    assert list(tr._graphs) == [key(A), key(C)]  # B went, not A
+    for _ in range(5):
+        tr.run_step(data[B])  # evicted: not back at its third sighting ...
+    assert key(B) not in tr._graphs
+    tr.run_step(data[B])      # ... but at its sixth (recapture 1 of 1)
+    assert key(B) in tr._graphs and tr._graph_recaptures == 1
+    evicted = [k for k in (key(A), key(C)) if k not in tr._graphs][0]
+    lay = A if evicted == key(A) else C
+    with pytest.warns(UserWarning, match="more training-step layouts in rotation"):
+        for _ in range(6):
+            losses = tr.run_step(data[lay])
+    assert evicted not in tr._graphs and all(torch.isfinite(v) for v in losses.values())
+    n = len(tr._graphs)
+    for _ in range(4):
+        tr.run_step(_varying_batches(1, [(32,)], H=192, W=192)[0])  # budget spent: new layouts stay eager too
+    assert len(tr._graphs) == n
+    tr.close()

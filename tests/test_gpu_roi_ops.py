@@ -255,3 +255,47 @@ def test_roi_loop_pool_generic_sizes_bit_exact(gpu, size, C):
         out, arg = H.roi_loop_pool_forward(feat.to(gpu), rois.to(gpu), 0.125, size)
         assert out.shape == (150, C) + size
         assert torch.equal(out.cpu(), ref) and torch.equal(arg.cpu(), ref_arg), (size, C, dtype)
+
+
+@pytest.mark.parametrize("C,size", [(16, (7, 7)), (70, (3, 5)), (256, (7, 7)), (512, (7, 7))])
+def test_pool_kernels_cover_every_output_element(gpu, monkeypatch, C, size):
+    """The pool outputs are allocated uninitialised; the backward scatters through argmax.  With every output byte
+    poisoned (0x7f) before the launch, no path of the kernels -- boxes off the map (empty bins: value 0, argmax -1),
+    zero-area boxes, an roi count that leaves a partly filled last workgroup, odd channel counts, generic pooled sizes --
+    may leave an element unwritten: outputs equal the C oracle's everywhere, argmax stays inside [-1, H*W)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    monkeypatch.setattr(H, "POISON_OUTPUTS", True)
+    g = torch.Generator().manual_seed(21)
+    Hh, Ww = 30, 41
+    feat = torch.relu(torch.randn(2, C, Hh, Ww, generator=g))
+    rois = random_rois(37, 2, 240, 328, seed=22)  # 37: a ragged tail for every rois-per-workgroup form
+    rois[3, 1:] = torch.tensor([500.0, 500.0, 600.0, 600.0])   # wholly off the map
+    rois[4, 1:] = torch.tensor([-90.0, -80.0, -20.0, -10.0])   # wholly negative
+    rois[5, 1:] = torch.tensor([100.0, 100.0, 100.0, 100.0])   # zero area
+    rois[6, 1:] = torch.tensor([0.0, 0.0, 327.0, 239.0])       # the whole map
+    poison_i = int.from_bytes(bytes([H.POISON_BYTE]) * 4, "little")
+    f = feat.to(gpu).contiguous(memory_format=torch.channels_last)
+    ref3, ref3_arg = O.roi_loop_pool_forward(feat, rois, 0.125, size)
+    out3, arg3 = H.roi_loop_pool_forward(f, rois.to(gpu), 0.125, size)
+    assert not bool((arg3 == poison_i).any()) and not bool((out3.view(torch.int32) == poison_i).any())
+    assert int(arg3.min()) >= -1 and int(arg3.max()) < Hh * Ww
+    assert torch.equal(out3.cpu(), ref3) and torch.equal(arg3.cpu(), ref3_arg)
+    for layout_f in (f, feat.to(gpu)):
+        ref, ref_arg = O.roi_pool_forward(feat, rois, 0.125, size)
+        out, arg = H.roi_pool_forward(layout_f, rois.to(gpu), 0.125, size)
+        assert not bool((arg == poison_i).any()) and not bool((out.view(torch.int32) == poison_i).any())
+        assert torch.equal(out.cpu(), ref) and torch.equal(arg.cpu(), ref_arg)
+        out_v, none = H.roi_pool_forward(layout_f, rois.to(gpu), 0.125, size, need_argmax=False)
+        assert none is None and torch.equal(out_v.cpu(), ref)
+    if size == (7, 7):
+        al = H.roi_align_forward(f, rois.to(gpu), 0.125, size, 0, True)
+        assert not bool((al.view(torch.int32) == poison_i).any()) and bool(torch.isfinite(al).all())
+    # a corrupted index is never scattered (bounds check in roi_pool_bwd): only the valid entries reach grad_in
+    grad = torch.randn(ref.shape, generator=g)
+    bad = ref_arg.clone()
+    bad[0, 0, 0, 0] = Hh * Ww + 12345
+    gi = H.roi_pool_backward(grad.to(gpu), rois.to(gpu), bad.to(gpu), (2, C, Hh, Ww))
+    fixed = ref_arg.clone()
+    fixed[0, 0, 0, 0] = -1
+    torch.testing.assert_close(gi.cpu(), O.roi_pool_backward(grad, rois, fixed, (2, C, Hh, Ww)), rtol=1e-5, atol=1e-5)

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd(const float* __restrict__ gr
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int am = argmax[idx];
-    if (am < 0) continue;
+    if (am < 0 || am >= H * W) continue;  // -1 = empty bin; anything else outside the map is never scattered
     const int c = (int)((idx / ((long long)PW * PH)) % C);
     const int r = (int)(idx / ((long long)PW * PH * C));
     const int n = (int)rois[(long long)r * 5];

@@ -362,6 +362,10 @@ class _StepGraph:
         else:
             if not self._load(batched_inputs):
                 return None
+            if len(self.graphs) == 1:
+                # an eager step (another layout) may have left its update deferred: it lands before this replay reads
+                # the weights and runs its own SGD launch (no-op when nothing is pending)
+                tr._finish_pending()
             tr._graph_bookkeeping()
         if len(self.graphs) == 1:
             self.graphs[0].replay()
@@ -374,7 +378,8 @@ class _StepGraph:
             tr._pending = [tr._reduce_block(lo, hi) for lo, hi in self.blocks]
             if not tr.overlap:
                 tr._wait_pending()
-        return self.losses
+        # fresh tensors, as the eager path returns: the static loss buffers are overwritten by the next replay
+        return {k: v.clone() for k, v in self.losses.items()}
 
 
 class HotPathTrainer:
@@ -463,6 +468,7 @@ class HotPathTrainer:
         # the WHOLE step as captured HIP graph(s) at small batches (WSOVOD_STEP_GRAPH=0: eager launches + backbone graph)
         self.graph_max_batch = 8 if os.environ.get("WSOVOD_STEP_GRAPH", "1") != "0" else 0
         self._graphs, self._graph_seen = {}, {}
+        self._graph_evicted, self._graph_recaptures = set(), 0
         self.iter = int(start_iter)  # the reference's global iteration (engine/trainer.py:72-84): pass it when resuming
         if self.iter_size < 1:
             raise ValueError(f"iter_size must be >= 1, got {iter_size}")
@@ -735,7 +741,8 @@ class HotPathTrainer:
 
     # ---- whole-step HIP graphs (small batches) ----
     GRAPH_AFTER = 3  # eager steps with a layout before it is captured (the first ones fill caches and allocator pools)
-    GRAPH_CACHE = 4
+    GRAPH_CACHE = 4  # captured layouts kept (least recently replayed goes first)
+    GRAPH_RECAPTURES = 8  # captures of layouts that had been captured before and evicted: beyond this, no new captures
 
     def _graph_key(self, data):
         m = self.model
@@ -779,14 +786,29 @@ class HotPathTrainer:
         if key is None or not key[-1]:
             return None
         g = self._graphs.get(key)
-        if g is None:
-            if len(self._graph_seen) > 64:
-                self._graph_seen.clear()
-            self._graph_seen[key] = self._graph_seen.get(key, 0) + 1
-            if self._graph_seen[key] < self.GRAPH_AFTER:
+        if g is not None:
+            self._graphs[key] = self._graphs.pop(key)  # least recently USED order: a replayed layout moves to the back
+        else:
+            if self._graph_recaptures > self.GRAPH_RECAPTURES:
+                return None  # more hot layouts than the cache holds (multi-scale input): captures would thrash, stay eager
+            seen = self._graph_seen
+            if key not in seen and len(seen) >= 256:  # bounded: forget the layout sighted longest ago
+                seen.pop(next(iter(seen)))
+            seen[key] = seen.pop(key, 0) + 1
+            if seen[key] < self.GRAPH_AFTER:
                 return None
+            if key in self._graph_evicted:
+                self._graph_recaptures += 1
+                if self._graph_recaptures > self.GRAPH_RECAPTURES:
+                    warnings.warn("wsovod_amd: more training-step layouts in rotation than the HIP-graph cache holds "
+                                  f"({self.GRAPH_CACHE}); further layouts keep the eager launches")
+                    return None
             if len(self._graphs) >= self.GRAPH_CACHE:
-                self._graphs.pop(next(iter(self._graphs)))
+                old = next(iter(self._graphs))
+                self._graphs.pop(old)
+                # an evicted layout starts over (and counts double: it has to show it is hotter than what replaced it)
+                seen[old] = -self.GRAPH_AFTER
+                self._graph_evicted.add(old)
             snap = self._counters()
             try:
                 g = _StepGraph(self, data, key)

@@ -4,6 +4,7 @@ Every function enqueues on torch's current HIP stream and never synchronises.  T
 CPU fallback: CPU tensors or a missing library raise RuntimeError.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -208,6 +209,20 @@ def _x2_hi_alloc(out):
     return hi
 
 
+POISON_OUTPUTS = os.environ.get("WSOVOD_POISON_OUTPUTS", "0") == "1"
+POISON_BYTE = 0x7F
+
+
+def _out_empty(shape, dtype, device):
+    """Output buffer a kernel must cover completely (pool values / argmax indices are allocated uninitialised).
+    POISON_OUTPUTS (tests, `WSOVOD_POISON_OUTPUTS=1`): every byte is 0x7f first, so an element a kernel path skipped
+    reads as 0x7f7f7f7f (3.4e38 / 2139062143) instead of whatever the allocator left there."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    if POISON_OUTPUTS and t.numel():
+        t.view(torch.uint8).fill_(POISON_BYTE)
+    return t
+
+
 def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out_dtype=None, need_argmax=True,
                      want_hi=False):
     """RoI max pool -> (out (R,C,ph,pw), argmax int32 or None).  want_hi (bf16x2 output only): also write the plain
@@ -218,8 +233,8 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     ph, pw = output_size
     R = rois.size(0)
     out_dtype = out_dtype or feat.dtype
-    out = torch.empty((R, Cc, ph, pw), dtype=storage_dtype(out_dtype), device=feat.device)
-    argmax = torch.empty((R, Cc, ph, pw), dtype=torch.int32, device=feat.device) if need_argmax else None
+    out = _out_empty((R, Cc, ph, pw), storage_dtype(out_dtype), feat.device)
+    argmax = _out_empty((R, Cc, ph, pw), torch.int32, feat.device) if need_argmax else None
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
@@ -247,8 +262,8 @@ def roi_loop_pool_forward(feat, rois, spatial_scale, output_size, context_ratio=
     rois = _rois_f32(rois)
     ph, pw = output_size
     R = rois.shape[0]
-    out = torch.empty((3 * R, Cc, ph, pw), dtype=torch.float32, device=feat.device)
-    arg = torch.empty((3 * R, Cc, ph, pw), dtype=torch.int32, device=feat.device)
+    out = _out_empty((3 * R, Cc, ph, pw), torch.float32, feat.device)
+    arg = _out_empty((3 * R, Cc, ph, pw), torch.int32, feat.device)
     check(lib().wsovod_roi_loop_pool_forward(ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), R, N, Cc, Hh, Ww, ph,
                                              pw, C.c_float(spatial_scale), C.c_float(context_ratio), ptr(out), ptr(arg),
                                              stream()), "roi_loop_pool_forward")
@@ -277,7 +292,7 @@ def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, al
     ph, pw = output_size
     R = rois.size(0)
     out_dtype = out_dtype or feat.dtype
-    out = torch.empty((R, Cc, ph, pw), dtype=storage_dtype(out_dtype), device=feat.device)
+    out = _out_empty((R, Cc, ph, pw), storage_dtype(out_dtype), feat.device)
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
