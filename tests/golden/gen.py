@@ -150,3 +150,31 @@ def strided_sample(t, n=4096):
         return flat.clone()
     idx = (torch.arange(n, dtype=torch.int64) * (flat.numel() - 1)) // (n - 1)
     return flat[idx].clone()
+
+
+def edge_batch(K=20, seed=7):
+    """The batch of G18's whole step (shared with the tests): 3 ragged images ~160x208, 24 proposals each; EVERY proposal
+    of image 1 has area <= 20 px^2 (the pseudo-GT miner filters them all: roi_heads.py:1090-1111 -> the empty-result
+    fallbacks :1181-1207), image 2's best-scoring candidates include filtered boxes next to normal ones."""
+    batch = seeded_batch(3, 24, K, 160, 208, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1000)
+    b = batch[1]
+    r = len(b["boxes"])
+    h, w = b["image"].shape[-2:]
+    x0 = torch.rand(r, generator=g) * (w - 8)
+    y0 = torch.rand(r, generator=g) * (h - 8)
+    wh = 2.0 + 2.4 * torch.rand(r, 2, generator=g)  # area <= 19.4
+    b["boxes"] = torch.stack([x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], dim=1)
+    b2 = batch[2]
+    b2["boxes"][2::3, 2:] = b2["boxes"][2::3, :2] + torch.tensor([4.0, 4.5])  # a third of image 2's boxes: area 18
+    return batch
+
+
+def edge_features(tag, rows, dim=4096):
+    """Box-feature matrix of G18's direct head calls (a function of the tag only: nothing to commit)."""
+    return torch.randn(rows, dim, generator=_gen("edge_features_" + tag, 0)) * 0.5
+
+
+def edge_embeddings(K=80, D=768):
+    """(class text embeddings (K,D) as the weight file holds them, a per-call classifier (17,D)) of G18's (d)."""
+    return torch.randn(K, D, generator=_gen("edge_emb", 0)), torch.randn(17, D, generator=_gen("edge_clsf", 0))

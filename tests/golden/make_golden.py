@@ -874,24 +874,6 @@ def golden_sampler():
     save("g11_multi_dataset_sampler", **arrays)
 
 
-def edge_batch(K=20, seed=7):
-    """The batch of G18's whole step (shared with the tests): 3 ragged images ~160x208, 24 proposals each; EVERY proposal
-    of image 1 has area <= 20 px^2 (the pseudo-GT miner filters them all: roi_heads.py:1090-1111 -> the empty-result
-    fallbacks :1181-1207), image 2's best-scoring candidates include filtered boxes next to normal ones."""
-    batch = gen.seeded_batch(3, 24, K, 160, 208, seed=seed)
-    g = torch.Generator().manual_seed(seed + 1000)
-    b = batch[1]
-    r = len(b["boxes"])
-    h, w = b["image"].shape[-2:]
-    x0 = torch.rand(r, generator=g) * (w - 8)
-    y0 = torch.rand(r, generator=g) * (h - 8)
-    wh = 2.0 + 2.4 * torch.rand(r, 2, generator=g)  # area <= 19.4
-    b["boxes"] = torch.stack([x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], dim=1)
-    b2 = batch[2]
-    b2["boxes"][2::3, 2:] = b2["boxes"][2::3, :2] + torch.tensor([4.0, 4.5])  # a third of image 2's boxes: area 18
-    return batch
-
-
 def golden_edges(r):
     """G18: the branches of the reference that the happy-path vectors never reach, each run through the reference's own
     code: (a) the MIL head at num_classes == 1 (fast_rcnn_open_vocabulary.py:338-357), directly and as a whole step;
@@ -912,7 +894,7 @@ def golden_edges(r):
     rh = model.roi_heads
 
     # ---- (b1) whole step on the edge batch ----
-    batch = edge_batch(K)
+    batch = gen.edge_batch(K)
     captured = {}
 
     def cap(name, fn):
@@ -1033,8 +1015,7 @@ def golden_edges(r):
         if isinstance(m, nn.Dropout):
             m.p = 1e-12
     om = model1.roi_heads.object_miner
-    x = torch.randn(40, 4096, generator=g) * 0.5
-    arrays["k1/x"] = x
+    x = gen.edge_features("k1", 40)
     arrays["k1/cls_w"], arrays["k1/cls_b"] = om.cls.weight, om.cls.bias
     arrays["k1/det_w"], arrays["k1/det_b"] = om.det.weight, om.det.bias
     pl = [S.Instances((96, 128), proposal_boxes=S.Boxes(torch.zeros(k_, 4))) for k_ in (25, 15)]
@@ -1067,19 +1048,17 @@ def golden_edges(r):
     Kc, Dc = 80, 768
     tmp = tempfile.mkdtemp(prefix="golden_")
     emb_path = os.path.join(tmp, "emb.pkl")
-    emb = torch.randn(Kc, Dc, generator=torch.Generator().manual_seed(61))
+    emb, clsf = gen.edge_embeddings(Kc, Dc)
     with open(emb_path, "wb") as f:
         pickle.dump(emb.numpy(), f)
-    xin = torch.randn(33, 4096, generator=torch.Generator().manual_seed(62)) * 0.5
-    clsf = torch.randn(17, Dc, generator=torch.Generator().manual_seed(63))
-    arrays["ovc/x"], arrays["ovc/emb"], arrays["ovc/classifier"] = xin, emb, clsf
+    xin = gen.edge_features("ovc", 33)
     for tag, kw in (("bias", dict(use_bias=-2.0, norm_weight=True)), ("nobias", dict(use_bias=0.0, norm_weight=True)),
                     ("bias_nonorm", dict(use_bias=0.75, norm_weight=False))):
         head = r.ovc.OpenVocabularyClassifier(S.ShapeSpec(channels=4096), num_classes=Kc, weight_path=emb_path,
                                               weight_dim=Dc, norm_temperature=50.0, **kw)
-        shp = {"projection." + k: tuple(v.shape) for k, v in head.projection.state_dict().items()}
+        shp = {"cls.projection." + k: tuple(v.shape) for k, v in head.projection.state_dict().items()}
         st = gen.seeded_state(shp, 23)  # the tests rebuild the projection from (shapes, seed 23)
-        head.projection.load_state_dict({k[len("projection."):]: v for k, v in st.items()})
+        head.projection.load_state_dict({k[len("cls.projection."):]: v for k, v in st.items()})
         xg = xin.clone().requires_grad_(True)
         out = head(xg, None, append_background=True)
         out.square().mean().backward()

@@ -298,3 +298,159 @@ def test_subsample_matches_reference():
         assert kept == min(int(num), len(lab)) or frac < 1.0 or int((lab != K).sum()) + int((lab == K).sum()) < num
         i += 1
     assert i == 5
+
+
+# ----------------------------------------------------------------------------------------
+# G18: the oracle's edge branches against the reference's own code (tests/golden/make_golden.py:golden_edges)
+# ----------------------------------------------------------------------------------------
+def test_edge_whole_step_with_empty_pseudo_gt_matches_reference():
+    """Image 1 of the batch has only boxes <= 20 px^2: the miner's candidate list is empty and the reference falls back
+    to one dummy target (box +-10000, class 0, score 1, weight 1: roi_heads.py:1181-1207), every proposal of that image
+    becomes background; a third of image 2's boxes are filtered too.  Losses, scores, labels (exact), gradients."""
+    g = load("g18_edge_branches")
+    sd = seeded_sd()
+    p = "step/"
+    train_keys = [k[len(p + "gradnorm/"):] for k in g if k.startswith(p + "gradnorm/")]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    batch = gen.edge_batch(20)
+    losses, inter = R.train_forward(sd, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD)
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+        torch.testing.assert_close(losses[k].detach(), g[p + "loss/" + k], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(inter["mining_scores"].detach(), g[p + "mining_scores"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(inter["refine_logits"].detach(), g[p + "refine_logits"], rtol=1e-4, atol=1e-4)
+    tg, lab = inter["targets"], inter["labelled"]
+    assert [len(t["gt_classes"]) for t in tg] == g[p + "pgt/num"].tolist()
+    assert torch.equal(torch.cat([t["gt_boxes"] for t in tg]), g[p + "pgt/gt_boxes"])
+    assert torch.equal(torch.cat([t["gt_classes"] for t in tg]), g[p + "pgt/gt_classes"])
+    torch.testing.assert_close(torch.cat([t["gt_weights"] for t in tg]), g[p + "pgt/gt_weights"], rtol=1e-5, atol=1e-8)
+    torch.testing.assert_close(torch.cat([t["gt_scores"] for t in tg]), g[p + "pgt/gt_scores"], rtol=1e-4, atol=1e-8)
+    assert tg[1]["gt_boxes"].tolist() == [[-10000.0, -10000.0, 10000.0, 10000.0]] and tg[1]["gt_classes"].tolist() == [0]
+    assert torch.equal(torch.cat([l["gt_classes"] for l in lab]), g[p + "label/gt_classes"])
+    assert torch.equal(torch.cat([l["gt_boxes"] for l in lab]), g[p + "label/gt_boxes"])
+    torch.testing.assert_close(torch.cat([l["gt_weights"] for l in lab]), g[p + "label/gt_weights"], rtol=1e-5, atol=1e-8)
+    assert bool((lab[1]["gt_classes"] == 20).all())  # the fallback image: all background
+    grads = torch.autograd.grad(sum(losses.values()), [sd[k] for k in train_keys])
+    for k, gr in zip(train_keys, grads):
+        torch.testing.assert_close(gr.norm(), g[p + "gradnorm/" + k], rtol=2e-4, atol=1e-9)
+        torch.testing.assert_close(gen.strided_sample(gr, 1024), g[p + "gradsample/" + k], rtol=2e-3, atol=1e-7)
+
+
+def _edge_direct_inputs(g):
+    p = "direct/"
+    nums = g[p + "nums"].tolist()
+    boxes = list(g[p + "boxes"].split(nums))
+    scores = list(g[p + "scores"].split(nums))
+    gt_int = list(g[p + "gt_int"].split(g[p + "gt_int_num"].tolist()))
+    return nums, boxes, scores, gt_int
+
+
+def test_edge_pseudo_gt_mining_on_filtered_candidates_matches_reference():
+    """get_pgt_top_k called directly: an image whose boxes all have area EXACTLY 20 (the cut is `> 20`), an image whose
+    best-scoring box is filtered (the runner-up must win: the filter precedes the top-k), an image with one survivor."""
+    g = load("g18_edge_branches")
+    p = "direct/"
+    nums, boxes, scores, gt_int = _edge_direct_inputs(g)
+    tg = R.get_pgt_top_k(boxes, scores, gt_int, g[p + "img_logits"], 20)
+    assert [len(t["gt_classes"]) for t in tg] == g[p + "pgt/num"].tolist() == [2, 1, 1, 2]
+    assert torch.equal(torch.cat([t["gt_boxes"] for t in tg]), g[p + "pgt/gt_boxes"])
+    assert torch.equal(torch.cat([t["gt_classes"] for t in tg]), g[p + "pgt/gt_classes"])
+    assert torch.equal(torch.cat([t["gt_scores"] for t in tg]), g[p + "pgt/gt_scores"])
+    assert torch.equal(torch.cat([t["gt_weights"] for t in tg]), g[p + "pgt/gt_weights"])
+    lab = R.label_and_sample_proposals_wsl(boxes, tg, 20)
+    assert torch.equal(torch.cat([l["gt_classes"] for l in lab]), g[p + "label/gt_classes"])
+    assert torch.equal(torch.cat([l["gt_boxes"] for l in lab]), g[p + "label/gt_boxes"])
+    assert torch.equal(torch.cat([l["gt_weights"] for l in lab]), g[p + "label/gt_weights"])
+    assert torch.equal(torch.cat([l["gt_scores"] for l in lab]), g[p + "label/gt_scores"])
+
+
+@pytest.mark.parametrize("case", ["ignores", "all_background", "zero_weights", "one_foreground"])
+def test_edge_refinement_losses_match_reference(case):
+    """Weighted CE / weighted smooth-L1 with -1 ignores (weight forced to 0, excluded from the valid count), an
+    all-background batch (no foreground: box loss exactly 0), weights at and below the 1e-12 validity threshold, and a
+    single foreground row: values and the gradients w.r.t. logits and deltas."""
+    g = load("g18_edge_branches")
+    lg = g["loss/logits"].clone().requires_grad_(True)
+    dl = g["loss/deltas"].clone().requires_grad_(True)
+    lc, lb = R.refinement_losses(lg, dl, g[f"loss/{case}/gt_classes"], g[f"loss/{case}/gt_weights"],
+                                 g["loss/proposal_boxes"], g["loss/gt_boxes"], 20)
+    torch.testing.assert_close(lc.detach(), g[f"loss/{case}/loss_cls"], rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(lb.detach().reshape(()), g[f"loss/{case}/loss_box"].reshape(()), rtol=1e-5, atol=1e-8)
+    (lc + lb).backward()
+    torch.testing.assert_close(lg.grad, g[f"loss/{case}/dlogits"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(dl.grad if dl.grad is not None else torch.zeros_like(dl), g[f"loss/{case}/ddeltas"],
+                               rtol=1e-4, atol=1e-9)
+    if case == "all_background":
+        assert float(g[f"loss/{case}/loss_box"]) == 0.0 and float(g[f"loss/{case}/ddeltas"].abs().max()) == 0.0
+
+
+def test_edge_mil_head_with_one_class_matches_reference():
+    """num_classes == 1: a zero column is appended to C and D before the two softmaxes and dropped afterwards
+    (fast_rcnn_open_vocabulary.py:338-340,356-357) -- two images, one image, `proposals=None`; BCE loss and gradients."""
+    g = load("g18_edge_branches")
+    x = gen.edge_features("k1", 40)
+    sd = {"m.cls.weight": g["k1/cls_w"].clone().requires_grad_(True), "m.cls.bias": g["k1/cls_b"],
+          "m.det.weight": g["k1/det_w"].clone().requires_grad_(True), "m.det.bias": g["k1/det_b"]}
+    with torch.no_grad():
+        torch.testing.assert_close(R.mining_forward(sd, x, [25, 15], prefix="m."), g["k1/scores_two_images"], rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(R.mining_forward(sd, x[:25], [25], prefix="m."), g["k1/scores_one_image"], rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(R.mining_forward(sd, x, [40], prefix="m."), g["k1/scores_no_proposals"], rtol=1e-5, atol=1e-9)
+    assert g["k1/scores_two_images"].shape == (40, 1)
+    xs = x.clone().requires_grad_(True)
+    loss = R.mining_loss(R.mining_forward(sd, xs, [25, 15], prefix="m."), [25, 15], g["k1/gt_oh"])
+    torch.testing.assert_close(loss.detach(), g["k1/loss"], rtol=1e-5, atol=1e-8)
+    loss.backward()
+    torch.testing.assert_close(gen.strided_sample(xs.grad, 2048), g["k1/dx_sample"], rtol=1e-4, atol=1e-10)
+    torch.testing.assert_close(sd["m.cls.weight"].grad, g["k1/dcls_w"], rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(sd["m.det.weight"].grad, g["k1/ddet_w"], rtol=1e-4, atol=1e-9)
+
+
+def test_edge_whole_step_with_one_class_matches_reference():
+    g = load("g18_edge_branches")
+    d = np.load(os.path.join(G, "shapes_r18_k1.npz"))
+    shapes = {str(k): eval(str(s)) for k, s in zip(d["keys"], d["shapes"])}
+    sd = gen.seeded_state(shapes, 5)
+    p = "k1/step/"
+    train_keys = [k[len(p + "gradnorm/"):] for k in g if k.startswith(p + "gradnorm/")]
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    losses, inter = R.train_forward(sd, gen.seeded_batch(2, 20, 1, 128, 160, seed=9), depth=18, num_classes=1,
+                                    pixel_std=gen.PIXEL_STD)
+    assert inter["mining_scores"].shape[1] == 1 and inter["refine_logits"].shape[1] == 2
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+        torch.testing.assert_close(losses[k].detach(), g[p + "loss/" + k], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(inter["pred_class_img_logits"], g[p + "pred_class_img_logits"], rtol=1e-5, atol=1e-8)
+    grads = torch.autograd.grad(sum(losses.values()), [sd[k] for k in train_keys])
+    for k, gr in zip(train_keys, grads):
+        torch.testing.assert_close(gr.norm(), g[p + "gradnorm/" + k], rtol=2e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("tag,use_bias,norm", [("bias", -2.0, True), ("nobias", 0.0, True), ("bias_nonorm", 0.75, False)])
+def test_edge_ov_classifier_bias_and_coco_shapes_match_reference(tag, use_bias, norm):
+    """OpenVocabularyClassifier at BASELINE config 3's shapes (K = 80 classes, D = 768 ViT-L/14 embeddings) with
+    `use_bias != 0` (a learnable scalar added to EVERY column, background included: open_vocabulary_classifier.py:35-37,
+    103-104) and with norm_weight off (raw dot products, no temperature)."""
+    g = load("g18_edge_branches")
+    emb, clsf = gen.edge_embeddings(80, 768)
+    x = gen.edge_features("ovc", 33)
+    sd = gen.seeded_state({"cls.projection.0.weight": (1024, 4096), "cls.projection.0.bias": (1024,),
+                           "cls.projection.2.weight": (768, 1024), "cls.projection.2.bias": (768,)}, 23)
+    cw = emb.t().contiguous()
+    sd["cls.class_weight"] = torch.nn.functional.normalize(cw, p=2, dim=0) if norm else cw
+    bias = torch.full((1,), use_bias, requires_grad=True) if use_bias else None
+    xg = x.clone().requires_grad_(True)
+    out = R.ov_classifier_forward(sd, xg, "cls.", norm_weight=norm, cls_bias=bias)
+    tol = dict(rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(out.detach(), g[f"ovc/{tag}/logits_bg"], **tol)
+    assert out.shape == (33, 81)
+    if use_bias:
+        assert torch.all(g[f"ovc/{tag}/logits_bg"][:, -1] == use_bias)  # the background logit is the bias itself
+    out.square().mean().backward()
+    torch.testing.assert_close(gen.strided_sample(xg.grad, 2048), g[f"ovc/{tag}/dx_sample"], rtol=2e-3, atol=1e-7)
+    if use_bias:
+        torch.testing.assert_close(bias.grad, g[f"ovc/{tag}/dcls_bias"], rtol=1e-4, atol=1e-7)
+    with torch.no_grad():
+        torch.testing.assert_close(R.ov_classifier_forward(sd, x, "cls.", norm_weight=norm, cls_bias=bias, append_background=False),
+                                   g[f"ovc/{tag}/logits_nobg"], **tol)
+        torch.testing.assert_close(R.ov_classifier_forward(sd, x, "cls.", norm_weight=norm, cls_bias=bias, classifier=clsf),
+                                   g[f"ovc/{tag}/logits_classifier"], **tol)

@@ -454,7 +454,8 @@ class _ImageBCE(Function):
 
 def image_bce(scores, seg_offsets, labels_onehot, norm):
     """-> (loss scalar, clamped image-level scores (N,K))."""
-    return _ImageBCE.apply(_contig2d(scores), seg_offsets, labels_onehot.to(torch.float32).contiguous(), float(norm))
+    # (the kernel reads a DENSE (M,K) matrix: the one-class head hands in a column view of its two-column scores)
+    return _ImageBCE.apply(scores.contiguous(), seg_offsets, labels_onehot.to(torch.float32).contiguous(), float(norm))
 
 
 class _WeightedCE(Function):

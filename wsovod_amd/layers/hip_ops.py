@@ -733,6 +733,9 @@ def mil_backward(dscores, P, Q, seg_offsets, K, tail=False):
 def image_bce_forward(scores, seg_offsets, labels_onehot, norm):
     require_gpu(scores, seg_offsets, labels_onehot)
     G, K = labels_onehot.shape
+    if scores.dim() != 2 or scores.size(1) != K or not scores.is_contiguous() or scores.dtype != torch.float32:
+        raise RuntimeError(f"image_bce_forward: scores must be a dense fp32 (M,{K}) matrix, got {tuple(scores.shape)} "
+                           f"strides {tuple(scores.stride())} {scores.dtype}")
     img = torch.empty((G, K), dtype=torch.float32, device=scores.device)
     dS = torch.empty_like(img)
     loss = torch.empty((1,), dtype=torch.float32, device=scores.device)
