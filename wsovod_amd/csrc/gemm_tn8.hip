@@ -38,14 +38,41 @@ struct TnArgs {
   // split-K of the LAST, partial round of tiles: blocks [0, full_tiles) own a whole tile; after them every remaining tile
   // is cut into `ksplit` slices of `slice_steps` K-steps whose partial sums meet by fp32 atomic adds (0 = no split)
   int full_tiles, ksplit, slice_steps;
+#if defined(TN_STAMPS)
+  float* dbg;  // instrumented builds only (tools/tn_phases.py): per-group cycle sums of the phase sections
+#endif
   int q_x2;  // Q is a bf16x2 matrix (include/wsovod_hip.h): only the hi halves of its values are read, column k at bf16
              // slot 64 (k / 32) + k % 32 of the row; ldq is then counted in bf16 slots (2 per value)
 };
 
+// LEAN = 1 (round 5): the same schedule with the per-phase address arithmetic removed from the half of a phase that the
+// other group's MFMAs have to cover (s_memtime stamps, tools/tn_phases.py: 24 reads + 4 DMA pieces took ~700 ticks
+// against the 512 of 32 MFMAs, and every v_add of it competes with the other wave's MFMAs for the SIMD's issue port):
+//  * LDS as [P: K-step 0 | K-step 1][Q: K-step 0 | K-step 1] (an operand's two buffers inside 64 KiB): the buffer and
+//    the 32-row half of a read are the instruction's IMMEDIATE offset (K loop unrolled by two), the 24 per-lane address
+//    registers are loop constants -- no v_add per read;
+//  * DMA source offsets advance by a running 32-bit add per phase (rows beyond the reduction and columns beyond the
+//    matrix fall to the buffer resource's range check: such a lane starts at 2^31) -- no 64-bit multiply, no selects.
+template <int OFF>
+__device__ __forceinline__ void tr_read_imm(__attribute__((ext_vector_type(2))) unsigned int& dst, unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
+}
+
+template <int LEAN>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   constexpr int BI = 256, BJ = 256, BK = 64;
   constexpr int OP_BYTES = 2 * BK * 256;        // one operand of one K-step: 2 sub-images x 64 rows x 256 B
   constexpr int STEP_BYTES = 2 * OP_BYTES;      // P + Q
+  // byte strides of the staging image: buffer (K-step parity) and operand
+  constexpr int BUF_STRIDE = LEAN ? OP_BYTES : STEP_BYTES, OPQ_BASE = LEAN == 2 ? 2 * 5 * 8192 : LEAN ? 2 * OP_BYTES : OP_BYTES;
+  // LEAN = 2: a ring of FIVE 32-row slots (160 KiB) laid out [operand][sub-image][slot][32 rows][256 B] -- a (operand,
+  // sub-image) region spans 40 KiB, so the slot is still an immediate of the reads -- and the DMA runs THREE phases ahead
+  // of its readers instead of one: with one phase (~700 cycles) of lead the counted wait in front of the barrier still
+  // stalled 125 - 230 cycles per phase on the pieces' L2 / HBM latency (tools/tn_phases.py).
+  constexpr int REG = 5 * 32 * 256;  // bytes of one (operand, sub-image) region
+  constexpr int SUB_STRIDE = LEAN == 2 ? REG : BK * 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int wg, slice = 0;
@@ -77,10 +104,6 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   // ---- DMA lane geometry: a pass = 32 rows x 256 B of one sub-image; lane -> (row tid>>4, 16-byte slot tid&15)
   const int lrow = tid >> 4, lslot = tid & 15;
   const int lchunk = lslot ^ (((lrow & 3) << 2) | ((lrow >> 2) & 3));  // inverse swizzle on the source (rows r, r+32 agree)
-  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.P, 0, (int)min((long long)p.Mred * p.ldp * 2, (long long)0x7fffffff), 0x00020000);
-  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcQ = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)p.Q, 0, (int)min((long long)p.Mred * p.ldq * 2, (long long)0x7fffffff), 0x00020000);
   // column offsets (bytes) of this lane's chunk in the two sub-images; <0 = beyond the matrix (zero fill)
   int pcol[2], qcol[2];
 #pragma unroll
@@ -94,18 +117,58 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   const int nk_all = (p.Mred + BK - 1) / BK;
   const int kt0 = sliced ? slice * p.slice_steps : 0;
   const int nk = sliced ? min(nk_all, kt0 + p.slice_steps) : nk_all;  // this block reduces K-steps [kt0, nk)
+  if (kt0 >= nk) return;  // (an empty slice: the even slice length of the host may leave the last one without K-steps)
+  // LEAN = 2 stages whole phases past the end of its K range (ring bookkeeping without branches): rows behind the range
+  // must read as zeros, so the resources end at the block's last row
+  const long long row_end = LEAN == 2 ? min((long long)p.Mred, (long long)nk * BK) : (long long)p.Mred;
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.P, 0, (int)min(row_end * p.ldp * 2, (long long)0x7fffffff), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcQ = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.Q, 0, (int)min(row_end * p.ldq * 2, (long long)0x7fffffff), 0x00020000);
   // stage rows [32*half, 32*half+32) of K-step kt into buffer buf: 4 DMA instructions
+  // LEAN: running byte offsets of this lane's pieces in the NEXT 32-row block to stage (blocks are staged in order)
+  [[maybe_unused]] unsigned voP[2], voQ[2];
+  [[maybe_unused]] const unsigned stepP = (unsigned)(32ll * p.ldp * 2), stepQ = (unsigned)(32ll * p.ldq * 2);
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const long long r0 = (long long)kt0 * BK + lrow;
+    voP[s] = pcol[s] >= 0 ? (unsigned)(r0 * p.ldp * 2 + pcol[s]) : 0x80000000u;
+    voQ[s] = qcol[s] >= 0 ? (unsigned)(r0 * p.ldq * 2 + qcol[s]) : 0x80000000u;
+  }
+  // LEAN = 2: the next 32-row block into ring slot `slot`
+  auto stage_slot = [&](int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    char* d = smem + slot * 8192 + wave_u * 1024;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void*)(d + s * REG), 16, (int)voP[s], 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_void*)(d + OPQ_BASE + s * REG), 16, (int)voQ[s], 0, 0, 0);
+      voP[s] += stepP;
+      voQ[s] += stepQ;
+    }
+#endif
+  };
   auto stage_half = [&](int kt, int buf, int half) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    char* d = smem + buf * BUF_STRIDE + half * 32 * 256 + wave_u * 1024;
+    if (LEAN) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void*)(d + s * (BK * 256)), 16, (int)voP[s], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_void*)(d + OPQ_BASE + s * (BK * 256)), 16, (int)voQ[s], 0, 0, 0);
+        voP[s] += stepP;
+        voQ[s] += stepQ;
+      }
+      return;
+    }
     const int m = kt * BK + half * 32 + lrow;
     const bool ok = m < p.Mred;
     const long long rp = (long long)m * p.ldp * 2, rq = (long long)m * p.ldq * 2;
-    char* d = smem + buf * STEP_BYTES + half * 32 * 256 + wave_u * 1024;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcP, (lds_void*)(d + s * (BK * 256)), 16,
                                                (ok && pcol[s] >= 0) ? (int)(rp + pcol[s]) : -1, 0, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_void*)(d + OP_BYTES + s * (BK * 256)), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcQ, (lds_void*)(d + OPQ_BASE + s * (BK * 256)), 16,
                                                (ok && qcol[s] >= 0) ? (int)(rq + qcol[s]) : -1, 0, 0, 0);
     }
 #endif
@@ -127,10 +190,10 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
     const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
 #pragma unroll
     for (int t = 0; t < 8; ++t)
-      offA[h][t] = (unsigned)(wr * (BK * 256) + row * 256 + (((2 * t + (pp >> 1)) ^ swz) << 4) + 8 * (pp & 1));
+      offA[h][t] = (unsigned)(wr * SUB_STRIDE + row * 256 + (((2 * t + (pp >> 1)) ^ swz) << 4) + 8 * (pp & 1));
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      offB[h][t] = (unsigned)(OP_BYTES + (wc >> 1) * (BK * 256) + row * 256 +
+      offB[h][t] = (unsigned)(OPQ_BASE + (wc >> 1) * SUB_STRIDE + row * 256 +
                               (((2 * ((wc & 1) * 4 + t) + (pp >> 1)) ^ swz) << 4) + 8 * (pp & 1));
   }
 
@@ -152,10 +215,30 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
 #define WS_VMCNT(N) (void)0
 #endif
 
+#if defined(TN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned long long st_t = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define TN_STAMP0() st_t = __builtin_amdgcn_s_memtime()
+#define TN_STAMP(k)                                              \
+  {                                                              \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    st_acc[k] += now - st_t;                                     \
+    st_t = now;                                                  \
+  }
+#else
+#define TN_STAMP0() (void)0
+#define TN_STAMP(k) (void)0
+#endif
   // ---- prologue: K-step 0 completely, then the stagger barrier
-  stage_half(kt0, 0, 0);
-  stage_half(kt0, 0, 1);
-  WS_VMCNT(0);
+  if (LEAN == 2) {
+    stage_slot(0);
+    stage_slot(1);
+    stage_slot(2);
+    WS_VMCNT(8);
+  } else {
+    stage_half(kt0, 0, 0);
+    stage_half(kt0, 0, 1);
+    WS_VMCNT(0);
+  }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second i-half runs one barrier behind
 
@@ -163,45 +246,148 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   // ago) and waits vmcnt(4): the half issued one phase earlier has landed before the barrier its readers pass first;
   // it is read one phase later.  (A three-phase-deep ring with the reads retired before the barrier was measured
   // 18 % slower: the loop no longer unrolls over the two halves and the LDS latency moves in front of the barrier.)
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    const bool more = kt + 1 < nk;
+  auto mfma_block = [&]() {
+    TN_STAMP(0);
+    __builtin_amdgcn_s_barrier();
+    TN_STAMP(1);
+    WS_LGKM0_ALL();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const unsigned base = lds0 + cur * STEP_BYTES + half * (32 * 256);
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  // Q fragment first: a lane holds 4 consecutive j
+            __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3)),
+            __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3)), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    TN_STAMP(2);
+    __builtin_amdgcn_s_barrier();
+    TN_STAMP(3);
+  };
+  if (LEAN == 2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) offA[h][t] += lds0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) offB[h][t] += lds0;
+    }
+#endif
+    // phase q reads slot q % 5 and refills slot (q + 3) % 5 (last read two phases ago) with the block of phase q + 3; the
+    // wait leaves the two youngest blocks in flight.  The phase count is padded to a multiple of five: blocks past the
+    // range are zero-filled by the resources' range check, their products add nothing
+    const int nph = 2 * (nk - kt0), nph5 = (nph + 4) / 5 * 5;
+    auto phase = [&](auto slot_c) {
+      constexpr int SLOT = decltype(slot_c)::value;
+      TN_STAMP0();
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        WS_TR_READ(bl[t], base + offB[0][t]);
-        WS_TR_READ(bh[t], base + offB[1][t]);
+        tr_read_imm<SLOT * 8192>(bl[t], offB[0][t]);
+        tr_read_imm<SLOT * 8192>(bh[t], offB[1][t]);
       }
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        WS_TR_READ(al[t], base + offA[0][t]);
-        WS_TR_READ(ah[t], base + offA[1][t]);
+        tr_read_imm<SLOT * 8192>(al[t], offA[0][t]);
+        tr_read_imm<SLOT * 8192>(ah[t], offA[1][t]);
       }
+      TN_STAMP(4);
+      stage_slot((SLOT + 3) % 5);
+      TN_STAMP(5);
+      WS_VMCNT(8);
+      mfma_block();
+    };
+    for (int q = 0; q < nph5; q += 5) {
+      phase(std::integral_constant<int, 0>{});
+      phase(std::integral_constant<int, 1>{});
+      phase(std::integral_constant<int, 2>{});
+      phase(std::integral_constant<int, 3>{});
+      phase(std::integral_constant<int, 4>{});
+    }
+    WS_VMCNT(0);  // the refills issued by the last phases (zero blocks) must not land in the epilogue's staging area
+  } else if (LEAN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the per-lane read addresses include the LDS base; buffer and half are immediates of the unrolled phases
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) offA[h][t] += lds0;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) offB[h][t] += lds0;
+    }
+#endif
+    // K-steps in pairs (static buffer index): an odd count is padded with one K-step beyond the reduction, which the DMA
+    // zero-fills (rows >= Mred are out of the resource's range; a slice that is not the last has an even count: host)
+    const int nkp = kt0 + ((nk - kt0 + 1) & ~1);
+    auto phase = [&](auto imm, bool more, int buf, int half) {
+      constexpr int IMM = decltype(imm)::value;  // buf * BUF_STRIDE + half * 8192
+      TN_STAMP0();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        tr_read_imm<IMM>(bl[t], offB[0][t]);
+        tr_read_imm<IMM>(bh[t], offB[1][t]);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        tr_read_imm<IMM>(al[t], offA[0][t]);
+        tr_read_imm<IMM>(ah[t], offA[1][t]);
+      }
+      TN_STAMP(4);
       if (more) {
-        stage_half(kt + 1, cur ^ 1, half);
+        stage_half(0, buf ^ 1, half);
+        TN_STAMP(5);
         WS_VMCNT(4);
       } else {
         WS_VMCNT(0);
       }
-      __builtin_amdgcn_s_barrier();
-      WS_LGKM0_ALL();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
+      mfma_block();
+    };
+    for (int kt = kt0; kt < nkp; kt += 2) {
+      const bool more = kt + 2 < nkp;
+      phase(std::integral_constant<int, 0>{}, true, 0, 0);
+      phase(std::integral_constant<int, 32 * 256>{}, true, 0, 1);
+      phase(std::integral_constant<int, BUF_STRIDE>{}, more, 1, 0);
+      phase(std::integral_constant<int, BUF_STRIDE + 32 * 256>{}, more, 1, 1);
+    }
+  } else {
+    for (int kt = kt0; kt < nk; ++kt) {
+      const int cur = (kt - kt0) & 1;
+      const bool more = kt + 1 < nk;
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int half = 0; half < 2; ++half) {
+        const unsigned base = lds0 + cur * STEP_BYTES + half * (32 * 256);
+        TN_STAMP0();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(  // Q fragment first: a lane holds 4 consecutive j
-              __builtin_bit_cast(bf16x8, __builtin_shufflevector(bl[j], bh[j], 0, 1, 2, 3)),
-              __builtin_bit_cast(bf16x8, __builtin_shufflevector(al[i], ah[i], 0, 1, 2, 3)), acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < 4; ++t) {
+          WS_TR_READ(bl[t], base + offB[0][t]);
+          WS_TR_READ(bh[t], base + offB[1][t]);
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          WS_TR_READ(al[t], base + offA[0][t]);
+          WS_TR_READ(ah[t], base + offA[1][t]);
+        }
+        if (more) {
+          stage_half(kt + 1, cur ^ 1, half);
+          WS_VMCNT(4);
+        } else {
+          WS_VMCNT(0);
+        }
+        mfma_block();
+      }
     }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();
+  if (LEAN == 2) __builtin_amdgcn_s_barrier();  // (every wave is past its vmcnt(0))
+#if defined(TN_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  if (p.dbg && lane == 0 && !sliced) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) atomicAdd(p.dbg + wr * 8 + k + (k >= 4 ? 1 : 0), (float)st_acc[k]);
+    atomicAdd(p.dbg + wr * 8 + 4, (float)(LEAN == 2 ? (2 * (nk - kt0) + 4) / 5 * 5 : 2 * (nk - kt0)));
+  }
+#endif
 
   // ---- epilogue: acc[i][j][r] = C[i0 + wr*128 + i*16 + (lane&15)][j0 + wc*64 + j*16 + (lane>>4)*4 + r]
   const int frow = lane & 15, fq = lane >> 4;
@@ -318,6 +504,9 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
   a.alpha = alpha;
   a.accumulate = accumulate & 1;
   a.q_x2 = q_x2 ? 1 : 0;
+#if defined(TN_STAMPS)
+  a.dbg = getenv("WSOVOD_TN_DEBUG_PTR") ? (float*)strtoull(getenv("WSOVOD_TN_DEBUG_PTR"), nullptr, 16) : nullptr;
+#endif
   a.tiles_i = ceil_div(NI, 256);
   a.tiles_j = ceil_div(NJ, 256);
   {
@@ -331,7 +520,9 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
   static bool attr_set = false;
   constexpr int lds_bytes = 2 * 2 * 2 * 64 * 256;  // 2 K-steps x (P, Q) x 2 sub-images x 64 rows x 256 B = 128 KiB
   if (!attr_set) {
-    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "wsovod_gemm_tn: LDS opt-in (160 KiB)");
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -355,7 +546,7 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
     if (S >= 2) {
       a.full_tiles = 0;
       a.ksplit = S;
-      a.slice_steps = ceil_div(nk, S);
+      a.slice_steps = (ceil_div(nk, S) + 1) & ~1;  // even: the kernel walks K-steps in pairs
       grid = ntiles * S;
       if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(ntiles), dim3(256), 0, s, a);
     }
@@ -365,12 +556,18 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
     if (nk >= 8 * S) {
       a.full_tiles = ntiles - tail;
       a.ksplit = S;
-      a.slice_steps = ceil_div(nk, S);
+      a.slice_steps = (ceil_div(nk, S) + 1) & ~1;
       grid = a.full_tiles + tail * S;
       if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(tail), dim3(256), 0, s, a);
     }
   }
-  hipLaunchKernelGGL(gemm_tn8_kernel, dim3(grid), dim3(512), lds_bytes, s, a);
+  static const int lean = getenv("WSOVOD_TN_LEAN") ? atoi(getenv("WSOVOD_TN_LEAN")) : 2;
+  if (lean == 2)
+    hipLaunchKernelGGL(gemm_tn8_kernel<2>, dim3(grid), dim3(512), 160 * 1024, s, a);
+  else if (lean == 1)
+    hipLaunchKernelGGL(gemm_tn8_kernel<1>, dim3(grid), dim3(512), lds_bytes, s, a);
+  else
+    hipLaunchKernelGGL(gemm_tn8_kernel<0>, dim3(grid), dim3(512), lds_bytes, s, a);
   WS_CHECK_LAUNCH("wsovod_gemm_tn");
   return WSOVOD_OK;
 }
