@@ -489,6 +489,7 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
             step()
         sync()
     events = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    trainer.stats_enable(world > 1 or dist.is_initialized())  # two event records per step: where the exchange went
     t0 = time.perf_counter()
     events[0].record()
     for i in range(steps):
@@ -496,13 +497,15 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
         events[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    comm = trainer.stats()
+    trainer.stats_enable(False)
     per_step = [events[i].elapsed_time(events[i + 1]) for i in range(steps)]
     last = step()  # outside the timed region: the run must have stayed finite
     final_losses = {k: float(v.detach()) for k, v in last.items()}
     if not all(v == v and abs(v) != float("inf") for v in final_losses.values()):
         raise RuntimeError(f"training diverged during the benchmark: {final_losses}")
     rec = {"elapsed": elapsed, "per_step_ms": per_step, "final_losses": final_losses, "wire": wire,
-           "exchange": trainer.exchange_algo, "exchange_ab": exchange_ab}
+           "exchange": trainer.exchange_algo, "exchange_ab": exchange_ab, "comm": comm}
 
     if want_roofline:
         # second pass over the same K steps with every launch bracketed by hipEvents on its stream
@@ -523,10 +526,58 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     return rec
 
 
+def measured_parity(args, dev, cfgv, images=1):
+    """The deviation of ONE side configuration from the ORACLE, measured in this run (never asserted from the precision's
+    name): one training step of the configuration's own model (depth, pooler, proposals, classes, embedding width, mixed
+    or not) on `images` full-size images, dropout off, through the HIP path in the configuration's precision, against
+    oracle/wsovod_ref.py on the same weights and inputs (1.5 - 6 s of host CPU per line).  The batch size of a line does
+    not enter: rows of different images never meet before the per-image softmaxes, which the 32-image check of the
+    headline (`parity.at_timed_batch`) and tests/test_gpu_full_size.py cover."""
+    from oracle import compare as OC
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.testing import build_hot_path_model, build_mixed_model, capture_full_step
+
+    depth, proposals = cfgv.get("depth") or args.depth, cfgv.get("proposals") or args.proposals
+    classes, embed_dim = cfgv.get("classes") or args.classes, cfgv.get("embed_dim") or args.embed_dim
+    precision, pooler, mixed = cfgv["precision"], cfgv["pooler"], bool(cfgv.get("mixed"))
+    host = make_batch(images, proposals, classes, seed=2468)
+    extra, source_id = {}, 2
+    if mixed:
+        cfg, model = build_mixed_model(seed=0, names=("voc_2007_train", "coco_2017_train", "lvis_v1_train"),
+                                       Ks=(20, 80, classes), D=embed_dim, depth=depth, precision=precision, pooler=pooler,
+                                       device=str(dev))
+        for x in host:
+            x["dataset_id"] = source_id
+        model.roi_heads.select_source(source_id)
+        prefix = f"roi_heads.object_miners.{source_id}."
+        extra = dict(classifier=model.classifier_train[source_id].detach().float().cpu(), miner_prefix=prefix)
+        train_keys = [k for k, p in model.named_parameters()
+                      if p.requires_grad and (not k.startswith("roi_heads.object_miners.") or k.startswith(prefix))]
+    else:
+        cfg, model = build_hot_path_model(seed=0, depth=depth, K=classes, D=embed_dim, precision=precision, pooler=pooler,
+                                          device=str(dev))
+        train_keys = [k for k, p in model.named_parameters() if p.requires_grad]
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    state = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    got = capture_full_step(model, to_device_batch(host, dev))
+    del model
+    torch.cuda.empty_cache()
+    t0 = time.time()
+    want = OC.oracle_step(state, host, train_keys, depth=depth, num_classes=classes, pooler_type=pooler, **extra)
+    rep = OC.compare(got, want)
+    keys = ("max_abs_logit_err", "max_abs_score_err", "max_abs_delta_err", "max_rel_loss_err", "labels_exact",
+            "label_boxes_exact", "pgt_exact", "max_rel_gradnorm_err", "meets_1e-3_logit_bound")
+    return dict({k: rep[k] for k in keys}, images=images, oracle_seconds=round(time.time() - t0, 1),
+                vs="oracle/wsovod_ref.py on the same weights and inputs, measured in this run")
+
+
 def side_measurements(args, dev):
     """Short runs in the SAME process as the headline line (N = 1): the reference's own per-GPU batch (1), 8 images,
     the north star's pooler, the two parity-grade precisions, and the variant with the input copy inside the step."""
-    out = []
+    out, parity_cache = [], {}
     variants = [
         ("b1 (the reference's images per GPU)", dict(batch_size=1, steps=max(20, args.side_steps))),
         ("b8", dict(batch_size=8)),
@@ -560,9 +611,22 @@ def side_measurements(args, dev):
             out.append({"name": name, "error": f"{type(e).__name__}: {e}"[:300]})
             continue
         ms = r["per_step_ms"]
+        # parity of the line: MEASURED against the oracle for this configuration (one comparison per distinct model /
+        # precision / pooler / shape; lines that differ only in images per step or in where the inputs live share it)
+        pkey = (cfgv["precision"], cfgv["pooler"], cfgv.get("depth"), cfgv.get("proposals"), cfgv.get("classes"),
+                cfgv.get("embed_dim"), bool(cfgv.get("mixed")))
+        if args.no_parity:
+            par = {"skipped": "--no-parity"}
+        else:
+            if pkey not in parity_cache:
+                try:
+                    parity_cache[pkey] = measured_parity(args, dev, cfgv)
+                except Exception as e:  # noqa: BLE001 -- reported in the line, never silently replaced by a claim
+                    parity_cache[pkey] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            par = parity_cache[pkey]
         out.append({"name": name, "precision": cfgv["precision"], "images_per_step": cfgv["batch_size"],
                     "warmup": cfgv["warmup"],
-                    "meets_1e-3_logit_bound": cfgv["precision"] in ("parity", "fp32", "bf16x3", "bf16x3f"),
+                    "meets_1e-3_logit_bound": par.get("meets_1e-3_logit_bound"), "parity": par,
                     "pooler": cfgv["pooler"], "steps": cfgv["steps"], "depth": cfgv.get("depth") or args.depth,
                     "proposals": cfgv.get("proposals") or args.proposals,
                     "images_per_sec": cfgv["batch_size"] * cfgv["steps"] / r["elapsed"],
@@ -700,12 +764,44 @@ def main():
                      want_roofline=not args.no_roofline, keep=True)
     elapsed, my_ms = rec["elapsed"], rec["elapsed"] / args.steps * 1e3
     rank_ms = [my_ms]
+    comm_ranks = None
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        c = rec.get("comm") or {}
+        t = torch.tensor([elapsed, c.get("exchange_wait_ms", 0.0), c.get("overlap_window_ms", 0.0)], device=dev,
+                         dtype=torch.float64)
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
-        rank_ms = [float(x.item()) / args.steps * 1e3 for x in allt]
-        elapsed = max(float(x.item()) for x in allt)  # the job is as slow as its slowest rank
+        rank_ms = [float(x[0].item()) / args.steps * 1e3 for x in allt]
+        elapsed = max(float(x[0].item()) for x in allt)  # the job is as slow as its slowest rank
+        # the line explains itself: per rank, how long the compute stream stood still for the exchange of the previous
+        # step (EXPOSED communication) next to the frozen forward it is scheduled behind
+        comm_ranks = {"exchange_wait_ms": [round(float(x[1].item()), 4) for x in allt],
+                      "overlap_window_ms": [round(float(x[2].item()), 4) for x in allt],
+                      "wire_bytes_per_step": c.get("wire_bytes_per_step"),
+                      "bytes_sent_per_rank_per_step": c.get("bytes_sent_per_rank_per_step"),
+                      "exchange": c.get("exchange"), "wire": c.get("wire"),
+                      "note": "exchange_wait_ms = hipEvent time on the compute stream across the waits for the previous "
+                              "step's collectives (0 = fully hidden behind the frozen forward of overlap_window_ms)"}
+    elif rec.get("comm"):
+        c = rec["comm"]
+        comm_ranks = {"exchange_wait_ms": [round(c["exchange_wait_ms"], 4)], "overlap_window_ms": [round(c["overlap_window_ms"], 4)],
+                      "wire_bytes_per_step": c["wire_bytes_per_step"], "exchange": c["exchange"], "wire": c["wire"]}
+    if world > 1 and args.backend == "nccl" and not args.share_device:
+        # one process per GPU means one GPU per process: a launcher that put two ranks on one device fails the run
+        # (identity = the device's UUID / PCI address, not its index: a launcher may show every rank one device as index 0)
+        props = torch.cuda.get_device_properties(dev)
+        ident = [getattr(props, a, None) for a in ("uuid", "pci_domain_id", "pci_bus_id", "pci_device_id")]
+        if any(v is not None for v in ident):
+            import zlib
+
+            me = torch.tensor([zlib.crc32(str(ident[0]).encode()) & 0x7FFFFFFF] + [int(v) if isinstance(v, int) else -1
+                                                                                   for v in ident[1:]],
+                              device=dev, dtype=torch.int64)
+            ids = [torch.zeros_like(me) for _ in range(world)]
+            dist.all_gather(ids, me)
+            seen = [tuple(int(v) for v in x.tolist()) for x in ids]
+            if len(set(seen)) != world:
+                raise RuntimeError(f"bench.py --gpus {world}: the ranks sit on devices {seen}, not on {world} different GPUs")
 
     roofline = None
     table = rec.get("kernel_table")
@@ -787,6 +883,7 @@ def main():
                                          "ranks_equal_gpus_flag": dist.get_world_size() == args.gpus}
                        if dist.is_initialized() else None,
                        "exchange_ab": rec.get("exchange_ab"),
+                       "communication": comm_ranks,
                        "final_losses": rec["final_losses"]},
         }
         if roofline is not None:

@@ -249,6 +249,33 @@ def test_state_read_between_steps_sees_the_applied_update_and_iter_size():
         tr.synchronize()
 
 
+def test_lr_scheduler_between_steps_does_not_move_the_deferred_update():
+    """The reference steps its LR scheduler AFTER run_step (an after_step hook: optimizer.step() of iteration t has used
+    lr_t by then).  The overlapped trainer applies step t's update inside run_step(t + 1): it must still be applied with
+    lr_t (and weight_decay_t), whatever the scheduler wrote into the param groups in between."""
+    from wsovod_amd.engine import HotPathTrainer, run_step
+
+    g = torch.Generator().manual_seed(9)
+    batches = [[{"x": torch.randn(8, generator=g)} for _ in range(3)] for _ in range(6)]
+    lrs = [0.01 * (0.001 * (1 - i / 200) + i / 200) * 500 for i in range(6)]  # a warm-up ramp (scaled up: visible steps)
+    plain, lazy = _LossDictModel(), _TwoPhaseModel()
+    popt = torch.optim.SGD(plain.parameters(), lr=lrs[0], momentum=0.9, weight_decay=1e-3)
+    lopt = torch.optim.SGD(lazy.parameters(), lr=lrs[0], momentum=0.9, weight_decay=1e-3)
+    tr = HotPathTrainer(lazy, lopt, overlap=True)
+    for it, b in enumerate(batches):
+        run_step(plain, popt, [{"x": d["x"] * 2.0} for d in b])
+        tr.run_step(b)
+        if it + 1 < len(lrs):  # the scheduler hook, after the step
+            for opt in (popt, lopt):
+                for grp in opt.param_groups:
+                    grp["lr"] = lrs[it + 1]
+                    grp["weight_decay"] = 1e-3 * (it + 2)
+    tr.flush()
+    assert lopt.param_groups[0]["lr"] == lrs[-1]  # the scheduler's value is back in place after the deferred step
+    torch.testing.assert_close(lazy.fc.weight.detach(), plain.fc.weight.detach(), rtol=1e-6, atol=1e-7)
+    tr.close()
+
+
 def _worker_bf16_wire(rank, world, port, q):
     """grad_wire="bf16" on CPU/gloo: the two HIP kernels of that path (gradient pack, SGD on bf16 slices) are replaced
     by torch stand-ins with the same contract, so that the trainer's own logic -- flat buffer slices, one collective,

@@ -368,14 +368,22 @@ class _StepGraph:
                 tr._finish_pending()
             tr._graph_bookkeeping()
         if len(self.graphs) == 1:
+            if tr._stats is not None:
+                tr._stats["steps"] += 1
             self.graphs[0].replay()
         else:
+            done = tr._bracket("frozen")
             self.graphs[0].replay()  # frozen forward, while the previous step's gradients are still on the wire
+            if done is not None:
+                done.record()
+            if tr._stats is not None:
+                tr._stats["steps"] += 1
             tr._finish_pending()     # wait for the exchange, SGD on the reduced wire slices (one eager launch)
             self.graphs[1].replay()
             for p, sl in self.wire:
                 p._wire_grad = sl
             tr._pending = [tr._reduce_block(lo, hi) for lo, hi in self.blocks]
+            tr._stamp_hyper()
             if not tr.overlap:
                 tr._wait_pending()
         # fresh tensors, as the eager path returns: the static loss buffers are overwritten by the next replay
@@ -453,6 +461,8 @@ class HotPathTrainer:
         self.exchange = dist.is_initialized()  # a 1-rank group still goes through RCCL (exercised by the GPU tests)
         self.overlap = overlap
         self._pending = None  # list of (work, param) of the in-flight exchange
+        self._pending_hyper = None  # (lr, weight_decay) per group at the time the pending step's gradients were produced
+        self._stats = None  # stats_enable(): hipEvent pairs around the exchange wait and the frozen forward
         self._used = None  # per-tensor "some rank has a gradient" flags of the in-flight exchange (reduce_unused)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if exchange == "auto":
@@ -559,11 +569,54 @@ class HotPathTrainer:
             p._used_flag = None
         self._reset_wire()
 
+    # ---- what a data-parallel step spent where (bench.py --gpus N puts it in the line, per rank) ----
+    def stats_enable(self, on=True):
+        """Bracket, from now on, (a) the wait for the previous step's gradient exchange and (b) the frozen forward it is
+        meant to hide behind with hipEvents on the compute stream (two event records per step each: no synchronisation,
+        no host read until stats())."""
+        self._stats = {"wait": [], "frozen": [], "steps": 0} if on else None
+
+    def _bracket(self, kind):
+        st = self._stats
+        if st is None or not self.params or not self.params[0].is_cuda:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        st[kind].append((e0, e1))
+        return e1
+
+    def stats(self):
+        """-> dict: per-step means (ms, on this rank's compute stream) of `exchange_wait_ms` -- how long the stream stood
+        still for the collectives of the previous step, i.e. the EXPOSED communication -- and `overlap_window_ms` -- the
+        frozen forward the exchange runs behind; `wire_bytes` per step and rank; the exchange form.  Synchronises."""
+        st = self._stats
+        if st is None:
+            return None
+        if self.params and self.params[0].is_cuda:
+            torch.cuda.synchronize(self.params[0].device)
+        n = max(st["steps"], 1)
+        wire = 0
+        if self.exchange:
+            if self.grad_wire == "bf16" and self._wire is not None:
+                wire = self._wire[0].numel() * 2
+            else:
+                wire = sum(p.numel() for p in self.params) * 4
+        return {"steps": st["steps"],
+                "exchange_wait_ms": sum(a.elapsed_time(b) for a, b in st["wait"]) / n,
+                "overlap_window_ms": sum(a.elapsed_time(b) for a, b in st["frozen"]) / n,
+                "wire_bytes_per_step": wire, "wire": self.grad_wire if self.exchange else None,
+                "exchange": self.exchange_algo, "world": self.world,
+                # a ring moves 2 (N-1)/N of the buffer over each GPU's links, the direct form the same bytes one hop
+                "bytes_sent_per_rank_per_step": int(2 * (self.world - 1) / max(self.world, 1) * wire)}
+
     def _wait_pending(self):
         if self._pending is not None:
+            done = self._bracket("wait") if any(w is not None for w in self._pending) else None
             for work in self._pending:
                 if work is not None:
                     work.wait()
+            if done is not None:
+                done.record()
             self._pending = [None] * len(self._pending)  # waited for, update not applied yet
 
     def _finish_pending(self):
@@ -572,8 +625,33 @@ class HotPathTrainer:
         self._wait_pending()
         self._apply_update()
 
+    def _stamp_hyper(self):
+        """The update of a step is applied lazily (inside the NEXT run_step); an LR scheduler stepping in between -- the
+        reference's LRScheduler hook runs after run_step, i.e. after optimizer.step() there (engine/trainer.py:57-84) --
+        must not change the rate that step is applied with: the groups' (lr, weight_decay) are recorded with the
+        pending gradients and put in place for the deferred optimizer.step()."""
+        self._pending_hyper = [(g["lr"], g["weight_decay"]) for g in self.optimizer.param_groups]
+
     def _apply_update(self):
         """The optimizer step on the exchanged gradients (everything _finish_pending does after the waits)."""
+        hyper, self._pending_hyper = self._pending_hyper, None
+        groups = self.optimizer.param_groups
+        now = None
+        if hyper is not None and len(hyper) == len(groups):
+            now = [(g["lr"], g["weight_decay"]) for g in groups]
+            if now == hyper:
+                now = None
+            else:
+                for g, (lr, wd) in zip(groups, hyper):
+                    g["lr"], g["weight_decay"] = lr, wd
+        try:
+            self._apply_update_now()
+        finally:
+            if now is not None:
+                for g, (lr, wd) in zip(groups, now):
+                    g["lr"], g["weight_decay"] = lr, wd
+
+    def _apply_update_now(self):
         if self._used is not None and not isinstance(self.optimizer, HipSGD):
             # a torch optimizer skips `grad is None`: restore that for tensors no rank touched (host read of a few flags;
             # the HIP optimizer reads the flags on the device instead)
@@ -857,7 +935,12 @@ class HotPathTrainer:
             if out is not None:
                 self.iter += 1
                 return out
+        done = self._bracket("frozen")
         st = self.model.forward_frozen(data)
+        if done is not None:
+            done.record()
+        if self._stats is not None:
+            self._stats["steps"] += 1
         self._finish_pending()
         loss_dict = self.model.forward_trainable(st)
         self._backward(loss_dict)
@@ -877,6 +960,7 @@ class HotPathTrainer:
                 if p.grad is not None:
                     works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
         self._pending = works
+        self._stamp_hyper()
         if not self.overlap:
             self._finish_pending()
         # (detached: the step's autograd graph dies here whatever the caller keeps)
