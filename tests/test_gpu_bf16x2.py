@@ -295,3 +295,50 @@ def test_sgd_refreshes_the_bf16x2_weight_operand(gpu):
         ref_opt.step()
         opt2.step()
     torch.testing.assert_close(p2.detach(), ref.detach(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["res4_residual", "res5_shortcut_dilated"])
+def test_conv_x2_split_k_at_few_tiles(gpu, case, monkeypatch):
+    """The implicit-GEMM conv as split-K slices of the 8-wavefront tile + the finalize pass (bias, residual, ReLU, bf16x2
+    encode), reachable with WSOVOD_CONV_SPLITK=1 (measured in round 5 at 1 - 4 images per step: equal to the 128x64 grid at
+    best -- res5 of one image 124 vs 124 us -- so the dispatcher does not choose it by itself).  Same result as the unsplit
+    tiles up to the summation order; slices start inside the filter taps, inside the channel chunks and inside the fused
+    1x1 shortcut's K range."""
+    from wsovod_amd.layers import hip_ops as H
+
+    monkeypatch.setenv("WSOVOD_CONV_SPLITK", "1")
+    torch.manual_seed(6)
+    if case == "res4_residual":
+        n, Hh, Ww, C1, Co, dil, C2 = 1, 38, 50, 256, 256, 1, 0
+    else:
+        n, Hh, Ww, C1, Co, dil, C2 = 1, 30, 41, 512, 512, 2, 256
+    h = torch.randn(n, C1, Hh, Ww) * 0.5
+    w, b = torch.randn(Co, C1, 3, 3) * 0.03, torch.randn(Co)
+    res = torch.randn(n, Co, Hh, Ww) if not C2 else None
+    x, ws = (torch.randn(n, C2, Hh, Ww) * 0.5, torch.randn(Co, C2, 1, 1) * 0.05) if C2 else (None, None)
+    ref = F.conv2d(h.double(), w.double(), b.double(), 1, dil, dil)
+    if C2:
+        ref = ref + F.conv2d(x.double(), ws.double())
+    else:
+        ref = ref + res.double()
+    ref = torch.relu(ref).float()
+    enc = lambda t, c: H.x2_encode(t.permute(0, 2, 3, 1).reshape(-1, c).contiguous().to(gpu)).view(n, Hh, Ww, c)
+    wrow = w.permute(0, 2, 3, 1).reshape(Co, -1)
+    wcat = (torch.cat([wrow, ws.reshape(Co, C2)], dim=1) if C2 else wrow).contiguous()
+    conv = dict(n_img=n, H=Hh, W=Ww, Cin=C1, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=dil, dil=dil)
+    kw = dict(conv=conv, x2=True, bias=b.to(gpu), relu=True, out_dtype=H.X2)
+    if C2:
+        kw["A2"] = enc(x, C2)
+    else:
+        kw.update(residual=H.x2_encode(res.permute(0, 2, 3, 1).reshape(-1, Co).contiguous().to(gpu)), residual_x2=True)
+    M = n * Hh * Ww
+    assert -(-M // 256) * -(-Co // 256) <= 128  # few tiles: the automatic choice is the split form
+    outs = {}
+    for tile in (0, 2256256, 1128128):
+        out = H.gemm_nt(enc(h, C1), H.x2_encode(wcat.to(gpu)), tile_hint=tile, **kw)
+        outs[tile] = H.x2_decode(out).view(n, Hh, Ww, Co).permute(0, 3, 1, 2).cpu()
+    scale = float(F.conv2d(h.abs().double(), w.abs().double(), None, 1, dil, dil).max())
+    for tile, got in outs.items():
+        assert float((got - ref).abs().max()) < 3e-5 * scale, tile
+    monkeypatch.delenv("WSOVOD_CONV_SPLITK")
+    assert float((outs[0] - outs[2256256]).abs().max()) < 1e-5 * scale

@@ -2075,6 +2075,24 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!d->tile_hint && !d->conv && d->M >= 256 && d->N >= 256 && d->K >= 8192 &&
         (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
       tile = 2256256;
+    // few rows, shorter K (fc2, the stacked heads, the convs of res4 / res5 at 1 - 4 images): re-measured in round 5 on bf16x2
+    // operands (tools/small_batch_tiles.py, profiles/r05_small_batch_tiles.md).  T = number of 256x256 tiles:
+    //   T >= 150           one partly filled round of the 256x256 tile beats two of 256x128 (3 images, res5: 250 vs 337 us)
+    //   T >= 100           256x128 (one round)
+    //   128x64 grid >= 200 the four-wavefront 128x64 tile, two workgroups per CU (1 - 2 images: fc2 74 vs 78 us on the
+    //                      64x64 grid, res4 57 vs 60, res5 124 vs 128 on 128x128)
+    //   else, K >= 2048    split-K of the 256x256 tile (the stacked heads, N = 1088: 48 vs 70 us)
+    if (!d->tile_hint && d->M >= 256 && d->N >= 256 && tile != 2256256 && tile != 256256) {
+      auto tiles = [&](int bm, int bn) { return (long long)ceil_div(d->M, bm) * ceil_div(d->N, bn); };
+      const char* cs = getenv("WSOVOD_CONV_SPLITK");  // "1": also convs may take the split form (experiments, tests)
+      if (tiles(256, 256) >= 150) tile = d->conv ? 256256 : 2256256;
+      else if (tiles(256, 128) >= 200) tile = 256128;
+      else if (tiles(128, 64) >= 200) tile = 1128064;
+      else if (d->K >= 2048 && (!d->conv || (cs && cs[0] == '1'))) tile = 2256256;
+    }
+    if (!d->tile_hint && d->conv && getenv("WSOVOD_CONV_SPLITK") && getenv("WSOVOD_CONV_SPLITK")[0] == '1' && d->M >= 256 &&
+        d->N >= 256 && d->K >= 2048 && (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
+      tile = 2256256;
     return d->conv ? dispatch_tile_x3<true>(a, tile, s, flops, bytes) : dispatch_tile_x3<false>(a, tile, s, flops, bytes);
   }
   if (d->dtype_in == WSOVOD_BF16)

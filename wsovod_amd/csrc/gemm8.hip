@@ -239,6 +239,17 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #define WS_VMCNT(N) (void)0
 #endif
   Tap t0{0, 0, 0};
+  if (CONV && kt_base > 0) {  // split-K slice of a conv: the (filter tap, channel chunk) of its first K-step
+    const int taps = p.KH * p.KW, nk_main = taps * (p.Cin / BKE);
+    if (kt_base >= nk_main) {
+      t0.c0 = p.Cin + (kt_base - nk_main) * BKE;
+    } else {
+      const int chunk = kt_base / taps, tap = kt_base - chunk * taps;
+      t0.r = tap / p.KW;
+      t0.q = tap - t0.r * p.KW;
+      t0.c0 = chunk * BKE;
+    }
+  }
   Tap t1 = tap_next(t0);   // K-step kt + 1
   Tap t2 = tap_next(t1);   // K-step kt + 2
   stage_A(0, 0, 0, t0); stage_A(0, 0, 2, t0);
@@ -581,7 +592,9 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   args.ksplit = args.slice_steps = 0;
   const int ntiles = args.tiles_m * args.tiles_n, nk = ceil_div(a.K, 64);
   int grid = ntiles;
-  if (allow_split && !conv && ntiles <= 128 && nk >= 32) {
+  // (round 5: also the implicit-GEMM convs at 1 - 4 images per step -- res5 of ONE 800x600 image is 30 x 2 tiles --
+  // where the alternative was a 128x128 / 64x64 grid at 0.12 - 0.25 of peak)
+  if (allow_split && ntiles <= 128 && nk >= 32) {
     const int S = std::min(std::min(8, 256 / ntiles), nk / 16);
     if (S >= 2) {
       static float* ws = nullptr;
