@@ -90,13 +90,15 @@ def test_gemm_x2_epilogue_and_x2_output(gpu):
     dict(n=1, H=16, W=16, Cin=256, Cout=512, k=1, s=1, p=0, d=1),
     dict(n=3, H=33, W=21, Cin=64, Cout=128, k=3, s=1, p=1, d=1),
 ])
-@pytest.mark.parametrize("tile", [0, 256256, 8256256, 2256256, 1256064])
+@pytest.mark.parametrize("tile", [0, 256256, 8256256, 2256256, 1256064, 512128])
 def test_conv_x2_against_fp64(gpu, geom, tile):
     from wsovod_amd.layers import hip_ops as H
 
     g = geom
     if tile == 1256064 and g["Cout"] > 64:
         pytest.skip("the tall 64-column tile is for 64 output channels")
+    if tile == 512128 and g["Cout"] != 128:
+        pytest.skip("the 512x128 tile serves the 128-channel convs of res3")
     torch.manual_seed(3)
     x = torch.randn(g["n"], g["Cin"], g["H"], g["W"])
     w = torch.randn(g["Cout"], g["Cin"], g["k"], g["k"]) * 0.05
@@ -342,3 +344,34 @@ def test_conv_x2_split_k_at_few_tiles(gpu, case, monkeypatch):
         assert float((got - ref).abs().max()) < 3e-5 * scale, tile
     monkeypatch.delenv("WSOVOD_CONV_SPLITK")
     assert float((outs[0] - outs[2256256]).abs().max()) < 1e-5 * scale
+
+
+def test_res3_convs_on_the_512x128_tile_equal_the_256x128_tile(gpu):
+    """Round 5: from ~14 images per step the 128-channel convs of res3 run on 512 x 128 tiles (16 wavefronts as 8 x 2, 160 KiB
+    of LDS).  Same products in the same order per output element as the 256 x 128 tile: bit-identical outputs -- stride 2
+    with the fused 1x1 projection shortcut, residual, ragged last tile (M not a multiple of 512)."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(8)
+    n, Hi, Wi = 3, 46, 62
+    enc = lambda t, c: H.x2_encode(t.reshape(-1, c).contiguous().to(gpu))
+    x64 = torch.randn(n, Hi, Wi, 64)
+    Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    w = torch.randn(128, 9 * 64) * 0.05
+    b = torch.randn(128)
+    geom = dict(n_img=n, H=Hi, W=Wi, Cin=64, Ho=Ho, Wo=Wo, KH=3, KW=3, stride=2, pad=1, dil=1)
+    outs = [H.gemm_nt(enc(x64, 64).view(n, Hi, Wi, 64), enc(w, 9 * 64), conv=geom, x2=True, bias=b.to(gpu), relu=True,
+                      out_dtype=H.X2, tile_hint=t) for t in (256128, 512128)]
+    assert (n * Ho * Wo) % 512 != 0 and torch.equal(outs[0], outs[1])
+    h = torch.randn(n, Ho, Wo, 128)
+    xs = torch.randn(n, Ho, Wo, 64)  # the block's input at the output resolution: the fused projection shortcut's operand
+    wcat = torch.cat([torch.randn(128, 9 * 128) * 0.03, torch.randn(128, 64) * 0.1], dim=1)
+    geom = dict(n_img=n, H=Ho, W=Wo, Cin=128, Ho=Ho, Wo=Wo, KH=3, KW=3, stride=1, pad=1, dil=1)
+    outs = [H.gemm_nt(enc(h, 128).view(n, Ho, Wo, 128), enc(wcat, wcat.shape[1]), conv=geom, x2=True, bias=b.to(gpu), relu=True,
+                      out_dtype=H.X2, A2=enc(xs, 64).view(n, Ho, Wo, 64), tile_hint=t) for t in (256128, 512128)]
+    assert torch.equal(outs[0], outs[1])
+    res = enc(torch.randn(n * Ho * Wo, 128), 128)
+    outs = [H.gemm_nt(enc(h, 128).view(n, Ho, Wo, 128), enc(wcat[:, :9 * 128].contiguous(), 9 * 128), conv=geom, x2=True,
+                      bias=b.to(gpu), relu=True, residual=res, residual_x2=True, out_dtype=H.X2, tile_hint=t)
+            for t in (256128, 512128)]
+    assert torch.equal(outs[0], outs[1])

@@ -1818,6 +1818,18 @@ int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, d
     case 256128:
       return launch<bf16_t, 256, 128, CONV, 4, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x128" : "gemm_nt_bf16x2_256x128",
                                                                flops, bytes);
+    case 9256256:  // experiment (tools/res3_ab.py): the generic tile with 8 wavefronts of 128 x 64 (2 per SIMD, 96 MFMAs per K-step)
+      if constexpr (CONV)
+        return launch<bf16_t, 256, 256, true, 2, 4, true, 2, true>(a, s, "conv_igemm_bf16x2_256x256_w8", flops, bytes);
+      wsovod::set_error("wsovod_gemm_nt: tile 9256256 is an implicit-GEMM conv tile");
+      return WSOVOD_ERR_UNSUPPORTED;
+    case 512128:  // round 5, the 128-channel convs of res3: 512 pixels x 128 channels, 16 wavefronts as 8 x 2 (64 x 64 each,
+                  // the register profile of the 256x256 tile), 160 KiB of LDS -- 48 MFMAs per wavefront and K-step where the
+                  // 256x128 tile has 24 for the same barrier, DMA issue and fragment-read latency
+      if constexpr (CONV)
+        return launch<bf16_t, 512, 128, true, 8, 2, true, 2, true>(a, s, "conv_igemm_bf16x2_512x128", flops, bytes);
+      wsovod::set_error("wsovod_gemm_nt: tile 512128 is an implicit-GEMM conv tile");
+      return WSOVOD_ERR_UNSUPPORTED;
     case 1256064:
       return launch<bf16_t, 256, 64, CONV, 4, 1, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x64" : "gemm_nt_bf16x2_256x64",
                                                               flops, bytes);
@@ -2090,6 +2102,11 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       else if (tiles(128, 64) >= 200) tile = 1128064;
       else if (d->K >= 2048 && (!d->conv || (cs && cs[0] == '1'))) tile = 2256256;
     }
+    // the 128-channel convs of res3 at >= 14 images: 512x128 tiles (tools/res3_ab.py, 32 images: 1029 -> 1220, 779 -> 908,
+    // 666 -> 828 TFLOP/s executed against 256x128 on the plain / residual / stride-2 layer; bit-identical results)
+    if (!d->tile_hint && d->conv && d->N > 64 && d->N <= 128 && (long long)ceil_div(d->M, 512) >= 200 &&
+        !(getenv("WSOVOD_CONV_512") && getenv("WSOVOD_CONV_512")[0] == '0'))
+      tile = 512128;
     if (!d->tile_hint && d->conv && getenv("WSOVOD_CONV_SPLITK") && getenv("WSOVOD_CONV_SPLITK")[0] == '1' && d->M >= 256 &&
         d->N >= 256 && d->K >= 2048 && (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
       tile = 2256256;
