@@ -95,6 +95,45 @@ def roi_align_backward(grad, rois, spatial_scale, sampling_ratio, aligned, input
     return gi
 
 
+class _RoIPoolFn(torch.autograd.Function):
+    """Differentiable front of the C restatement (forward + the argmax scatter of ROILoopPool_cpu.cpp:82-123): the
+    oracle's pooling when a backbone stage is trainable (MODEL.BACKBONE.FREEZE_AT < 5)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, spatial_scale, output_size):
+        out, arg = roi_pool_forward(feat, rois, spatial_scale, output_size)
+        ctx.save_for_backward(rois, arg)
+        ctx.shape = tuple(feat.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        rois, arg = ctx.saved_tensors
+        return roi_pool_backward(grad, rois, arg, ctx.shape), None, None, None
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, spatial_scale, output_size, sampling_ratio, aligned):
+        ctx.save_for_backward(rois)
+        ctx.cfg = (spatial_scale, sampling_ratio, aligned, tuple(feat.shape))
+        return roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (rois,) = ctx.saved_tensors
+        scale, sr, aligned, shape = ctx.cfg
+        return roi_align_backward(grad, rois, scale, sr, aligned, shape), None, None, None, None, None
+
+
+def roi_pool(feat, rois, spatial_scale, output_size):
+    return _RoIPoolFn.apply(feat, rois, spatial_scale, tuple(output_size))
+
+
+def roi_align(feat, rois, spatial_scale, output_size, sampling_ratio, aligned):
+    return _RoIAlignFn.apply(feat, rois, spatial_scale, tuple(output_size), sampling_ratio, aligned)
+
+
 # ---- the reference's own compiled RoIPool (oracle/_ref) ----
 def ref_roi_pool_forward(feat, rois, spatial_scale, output_size):
     feat, rois = _prep(feat, rois)

@@ -105,6 +105,12 @@ def roi_pooler(feat, boxes_list, pooler_type="ROIPool", output_size=7, scale=0.1
     """poolers.py:169-197,277-284 (single level)."""
     rois = pooler_format(boxes_list)
     size = (output_size, output_size)
+    if feat.requires_grad:  # a trainable backbone stage (FREEZE_AT < 5): the differentiable fronts
+        if pooler_type == "ROIPool":
+            return roi_ops.roi_pool(feat, rois, scale, size)
+        if pooler_type in ("ROIAlignV2", "ROIAlign"):
+            return roi_ops.roi_align(feat, rois, scale, size, sampling_ratio, pooler_type == "ROIAlignV2")
+        raise ValueError(f"{pooler_type}: no differentiable oracle")
     if pooler_type == "ROIPool":
         return roi_ops.roi_pool_forward(feat, rois, scale, size)[0]
     if pooler_type == "ROILoopPool":  # (3R, C, ph, pw) = [region | frame | context]
@@ -584,7 +590,7 @@ def rpn_losses(anchors, logits, deltas, targets, subsample, batch_size_per_image
 def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool", temperature=50.0,
                   pixel_mean=(102.9801, 115.9465, 122.7717), pixel_std=(1.0, 1.0, 1.0), data_aware=True,
                   mean_loss=True, sampling_ratio=0, dropout_masks=None, refine_prefix="roi_heads.box_refinery_0.",
-                  miner_prefix="roi_heads.object_miner.", classifier=None, rpn=None, sampling=None):
+                  miner_prefix="roi_heads.object_miner.", classifier=None, rpn=None, sampling=None, backbone_grad=False):
     """batch: list of dicts {image uint8 (3,H,W), boxes (R,4), objectness (R), gt_classes (G)}.
     Returns (losses dict, intermediates dict).  REFINE_NUM=1, REFINE_REG=[True], SAMPLING_ON.
     sampling: None (every proposal kept: R <= 4096, fraction 1) or dict(batch_size_per_image, positive_fraction,
@@ -609,7 +615,9 @@ def train_forward(sd, batch, *, depth=18, num_classes=20, pooler_type="ROIPool",
         boxes_list = [torch.cat([pb, b]) for (pb, _), b in zip(props, boxes_list)]
         obj_list = [torch.cat([torch.sigmoid(ps) * ramp, o]) for (_, ps), o in zip(props, obj_list)]
     nums = [len(b) for b in boxes_list]
-    pooled = roi_pooler(res5.detach(), boxes_list, pooler_type, 7, 0.125, sampling_ratio)
+    # backbone_grad: a backbone stage is trainable (MODEL.BACKBONE.FREEZE_AT < 5, resnet_wsl.py:530-552): the gradient
+    # runs through the pooling into res5 (the shipped configs freeze all five stages: the detach is then a no-op)
+    pooled = roi_pooler(res5 if backbone_grad else res5.detach(), boxes_list, pooler_type, 7, 0.125, sampling_ratio)
     objectness = torch.cat([o + 1 for o in obj_list], dim=0)
     loop = pooler_type == "ROILoopPool"
     if loop:

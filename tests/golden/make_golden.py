@@ -142,8 +142,25 @@ class RefRoIPool(nn.Module):
         self.spatial_scale = spatial_scale
 
     def forward(self, input, rois):
-        assert not input.requires_grad  # backbone is frozen on this path
+        if input.requires_grad:  # a trainable backbone stage (G19): forward AND backward of the reference's compiled op
+            return _RefRoIPoolFn.apply(input, rois, self.spatial_scale, self.output_size)
         return roi_ops.ref_roi_pool_forward(input, rois, self.spatial_scale, self.output_size)[0]
+
+
+class _RefRoIPoolFn(torch.autograd.Function):
+    """The reference's own autograd front (wsovod/layers/roi_loop_pool.py:9-35) over its compiled CPU op (oracle/_ref)."""
+
+    @staticmethod
+    def forward(ctx, input, rois, spatial_scale, output_size):
+        out, arg = roi_ops.ref_roi_pool_forward(input, rois, spatial_scale, output_size)
+        ctx.save_for_backward(rois, arg)
+        ctx.cfg = (spatial_scale, tuple(input.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        rois, arg = ctx.saved_tensors
+        return roi_ops.ref_roi_pool_backward(grad, rois, arg, ctx.cfg[0], ctx.cfg[1]), None, None, None
 
 
 class OracleROIAlign(nn.Module):
@@ -284,7 +301,7 @@ def save(name, **arrays):
     print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
 
 
-def build_ref_model(r, depth, K, D, seed):
+def build_ref_model(r, depth, K, D, seed, freeze_at=None):
     import pickle
     import tempfile
 
@@ -293,6 +310,8 @@ def build_ref_model(r, depth, K, D, seed):
     with open(emb, "wb") as f:
         pickle.dump(torch.randn(K, D), f)  # placeholder; class_weight is overwritten from the seeded state
     cfg = ref_cfg(depth, K, D, emb)
+    if freeze_at is not None:
+        cfg.MODEL.BACKBONE.FREEZE_AT = freeze_at
     model = r.meta.GeneralizedRCNN_WSOVOD(cfg)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     sd = gen.seeded_state(shapes, seed)
@@ -1073,6 +1092,47 @@ def golden_edges(r):
 
 
 
+def golden_trainable_stage(r):
+    """G19: MODEL.BACKBONE.FREEZE_AT = 4 (resnet_wsl.py:530-552: res5 trainable, the stem and res2 - res4 frozen) -- one
+    whole training step of the reference with the gradient running through the reference's own RoIPool backward into
+    res5: losses, logits, labels and the gradient of EVERY trainable tensor, the eight res5 conv weights included."""
+    K, D = 20, 512
+    cfg, model, sd, shapes = build_ref_model(r, 18, K, D, seed=1, freeze_at=4)  # the state of g8 (shapes_r18_k20, seed 1)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 1e-12
+    train = [k for k, p_ in model.named_parameters() if p_.requires_grad]
+    assert any(k.startswith("backbone.res5.") for k in train) and not any(k.startswith("backbone.res4.") for k in train)
+    batch = gen.seeded_batch(2, 24, K, 160, 208, seed=11)
+    rh = model.roi_heads
+    captured = {}
+
+    def cap(name, fn):
+        def wrapped(*a, **k):
+            o = fn(*a, **k)
+            captured[name] = o
+            return o
+        return wrapped
+
+    rh.object_miner.forward = cap("miner", rh.object_miner.forward)
+    rh.box_refinery[0].forward = cap("refine", rh.box_refinery[0].forward)
+    rh.label_and_sample_proposals_wsl = cap("proposals_k", rh.label_and_sample_proposals_wsl)
+    loss_dict = model(to_inputs(batch))
+    sum(loss_dict.values()).backward()
+    arrays = {f"loss/{k}": v for k, v in loss_dict.items()}
+    arrays["mining_scores"] = captured["miner"][0]
+    arrays["refine_logits"] = captured["refine"][0]
+    arrays["label/gt_classes"] = torch.cat([q.gt_classes for q in captured["proposals_k"]])
+    arrays["train_keys"] = np.array(train)
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None, k
+            arrays[f"gradnorm/{k}"] = q.grad.norm()
+            arrays[f"gradsample/{k}"] = gen.strided_sample(q.grad, 1024)
+    save("g19_freeze_at_4", **arrays)
+
+
 def main():
     if "--only-sampler" in sys.argv:
         return golden_sampler()
@@ -1089,6 +1149,8 @@ def main():
         return golden_tta_union(r)
     if "--only-edges" in sys.argv:
         return golden_edges(r)
+    if "--only-trainable" in sys.argv:
+        return golden_trainable_stage(r)
     if "--only-eval" in sys.argv:
         golden_eval_tail(r)
         golden_subsample(r)
@@ -1199,6 +1261,7 @@ def main():
     golden_rpn(r)
     golden_formats()
     golden_edges(r)
+    golden_trainable_stage(r)
 
 
 if __name__ == "__main__":

@@ -84,10 +84,14 @@ def test_out_of_scope_features_fail_loudly():
     with pytest.raises(NotImplementedError, match="SAM"):
         build_model(cfg)
     cfg = hot_path_cfg(device="cpu")
+    cfg.MODEL.BACKBONE.FREEZE_AT = 0  # a trainable STEM (fused with the uint8 normalisation, forward only) is refused;
+    model = build_model(cfg)          # FREEZE_AT 1 - 4 train the residual stages (tests/test_gpu_freeze_at.py)
+    with pytest.raises(NotImplementedError, match="FREEZE_AT = 0"):
+        model.backbone(torch.zeros(1, 3, 32, 32))
     cfg.MODEL.BACKBONE.FREEZE_AT = 2
     model = build_model(cfg)
-    with pytest.raises(NotImplementedError, match="forward-only"):
-        model.backbone(torch.zeros(1, 3, 32, 32))
+    assert model.backbone.has_trainable_stage and not any(p.requires_grad for p in model.backbone.res2.parameters())
+    assert all(p.requires_grad for p in model.backbone.res3.parameters())
 
 
 def test_rpn_host_pieces():

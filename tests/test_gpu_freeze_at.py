@@ -1,0 +1,103 @@
+"""GPU: MODEL.BACKBONE.FREEZE_AT < 5 (reference: backbone/resnet_wsl.py:530-552).  The trainable stages run their FORWARD
+on the HIP kernels; their backward is the torch-autograd re-evaluation of `modeling/backbone.py:_TrainableStage` (MIOpen
+convs on the GPU -- no conv dgrad / wgrad kernel exists, the shipped configs freeze all five stages).  Pinned to the
+REFERENCE's own step at FREEZE_AT = 4 (tests/golden/g19_freeze_at_4.npz, make_golden.py:golden_trainable_stage): the
+gradient runs through the HIP RoIPool backward (argmax scatter) and the GAP of the data-aware head into res5."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import gen
+from tests.helpers import load_golden, seeded_sd, to_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(precision, freeze_at):
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, precision=precision, device="cuda:0", calibrate_synthetic=False,
+                                      freeze_at=freeze_at)
+    cfg.MODEL.PIXEL_STD = list(gen.PIXEL_STD)
+    model._std = [float(v) for v in gen.PIXEL_STD]
+    model.load_state_dict(seeded_sd(1), strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    return cfg, model
+
+
+@pytest.mark.parametrize("precision", ["fp32", "parity", "bf16"])
+def test_res5_trainable_step_matches_reference_golden(gpu, precision):
+    g = load_golden("g19_freeze_at_4")
+    cfg, model = _model(precision, 4)
+    train = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert sorted(train) == sorted(str(k) for k in g["train_keys"])  # the same tensors are trainable as in the reference
+    assert model.backbone.has_trainable_stage
+    captured = {}
+    rh = model.roi_heads
+    om, rf = rh.object_miner.forward, rh.box_refinery[0].forward
+    rh.object_miner.forward = lambda *a, **k: captured.setdefault("miner", om(*a, **k))
+    rh.box_refinery[0].forward = lambda *a, **k: captured.setdefault("refine", rf(*a, **k))
+    losses = model(to_inputs(gen.seeded_batch(2, 24, 20, 160, 208, seed=11)))
+    rh.object_miner.forward, rh.box_refinery[0].forward = om, rf
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    scores, logits = captured["miner"][0].detach().float().cpu(), captured["refine"][0].detach().float().cpu()
+    if precision != "bf16":
+        assert (scores - g["mining_scores"]).abs().max() < 1e-3 and (logits - g["refine_logits"]).abs().max() < 1e-3
+        assert torch.equal(rh._last_pgt["gt_classes"].cpu(), g["label/gt_classes"])
+        for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+            torch.testing.assert_close(losses[k].detach().cpu(), g["loss/" + k], rtol=1e-3, atol=1e-5)
+    # gradients: the heads as with a frozen backbone; the res5 convs through pooling backward + the re-evaluated stage
+    rtol = {"fp32": 3e-3, "parity": 2e-2, "bf16": 0.15}[precision]
+    for k, p in model.named_parameters():
+        if not p.requires_grad:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+        gr = p.grad.detach().float().cpu()
+        torch.testing.assert_close(gr.norm(), g["gradnorm/" + k], rtol=rtol, atol=1e-7, msg=lambda m: f"{k}: {m}")
+        if precision == "fp32":
+            ref = g["gradsample/" + k]
+            assert (gen.strided_sample(gr, 1024) - ref).abs().max() <= 5e-3 * ref.abs().max() + 1e-8, k
+
+
+def test_trainer_and_optimizer_with_a_trainable_stage(gpu):
+    """HotPathTrainer + HipSGD at FREEZE_AT = 3 (res4 and res5 trainable: the gradient crosses a bf16x2 stage boundary in
+    the headline precision): the backbone runs BEHIND the pending update (no frozen-forward overlap, no step graph), the
+    loss goes down on a fixed batch, res3 stays untouched, inference afterwards sees the trained stage."""
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, precision="parity", device="cuda:0", freeze_at=3)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.eval()
+    cfg.SOLVER.BASE_LR = 2e-4
+    frozen = {k: v.detach().clone() for k, v in model.named_parameters() if k.startswith("backbone.res3.")}
+    w0 = model.backbone.res4[0].conv1.weight.detach().clone()
+    tr = HotPathTrainer(model, build_optimizer(cfg, model))
+    batch = make_batch(2, 48, 20, H=192, W=256, seed=5)
+    hist = [sum(float(v) for v in tr.run_step(batch).values()) for _ in range(8)]
+    tr.flush()
+    assert not tr._graphs and all(np.isfinite(hist)) and hist[-1] < hist[0], hist
+    assert not torch.equal(model.backbone.res4[0].conv1.weight.detach(), w0)
+    assert all(torch.equal(dict(model.named_parameters())[k].detach(), v) for k, v in frozen.items())
+    model.eval()
+    out = model.inference(make_batch(1, 32, 20, H=192, W=256, seed=6))
+    assert len(out) == 1 and "instances" in out[0]
+    tr.close()
+
+
+def test_trainable_stem_is_refused(gpu):
+    from wsovod_amd.testing import build_hot_path_model
+
+    cfg, model = build_hot_path_model(seed=0, precision="fp32", device="cuda:0", freeze_at=0)
+    model.train()
+    with pytest.raises(NotImplementedError, match="FREEZE_AT = 0"):
+        model(to_inputs(gen.seeded_batch(2, 16, 20, 96, 128, seed=1)))

@@ -454,3 +454,27 @@ def test_edge_ov_classifier_bias_and_coco_shapes_match_reference(tag, use_bias, 
                                    g[f"ovc/{tag}/logits_nobg"], **tol)
         torch.testing.assert_close(R.ov_classifier_forward(sd, x, "cls.", norm_weight=norm, cls_bias=bias, classifier=clsf),
                                    g[f"ovc/{tag}/logits_classifier"], **tol)
+
+
+def test_trainable_res5_step_matches_reference():
+    """G19: MODEL.BACKBONE.FREEZE_AT = 4 -- the reference's whole step with res5 trainable (gradient through its own RoIPool
+    backward and through the GAP of the data-aware head into the stage).  The oracle with `backbone_grad=True`: losses,
+    scores, logits, labels and the gradient of every trainable tensor, the res5 convs included."""
+    g = load("g19_freeze_at_4")
+    sd = seeded_sd()
+    train_keys = [str(k) for k in g["train_keys"]]
+    assert sum(k.startswith("backbone.res5.") for k in train_keys) >= 5
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    batch = gen.seeded_batch(2, 24, 20, 160, 208, seed=11)
+    losses, inter = R.train_forward(sd, batch, depth=18, num_classes=20, pixel_std=gen.PIXEL_STD, backbone_grad=True)
+    for k in ("loss_cls_object_mining", "loss_cls_r0", "loss_box_reg_r0"):
+        torch.testing.assert_close(losses[k].detach(), g["loss/" + k], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(inter["mining_scores"].detach(), g["mining_scores"], rtol=1e-4, atol=1e-8)
+    torch.testing.assert_close(inter["refine_logits"].detach(), g["refine_logits"], rtol=1e-4, atol=1e-4)
+    assert torch.equal(torch.cat([l["gt_classes"] for l in inter["labelled"]]), g["label/gt_classes"])
+    grads = torch.autograd.grad(sum(losses.values()), [sd[k] for k in train_keys])
+    for k, gr in zip(train_keys, grads):
+        torch.testing.assert_close(gr.norm(), g["gradnorm/" + k], rtol=3e-4, atol=1e-9, msg=lambda m: f"{k}: {m}")
+        torch.testing.assert_close(gen.strided_sample(gr, 1024), g["gradsample/" + k], rtol=3e-3,
+                                   atol=1e-5 * float(g["gradsample/" + k].abs().max()) + 1e-9, msg=lambda m: f"{k}: {m}")

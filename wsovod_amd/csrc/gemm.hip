@@ -1818,11 +1818,6 @@ int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, d
     case 256128:
       return launch<bf16_t, 256, 128, CONV, 4, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_256x128" : "gemm_nt_bf16x2_256x128",
                                                                flops, bytes);
-    case 9256256:  // experiment (tools/res3_ab.py): the generic tile with 8 wavefronts of 128 x 64 (2 per SIMD, 96 MFMAs per K-step)
-      if constexpr (CONV)
-        return launch<bf16_t, 256, 256, true, 2, 4, true, 2, true>(a, s, "conv_igemm_bf16x2_256x256_w8", flops, bytes);
-      wsovod::set_error("wsovod_gemm_nt: tile 9256256 is an implicit-GEMM conv tile");
-      return WSOVOD_ERR_UNSUPPORTED;
     case 512128:  // round 5, the 128-channel convs of res3: 512 pixels x 128 channels, 16 wavefronts as 8 x 2 (64 x 64 each,
                   // the register profile of the 256x256 tile), 160 KiB of LDS -- 48 MFMAs per wavefront and K-step where the
                   // 256x128 tile has 24 for the same barrier, DMA issue and fragment-read latency

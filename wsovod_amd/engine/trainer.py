@@ -834,6 +834,8 @@ class HotPathTrainer:
             return None
         if hasattr(m, "classifier_train") or "dataset_id" in x0:
             return None  # mixed-dataset model: miner, class count and text embeddings change with the batch's source
+        if getattr(getattr(m, "backbone", None), "has_trainable_stage", False):
+            return None  # FREEZE_AT < 5: the stage's backward is torch autograd over MIOpen convs, not capturable launches
         shape = tuple(x0["image"].shape)
         if any(tuple(x["image"].shape) != shape or x["image"].dtype != torch.uint8 for x in data):
             return None

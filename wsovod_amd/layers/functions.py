@@ -520,6 +520,26 @@ def data_aware_features(gap, W1, b1, W2, b2, E):
     return _DataAware.apply(gap, W1, b1, W2, b2, E)
 
 
+class _GapNHWC(Function):
+    """Global average pool of an NHWC map -> (N, C) fp32.  The backward (the mean's gradient spread over the pixels) only
+    runs when a backbone stage is trainable (MODEL.BACKBONE.FREEZE_AT < 5): a broadcast, left to torch."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape, ctx.dtype = tuple(x.shape), x.dtype
+        return H.global_avgpool_nhwc(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        n, h, w, c = ctx.shape
+        return (dy.to(torch.float32) / float(h * w)).view(n, 1, 1, c).expand(n, h, w, c).to(ctx.dtype)
+
+
+def global_avgpool_nhwc(x):
+    return _GapNHWC.apply(x) if x.requires_grad else H.global_avgpool_nhwc(x)
+
+
 class _AddGroupRows(Function):
     @staticmethod
     def forward(ctx, x, add, row_group, seg_offsets):

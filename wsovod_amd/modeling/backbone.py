@@ -9,8 +9,11 @@ implicit-GEMM kernel over NHWC activations, pools are the NHWC max-pool kernel. 
 feature map is logically NCHW but stored NHWC (torch.channels_last), which the ROIPooler reads
 directly.
 
-Scope: every shipped WSR config freezes the whole backbone (FREEZE_AT: 5), so only the
-forward exists; a trainable stage raises NotImplementedError instead of silently using torch.
+Scope: every shipped WSR config freezes the whole backbone (FREEZE_AT: 5): the HIP kernels are the
+FORWARD of every conv.  A trainable stage (FREEZE_AT < 5, resnet_wsl.py:530-552) still runs its forward on those kernels;
+its backward -- outside the benchmarked path, no conv dgrad / wgrad kernel exists -- is `_TrainableStage`: the stage is
+re-evaluated from its saved input with torch's GPU convolution (MIOpen) under autograd, which yields the gradients of
+the stage's weights and of its input.  Never a CPU path; tests/test_gpu_freeze_at.py pins it to the reference (G19).
 """
 import os
 
@@ -330,6 +333,62 @@ class BasicStem(CNNBlockBase):
         return self._tail(x)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# trainable stages (MODEL.BACKBONE.FREEZE_AT < 5): HIP forward, torch-autograd backward by re-evaluation
+# ---------------------------------------------------------------------------------------------------------------
+def _torch_conv(conv, x):
+    """conv + FrozenBN as torch ops on NCHW fp32 (resnet_wsl.py / detectron2 Conv2d.forward): the backward's restatement."""
+    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding, conv.dilation)
+    if conv.norm is not None:
+        scale, shift = conv.norm.scale_shift()
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    return y
+
+
+def _torch_block(block, x):
+    """resnet_wsl.py:94-110 (BasicBlock) / :224-241 (BottleneckBlock) in torch ops."""
+    out = F.relu(_torch_conv(block.conv1, x))
+    if isinstance(block, BottleneckBlock):
+        out = _torch_conv(block.conv3, F.relu(_torch_conv(block.conv2, out)))
+    else:
+        out = _torch_conv(block.conv2, out)
+    out = F.relu(out + (_torch_conv(block.shortcut, x) if block.shortcut is not None else x))
+    if block.has_pool:  # resnet_wsl.py:85-92
+        out = F.max_pool2d(F.pad(out, (0, 1, 0, 1)), 2, 1) if block.pool_stride == 1 else F.max_pool2d(out, 2, block.pool_stride)
+    return out
+
+
+class _TrainableStage(torch.autograd.Function):
+    """One backbone stage with trainable weights.  forward: the HIP kernels (as for a frozen stage).  backward: the
+    stage re-evaluated from its saved input in fp32 torch ops on the GPU under autograd -> d input, d weights."""
+
+    @staticmethod
+    def forward(ctx, stage, x3, x, *params):
+        with torch.no_grad(), H.x3_mode(x3):
+            y = stage(x)
+        ctx.stage, ctx.x3 = stage, x3
+        ctx.save_for_backward(x, *params)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, *params = ctx.saved_tensors
+        with torch.no_grad():  # the saved map in its on-device format (bf16x2 carrier / bf16 / fp32 NHWC) -> fp32 NCHW
+            x32 = H.x2_decode(x.reshape(-1, x.shape[-1])).view(x.shape) if ctx.x3 == "x2" else x.float()
+            x32 = x32.permute(0, 3, 1, 2).contiguous()
+        need_dx = ctx.needs_input_grad[2]
+        x32.requires_grad_(need_dx)
+        with torch.enable_grad():
+            y = x32
+            for block in ctx.stage.children():
+                y = _torch_block(block, y)
+        wanted = ([x32] if need_dx else []) + [p for p in params if p.requires_grad]
+        grads = list(torch.autograd.grad(y, wanted, dy.float().permute(0, 3, 1, 2), allow_unused=True))
+        dx = grads.pop(0).permute(0, 2, 3, 1).contiguous().to(x.dtype if ctx.x3 != "x2" else torch.float32) if need_dx else None
+        it = iter(grads)
+        return (None, None, dx, *[next(it) if p.requires_grad else None for p in params])
+
+
 class ResNet(nn.Module):
     """resnet_wsl.py:424-607."""
 
@@ -380,10 +439,18 @@ class ResNet(nn.Module):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32  # "fp32" and "bf16x3" carry fp32 tensors
 
     def _check_frozen(self):
-        if any(p.requires_grad for p in self._param_list()):
+        """The stem's first conv is fused with the image normalisation (no weight gradient there): a trainable STEM
+        (FREEZE_AT = 0) stays unsupported; trainable stages res2 - res5 go through _TrainableStage."""
+        if any(p.requires_grad for p in self.stem.parameters()):
             raise NotImplementedError(
-                "wsovod_amd: the HIP backbone is forward-only; all shipped WSR configs use "
-                "MODEL.BACKBONE.FREEZE_AT=5 (conv backward is outside the hot path, SURVEY F3)")
+                "wsovod_amd: MODEL.BACKBONE.FREEZE_AT = 0 (a trainable stem) is not supported: the stem runs fused with the "
+                "uint8 normalisation, forward only; FREEZE_AT >= 1 trains the residual stages through the torch fallback")
+
+    @property
+    def has_trainable_stage(self):
+        """True when a residual stage is trainable (FREEZE_AT < 5): the backbone forward then reads weights the optimizer
+        updates, and the trainers may no longer run it ahead of the previous step's update."""
+        return any(p.requires_grad for p in self._param_list())
 
     def _param_list(self):
         cached = getattr(self, "_params_cache", None)
@@ -396,12 +463,16 @@ class ResNet(nn.Module):
         if "stem" in self._out_features:
             outputs["stem"] = x.permute(0, 3, 1, 2)
         for name, stage in zip(self.stage_names, self.stages):
-            x = stage(x)
+            params = [p for p in stage.parameters()]
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                x = _TrainableStage.apply(stage, H.x3_active(), x, *params)
+            else:
+                with torch.no_grad():
+                    x = stage(x)
             if name in self._out_features:
                 outputs[name] = x.permute(0, 3, 1, 2)  # logical NCHW, NHWC memory (channels_last)
         return outputs
 
-    @torch.no_grad()
     def forward(self, x):
         """x: (N,C,H,W) normalised float image batch -> {name: (N,C',H/8,W/8) channels_last}."""
         assert x.dim() == 4, f"ResNet takes an input of shape (N, C, H, W). Got {x.shape} instead!"
@@ -409,19 +480,22 @@ class ResNet(nn.Module):
         cd = self.compute_dtype
         x3 = {"bf16x3": "full", "bf16x3f": "fwd", "parity": "fwd"}.get(self.precision, False)  # (float entry: no bf16x2 stem)
         kstep = 64 if (cd == torch.bfloat16 or x3) else 32
-        xn = x.permute(0, 2, 3, 1).to(cd)
-        xn = F.pad(xn, (0, kstep - xn.size(-1))).contiguous()  # Cin 3 -> one K-step (generic float entry)
+        with torch.no_grad():
+            xn = x.permute(0, 2, 3, 1).to(cd)
+            xn = F.pad(xn, (0, kstep - xn.size(-1))).contiguous()  # Cin 3 -> one K-step (generic float entry)
         with H.x3_mode(x3):
-            return self._run(self.stem(xn))
+            with torch.no_grad():
+                xs = self.stem(xn)
+            return self._run(xs)
 
-    @torch.no_grad()
     def forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std, allow_graph=False):
         """Fused entry used by the meta-arch: uint8 canvas -> normalise + im2col -> stem conv1 GEMM.
         allow_graph: the caller consumes the maps before its next call with this shape (the training step's frozen
         forward): small batches may then come from a captured HIP graph, whose outputs are that graph's STATIC buffers
         -- overwritten by the next replay.  inference() / TTA keep the eager launches (fresh tensors)."""
         with H.x3_mode({"bf16x3": "full", "bf16x3f": "fwd", "parity": "x2"}.get(self.precision, False)):
-            if allow_graph and self.graph_max_batch and images_u8.is_cuda and images_u8.size(0) <= self.graph_max_batch:
+            if allow_graph and self.graph_max_batch and images_u8.is_cuda and images_u8.size(0) <= self.graph_max_batch \
+                    and not self.has_trainable_stage:
                 g = self._graph_for(images_u8, sizes, pixel_mean, pixel_std)
                 if g is not None:
                     return g(images_u8)
@@ -475,11 +549,14 @@ class ResNet(nn.Module):
 
     def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
         self._check_frozen()
-        if (self.compute_dtype == torch.bfloat16 or _x2()) and self.stem.out_channels == 64 and self.stem.in_channels == 3:
-            # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)
-            return self._run(self.stem.forward_uint8(images_u8, sizes, pixel_mean, pixel_std))
-        a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
-        return self._run(self.stem.forward_im2col(a, images_u8.size(0), ho, wo))
+        with torch.no_grad():
+            if (self.compute_dtype == torch.bfloat16 or _x2()) and self.stem.out_channels == 64 and self.stem.in_channels == 3:
+                # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)
+                xs = self.stem.forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
+            else:
+                a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
+                xs = self.stem.forward_im2col(a, images_u8.size(0), ho, wo)
+        return self._run(xs)
 
     def output_shape(self):
         return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])

@@ -143,7 +143,7 @@ class DataAwareFeaturesHead(nn.Module):
                 nhwc = f.permute(0, 2, 3, 1)
             else:
                 nhwc = f.permute(0, 2, 3, 1).contiguous()
-            gaps.append(H.global_avgpool_nhwc(nhwc))
+            gaps.append(Fn.global_avgpool_nhwc(nhwc))  # (differentiable when a backbone stage is trainable)
         return gaps
 
     def from_stats(self, gaps):

@@ -215,9 +215,15 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             # would block the host until the stream drains).
             st["gt_instances"] = [x["instances"] if st["image_level_gt"] is not None else x["instances"].to(self.device)
                                   for x in batched_inputs]
+        st["proposals"] = self._proposals(batched_inputs) if "proposals" in batched_inputs[0] else None
+        if getattr(self.backbone, "has_trainable_stage", False):
+            # MODEL.BACKBONE.FREEZE_AT < 5: the backbone reads weights the optimizer updates and takes part in autograd --
+            # it runs in the trainable part (behind the pending update of an overlapped trainer), with gradients enabled
+            st["sizes_t"] = sizes_t
+            st["features"] = st["gaps"] = st["pooled"] = None
+            return st
         features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std, allow_graph=True)
         st["features"] = features
-        st["proposals"] = self._proposals(batched_inputs) if "proposals" in batched_inputs[0] else None
         st["gaps"] = self.data_aware_head.pooled_stats(features) if self.data_aware_head is not None else None
         # with an RPN the box set depends on trainable weights: pooling moves to the trainable part
         st["pooled"] = self.roi_heads.pool_features(features, st["proposals"]) if self.proposal_generator is None \
@@ -233,6 +239,11 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
     def _forward_trainable(self, st):
         """The trainable remainder: data-aware MLP, neck, object mining, refinement, losses."""
         self.roi_heads.image_level_gt = st["image_level_gt"]
+        if st["features"] is None:  # a trainable backbone stage: see _forward_frozen
+            st["features"] = self.backbone.forward_uint8(st["canvas"], st["sizes_t"], self._mean, self._std)
+            st["gaps"] = self.data_aware_head.pooled_stats(st["features"]) if self.data_aware_head is not None else None
+            if self.proposal_generator is None:
+                st["pooled"] = self.roi_heads.pool_features(st["features"], st["proposals"])
         daf = self.data_aware_head.from_stats(st["gaps"]) if self.data_aware_head is not None else None
         images = ImageList(st["canvas"], st["sizes"])
         proposals = st["proposals"]

@@ -12,7 +12,7 @@ _CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs"
 
 
 def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", device="cuda", weight_path=None,
-                 emb_seed=7, rpn=False):
+                 emb_seed=7, rpn=False, freeze_at=None):
     """WSOVOD_WSR_{18,50}_DC5_1x in proposals-only mode: the keys below are the values of
     /root/reference/configs/PascalVOC-Detection/{Base-RCNN-DilatedC5,WSOVOD_WSR_18_DC5_1x}.yaml
     that the hot path reads, with PROPOSAL_GENERATOR=PrecomputedProposals, BBOX_REFINE off."""
@@ -34,6 +34,8 @@ def hot_path_cfg(depth=18, K=20, D=512, precision="bf16", pooler="ROIPool", devi
         "MODEL.HIP.PRECISION", precision,
         "MODEL.DEVICE", device,
     ])
+    if freeze_at is not None:  # (every shipped WSR config: 5 = the whole backbone frozen)
+        cfg.MODEL.BACKBONE.FREEZE_AT = int(freeze_at)
     return cfg
 
 
