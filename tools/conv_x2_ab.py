@@ -1,6 +1,9 @@
 """res4 / res5 implicit-GEMM convs on bf16x2 maps under given tiles, interleaved rounds.  python tools/conv_x2_ab.py [images] [tiles]"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import wsovod_amd._lib as _L
+if os.environ.get("WSOVOD_LIB"):  # another build of the library (ablation builds) for an A/B on one box
+    _L.LIB_PATH = os.environ["WSOVOD_LIB"]
 from wsovod_amd.layers import hip_ops as H
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 tiles = [int(t) for t in sys.argv[2].split(",")] if len(sys.argv) > 2 else [256256, 9256256]

@@ -2065,7 +2065,10 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       GemmArgs am = a, at = a;
       am.M = main_tm * 256;
       at.m_base = main_tm * 256;
-      int rc = x2 ? dispatch_tile_x3<true>(am, 256256, s, flops * fmain, bytes * fmain)
+      // bf16x2: the main rounds on the lean two-phase 8-wavefront tile (round 5: 1331 / 1452 / 1384 against 1270 / 1366 /
+      // 1315 TFLOP/s executed for the 16-wavefront tile on res4 / res5 / res5a, tools/conv_x2_ab.py; WSOVOD_CONV_8PH=0: A/B)
+      static const bool conv8 = !(getenv("WSOVOD_CONV_8PH") && getenv("WSOVOD_CONV_8PH")[0] == '0');
+      int rc = x2 ? dispatch_tile_x3<true>(am, conv8 ? 2256256 : 256256, s, flops * fmain, bytes * fmain)
                   : dispatch_tile<bf16_t, true>(am, 256256, s, flops * fmain, bytes * fmain);
       if (rc != WSOVOD_OK) return rc;
       return x2 ? dispatch_tile_x3<true>(at, 256128, s, flops * (1.0 - fmain), bytes * (1.0 - fmain))
@@ -2076,7 +2079,9 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     // plain contractions: the 8-wavefront tile in its two-phase form (48 MFMAs per phase; measured on the fc1 / fc2 /
     // projection shapes: 6.63 -> 6.14, 1.12 -> 1.03, 0.274 -> 0.263 ms against the four-phase form, tools/x2_probe.py);
     // the implicit-GEMM convs stay on the 16-wavefront tile (res5: 2.32 vs 2.40 ms)
-    if (!d->tile_hint && tile == 256256 && !d->conv) tile = 2256256;
+    if (!d->tile_hint && tile == 256256 &&
+        (!d->conv || !(getenv("WSOVOD_CONV_8PH") && getenv("WSOVOD_CONV_8PH")[0] == '0')))
+      tile = 2256256;  // (round 5: also the implicit-GEMM convs, in the lean form of that tile)
     // few rows, long K (fc1 at 1-4 images per step): the same tile with split-K, as for plain bf16 above -- a 64x64 grid
     // re-reads the 411-MB bf16x2 weight through L2 eight times over (M = 512: 0.80 ms at 130 TFLOP/s algorithmic)
     if (!d->tile_hint && !d->conv && d->M >= 256 && d->N >= 256 && d->K >= 8192 &&
@@ -2092,7 +2097,7 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!d->tile_hint && d->M >= 256 && d->N >= 256 && tile != 2256256 && tile != 256256) {
       auto tiles = [&](int bm, int bn) { return (long long)ceil_div(d->M, bm) * ceil_div(d->N, bn); };
       const char* cs = getenv("WSOVOD_CONV_SPLITK");  // "1": also convs may take the split form (experiments, tests)
-      if (tiles(256, 256) >= 150) tile = d->conv ? 256256 : 2256256;
+      if (tiles(256, 256) >= 150) tile = 2256256;
       else if (tiles(256, 128) >= 200) tile = 256128;
       else if (tiles(128, 64) >= 200) tile = 1128064;
       else if (d->K >= 2048 && (!d->conv || (cs && cs[0] == '1'))) tile = 2256256;

@@ -41,8 +41,26 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // 61 %), so doubling the MFMAs per phase raises the busy share.  DMA schedule: phase A stages B and A_lo of K-step kt+1
 // (their LDS rows were last read two phases earlier) and waits for A_hi(kt); phase B stages A_hi(kt+1) and waits for the
 // six instructions of phase A.  Same products in the same order as PH = 4: bit-identical results.
-template <bool CONV, bool X3 = false, int PH = 4>
+// LEAN (round 5, two-phase form only; K a whole number of K-steps): the half of a phase that the other group's MFMAs have
+// to cover -- fragment reads + DMA issue + the counted wait -- without its address arithmetic (s_memtime stamps,
+// tools/g8_phases.py: the read section of phase A took 737 ticks on a plain GEMM against 586 (bf16) / 840 (bf16x2) of MFMAs,
+// and 1130 on the implicit-GEMM conv, whose tap decode / validity selects sat in front of every DMA instruction):
+//  * fragment reads address four per-lane constants; the K-step buffer and the 16-row block are the instruction's
+//    immediate offset (K loop unrolled by two);
+//  * a DMA instruction = a per-lane CONSTANT offset (rows / columns outside the matrix: 2^31, beyond the resource's range)
+//    + a scalar K offset in `soffset` (it takes part in the hardware range check on gfx950: tools/_scratch probe);
+//  * conv: the per-lane offsets of the NEXT K-step's tap (the pixel offset where the tap lies inside the image, 2^31
+//    where it does not) are computed under the MFMAs of phase B, not in front of the DMA.
+template <int OFF>
+__device__ __forceinline__ void g8_read_imm(__attribute__((ext_vector_type(4))) unsigned int& dst, unsigned addr) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#endif
+}
+
+template <bool CONV, bool X3 = false, int PH = 4, bool LEAN = false>
 __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
+  static_assert(!LEAN || PH == 2, "the lean form is a two-phase K-step");
   constexpr int BM = 256, BN = 256, BKE = 64, EPC = 8, esz = 2;
   constexpr int LR = 64;  // rows staged per DMA pass (512 threads x 16 B = 64 rows x 128 B)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,6 +256,20 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #else
 #define WS_VMCNT(N) (void)0
 #endif
+#if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  // instrumented builds only (tools/g8_phases.py): s_memtime ticks per section of the two-phase K-step
+  unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define G8_STAMP0() st_t = __builtin_amdgcn_s_memtime()
+#define G8_STAMP(k)                                              \
+  {                                                              \
+    const unsigned long long now = __builtin_amdgcn_s_memtime(); \
+    st_acc[k] += now - st_t;                                     \
+    st_t = now;                                                  \
+  }
+#else
+#define G8_STAMP0() (void)0
+#define G8_STAMP(k) (void)0
+#endif
   Tap t0{0, 0, 0};
   if (CONV && kt_base > 0) {  // split-K slice of a conv: the (filter tap, channel chunk) of its first K-step
     const int taps = p.KH * p.KW, nk_main = taps * (p.Cin / BKE);
@@ -260,12 +292,156 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second M-half runs one barrier behind
 
+  if constexpr (LEAN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // ---- per-lane constants of the lean form
+    const unsigned rA0 = ldsA + offA + c0, rA1 = ldsA + offA + c1, rB0 = ldsB + offB + c0, rB1 = ldsB + offB + c1;
+    constexpr unsigned OOB = 0x80000000u;
+    // conv: a pixel offset with the filter at its top-left tap is negative along the image's top / left border, and the
+    // range check adds voffset + soffset without wrapping: the resource starts `bias` bytes in front of the map and every
+    // per-lane offset carries +bias (the bytes in front are never addressed: their taps are the invalid ones)
+    const int bias = CONV ? (p.pad * p.W + p.pad) * p.Cin * esz : 0;
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrcAl = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.A - bias), 0, (int)min(p.a_bytes + (long long)bias, (long long)0x7fffffff), 0x00020000);
+    unsigned vb[4], va[4];  // DMA source offsets: B rows (loop constants); A rows of the K-step staged next
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      vb[i] = b_off[i] >= 0 ? (unsigned)b_off[i] : OOB;
+      va[i] = CONV ? 0u : (a_off[i] >= 0 ? (unsigned)a_off[i] : OOB);
+    }
+    // conv: offsets of tap t for this lane's four rows -- the pixel offset (filter at its top-left tap) where the tap
+    // lies inside the image, out of range where it does not; the tap's own displacement is the scalar `soffset`.
+    // Branch-free (16 VALU instructions on loop constants): it is issued BETWEEN the products of phase B
+    unsigned pixb[4], pix2v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      pixb[i] = CONV ? (unsigned)(pix_off[i] + bias) : 0u;
+      pix2v[i] = (CONV && pix2_off[i] >= 0) ? (unsigned)pix2_off[i] : OOB;
+    }
+    auto conv_va = [&](const Tap t) {
+      const bool sec = t.c0 >= p.Cin;                                    // the fused 1x1 shortcut's K-steps (scalar)
+      const unsigned tapbit = sec ? 0u : (1u << (t.r * p.KW + t.q));     // scalar
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned alt = sec ? pix2v[i] : OOB;
+        va[i] = (vmask[i] & tapbit) ? pixb[i] : alt;
+      }
+    };
+    // scalar byte offsets of a K-step: into the A operand (conv: the tap's displacement + channel chunk) and the B rows
+    auto soff_a = [&](int kt, const Tap t) -> int {
+      if (!CONV) return (kt + kt_base) * (BKE * esz);
+      if (t.c0 >= p.Cin) return (t.c0 - p.Cin) * esz;
+      return (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;
+    };
+    auto soff_b = [&](int kt, const Tap t) -> int {
+      if (!CONV) return (kt + kt_base) * (BKE * esz);
+      return (t.c0 >= p.Cin ? p.KH * p.KW * p.Cin + (t.c0 - p.Cin) : (t.r * p.KW + t.q) * p.Cin + t.c0) * esz;
+    };
+    auto dma_a = [&](int buf, int i, int so, bool second) {
+      char* dA = sA + buf * BM * 128 + wave_u * 1024 + LR * i * 128;
+      if (CONV && second)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void*)dA, 16, (int)va[i], so, 0, 0);
+      else if (CONV)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcAl, (lds_void*)dA, 16, (int)va[i], so, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, (int)va[i], so, 0, 0);
+    };
+    auto dma_b = [&](int buf, int i, int so) {
+      char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16, (int)vb[i], so, 0, 0);
+    };
+    // one K-step on buffer CUR; `more`: K-step kt + 1 exists (its tap is t1, its A offsets are in va)
+    auto kstep = [&](auto cur_c, int kt) {
+      constexpr int CUR = decltype(cur_c)::value;
+      constexpr int IA = CUR * (BM * 128), IB = CUR * (BN * 128);
+      const bool more = kt + 1 < nk;
+      const bool second = CONV && t1.c0 >= p.Cin;
+      const int sa = soff_a(kt + 1, t1), sb = soff_b(kt + 1, t1);
+      // ---- phase A: A rows 0-63 x all 64 columns of this wavefront (16 fragment reads)
+      G8_STAMP0();
+      g8_read_imm<IB + 0 * 2048>(bl[0][0], rB0); g8_read_imm<IB + 0 * 2048>(bl[0][1], rB1);
+      g8_read_imm<IB + 1 * 2048>(bl[1][0], rB0); g8_read_imm<IB + 1 * 2048>(bl[1][1], rB1);
+      g8_read_imm<IA + 0 * 2048>(af[0][0], rA0); g8_read_imm<IA + 0 * 2048>(af[0][1], rA1);
+      g8_read_imm<IA + 1 * 2048>(af[1][0], rA0); g8_read_imm<IA + 1 * 2048>(af[1][1], rA1);
+      g8_read_imm<IA + 2 * 2048>(af[2][0], rA0); g8_read_imm<IA + 2 * 2048>(af[2][1], rA1);
+      g8_read_imm<IA + 3 * 2048>(af[3][0], rA0); g8_read_imm<IA + 3 * 2048>(af[3][1], rA1);
+      g8_read_imm<IB + 2 * 2048>(bh[0][0], rB0); g8_read_imm<IB + 2 * 2048>(bh[0][1], rB1);
+      g8_read_imm<IB + 3 * 2048>(bh[1][0], rB0); g8_read_imm<IB + 3 * 2048>(bh[1][1], rB1);
+      G8_STAMP(0);
+      if (more) {  // rows last read two phases ago (phase A of kt-1)
+        dma_b(CUR ^ 1, 0, sb); dma_b(CUR ^ 1, 1, sb); dma_b(CUR ^ 1, 2, sb); dma_b(CUR ^ 1, 3, sb);
+        dma_a(CUR ^ 1, 0, sa, second); dma_a(CUR ^ 1, 2, sa, second);
+        G8_STAMP(1);
+        WS_VMCNT(6);  // younger: these six -> A_hi(kt) has landed (read in phase B)
+      } else {
+        WS_VMCNT(0);
+      }
+      G8_STAMP(2);
+      __builtin_amdgcn_s_barrier();
+      G8_STAMP(3);
+      WS_LGKM0_16();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      WS_MFMA_QUAD(0, bl, 0);
+      WS_MFMA_QUAD(0, bh, 2);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      G8_STAMP(4);
+      __builtin_amdgcn_s_barrier();
+      G8_STAMP(5);
+      // ---- phase B: A rows 64-127 (into the same registers) x all 64 columns
+      g8_read_imm<IA + 4 * 2048>(af[0][0], rA0); g8_read_imm<IA + 4 * 2048>(af[0][1], rA1);
+      g8_read_imm<IA + 5 * 2048>(af[1][0], rA0); g8_read_imm<IA + 5 * 2048>(af[1][1], rA1);
+      g8_read_imm<IA + 6 * 2048>(af[2][0], rA0); g8_read_imm<IA + 6 * 2048>(af[2][1], rA1);
+      g8_read_imm<IA + 7 * 2048>(af[3][0], rA0); g8_read_imm<IA + 7 * 2048>(af[3][1], rA1);
+      if (more) {  // rows last read two phases ago (phase B of kt-1)
+        dma_a(CUR ^ 1, 1, sa, second); dma_a(CUR ^ 1, 3, sa, second);
+        WS_VMCNT(2);  // younger: these two -> B(kt+1) and A_lo(kt+1) have landed (read in the next phase A)
+      } else {
+        WS_VMCNT(0);
+      }
+      if (CONV) t1 = tap_next(t1);  // the tap after next (scalar state; its per-lane offsets follow under the products)
+      G8_STAMP(6);
+      __builtin_amdgcn_s_barrier();
+      WS_LGKM0_A();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      WS_MFMA_QUAD(4, bh, 2);
+      if (CONV) {
+        // (the empty asm pins the results HERE: hipcc otherwise sinks the selects to their use, in front of the next
+        // K-step's DMA instructions -- the section the other group's products have to cover)
+        conv_va(t1);
+        asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]));
+      }
+      WS_MFMA_QUAD(4, bl, 0);
+      if (CONV) {  // conv_va's instructions one at a time behind the products: they issue in the matrix pipe's shadow
+#pragma unroll
+        for (int g_ = 0; g_ < 20; ++g_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      G8_STAMP(7);
+    };
+    if (CONV) conv_va(t1);  // (the prologue above staged K-step 0 through the generic path; t1 = K-step 1)
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      kstep(std::integral_constant<int, 0>{}, kt);
+      kstep(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    if (kt < nk) kstep(std::integral_constant<int, 0>{}, kt);
+#endif
+  } else
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
     const unsigned bA = ldsA + cur * (BM * 128) + offA, bB = ldsB + cur * (BN * 128) + offB;
     if constexpr (PH == 2) {
       // ---- phase A: A rows 0-63 x all 64 columns of this wavefront (16 fragment reads)
+      G8_STAMP0();
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         WS_DS_READ(bl[j][0], bB + j * 2048 + c0);
@@ -281,15 +457,19 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
         WS_DS_READ(bh[j][0], bB + (2 + j) * 2048 + c0);
         WS_DS_READ(bh[j][1], bB + (2 + j) * 2048 + c1);
       }
+      G8_STAMP(0);
       if (more) {  // rows last read two phases ago (phase A of kt-1)
         stage_B(kt + 1, cur ^ 1, 0, t1); stage_B(kt + 1, cur ^ 1, 1, t1);
         stage_B(kt + 1, cur ^ 1, 2, t1); stage_B(kt + 1, cur ^ 1, 3, t1);
         stage_A(kt + 1, cur ^ 1, 0, t1); stage_A(kt + 1, cur ^ 1, 2, t1);
+        G8_STAMP(1);
         WS_VMCNT(6);  // younger: these six -> A_hi(kt) has landed (read in phase B)
       } else {
         WS_VMCNT(0);
       }
+      G8_STAMP(2);
       __builtin_amdgcn_s_barrier();
+      G8_STAMP(3);
       WS_LGKM0_16();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
@@ -297,7 +477,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       WS_MFMA_QUAD(0, bh, 2);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
+      G8_STAMP(4);
       __builtin_amdgcn_s_barrier();
+      G8_STAMP(5);
       // ---- phase B: A rows 64-127 (into the same registers) x all 64 columns
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -310,6 +492,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       } else {
         WS_VMCNT(0);
       }
+      G8_STAMP(6);
       __builtin_amdgcn_s_barrier();
       WS_LGKM0_A();
       __builtin_amdgcn_sched_barrier(0);
@@ -319,6 +502,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
+      G8_STAMP(7);
       if (CONV) { t1 = tap_next(t1); }
       continue;
     }
@@ -393,6 +577,13 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     if (CONV) { t1 = t2; t2 = tap_next(t2); }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
+#if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  if (p.partial && lane == 0 && p.ksplit <= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(p.partial + wr * 16 + k, (float)st_acc[k]);
+    atomicAdd(p.partial + wr * 16 + 8, (float)nk);
+  }
+#endif
 #undef WS_VMCNT
 
   // ---- epilogue (fp32).  The MFMAs were issued with the operands swapped (B fragment first) and the B rows permuted
@@ -571,9 +762,16 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<false, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_8ph_kernel<true, true, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_nt (8-phase tile): LDS opt-in");
     attr_set = true;
   }
   GemmArgs args = a;
+#if defined(G8_STAMPS)
+  if (const char* dp = getenv("WSOVOD_G8_DEBUG_PTR")) args.partial = (float*)strtoull(dp, nullptr, 16);
+#endif
   args.tiles_m = ceil_div(a.M, 256);
   args.tiles_n = ceil_div(a.N, 256);
   {
@@ -620,7 +818,18 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   }
   wsovod::ProfScope prof(x3 ? (conv ? slot_c3 : slot_g3) : (conv ? slot_c : slot_g), s, flops, bytes);
 #define WS_L8(C, X, P) hipLaunchKernelGGL((gemm256_8ph_kernel<C, X, P>), dim3(grid), dim3(512), lds_bytes, s, args)
-  if (merged) {
+#define WS_L8L(C, X) hipLaunchKernelGGL((gemm256_8ph_kernel<C, X, 2, true>), dim3(grid), dim3(512), lds_bytes, s, args)
+  // the lean two-phase form: whole K-steps only (no K tail select in front of its DMA instructions)
+  const char* le = getenv("WSOVOD_G8_LEAN");
+  const bool lean = merged && a.K % 64 == 0 && !(le && le[0] == '0') &&
+                    (!conv || (a.Cin % 64 == 0 && (!a.A2 || a.Cin2 % 64 == 0) &&
+                               a.a_bytes + (long long)(a.pad * a.W + a.pad) * a.Cin * 2 < (1ll << 31)));
+  if (lean) {
+    if (x3 && conv) WS_L8L(true, true);
+    else if (x3) WS_L8L(false, true);
+    else if (conv) WS_L8L(true, false);
+    else WS_L8L(false, false);
+  } else if (merged) {
     if (x3 && conv) WS_L8(true, true, 2);
     else if (x3) WS_L8(false, true, 2);
     else if (conv) WS_L8(true, false, 2);
@@ -632,6 +841,7 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
     else WS_L8(false, false, 4);
   }
 #undef WS_L8
+#undef WS_L8L
   if (args.ksplit > 1) {
     const long long quads = (long long)a.M * ((a.N + 3) / 4);
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, args);
