@@ -101,7 +101,7 @@ def pmc_traffic(kernel_name, args):
 
     path = None
     prec = args.precision
-    for rnd in ("r04", "r03", "r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
         cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{args.batch}_{prec}.json")
         if os.path.exists(cand):
             path = cand
@@ -114,7 +114,7 @@ def pmc_traffic(kernel_name, args):
     if not m:
         return None, None
     conv, x3 = m.group(1) == "conv_igemm", m.group(2) == "bf16x2"
-    if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled: gemm256_8ph_kernel<CONV, X3, PH>
+    if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled: gemm256_8ph_kernel<CONV, X3, PH, LEAN>
         c, x = ("true" if conv else "false"), ("true" if x3 else "false")
         tags = (f"gemm256_8ph_kernel<{c}, {x},", f"gemm256_8ph_kernel<{c}>") if not x3 else (f"gemm256_8ph_kernel<{c}, {x},",)
     else:

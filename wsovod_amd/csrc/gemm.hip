@@ -2041,12 +2041,15 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   int tile = d->tile_hint ? d->tile_hint : auto_tile(d->M, d->N);
   // plain bf16 contractions take the staggered 8-wavefront form of the 256x256 tile (measured +11-13 % on the FC
   // shapes, tools/gemm_ab.py); the implicit-GEMM conv stays on the 16-wavefront form (tools/conv_ab.py)
-  if (!d->tile_hint && tile == 256256 && d->dtype_in == WSOVOD_BF16 && !d->conv) tile = 8256256;
+  // (round 5: in its lean two-phase form -- 1080 -> 1230, 705 -> 770, 1196 -> 1229 TFLOP/s against the four-phase form on
+  // the dX shapes 16384 x 4096 x 4096 / x 1088 and 16384 x 25088 x 4096, bit-identical; tools/gemm_ab.py)
+  static const int bf16_tile = getenv("WSOVOD_BF16_TILE") ? atoi(getenv("WSOVOD_BF16_TILE")) : 2256256;
+  if (!d->tile_hint && tile == 256256 && d->dtype_in == WSOVOD_BF16 && !d->conv) tile = bf16_tile;
   // few rows, long K (the FC layers at 1-4 images per step): the same tile with split-K instead of a small-tile grid
   // (measured, M = 512: K = 25088 230 -> 143 us; at K = 4096 the workspace round trip costs more than it saves: 40 -> 53 us)
   if (!d->tile_hint && d->dtype_in == WSOVOD_BF16 && !d->conv && d->M >= 256 && d->N >= 256 && d->K >= 8192 &&
       (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
-    tile = 8256256;
+    tile = bf16_tile;
   a.ksplit = d->tile_hint == 0 ? -1 : 0;  // split-K may only change the summation order when the caller named no tile
   // Tile-round tail of the one-workgroup-per-CU 256x256 conv tile: the last, partly filled round of 256 tiles costs a whole
   // tile time (32 images of 75x100, 512 channels: 1876 tiles = 7.33 rounds -> 8).  When the leftover tiles, cut in halves
