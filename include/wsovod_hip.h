@@ -43,7 +43,13 @@ typedef enum {
  * bf16x2 operands are counted in VALUES (4-byte slots), as for fp32.  A contraction over bf16x2 operands evaluates
  * sum_k (ah*bh + ah*bl + al*bh) on the bf16 MFMA pipe with fp32 accumulation: relative error ~2^-16 per product
  * instead of bf16's 2^-8 -- the precision the north star's 1e-3 logit bound needs. */
-typedef enum { WSOVOD_F32 = 0, WSOVOD_BF16 = 1, WSOVOD_BF16X2 = 2 } wsovod_dtype;
+/* WSOVOD_BF16X2P (round 5, "planar" bf16x2): the same (hi, lo) pairs as TWO bf16 matrices of the tensor's shape, all hi
+ * values first, all lo values `numel` elements further -- the 4 bytes per value of WSOVOD_BF16X2 in another order.  It is
+ * an OUTPUT format of the RoI poolers (wsovod_roi_pool_forward_ws / wsovod_roi_align_forward_x2hi, out_dtype) and an
+ * INPUT format of wsovod_gemm_nt's A operand (wsovod_gemm_desc.a_plane_bytes): the pooled tensor feeds the first FC layer's
+ * three-product forward (hi and lo planes) AND its bf16 weight-gradient contraction (the hi plane alone, a plain bf16
+ * matrix), which in the interleaved format needed a second, plain-bf16 copy of every pooled value (822 MB per 32 images). */
+typedef enum { WSOVOD_F32 = 0, WSOVOD_BF16 = 1, WSOVOD_BF16X2 = 2, WSOVOD_BF16X2P = 3 } wsovod_dtype;
 /* Feature-map layout.  NCHW is the reference's layout; NHWC is what the HIP backbone
  * produces (torch.channels_last memory format on the Python side). */
 typedef enum { WSOVOD_NCHW = 0, WSOVOD_NHWC = 1 } wsovod_layout;
@@ -212,6 +218,10 @@ typedef struct {
    * step (box_head.py: the training-step counter) kept in memory, so that a captured HIP graph of the training step draws
    * a new mask at every replay although its kernel arguments are frozen.  NULL = dropout_seed alone. */
   const unsigned long long* dropout_seed_add;
+  /* dtype_in = WSOVOD_BF16X2, plain GEMM only: A is PLANAR bf16x2 (WSOVOD_BF16X2P) -- an (M, lda) bf16 matrix of hi halves at
+   * A and the matrix of lo halves a_plane_bytes further (lda in values = bf16 elements of a plane row).  0 = the interleaved
+   * layout.  Served by the lean two-phase 8-wavefront tile (K a multiple of 32 values; a_plane_bytes + 256 rows < 2 GiB). */
+  long long a_plane_bytes;
 } wsovod_gemm_desc;
 
 int wsovod_gemm_nt(const wsovod_gemm_desc* desc_host, wsovod_stream_t stream);

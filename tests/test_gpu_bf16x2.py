@@ -375,3 +375,67 @@ def test_res3_convs_on_the_512x128_tile_equal_the_256x128_tile(gpu):
                       bias=b.to(gpu), relu=True, residual=res, residual_x2=True, out_dtype=H.X2, tile_hint=t)
             for t in (256128, 512128)]
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 2048), (300, 4096, 25088), (16384, 1024, 1024)])
+def test_planar_bf16x2_operand_equals_the_interleaved_one(gpu, M, N, K):
+    """Round 5: the poolers' training output is PLANAR bf16x2 (all hi values, then all lo values: the hi plane doubles as the
+    plain bf16 operand of fc1's weight gradient).  The lean two-phase tile reads it as the A operand -- 64 bytes of each
+    plane per K-step into the SAME LDS image as the interleaved layout: identical products in identical order, so the
+    result equals the interleaved operand's bit for bit, split-K (M = 300, K = 25088) included."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(13)
+    x = torch.randn(M, K, device=gpu)
+    w = H.x2_encode(torch.randn(N, K, device=gpu) * 0.02)
+    b = torch.randn(N, device=gpu)
+    inter = H.x2_encode(x)
+    hi = x.to(torch.bfloat16)
+    lo = (x - hi.float()).to(torch.bfloat16)
+    planar = torch.cat([hi.reshape(-1), lo.reshape(-1)]).view(torch.float32).view(M, K)
+    assert torch.equal(H.x2_decode(inter), hi.float() + lo.float())  # the same (hi, lo) pairs in the two layouts
+    # (no tile hint on either side: both take the lean two-phase tile, with the same split along K where the grid is small)
+    want = H.gemm_nt(inter, w, x2=True, bias=b, relu=True, out_dtype=H.X2)
+    got = H.gemm_nt(planar, w, x2=True, bias=b, relu=True, out_dtype=H.X2, a_planar=True)
+    assert torch.equal(got, want)
+    if M >= 512 and N >= 512:  # and against the unsplit tile named explicitly: the same values up to the summation order
+        ref = H.x2_decode(H.gemm_nt(inter, w, x2=True, bias=b, relu=True, out_dtype=H.X2, tile_hint=2256256))
+        assert float((H.x2_decode(got) - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    with pytest.raises(RuntimeError, match="planar"):
+        H.gemm_nt(planar, w, x2=True, out_dtype=H.X2, a_planar=True, tile_hint=256256)
+
+
+def test_pooled_planar_output_feeds_fc1_forward_and_weight_gradient(gpu, monkeypatch):
+    """RoIPool / ROIAlign with `want_hi` (training, "parity") write planar bf16x2; fc1's forward and dW on it equal the
+    round-4 form (interleaved bf16x2 + a plain bf16 copy, `X2_PLANAR = False`) bit for bit."""
+    from tests.util import random_rois
+    from wsovod_amd.layers import functions as Fn
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(14)
+    feat = torch.relu(torch.randn(2, 256, 30, 41, device=gpu)).contiguous(memory_format=torch.channels_last)
+    rois = random_rois(512, 2, 240, 328, seed=15).to(gpu)  # (one image's worth of rows: both forms take the same tile)
+    w = (torch.randn(512, 256 * 49, device=gpu) * 0.01).requires_grad_(True)
+    b = torch.zeros(512, device=gpu, requires_grad=True)
+    dy = torch.randn(512, 512, device=gpu)
+    res = {}
+    for planar in (True, False):
+        monkeypatch.setattr(H, "X2_PLANAR", planar)
+        for pooler in ("pool", "align"):
+            Fn._WANT_HI.on = True
+            try:
+                with H.x3_mode("x2"):
+                    pooled = Fn.roi_pool(feat, rois, (7, 7), 0.125, out_dtype=H.X2) if pooler == "pool" else \
+                        Fn.roi_align(feat, rois, (7, 7), 0.125, 0, True, out_dtype=H.X2)
+                    assert H.x2_planar_of(pooled) == planar
+                    y = Fn.linear(torch.flatten(pooled, start_dim=1), w, b, relu=True, out_dtype=H.X2)
+                    gw, gb = torch.autograd.grad(y, [w, b], dy)
+            finally:
+                Fn._WANT_HI.on = False
+            res[(planar, pooler)] = (H.x2_to_f32(pooled).clone(), y.detach().clone(), gw.clone(), gb.clone())
+    for pooler in ("pool", "align"):
+        for name, a, c in zip(("pooled", "y", "dW", "db"), res[(True, pooler)], res[(False, pooler)]):
+            if name == "db":  # (the bias gradient's column sums meet by float atomics: equal to the last bits, run to run)
+                torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-4)
+            else:
+                assert torch.equal(a, c), (pooler, name, float((a.float() - c.float()).abs().max()))

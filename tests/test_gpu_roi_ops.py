@@ -217,8 +217,11 @@ def test_roi_pool_through_the_2x2_max_map_is_bit_identical(gpu, monkeypatch, dty
                                       need_argmax=False, want_hi=out_fmt == "x2hi")
         assert arg is None
         hi = H.x2_hi_pop(out) if out_fmt == "x2hi" else None
+        if out_fmt == "x2hi":  # round 5: the training output is PLANAR bf16x2 -- the bf16 rounding IS its first plane
+            assert H.x2_planar_of(out) and hi.data_ptr() == out.data_ptr() and hi.dtype == torch.bfloat16
+            assert H.x2_planar_of(torch.flatten(out, start_dim=1)) and H.x2_hi_pop(torch.flatten(out, start_dim=1)) is not None
         if od == H.X2:
-            out = H.x2_decode(out.view(len(rois), -1)).view(out.shape)
+            out = H.x2_to_f32(out)
         return out, hi
 
     got, hi = run()

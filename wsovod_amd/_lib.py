@@ -13,7 +13,7 @@ import torch  # must be imported first: the library resolves libamdhip64.so.7 to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwsovod_hip.so")
 
-F32, BF16, BF16X2 = 0, 1, 2  # wsovod_dtype (bf16x2: include/wsovod_hip.h)
+F32, BF16, BF16X2, BF16X2P = 0, 1, 2, 3  # wsovod_dtype (bf16x2 / its planar form: include/wsovod_hip.h)
 NCHW, NHWC = 0, 1
 
 
@@ -42,6 +42,7 @@ class GemmDesc(C.Structure):
         ("tile_hint", C.c_int), ("prof_tag", C.c_int),
         ("A2", C.c_void_p), ("Cin2", C.c_int),
         ("dropout_seed_add", C.c_void_p),
+        ("a_plane_bytes", C.c_longlong),
     ]
 
 
@@ -51,7 +52,7 @@ class ProfEntry(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
-ABI_VERSION = 5  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
+ABI_VERSION = 6  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
 
 # name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
 SIGNATURES = {

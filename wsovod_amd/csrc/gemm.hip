@@ -1887,7 +1887,12 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
   memset(&a, 0, sizeof(a));
   a.A = (const char*)d->A;
   a.B = (const char*)d->B;
-  a.lda = d->lda * xs;
+  const bool planar = d->a_plane_bytes != 0;
+  WS_CHECK_ARG(!planar || (x2 && !d->conv && d->a_plane_bytes > 0 && d->a_plane_bytes % 16 == 0 &&
+                           d->a_plane_bytes + 256ll * d->lda * 2 < (1ll << 31) && d->lda % 8 == 0),
+               "wsovod_gemm_nt: a_plane_bytes needs a bf16x2 plain GEMM, 16-byte aligned planes and planes + 256 rows < 2 GiB");
+  a.a_plane = d->a_plane_bytes;
+  a.lda = planar ? d->lda : d->lda * xs;  // (a plane row holds lda bf16 values; the interleaved row 2 * lda slots)
   a.ldb = d->ldb * xs;
   a.M = d->M;
   a.N = d->N;
@@ -2113,6 +2118,10 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!d->tile_hint && d->conv && getenv("WSOVOD_CONV_SPLITK") && getenv("WSOVOD_CONV_SPLITK")[0] == '1' && d->M >= 256 &&
         d->N >= 256 && d->K >= 2048 && (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
       tile = 2256256;
+    if (planar) {  // the planar A operand exists in the lean two-phase tile (split-K included)
+      WS_CHECK_ARG(!d->tile_hint || d->tile_hint == 2256256, "wsovod_gemm_nt: a planar A operand takes tile 2256256 only");
+      tile = 2256256;
+    }
     return d->conv ? dispatch_tile_x3<true>(a, tile, s, flops, bytes) : dispatch_tile_x3<false>(a, tile, s, flops, bytes);
   }
   if (d->dtype_in == WSOVOD_BF16)

@@ -48,7 +48,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 //  * fragment reads address four per-lane constants; the K-step buffer and the 16-row block are the instruction's
 //    immediate offset (K loop unrolled by two);
 //  * a DMA instruction = a per-lane CONSTANT offset (rows / columns outside the matrix: 2^31, beyond the resource's range)
-//    + a scalar K offset in `soffset` (it takes part in the hardware range check on gfx950: tools/_scratch probe);
+//    + a scalar K offset in `soffset` (it takes part in the hardware range check on gfx950: tools/soffset_probe.hip);
 //  * conv: the per-lane offsets of the NEXT K-step's tap (the pixel offset where the tap lies inside the image, 2^31
 //    where it does not) are computed under the MFMAs of phase B, not in front of the DMA.
 template <int OFF>
@@ -95,9 +95,10 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)p.a_bytes, 0x00020000);
     rsrcA2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0), 0x00020000);
   } else {
+    // (planar bf16x2 A: the resource spans the tile's rows in the hi plane up to the same rows in the lo plane)
     const long long rows = min(BM, p.M - m0);
-    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * esz), 0, (int)(rows * p.lda * esz),
-                                              0x00020000);
+    rsrcA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (long long)m0 * p.lda * esz), 0,
+                                              (int)(p.a_plane + rows * p.lda * esz), 0x00020000);
   }
   {
     const long long rows = min(BN, p.N - n0);
@@ -121,7 +122,11 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       pix2_off[i] = ok ? (((img * p.Ho + ho) * p.Wo + wo) * p.Cin2 + lchunk * EPC) * esz : -1;
     } else {
       hi0[i] = wi0[i] = 0;
-      a_off[i] = ok ? (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz) : -1;
+      // planar bf16x2 A (LEAN, X3): chunks 0-3 of a K-step's 128 bytes are 64 bytes of the hi plane's row, chunks 4-7 the
+      // same 64 bytes of the lo plane's row
+      a_off[i] = !ok ? -1
+                 : p.a_plane ? (int)((long long)(lrow + LR * i) * p.lda * esz + (lchunk & 3) * 16 + (lchunk >> 2) * p.a_plane)
+                             : (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz);
     }
     // B pass i = the 64 columns of the wavefronts with wc == i; LDS row (tile j = lrow >> 4, tile row f = lrow & 15) is
     // fed from B row 16*(f>>2) + 4*j + (f&3), so that after the MFMAs a lane owns 16 CONSECUTIVE output columns
@@ -182,7 +187,8 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     } else {
       const bool k_ok = kbase + lchunk * EPC < p.K;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16,
-                                               (k_ok && a_off[i] >= 0) ? a_off[i] + kbase * esz : -1, 0, 0, 0);
+                                               (k_ok && a_off[i] >= 0) ? a_off[i] + ((kbase * esz) >> (p.a_plane ? 1 : 0)) : -1,
+                                               0, 0, 0);
     }
 #endif
   };
@@ -329,7 +335,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     };
     // scalar byte offsets of a K-step: into the A operand (conv: the tap's displacement + channel chunk) and the B rows
     auto soff_a = [&](int kt, const Tap t) -> int {
-      if (!CONV) return (kt + kt_base) * (BKE * esz);
+      if (!CONV) return ((kt + kt_base) * (BKE * esz)) >> (p.a_plane ? 1 : 0);  // planar A: 64 bytes of each plane per K-step
       if (t.c0 >= p.Cin) return (t.c0 - p.Cin) * esz;
       return (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;
     };
@@ -824,6 +830,11 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   const bool lean = merged && a.K % 64 == 0 && !(le && le[0] == '0') &&
                     (!conv || (a.Cin % 64 == 0 && (!a.A2 || a.Cin2 % 64 == 0) &&
                                a.a_bytes + (long long)(a.pad * a.W + a.pad) * a.Cin * 2 < (1ll << 31)));
+  if (a.a_plane && !(lean && x3 && !conv)) {
+    wsovod::set_error("wsovod_gemm_nt: a planar bf16x2 A operand is served by the lean two-phase tile only (plain GEMM, "
+                      "K a multiple of 32 values)");
+    return WSOVOD_ERR_UNSUPPORTED;
+  }
   if (lean) {
     if (x3 && conv) WS_L8L(true, true);
     else if (x3) WS_L8L(false, true);

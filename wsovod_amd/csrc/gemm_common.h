@@ -43,6 +43,7 @@ struct GemmArgs {
   float* partial;
   long long partial_ld;
   long long a_bytes;  // conv: byte size of the NHWC input (must be < 2^31)
+  long long a_plane;  // plain GEMM on a PLANAR bf16x2 A (WSOVOD_BF16X2P): bytes from the hi plane to the lo plane, 0 = interleaved
   int tiles_m, tiles_n;
   int m_base;  // gemm_nt_kernel: first output row of this launch (a launch may cover rows [m_base, M) only: tail launches)
   int group_m;  // tile-order group height (see the XCD remap in the kernel)

@@ -361,10 +361,13 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
     else
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
-  } else if (out_dtype == WSOVOD_BF16X2) {
+  } else if (out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P) {
     // bf16x2 (include/wsovod_hip.h): the run [obase, obase + nvalid) covers whole 32-value groups (launcher); 8 values per
-    // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form
+    // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form.  PLANAR (round 5): hi to the
+    // first bf16 matrix of the output, lo to the second (`out_hi` = its base, set by the launcher): the hi plane is at once
+    // the plain bf16 operand of the first FC layer's weight gradient -- no third store per value
     bf16_t* o = (bf16_t*)out;
+    const bool planar = out_dtype == WSOVOD_BF16X2P;
     for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
       const f32x4 q0 = *(const f32x4*)(sval + i), q1 = *(const f32x4*)(sval + i + 4);
       bf16x8 hi, lo;
@@ -377,6 +380,11 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
         lo[4 + e] = (bf16_t)(__builtin_isinf(h1) ? 0.f : q1[e] - h1);
       }
       const long long k = obase + i;
+      if (planar) {
+        __builtin_nontemporal_store(hi, (bf16x8*)(o + k));
+        __builtin_nontemporal_store(lo, (bf16x8*)((bf16_t*)out_hi + k));
+        continue;
+      }
       bf16_t* d = o + ((k >> 5) << 6) + (k & 31);
       __builtin_nontemporal_store(hi, (bf16x8*)d);
       __builtin_nontemporal_store(lo, (bf16x8*)(d + 32));
@@ -990,10 +998,13 @@ __global__ __launch_bounds__(512, WPE) void roi_align_fwd_nhwc_rows(const T* __r
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
     else
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
-  } else if (out_dtype == WSOVOD_BF16X2) {
+  } else if (out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P) {
     // bf16x2 (include/wsovod_hip.h): the run [obase, obase + nvalid) covers whole 32-value groups (launcher); 8 values per
-    // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form
+    // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form.  PLANAR (round 5): hi to the
+    // first bf16 matrix of the output, lo to the second (`out_hi` = its base, set by the launcher): the hi plane is at once
+    // the plain bf16 operand of the first FC layer's weight gradient -- no third store per value
     bf16_t* o = (bf16_t*)out;
+    const bool planar = out_dtype == WSOVOD_BF16X2P;
     for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
       const f32x4 q0 = *(const f32x4*)(sval + i), q1 = *(const f32x4*)(sval + i + 4);
       bf16x8 hi, lo;
@@ -1006,6 +1017,11 @@ __global__ __launch_bounds__(512, WPE) void roi_align_fwd_nhwc_rows(const T* __r
         lo[4 + e] = (bf16_t)(__builtin_isinf(h1) ? 0.f : q1[e] - h1);
       }
       const long long k = obase + i;
+      if (planar) {
+        __builtin_nontemporal_store(hi, (bf16x8*)(o + k));
+        __builtin_nontemporal_store(lo, (bf16x8*)((bf16_t*)out_hi + k));
+        continue;
+      }
       bf16_t* d = o + ((k >> 5) << 6) + (k & 31);
       __builtin_nontemporal_store(hi, (bf16x8*)d);
       __builtin_nontemporal_store(lo, (bf16x8*)(d + 32));
@@ -1184,11 +1200,16 @@ int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const fl
   WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
                "wsovod_roi_pool_forward_x2hi: the bf16 copy goes with a bf16x2 output");
   if (rc) return rc;
-  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2,
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P,
                "wsovod_roi_pool_forward: bad out_dtype");
+  const bool planar_out = out_dtype == WSOVOD_BF16X2P;  // same constraints as the interleaved form; lo plane behind the hi plane
+  if (planar_out) {
+    WS_CHECK_ARG(((long long)R * C * ph * pw) % 8 == 0, "wsovod_roi_pool_forward: planar bf16x2 output needs 16-byte aligned planes");
+    out_hi = (char*)out + (long long)R * C * ph * pw * 2;
+  }
   // bf16x2 output: the wavefront-per-pooled-row kernel only (NHWC, 7 bins wide), whole 128-channel groups, so that every
   // workgroup's run of outputs is whole 32-value groups
-  WS_CHECK_ARG(out_dtype != WSOVOD_BF16X2 || (layout == WSOVOD_NHWC && pw == 7 && ph <= 16 && C % 256 == 0 &&
+  WS_CHECK_ARG((out_dtype != WSOVOD_BF16X2 && !planar_out) || (layout == WSOVOD_NHWC && pw == 7 && ph <= 16 && C % 256 == 0 &&
                                               (C * ph * pw) % 32 == 0 && ((uintptr_t)feat & 7) == 0 && ((uintptr_t)out & 15) == 0),
                "wsovod_roi_pool_forward: bf16x2 output needs NHWC, pw = 7, C a multiple of 256");
   if (R == 0) return WSOVOD_OK;
@@ -1394,9 +1415,14 @@ int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const
   WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
                "wsovod_roi_align_forward_x2hi: the bf16 copy goes with a bf16x2 output");
   if (rc) return rc;
-  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2,
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P,
                "wsovod_roi_align_forward: bad out_dtype");
-  WS_CHECK_ARG(out_dtype != WSOVOD_BF16X2 || (layout == WSOVOD_NHWC && pw == 7 && ph >= 7 && ph <= 8 && C % 256 == 0 &&
+  const bool planar_out = out_dtype == WSOVOD_BF16X2P;
+  if (planar_out) {
+    WS_CHECK_ARG(((long long)R * C * ph * pw) % 8 == 0, "wsovod_roi_align_forward: planar bf16x2 output needs 16-byte aligned planes");
+    out_hi = (char*)out + (long long)R * C * ph * pw * 2;
+  }
+  WS_CHECK_ARG((out_dtype != WSOVOD_BF16X2 && !planar_out) || (layout == WSOVOD_NHWC && pw == 7 && ph >= 7 && ph <= 8 && C % 256 == 0 &&
                                               (C * ph * pw) % 32 == 0 && ((uintptr_t)feat & 7) == 0 && ((uintptr_t)out & 15) == 0),
                "wsovod_roi_align_forward: bf16x2 output needs NHWC, 7x7 / 8x7 bins, C a multiple of 256");
   if (R == 0) return WSOVOD_OK;

@@ -72,7 +72,7 @@ class _Linear(Function):
         x_hi = None
         if ctx.x2:
             y = H.gemm_nt(x, H.x2_cached(weight), x2=True, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
-                          dropout_seed_add=seed_add, out_dtype=out_dtype)
+                          dropout_seed_add=seed_add, out_dtype=out_dtype, a_planar=H.x2_planar_of(x))
             x_hi = H.x2_hi_pop(x)  # the pooler's plain bf16 copy of x, if it wrote one: the operand of dW
         else:
             wq = weight_shadow(weight, x.dtype)

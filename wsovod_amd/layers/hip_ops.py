@@ -10,7 +10,7 @@ import threading
 import torch
 
 from .. import _lib
-from .._lib import BF16, BF16X2, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
+from .._lib import BF16, BF16X2, BF16X2P, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
 
 
 _CONST_CACHE = {}
@@ -209,6 +209,36 @@ def _x2_hi_alloc(out):
     return hi
 
 
+def _x2_planar_tag(out):
+    """`out` (an fp32-typed carrier) was written as PLANAR bf16x2 (include/wsovod_hip.h: WSOVOD_BF16X2P): its first half is
+    the bf16 matrix of hi values -- attached as the tensor's plain bf16 rounding (`x2_hi_of`), no copy -- its second half
+    the lo values.  The first FC layer's forward reads both planes, its weight gradient the hi plane."""
+    n = out.numel()
+    out._x2_hi = out.view(-1).view(torch.bfloat16)[:n].view(out.shape)
+    out._x2_planar = True
+    return out
+
+
+def x2_planar_of(x):
+    """True when `x` (or the tensor it is a whole view of) is a planar bf16x2 carrier."""
+    if getattr(x, "_x2_planar", False):
+        return True
+    b = getattr(x, "_base", None)
+    return bool(b is not None and b.data_ptr() == x.data_ptr() and b.numel() == x.numel() and getattr(b, "_x2_planar", False))
+
+
+def x2_to_f32(x):
+    """fp32 values of a bf16x2 tensor in either layout (tests, debugging)."""
+    if x2_planar_of(x):
+        n = x.numel()
+        flat = x.reshape(-1).view(torch.bfloat16)
+        return (flat[:n].float() + flat[n:].float()).view(x.shape)
+    return x2_decode(x.reshape(x.shape[0], -1)).view(x.shape)  # (groups of 32 run along the flattened row)
+
+
+# round 5: with `want_hi` (training, "parity") the poolers write PLANAR bf16x2 instead of the interleaved layout plus a plain
+# bf16 copy (WSOVOD_X2_PLANAR=0: the round-4 form, for A/B runs)
+X2_PLANAR = os.environ.get("WSOVOD_X2_PLANAR", "1") != "0"
 POISON_OUTPUTS = os.environ.get("WSOVOD_POISON_OUTPUTS", "0") == "1"
 POISON_BYTE = 0x7F
 
@@ -237,15 +267,18 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     argmax = _out_empty((R, Cc, ph, pw), torch.int32, feat.device) if need_argmax else None
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
-    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
+    planar = bool(want_hi and out_dtype == X2 and R > 0 and X2_PLANAR and (R * Cc * ph * pw) % 8 == 0)
+    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0 and not planar) else None
     # scratch for the map's 2x2 maxima (0 bytes: this shape keeps the cell scan; include/wsovod_hip.h)
     ws_bytes = int(lib().wsovod_roi_pool_workspace_bytes(dtype_code(feat.dtype), layout, R, N, Cc, H, W, ph, pw,
                                                          int(need_argmax))) if R > 0 else 0
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=feat.device) if ws_bytes > 0 else None
     check(lib().wsovod_roi_pool_forward_ws(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), ptr(out), fmt_code(out_dtype), ptr(argmax), ptr(hi), ptr(ws), ws_bytes, stream()),
-        "roi_pool_forward")
+        C.c_float(spatial_scale), ptr(out), BF16X2P if planar else fmt_code(out_dtype), ptr(argmax), ptr(hi), ptr(ws), ws_bytes,
+        stream()), "roi_pool_forward")
+    if planar:
+        _x2_planar_tag(out)
     return out, argmax
 
 
@@ -295,11 +328,14 @@ def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, al
     out = _out_empty((R, Cc, ph, pw), storage_dtype(out_dtype), feat.device)
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
-    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0) else None
+    planar = bool(want_hi and out_dtype == X2 and R > 0 and X2_PLANAR and (R * Cc * ph * pw) % 8 == 0)
+    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0 and not planar) else None
     check(lib().wsovod_roi_align_forward_x2hi(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out), fmt_code(out_dtype), ptr(hi),
-        stream()), "roi_align_forward")
+        C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out),
+        BF16X2P if planar else fmt_code(out_dtype), ptr(hi), stream()), "roi_align_forward")
+    if planar:
+        _x2_planar_tag(out)
     return out
 
 
@@ -486,8 +522,9 @@ def _ld(t):
 def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=None, bias=None, residual=None,
             relu=False, dropout_p=0.0, dropout_seed=0, row_group=None, group_add=None, mask_src=None,
             mask_scale=1.0, accumulate=False, M=None, N=None, K=None, conv=None, tile_hint=0, want_c=True, A2=None,
-            x2=False, residual_x2=False, dropout_seed_add=None):
+            x2=False, residual_x2=False, dropout_seed_add=None, a_planar=False):
     """C[M][N] = epilogue(sum_k A[m][k]*B[n][k]); see include/wsovod_hip.h for the epilogue order.
+    a_planar (x2 only, plain GEMM): A is a PLANAR bf16x2 carrier (the poolers' training output: hi matrix, then lo matrix).
 
     A: (M,K) or, with `conv` (a dict of geometry), the NHWC input tensor.  B: (N,K).
     x2: A, B (and A2) are bf16x2 tensors (fp32-typed carriers, see above): three-MFMA products.  out_dtype = X2 asks
@@ -531,6 +568,10 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
     else:
         d.M = A.size(0) if M is None else M
         d.A, d.lda = A.data_ptr(), _ld(A)
+        if a_planar:
+            if not x2 or not A.is_contiguous() or M is not None:
+                raise RuntimeError("wsovod_hip gemm: a planar bf16x2 A is a whole contiguous bf16x2 carrier")
+            d.a_plane_bytes = A.numel() * 2
     if want_c:
         if out is None:
             rows = d.M if not (conv is not None and d.geom.pool) else d.geom.n_img * (d.geom.Ho // 2) * (d.geom.Wo // 2)
