@@ -209,6 +209,13 @@ def _x2_hi_alloc(out):
     return hi
 
 
+def _x2_planar_ok(R, row_values):
+    """The planar form is addressed through one buffer resource per 256-row tile: hi plane + 256 rows must stay below 2 GiB
+    (R18: ~83 images x 512 proposals per step; R50 / 1024 proposals: 10 images).  Larger steps keep the interleaved layout +
+    the plain bf16 copy (round 4's form)."""
+    return X2_PLANAR and (R * row_values) % 8 == 0 and (R + 256) * row_values * 2 < (1 << 31)
+
+
 def _x2_planar_tag(out):
     """`out` (an fp32-typed carrier) was written as PLANAR bf16x2 (include/wsovod_hip.h: WSOVOD_BF16X2P): its first half is
     the bf16 matrix of hi values -- attached as the tensor's plain bf16 rounding (`x2_hi_of`), no copy -- its second half
@@ -267,7 +274,7 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     argmax = _out_empty((R, Cc, ph, pw), torch.int32, feat.device) if need_argmax else None
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
-    planar = bool(want_hi and out_dtype == X2 and R > 0 and X2_PLANAR and (R * Cc * ph * pw) % 8 == 0)
+    planar = bool(want_hi and out_dtype == X2 and R > 0 and _x2_planar_ok(R, Cc * ph * pw))
     hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0 and not planar) else None
     # scratch for the map's 2x2 maxima (0 bytes: this shape keeps the cell scan; include/wsovod_hip.h)
     ws_bytes = int(lib().wsovod_roi_pool_workspace_bytes(dtype_code(feat.dtype), layout, R, N, Cc, H, W, ph, pw,
@@ -328,7 +335,7 @@ def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, al
     out = _out_empty((R, Cc, ph, pw), storage_dtype(out_dtype), feat.device)
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
-    planar = bool(want_hi and out_dtype == X2 and R > 0 and X2_PLANAR and (R * Cc * ph * pw) % 8 == 0)
+    planar = bool(want_hi and out_dtype == X2 and R > 0 and _x2_planar_ok(R, Cc * ph * pw))
     hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0 and not planar) else None
     check(lib().wsovod_roi_align_forward_x2hi(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
