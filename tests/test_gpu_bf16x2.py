@@ -433,6 +433,7 @@ def test_pooled_planar_output_feeds_fc1_forward_and_weight_gradient(gpu, monkeyp
             finally:
                 Fn._WANT_HI.on = False
             res[(planar, pooler)] = (H.x2_to_f32(pooled).clone(), y.detach().clone(), gw.clone(), gb.clone())
+    monkeypatch.setattr(H, "X2_PLANAR", True)
     assert H._x2_planar_ok(32 * 512, 25088) and H._x2_planar_ok(8 * 1024, 100352)      # the bench's step, config 3 / 5 shapes
     assert not H._x2_planar_ok(96 * 512, 25088) and not H._x2_planar_ok(16 * 1024, 100352)  # beyond one resource: round-4 form
     for pooler in ("pool", "align"):

@@ -34,12 +34,12 @@ def bench(fns, rounds=6, inner=3):
     return {k: sorted(v)[len(v) // 2] for k, v in times.items()}
 
 
-def conv_case(name, Hh, Ww, Cin, Cout, k, dil, tiles, residual=False):
+def conv_case(name, Hh, Ww, Cin, Cout, k, dil, tiles, residual=False, pool=0):
     x = H.x2_encode(torch.randn(n * Hh * Ww, Cin, device=dev)).view(n, Hh, Ww, Cin)
     w = H.x2_encode(torch.randn(Cout, k * k * Cin, device=dev) * 0.05)
     b = torch.randn(Cout, device=dev)
     pad = dil * (k // 2)
-    geom = dict(n_img=n, H=Hh, W=Ww, Cin=Cin, Ho=Hh, Wo=Ww, KH=k, KW=k, stride=1, pad=pad, dil=dil)
+    geom = dict(n_img=n, H=Hh, W=Ww, Cin=Cin, Ho=Hh, Wo=Ww, KH=k, KW=k, stride=1, pad=pad, dil=dil, pool=pool)
     res = H.x2_encode(torch.randn(n * Hh * Ww, Cout, device=dev)) if residual else None
     fns = {}
     for t in tiles:
@@ -63,6 +63,10 @@ def gemm_case(name, M, N, K, tiles):
 if __name__ == "__main__":
     conv_case("stem 64->64 300x400 (c64 halo vs generic)", 300, 400, 64, 64, 3, 1, [0, 1256064])
     conv_case("res2 64->64 150x200", 150, 200, 64, 64, 3, 1, [0, 1256064], residual=True)
+    if os.environ.get("X2_PROBE_C64_ONLY"):  # (WSOVOD_C64X_LEPI=0 / 1 in two processes: the switch is read once)
+        conv_case("stem 64->64 300x400 + 2x2 max pool", 300, 400, 64, 64, 3, 1, [0], pool=2)
+        conv_case("res2 64->64 150x200, no residual", 150, 200, 64, 64, 3, 1, [0])
+        sys.exit(0)
     conv_case("res3 128->128 75x100", 75, 100, 128, 128, 3, 1, [0, 256128, 256256, 8256256])
     conv_case("res4 256->256 d2", 75, 100, 256, 256, 3, 2, [256256, 8256256, 2256256, 256128])
     conv_case("res5 512->512 d2", 75, 100, 512, 512, 3, 2, [256256, 8256256, 2256256])

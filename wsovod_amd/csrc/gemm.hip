@@ -1293,7 +1293,8 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
 // Epilogue of the bf16x2 64-channel kernels: bias + (bf16x2) residual + ReLU (+ 2x2 / stride-2 max pool), bf16x2 stores.
 template <int XG, int NI>
 __device__ __forceinline__ void c64x_epilogue(const GemmArgs& p, const f32x4 (&acc)[NI][4], const f32x4 (&bias4)[4], const int img,
-                                              const int y0, const int x0, const int wave, const int frow, const int fq) {
+                                              const int y0, const int x0, const int wave, const int frow, const int fq,
+                                              char* sE = nullptr) {
   // ---- epilogue: lane (frow, fq) holds, for pixel group i, channels 16 fq + 4 j + r of pixel frow: slots
   // 64 (fq >> 1) + 16 (fq & 1) (hi) and 32 further (lo) of the pixel's 128
   const float lo_clip = p.relu ? 0.f : -__builtin_inff();
@@ -1319,6 +1320,36 @@ __device__ __forceinline__ void c64x_epilogue(const GemmArgs& p, const f32x4 (&a
     *(bf16x8*)(q + 8) = h1;
     *(bf16x8*)(q + 32) = l0;
     *(bf16x8*)(q + 40) = l1;
+  };
+  // Through LDS (sE = 4 KiB private to the wavefront; round 5): a lane's four 16-byte pieces of a pixel lie 256 B from its
+  // neighbour lane's, so a direct store instruction is 64 separate 16-byte write requests.  The pieces are parked as
+  // [pixel][16 chunks] (chunk ^= pixel: conflict-free both ways) and leave as whole pixels, 1 KiB contiguous per instruction.
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  auto park16 = [&](const int prow, const float (&v)[16]) {
+    bf16x8 h0, h1, l0, l1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      h0[e] = (bf16_t)v[e];
+      h1[e] = (bf16_t)v[8 + e];
+      l0[e] = x2_lo(v[e], h0[e]);
+      l1[e] = x2_lo(v[8 + e], h1[e]);
+    }
+    const int c0 = 8 * (fq >> 1) + 2 * (fq & 1);
+    char* row = sE + prow * 256;
+    *(bf16x8*)(row + ((c0 ^ prow) << 4)) = h0;
+    *(bf16x8*)(row + (((c0 + 1) ^ prow) << 4)) = h1;
+    *(bf16x8*)(row + (((c0 + 4) ^ prow) << 4)) = l0;
+    *(bf16x8*)(row + (((c0 + 5) ^ prow) << 4)) = l1;
+  };
+  auto flush = [&](const int npix, char* gbase, const long long pix_bytes, const int nvalid) {  // gbase: pixel 0 of the group
+    const int lp = (fq * 16 + frow) >> 4, c = frow;  // lane = 16 fq + frow -> (pixel within a pass of 4, chunk)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (4 * k >= npix) break;
+      const int P = 4 * k + lp;
+      const u32x4 d = *(const u32x4*)(sE + P * 256 + ((c ^ P) << 4));
+      if (P < nvalid) *(u32x4*)(gbase + P * pix_bytes + c * 16) = d;
+    }
   };
   if (p.pool) {  // MaxPool2d(2, 2): the wavefront's two image rows are one pooled row, the horizontal partner is lane frow ^ 1
     const int Hp = p.H >> 1, Wp = p.W >> 1;
@@ -1349,6 +1380,13 @@ __device__ __forceinline__ void c64x_epilogue(const GemmArgs& p, const f32x4 (&a
 #pragma unroll
       for (int e = 0; e < 16; ++e) best[e] = fmaxf(best[e], __shfl_xor(best[e], 1));
       const int py = (y0 >> 1) + wave, px = (x0 + ih * 16 + frow) >> 1;
+      if (sE) {
+        if ((frow & 1) == 0) park16(frow >> 1, best);
+        const int px0 = (x0 + ih * 16) >> 1;
+        if (py < Hp && px0 < Wp)
+          flush(8, (char*)((bf16_t*)p.C + 2 * (((long long)img * Hp + py) * Wp + px0) * p.ldc), 4ll * p.ldc, Wp - px0);
+        continue;
+      }
       if ((frow & 1) == 0 && py < Hp && px < Wp)
         store16((bf16_t*)p.C + 2 * (((long long)img * Hp + py) * Wp + px) * p.ldc + slot, best);
     }
@@ -1358,6 +1396,27 @@ __device__ __forceinline__ void c64x_epilogue(const GemmArgs& p, const f32x4 (&a
   for (int i = 0; i < NI; ++i) {
     const int y = y0 + wave * 2 + (i / XG);
     const int x = x0 + (i % XG) * 16 + frow;
+    if (sE) {
+      const int xg = x0 + (i % XG) * 16;
+      if (y >= p.H || xg >= p.W) continue;  // (wave-uniform)
+      const long long mc = ((long long)img * p.H + y) * p.W + min(x, p.W - 1);  // clamped: parked, never flushed
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[4 * j + r] = acc[i][j][r] * p.alpha + bias4[j][r];
+      if (p.residual) {
+        float rv[16];
+        load16((const bf16_t*)p.residual + 2 * mc * p.ldr + slot, rv);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] += rv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], lo_clip);
+      park16(frow, v);
+      flush(16, (char*)((bf16_t*)p.C + 2 * (((long long)img * p.H + y) * p.W + xg) * p.ldc), 4ll * p.ldc, p.W - xg);
+      continue;
+    }
     if (y >= p.H || x >= p.W) continue;
     const long long m = ((long long)img * p.H + y) * p.W + x;
     float v[16];
@@ -1522,6 +1581,7 @@ struct C64XH {
   static constexpr int LDS_BYTES = PATCH_BYTES + 2 * W_BYTES;
 };
 
+template <bool LEPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3h_kernel(const GemmArgs p, int tiles_x, int tiles_y) {
   using G = C64XH;
   constexpr int XG = G::XG, NI = G::NI, PW = G::PW;
@@ -1698,7 +1758,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_x3h_kernel(const GemmArgs 
   trip(16, std::integral_constant<int, 2>{});
   f32x4 bias4[4];  // (loaded here: 16 registers the loop's two fragment sets leave no room for)
   c64_load_bias(p, fq, bias4);
-  c64x_epilogue<XG, NI>(p, acc, bias4, img, y0, x0, wave, frow, fq);
+  // (the patch is dead: every fragment of step 17 was read in front of trip 16's first barrier)
+  c64x_epilogue<XG, NI>(p, acc, bias4, img, y0, x0, wave, frow, fq, LEPI ? sP + wave_u * 4096 : nullptr);
 #if C64XH_PHASES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   C64XH_MARK(5);
@@ -2021,7 +2082,8 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!attr) {
       WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<16>::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
       WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, C64X<32>::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
-      WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, C64XH::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, C64XH::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
+      WS_CHECK_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_x3h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, C64XH::LDS_BYTES), "wsovod_gemm_nt: LDS opt-in");
       attr = true;
     }
     const char* tw = getenv("WSOVOD_C64X_TW");  // "16" / "32": the whole-K forms (A/B runs); default: the half-K 8 x 32 tile
@@ -2032,8 +2094,12 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (const char* dp = getenv("WSOVOD_C64_DEBUG_PTR")) a.partial = (float*)strtoull(dp, nullptr, 16);
 #endif
     wsovod::ProfScope prof(slot, s, flops, bytes);
-    if (halfk)
-      hipLaunchKernelGGL(conv3x3_c64_x3h_kernel, dim3(n_tiles), dim3(256), C64XH::LDS_BYTES, s, a, tiles_x, tiles_y);
+    // epilogue through LDS (whole-pixel stores): output rows of exactly one pixel's 256 B ("0": direct stores; A/B runs)
+    static const bool lepi_on = !(getenv("WSOVOD_C64X_LEPI") && getenv("WSOVOD_C64X_LEPI")[0] == '0');
+    if (halfk && lepi_on && ((uintptr_t)d->C & 15) == 0 && d->ldc % 4 == 0)
+      hipLaunchKernelGGL(conv3x3_c64_x3h_kernel<true>, dim3(n_tiles), dim3(256), C64XH::LDS_BYTES, s, a, tiles_x, tiles_y);
+    else if (halfk)
+      hipLaunchKernelGGL(conv3x3_c64_x3h_kernel<false>, dim3(n_tiles), dim3(256), C64XH::LDS_BYTES, s, a, tiles_x, tiles_y);
     else if (wide)
       hipLaunchKernelGGL(conv3x3_c64_x3_kernel<32>, dim3(n_tiles), dim3(256), C64X<32>::LDS_BYTES, s, a, tiles_x, tiles_y);
     else
