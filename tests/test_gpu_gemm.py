@@ -590,3 +590,37 @@ def test_conv_tile_round_tail_launch_is_bit_identical(gpu, mode, monkeypatch):
     narrow = run(256128)
     assert torch.equal(narrow.view(torch.int16) if narrow.dtype != torch.float32 else narrow.view(torch.int32),
                        split.view(torch.int16) if split.dtype != torch.float32 else split.view(torch.int32))
+
+
+@pytest.mark.parametrize("shortcut", [False, True])
+def test_conv_tile_round_tail_as_split_k_slices(gpu, shortcut, monkeypatch):
+    """Round 5: a tile-round tail of few tiles and a long K (res5 at 32 images: 84 tiles of 72 K-steps) runs as split-K slices
+    of the lean 8-wavefront tile + the finalize pass (gemm8.hip: `m_base`, workspace rows counted from it).  The rows of the
+    full rounds keep their bits; the tail rows equal the unsplit form up to the summation order; residual / fused-shortcut
+    rows are addressed absolutely."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(9)
+    n, Hh, Ww, Cin, Cout = 5, 75, 100, 256, 512  # 147 x 2 tiles = 1 full round + 38 tiles; K = 2304 (+ 64): two slices
+    x = torch.randn(n * Hh * Ww, Cin, device=gpu) * 0.5
+    w = torch.randn(Cout, 9 * Cin, device=gpu) * 0.03
+    b = torch.randn(Cout, device=gpu)
+    geom = dict(n_img=n, H=Hh, W=Ww, Cin=Cin, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=2, dil=2)
+    kw = dict(x2=True, out_dtype=H.X2, bias=b, relu=True)
+    if shortcut:
+        x2in = torch.randn(n * Hh * Ww, 64, device=gpu)
+        w = torch.cat([w, torch.randn(Cout, 64, device=gpu) * 0.05], 1)
+        kw["A2"] = H.x2_encode(x2in).view(n, Hh, Ww, 64)
+    else:
+        kw.update(residual=H.x2_encode(torch.randn(n * Hh * Ww, Cout, device=gpu)), residual_x2=True)
+    xa, wa = H.x2_encode(x).view(n, Hh, Ww, Cin), H.x2_encode(w)
+    monkeypatch.setenv("WSOVOD_CONV_TAIL_SPLITK", "0")
+    plain = H.x2_decode(H.gemm_nt(xa, wa, conv=geom, **kw))
+    monkeypatch.delenv("WSOVOD_CONV_TAIL_SPLITK")
+    split = H.x2_decode(H.gemm_nt(xa, wa, conv=geom, **kw))
+    torch.cuda.synchronize()
+    main_rows = 128 * 256
+    assert torch.equal(plain[:main_rows], split[:main_rows])
+    assert not torch.equal(plain[main_rows:], split[main_rows:])  # (the tail did take the split form)
+    scale = float(plain.abs().max())
+    assert float((plain[main_rows:] - split[main_rows:]).abs().max()) < 1e-5 * scale

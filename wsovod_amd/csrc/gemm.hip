@@ -2145,6 +2145,13 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
       int rc = x2 ? dispatch_tile_x3<true>(am, conv8 ? 2256256 : 256256, s, flops * fmain, bytes * fmain)
                   : dispatch_tile<bf16_t, true>(am, 256256, s, flops * fmain, bytes * fmain);
       if (rc != WSOVOD_OK) return rc;
+      // round 5: a tail of few tiles and a long K (res5: 84 tiles, 72 K-steps) as split-K slices of the lean 8-wavefront
+      // tile (3 x 84 workgroups of 24 K-steps + the finalize pass) instead of 168 half-width tiles of 72
+      // (WSOVOD_CONV_TAIL_SPLITK=0: A/B runs; changes the summation order of the tail rows only)
+      const bool tail_split = !(getenv("WSOVOD_CONV_TAIL_SPLITK") && getenv("WSOVOD_CONV_TAIL_SPLITK")[0] == '0');
+      const int tail_t = ceil_div((int)tail_rows, 256) * tn, nk64 = ceil_div(d->K, 64);
+      if (x2 && conv8 && tail_split && tail_t <= 128 && nk64 >= 32 && std::min(std::min(8, 256 / tail_t), nk64 / 16) >= 2)
+        return dispatch_tile_x3<true>(at, 2256256, s, flops * (1.0 - fmain), bytes * (1.0 - fmain));
       return x2 ? dispatch_tile_x3<true>(at, 256128, s, flops * (1.0 - fmain), bytes * (1.0 - fmain))
                 : dispatch_tile<bf16_t, true>(at, 256128, s, flops * (1.0 - fmain), bytes * (1.0 - fmain));
     }

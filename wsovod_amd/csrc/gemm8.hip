@@ -81,7 +81,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const int in_group = wg - group_id * group_size;
   const int tile_m = first_m + in_group % gm;
   const int tile_n = in_group / gm;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;  // (m_base: a launch may cover rows [m_base, M) only)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   // per output row a wavefront writes 64 contiguous elements as 16-byte stores.
   // Tile indices are compile-time constants (a runtime index into acc would put the accumulators in scratch).
   if (p.ksplit > 1) {  // split-K: raw partial sums of this K slice; the epilogue runs in splitk_finalize_kernel
-    float* part = p.partial + (long long)kslice * p.M * p.partial_ld;
+    float* part = p.partial + ((long long)kslice * (p.M - p.m_base) - p.m_base) * p.partial_ld;  // rows from m_base
     const int ncol0 = n0 + wc * 64 + 16 * fq;
 #define WS_PART_ROW(I)                                                                                     \
     {                                                                                                        \
@@ -732,11 +732,12 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 __global__ __launch_bounds__(256) void splitk_finalize_kernel(const GemmArgs p) {
   const int n4 = (p.N + 3) >> 2;
   const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long long)p.M * n4) return;
-  const int m = (int)(idx / n4), nb = (int)(idx - (long long)m * n4) * 4;
+  const int rows = p.M - p.m_base;
+  if (idx >= (long long)rows * n4) return;
+  const int mr = (int)(idx / n4), nb = (int)(idx - (long long)mr * n4) * 4, m = p.m_base + mr;
   float v[4] = {0.f, 0.f, 0.f, 0.f};
   for (int z = 0; z < p.ksplit; ++z) {
-    const float* src = p.partial + ((long long)z * p.M + m) * p.partial_ld + nb;
+    const float* src = p.partial + ((long long)z * rows + mr) * p.partial_ld + nb;
     if (nb + 3 < p.N) {
       const f32x4 t = *(const f32x4*)src;
       v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
@@ -778,7 +779,7 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
 #if defined(G8_STAMPS)
   if (const char* dp = getenv("WSOVOD_G8_DEBUG_PTR")) args.partial = (float*)strtoull(dp, nullptr, 16);
 #endif
-  args.tiles_m = ceil_div(a.M, 256);
+  args.tiles_m = ceil_div(a.M - a.m_base, 256);
   args.tiles_n = ceil_div(a.N, 256);
   {
     // Tile-order group height.  What has to share L2 is the set of workgroups an XCD runs AT THE SAME TIME (32 CUs x 1
@@ -804,7 +805,7 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
       static float* ws = nullptr;
       static size_t ws_bytes = 0;
       const long long ldp = ((long long)a.N + 3) / 4 * 4;
-      const size_t need = (size_t)S * a.M * ldp * sizeof(float);
+      const size_t need = (size_t)S * (a.M - a.m_base) * ldp * sizeof(float);
       if (need > ws_bytes) {  // grow-only workspace of this process (single-stream use, as the rest of the library)
         if (ws) (void)hipFree(ws);
         ws = nullptr;
@@ -854,7 +855,7 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
 #undef WS_L8
 #undef WS_L8L
   if (args.ksplit > 1) {
-    const long long quads = (long long)a.M * ((a.N + 3) / 4);
+    const long long quads = (long long)(a.M - a.m_base) * ((a.N + 3) / 4);
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, args);
   }
   WS_CHECK_LAUNCH("wsovod_gemm_nt(256x256 8-phase)");
