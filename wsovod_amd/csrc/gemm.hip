@@ -2168,6 +2168,12 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!d->tile_hint && !d->conv && d->M >= 256 && d->N >= 256 && d->K >= 8192 &&
         (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
       tile = 2256256;
+    // skinny heads (the MIL [cls | det] rows, N = 2K <= 64, on the 4096 box features): the 64x64 grid is M / 64 workgroups
+    // streaming 1 MB of A each behind a two-stage register pipeline (125 us at 32 images = 2.1 TB/s); split-K slices of the
+    // 256-wide tile stream the same rows by DMA (the B rows past N are range-checked away: their MFMAs run on zeros)
+    if (!d->tile_hint && !d->conv && d->N <= 64 && d->M >= 256 && d->K >= 2048 && ceil_div(d->M, 256) <= 128 &&
+        !(getenv("WSOVOD_X2_SKINNY") && getenv("WSOVOD_X2_SKINNY")[0] == '0'))
+      tile = 2256256;
     // few rows, shorter K (fc2, the stacked heads, the convs of res4 / res5 at 1 - 4 images): re-measured in round 5 on bf16x2
     // operands (tools/small_batch_tiles.py, profiles/r05_small_batch_tiles.md).  T = number of 256x256 tiles:
     //   T >= 150           one partly filled round of the 256x256 tile beats two of 256x128 (3 images, res5: 250 vs 337 us)
