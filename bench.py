@@ -788,6 +788,7 @@ def main():
         c = rec["comm"]
         comm_ranks = {"exchange_wait_ms": [round(c["exchange_wait_ms"], 4)], "overlap_window_ms": [round(c["overlap_window_ms"], 4)],
                       "wire_bytes_per_step": c["wire_bytes_per_step"], "exchange": c["exchange"], "wire": c["wire"]}
+    device_identity_warning = None
     if world > 1 and args.backend == "nccl" and not args.share_device:
         # one process per GPU means one GPU per process: a launcher that put two ranks on one device fails the run
         # (identity = the device's UUID / PCI address, not its index: a launcher may show every rank one device as index 0)
@@ -797,13 +798,18 @@ def main():
             import zlib
 
             me = torch.tensor([zlib.crc32(str(ident[0]).encode()) & 0x7FFFFFFF] + [int(v) if isinstance(v, int) else -1
-                                                                                   for v in ident[1:]],
-                              device=dev, dtype=torch.int64)
+                                                                                   for v in ident[1:]]
+                              + [torch.cuda.current_device(), torch.cuda.device_count()], device=dev, dtype=torch.int64)
             ids = [torch.zeros_like(me) for _ in range(world)]
             dist.all_gather(ids, me)
             seen = [tuple(int(v) for v in x.tolist()) for x in ids]
-            if len(set(seen)) != world:
-                raise RuntimeError(f"bench.py --gpus {world}: the ranks sit on devices {seen}, not on {world} different GPUs")
+            if len(set(t[:4] for t in seen)) != world:
+                # the same identity twice: fatal when the ranks also name the same device index (or see one device only);
+                # with DIFFERENT indices of a multi-device process the identity fields are not trustworthy on this host
+                # (virtualised PCI addresses / no UUID): reported in the line, not fatal
+                if len(set(t[4] for t in seen)) != world or any(t[5] < world for t in seen):
+                    raise RuntimeError(f"bench.py --gpus {world}: the ranks sit on devices {seen}, not on {world} different GPUs")
+                device_identity_warning = f"device identities (uuid crc, pci domain / bus / device) repeat across ranks: {seen}"
 
     roofline = None
     table = rec.get("kernel_table")
@@ -882,7 +888,8 @@ def main():
                        "rank_ms_per_step": {"max": max(rank_ms), "min": min(rank_ms), "all": rank_ms},
                        "process_group_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        "process_group": {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl": rccl,
-                                         "ranks_equal_gpus_flag": dist.get_world_size() == args.gpus}
+                                         "ranks_equal_gpus_flag": dist.get_world_size() == args.gpus,
+                                         "device_identity_warning": device_identity_warning}
                        if dist.is_initialized() else None,
                        "exchange_ab": rec.get("exchange_ab"),
                        "communication": comm_ranks,
