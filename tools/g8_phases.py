@@ -24,9 +24,18 @@ def report(tag, fl, run):
     print(f"{tag}: {ms:.3f} ms ({fl / ms / 1e9:.0f} TF executed, instrumented)")
     for g in range(2):
         n = float(d[g, 8])
-        if n:
+        if n and float(d[g, :8].sum()) == 0:  # -DG8_STAMPS=2: tile-level stamps only
+            w = float(d[g, 11])
+            print(f"  group {g} per tile: setup + K-step 0 requested {float(d[g, 9]) / w:.0f}, its data + barriers {float(d[g, 12]) / w:.0f}, "
+                  f"loop {float(d[g, 10]) / w:.0f}, epilogue issue {float(d[g, 13]) / w:.0f}, store drain {float(d[g, 14]) / w:.0f} ticks", flush=True)
+        elif n:
             print(f"  group {g}: ticks per K-step: " + ", ".join(f"{nm} {float(d[g, k]) / n:.0f}" for k, nm in enumerate(names)) +
                   f"; total {float(d[g, :8].sum()) / n:.0f}", flush=True)
+            w = float(d[g, 11])
+            if w:  # per workgroup (the tile's wall time is the caller's: ms x CUs / tiles)
+                print(f"    per tile: setup + K-step 0 requested {float(d[g, 9]) / w:.0f}, its data + barriers {float(d[g, 12]) / w:.0f}, "
+                      f"loop {float(d[g, 10]) / w:.0f}, epilogue issue {float(d[g, 13]) / w:.0f}, store drain {float(d[g, 14]) / w:.0f} ticks",
+                      flush=True)
 M, N, K = 8192, 4096, 25088
 a = H.x2_encode(torch.randn(M, K, device="cuda")); b = H.x2_encode(torch.randn(N, K, device="cuda") * 0.01)
 bias = torch.randn(N, device="cuda")
@@ -39,3 +48,18 @@ x = H.x2_encode(torch.randn(n * Hi * Wi, Cin, device="cuda")).view(n, Hi, Wi, Ci
 w = H.x2_encode(torch.randn(Cout, 9 * Cin, device="cuda") * 0.05)
 geom = dict(n_img=n, H=Hi, W=Wi, Cin=Cin, Ho=Hi, Wo=Wi, KH=3, KW=3, stride=1, pad=2, dil=2)
 report("res5 conv x2 (two-phase)", 6.0 * n * Hi * Wi * Cout * 9 * Cin, lambda: H.gemm_nt(x, w, conv=geom, x2=True, bias=bias[:Cout], relu=True, out_dtype=H.X2, tile_hint=2256256))
+
+n, Hi, Wi, Cin, Cout = 32, 75, 100, 256, 256
+x = H.x2_encode(torch.randn(n * Hi * Wi, Cin, device="cuda")).view(n, Hi, Wi, Cin)
+w = H.x2_encode(torch.randn(Cout, 9 * Cin, device="cuda") * 0.05)
+geom = dict(n_img=n, H=Hi, W=Wi, Cin=Cin, Ho=Hi, Wo=Wi, KH=3, KW=3, stride=1, pad=2, dil=2)
+report("res4 conv x2, 32 images (938 tiles = 3.66 rounds)", 6.0 * n * Hi * Wi * Cout * 9 * Cin,
+       lambda: H.gemm_nt(x, w, conv=geom, x2=True, bias=bias[:Cout], relu=True, out_dtype=H.X2, tile_hint=2256256))
+n = 7  # 206 tiles: ONE partly filled round -> ms = the wall time of a tile
+x = H.x2_encode(torch.randn(n * Hi * Wi, Cin, device="cuda")).view(n, Hi, Wi, Cin)
+geom["n_img"] = n
+report("res4 conv x2, 7 images (206 tiles: ms = one tile's wall time)", 6.0 * n * Hi * Wi * Cout * 9 * Cin,
+       lambda: H.gemm_nt(x, w, conv=geom, x2=True, bias=bias[:Cout], relu=True, out_dtype=H.X2, tile_hint=2256256))
+a = H.x2_encode(torch.randn(256 * 14, 4096, device="cuda")); b = H.x2_encode(torch.randn(4096, 4096, device="cuda") * 0.01)
+report("fc2 fwd x2, 224 tiles (ms = one tile's wall time, 64 K-steps)", 6.0 * 256 * 14 * 4096 * 4096,
+       lambda: H.gemm_nt(a, b, x2=True, bias=bias, relu=True, out_dtype=H.X2, tile_hint=2256256))

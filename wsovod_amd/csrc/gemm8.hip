@@ -83,6 +83,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const int tile_n = in_group / gm;
   const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;  // (m_base: a launch may cover rows [m_base, M) only)
 
+#if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();  // (workgroup start: prologue / loop / rest of the tile)
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 2, wc = wave & 3;
   const int lrow = tid >> 3;
@@ -105,6 +108,47 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     rsrcB = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (long long)n0 * p.ldb * esz), 0, (int)(rows * p.ldb * esz),
                                               0x00020000);
   }
+  // ---- B rows first: their DMA for K-step 0 is in flight while the A rows' (conv: pixel decode, tap masks) setup runs
+  // (round 5: the conv tile's prologue was ~3x the GEMM's; tools/tile_fixed_cost.py)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    // B pass i = the 64 columns of the wavefronts with wc == i; LDS row (tile j = lrow >> 4, tile row f = lrow & 15) is
+    // fed from B row 16*(f>>2) + 4*j + (f&3), so that after the MFMAs a lane owns 16 CONSECUTIVE output columns
+    const int src = LR * i + 16 * ((lrow & 15) >> 2) + 4 * (lrow >> 4) + (lrow & 3);
+    b_off[i] = n0 + src < p.N ? (int)(((long long)src * p.ldb + lchunk * EPC) * esz) : -1;
+  }
+  const int kslice = p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;
+  const int kt_base = kslice * p.slice_steps;  // first K-step of this block (0 unless split-K)
+  const int nk = p.ksplit > 1 ? max(0, min((p.K + BKE - 1) / BKE - kt_base, p.slice_steps)) : (p.K + BKE - 1) / BKE;
+  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // conv: (filter row, filter column, first channel) of a K-step, advanced incrementally (scalar adds instead of the
+  // two integer divisions per staged K-step)
+  struct Tap { int r, q, c0; };  // c0 >= Cin: the K-steps of the fused 1x1 shortcut (second input A2 at channel c0 - Cin)
+  Tap t0{0, 0, 0};
+  if (CONV && kt_base > 0) {  // split-K slice of a conv: the (filter tap, channel chunk) of its first K-step
+    const int taps = p.KH * p.KW, nk_main = taps * (p.Cin / BKE);
+    if (kt_base >= nk_main) {
+      t0.c0 = p.Cin + (kt_base - nk_main) * BKE;
+    } else {
+      const int chunk = kt_base / taps, tap = kt_base - chunk * taps;
+      t0.r = tap / p.KW;
+      t0.q = tap - t0.r * p.KW;
+      t0.c0 = chunk * BKE;
+    }
+  }
+  auto stage_B = [&](int kt, int buf, int i, const Tap t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // conv: weight rows are [kh][kw][Cin] (+ [Cin2] of the fused shortcut behind them)
+    const int kbase = CONV ? (t.c0 >= p.Cin ? p.KH * p.KW * p.Cin + (t.c0 - p.Cin) : (t.r * p.KW + t.q) * p.Cin + t.c0)
+                           : (kt + kt_base) * BKE;
+    const bool k_ok = kbase + lchunk * EPC < p.K;
+    char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16,
+                                             (k_ok && b_off[i] >= 0) ? b_off[i] + kbase * esz : -1, 0, 0, 0);
+#endif
+  };
+  stage_B(0, 0, 0, t0); stage_B(0, 0, 1, t0); stage_B(0, 0, 2, t0); stage_B(0, 0, 3, t0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + lrow + LR * i;
@@ -128,40 +172,58 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
                  : p.a_plane ? (int)((long long)(lrow + LR * i) * p.lda * esz + (lchunk & 3) * 16 + (lchunk >> 2) * p.a_plane)
                              : (int)(((long long)(lrow + LR * i) * p.lda + lchunk * EPC) * esz);
     }
-    // B pass i = the 64 columns of the wavefronts with wc == i; LDS row (tile j = lrow >> 4, tile row f = lrow & 15) is
-    // fed from B row 16*(f>>2) + 4*j + (f&3), so that after the MFMAs a lane owns 16 CONSECUTIVE output columns
-    const int src = LR * i + 16 * ((lrow & 15) >> 2) + 4 * (lrow >> 4) + (lrow & 3);
-    b_off[i] = n0 + src < p.N ? (int)(((long long)src * p.ldb + lchunk * EPC) * esz) : -1;
   }
-  const int kslice = p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;
-  const int kt_base = kslice * p.slice_steps;  // first K-step of this block (0 unless split-K)
-  const int nk = p.ksplit > 1 ? max(0, min((p.K + BKE - 1) / BKE - kt_base, p.slice_steps)) : (p.K + BKE - 1) / BKE;
   // conv: per-lane pixel offset (filter at its top-left tap) and one validity bit per tap, hoisted out of the K loop
   // exactly as in gemm.hip
   [[maybe_unused]] int pix_off[4];
   [[maybe_unused]] unsigned vmask[4];
   if (CONV) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i)
       pix_off[i] = hi0[i] > -(1 << 27) ? a_off[i] + ((hi0[i] * p.W + wi0[i]) * p.Cin) * esz : 0;
-      unsigned mk = 0;
-      for (int r = 0; r < p.KH; ++r)
-        for (int q = 0; q < p.KW; ++q) {
-          const int hi = hi0[i] + r * p.dil, wi = wi0[i] + q * p.dil;
-          if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) mk |= 1u << (r * p.KW + q);
+  }
+  {  // A rows of K-step 0 (passes 0, 2, 1, 3); conv: the tap's validity tested directly -- the masks are built behind the DMA
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = ((ii & 1) << 1) | (ii >> 1);
+      char* dA = sA + wave_u * 1024 + LR * i * 128;
+      int off;
+      if (CONV) {
+        if (t0.c0 >= p.Cin) {
+          off = pix2_off[i] >= 0 ? pix2_off[i] + (t0.c0 - p.Cin) * esz : -1;
+        } else {
+          const bool in = (unsigned)(hi0[i] + t0.r * p.dil) < (unsigned)p.H && (unsigned)(wi0[i] + t0.q * p.dil) < (unsigned)p.W;
+          off = in ? pix_off[i] + (((t0.r * p.W + t0.q) * p.dil) * p.Cin + t0.c0) * esz : -1;
         }
+        if (t0.c0 >= p.Cin) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void*)dA, 16, off, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, off, 0, 0, 0);
+      } else {
+        const int kbase = kt_base * BKE;
+        const bool k_ok = kbase + lchunk * EPC < p.K;
+        off = (k_ok && a_off[i] >= 0) ? a_off[i] + ((kbase * esz) >> (p.a_plane ? 1 : 0)) : -1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, off, 0, 0, 0);
+      }
+    }
+#endif
+  }
+  if (CONV) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // branch-free, KH + KW steps (round 5: the KH x KW double loop with a per-lane `if` was ~1500 instructions of exec
+      // masking and scalar branches per tile): valid filter rows x valid filter columns (a row past M: hi0 = -2^28)
+      unsigned rowm = 0, colm = 0;
+      for (int r = 0; r < p.KH; ++r) rowm |= (unsigned)((unsigned)(hi0[i] + r * p.dil) < (unsigned)p.H) << r;
+      for (int q = 0; q < p.KW; ++q) colm |= (unsigned)((unsigned)(wi0[i] + q * p.dil) < (unsigned)p.W) << q;
+      unsigned mk = 0;
+      for (int r = 0; r < p.KH; ++r) mk |= ((rowm >> r) & 1u) ? (colm << (r * p.KW)) : 0u;
       vmask[i] = mk;
     }
   }
 
-  typedef __attribute__((address_space(3))) void lds_void [[maybe_unused]];
-  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // one DMA pass = 64 tile rows x 128 B (8 rows per wavefront instruction).  A passes 0 / 2 hold the rows the two
   // wavefront groups read in phase 1 ("A_lo"), passes 1 / 3 the rows they read in phase 3 ("A_hi"); B pass i holds
   // the 64 columns of the wavefronts with wc == i.
-  // conv: (filter row, filter column, first channel) of a K-step, advanced incrementally (scalar adds instead of the
-  // two integer divisions per staged K-step)
-  struct Tap { int r, q, c0; };  // c0 >= Cin: the K-steps of the fused 1x1 shortcut (second input A2 at channel c0 - Cin)
   auto tap_next = [&](Tap t) {  // (channel chunk, tap) order with the tap innermost, as gemm.hip: the taps of a chunk
     if (t.c0 >= p.Cin) { t.c0 += BKE; return t; }
     if (++t.q >= p.KW) {        // re-read the same input pixels while they are still in L2
@@ -190,17 +252,6 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
                                                (k_ok && a_off[i] >= 0) ? a_off[i] + ((kbase * esz) >> (p.a_plane ? 1 : 0)) : -1,
                                                0, 0, 0);
     }
-#endif
-  };
-  auto stage_B = [&](int kt, int buf, int i, const Tap t) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    // conv: weight rows are [kh][kw][Cin] (+ [Cin2] of the fused shortcut behind them)
-    const int kbase = CONV ? (t.c0 >= p.Cin ? p.KH * p.KW * p.Cin + (t.c0 - p.Cin) : (t.r * p.KW + t.q) * p.Cin + t.c0)
-                           : (kt + kt_base) * BKE;
-    const bool k_ok = kbase + lchunk * EPC < p.K;
-    char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16,
-                                             (k_ok && b_off[i] >= 0) ? b_off[i] + kbase * esz : -1, 0, 0, 0);
 #endif
   };
 
@@ -262,8 +313,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #else
 #define WS_VMCNT(N) (void)0
 #endif
-#if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(G8_STAMPS) && (G8_STAMPS == 1) && defined(__HIP_DEVICE_COMPILE__)
   // instrumented builds only (tools/g8_phases.py): s_memtime ticks per section of the two-phase K-step
+  // (-DG8_STAMPS=2: the tile-level stamps only -- setup / first wait / loop / epilogue / store drain -- the loop undisturbed)
   unsigned long long st_t = 0, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define G8_STAMP0() st_t = __builtin_amdgcn_s_memtime()
 #define G8_STAMP(k)                                              \
@@ -276,27 +328,19 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
 #define G8_STAMP0() (void)0
 #define G8_STAMP(k) (void)0
 #endif
-  Tap t0{0, 0, 0};
-  if (CONV && kt_base > 0) {  // split-K slice of a conv: the (filter tap, channel chunk) of its first K-step
-    const int taps = p.KH * p.KW, nk_main = taps * (p.Cin / BKE);
-    if (kt_base >= nk_main) {
-      t0.c0 = p.Cin + (kt_base - nk_main) * BKE;
-    } else {
-      const int chunk = kt_base / taps, tap = kt_base - chunk * taps;
-      t0.r = tap / p.KW;
-      t0.q = tap - t0.r * p.KW;
-      t0.c0 = chunk * BKE;
-    }
-  }
   Tap t1 = tap_next(t0);   // K-step kt + 1
   Tap t2 = tap_next(t1);   // K-step kt + 2
-  stage_A(0, 0, 0, t0); stage_A(0, 0, 2, t0);
-  stage_B(0, 0, 0, t0); stage_B(0, 0, 1, t0); stage_B(0, 0, 2, t0); stage_B(0, 0, 3, t0);
-  stage_A(0, 0, 1, t0); stage_A(0, 0, 3, t0);
+  // (K-step 0 was requested at the top of the kernel: B rows, then A rows, ahead of the rest of the setup)
   if (PH == 4 && nk > 1) { stage_A(1, 1, 0, t1); stage_A(1, 1, 2, t1); }
+#if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long st_setup = __builtin_amdgcn_s_memtime();
+#endif
   WS_VMCNT(0);
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second M-half runs one barrier behind
+#if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
 
   if constexpr (LEAN) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -584,11 +628,32 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
 #if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned long long st_loop1 = __builtin_amdgcn_s_memtime();
   if (p.partial && lane == 0 && p.ksplit <= 1) {
+#if G8_STAMPS == 1
 #pragma unroll
     for (int k = 0; k < 8; ++k) atomicAdd(p.partial + wr * 16 + k, (float)st_acc[k]);
+#endif
     atomicAdd(p.partial + wr * 16 + 8, (float)nk);
   }
+  // tile level, one wavefront per group: [9] entry -> K-step 0 requested and the setup done, [12] -> its data landed +
+  // barriers, [10] the K loop, [13] epilogue until the last store is issued, [14] until the stores are acknowledged
+  auto g8_tile_end = [&]() {
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();
+    if (p.partial && lane == 0 && p.ksplit <= 1 && (wave == 0 || wave == 4)) {
+      atomicAdd(p.partial + wr * 16 + 9, (float)(st_setup - st_begin));
+      atomicAdd(p.partial + wr * 16 + 12, (float)(st_loop0 - st_setup));
+      atomicAdd(p.partial + wr * 16 + 10, (float)(st_loop1 - st_loop0));
+      atomicAdd(p.partial + wr * 16 + 13, (float)(st_e0 - st_loop1));
+      atomicAdd(p.partial + wr * 16 + 14, (float)(st_e1 - st_e0));
+      atomicAdd(p.partial + wr * 16 + 11, 1.0f);
+    }
+  };
+#define G8_TILE_END() g8_tile_end()
+#else
+#define G8_TILE_END() (void)0
 #endif
 #undef WS_VMCNT
 
@@ -714,11 +779,13 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   }
     WS_FAST_ROW(0) WS_FAST_ROW(1) WS_FAST_ROW(2) WS_FAST_ROW(3) WS_FAST_ROW(4) WS_FAST_ROW(5) WS_FAST_ROW(6) WS_FAST_ROW(7)
 #undef WS_FAST_ROW
+    G8_TILE_END();
     return;
   }
 #define WS_EMIT_ROW(I) emit(acc[I][0], I, 0); emit(acc[I][1], I, 1); emit(acc[I][2], I, 2); emit(acc[I][3], I, 3)
   WS_EMIT_ROW(0); WS_EMIT_ROW(1); WS_EMIT_ROW(2); WS_EMIT_ROW(3);
   WS_EMIT_ROW(4); WS_EMIT_ROW(5); WS_EMIT_ROW(6); WS_EMIT_ROW(7);
+  G8_TILE_END();
 #undef WS_EMIT_ROW
 #undef WS_DS_READ
 #undef WS_LGKM0_12
