@@ -124,12 +124,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
       pix_off[i] = hi0[i] > -(1 << 27) ? a_off[i] + ((hi0[i] * p.W + wi0[i]) * p.Cin) * esz : 0;  // rows past M: unused
+      // branch-free in KH + KW steps (valid filter rows x valid filter columns; a row past M: hi0 = -2^28), as gemm8.hip
+      unsigned rowm = 0, colm = 0;
+      for (int r = 0; r < p.KH; ++r) rowm |= (unsigned)((unsigned)(hi0[i] + r * p.dil) < (unsigned)p.H) << r;
+      for (int q = 0; q < p.KW; ++q) colm |= (unsigned)((unsigned)(wi0[i] + q * p.dil) < (unsigned)p.W) << q;
       unsigned mk = 0;
-      for (int r = 0; r < p.KH; ++r)
-        for (int q = 0; q < p.KW; ++q) {
-          const int hi = hi0[i] + r * p.dil, wi = wi0[i] + q * p.dil;
-          if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) mk |= 1u << (r * p.KW + q);
-        }
+      for (int r = 0; r < p.KH; ++r) mk |= ((rowm >> r) & 1u) ? (colm << (r * p.KW)) : 0u;
       vmask[i] = mk;
     }
   }
