@@ -161,7 +161,8 @@ int wsovod_roi_align_backward(const float* grad_out, const float* rois, const fl
  * an NHWC input (A is never materialised).
  *
  * Epilogue order:  v = alpha*acc; v *= row_scale[m]; v += bias[n]; v += residual[m][n];
- *   relu; dropout (inverted, keep-prob 1-p, counter-based RNG on (seed,m,n));
+ *   relu; dropout (inverted, keep-prob 1-p, counter-based RNG on (seed, m, n): one splitmix64
+ *   value per quad of columns n & ~3 .. n | 3, 16 bits per element, keep iff bits >= p * 2^16);
  *   v += group_add[row_group[m]][n];  if mask_src: v = mask_src[m][n] > 0 ? v*mask_scale : 0;
  *   if accumulate: v += C_old.   C and the optional transposed copy Ct are then stored.
  * ---------------------------------------------------------------------------------- */

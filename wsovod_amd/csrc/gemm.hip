@@ -421,6 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   // n = ncol + 4*j + r: row-major outputs move as 16-byte stores, 16*TN contiguous elements per row and wavefront.
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
   [[maybe_unused]] const unsigned long long dseed = p.dropout_p > 0.f ? WS_DROPOUT_SEED(p) : 0ull;
+  [[maybe_unused]] const unsigned dthr = dropout_threshold(p.dropout_p);
   const bool vec_c = p.C && (p.dtype_c == WSOVOD_BF16X2 ? vec4_ok(p.C, p.ldc, p.dtype_c)
                                                         : (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0);
   const bool vec_r = !p.residual || (p.dtype_r == WSOVOD_BF16X2 ? vec4_ok(p.residual, p.ldr, p.dtype_r)
@@ -448,9 +449,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
         if (has_res) x[j] += load4_as_f32(p.residual, mm, p.ldr, ncol + 4 * j, p.dtype_r);
         x[j] = f32x4{fmaxf(x[j][0], lo), fmaxf(x[j][1], lo), fmaxf(x[j][2], lo), fmaxf(x[j][3], lo)};
         if (drop) {
-          const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);
+          const unsigned long long dz = dropout_quad(dseed, mm, p.N, ncol + 4 * j);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) x[j][r] = uniform01(dseed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;
+          for (int r = 0; r < 4; ++r) x[j][r] = dropout_keep(dz, r, dthr) ? x[j][r] * keep_scale : 0.f;
         }
       }
       if (p.dtype_c == WSOVOD_BF16X2) {
@@ -479,6 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
       const int nb = ncol + 4 * j;
       if (nb >= p.N) continue;
       float v[4];
+      const unsigned long long dz = p.dropout_p > 0.f ? dropout_quad(dseed, m, p.N, nb) : 0ull;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = nb + r;
@@ -488,10 +490,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
           if (p.bias) x += p.bias[n];
           if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
           if (p.relu) x = fmaxf(x, 0.f);
-          if (p.dropout_p > 0.f) {
-            const float u = uniform01(dseed, (unsigned long long)m * (unsigned long long)p.N + n);
-            x = u >= p.dropout_p ? x * keep_scale : 0.f;
-          }
+          if (p.dropout_p > 0.f) x = dropout_keep(dz, r, dthr) ? x * keep_scale : 0.f;
           if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
           if (p.mask_src)
             x = load_as_f32(p.mask_src, m, p.ldm, n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;

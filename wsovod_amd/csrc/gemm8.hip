@@ -682,6 +682,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   }
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
   [[maybe_unused]] const unsigned long long dseed = p.dropout_p > 0.f ? WS_DROPOUT_SEED(p) : 0ull;
+  [[maybe_unused]] const unsigned dthr = dropout_threshold(p.dropout_p);
   const bool vec_c = p.C && (p.dtype_c == WSOVOD_BF16X2 ? vec4_ok(p.C, p.ldc, p.dtype_c)
                                                         : (p.ldc & 7) == 0 && ((uintptr_t)p.C & 15) == 0);
   const int ncol = n0 + wc * 64 + 16 * fq;
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     if (m >= p.M || nb >= p.N) return;
     const float rs = p.row_scale ? p.row_scale[m] : 1.f;
     const bool full = nb + 3 < p.N;
+    const unsigned long long dz = p.dropout_p > 0.f ? dropout_quad(dseed, m, p.N, nb) : 0ull;
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -701,10 +703,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
         if (p.bias) x += p.bias[n];
         if (p.residual) x += load_as_f32(p.residual, m, p.ldr, n, p.dtype_r);
         if (p.relu) x = fmaxf(x, 0.f);
-        if (p.dropout_p > 0.f) {
-          const float u = uniform01(dseed, (unsigned long long)m * (unsigned long long)p.N + n);
-          x = u >= p.dropout_p ? x * keep_scale : 0.f;
-        }
+        if (p.dropout_p > 0.f) x = dropout_keep(dz, r, dthr) ? x * keep_scale : 0.f;
         if (p.group_add) x += p.group_add[(long long)p.row_group[m] * p.ld_ga + n];
         if (p.mask_src)
           x = load_as_f32(p.mask_src, m, p.ldm, n, p.dtype_m) > 0.f ? x * p.mask_scale : 0.f;
@@ -752,9 +751,9 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       if (has_res) x[j] += load4_as_f32(p.residual, mm, p.ldr, ncol + 4 * j, p.dtype_r);                      \
       x[j] = f32x4{fmaxf(x[j][0], lo), fmaxf(x[j][1], lo), fmaxf(x[j][2], lo), fmaxf(x[j][3], lo)};           \
       if (drop) {                                                                                             \
-        const unsigned long long ctr = (unsigned long long)mm * (unsigned long long)p.N + (ncol + 4 * j);     \
+        const unsigned long long dz = dropout_quad(dseed, mm, p.N, ncol + 4 * j);                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
-            x[j][r] = uniform01(dseed, ctr + r) >= p.dropout_p ? x[j][r] * keep_scale : 0.f;                 \
+            x[j][r] = dropout_keep(dz, r, dthr) ? x[j][r] * keep_scale : 0.f;                                 \
       }                                                                                                       \
     }                                                                                                         \
     if (p.dtype_c == WSOVOD_BF16X2) { /* 16 consecutive values: 32 B of hi, 32 B of lo one half-line further */  \

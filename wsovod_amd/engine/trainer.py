@@ -6,6 +6,7 @@ backward, optimizer step every ITER_SIZE) and engine/defaults.py:135-153,274-318
 parameter update itself is the fused HIP kernel `wsovod_sgd_momentum`; gradient exchange is
 torch DistributedDataParallel over RCCL ("nccl" backend on ROCm) -- the only collective on the path.
 """
+import gc as _gc
 import os
 import warnings
 import weakref
@@ -323,6 +324,11 @@ class _StepGraph:
         # the learning rates are read from memory by the captured SGD launch (an LR scheduler moves them between replays)
         tr.optimizer.lr_device = {p: self.meta.lr[i:i + 1] for i, g in enumerate(tr.optimizer.param_groups)
                                   for p in g["params"]}
+        # no cyclic garbage collection while a stream is capturing: a collector run in the middle of the capture may
+        # finalise an unreachable CUDAGraph / private pool of an earlier trainer -- HIP refuses that under capture and the
+        # process aborts (seen once in ~10 full test runs).  torch.cuda.graph() collects BEFORE it starts capturing.
+        gc_was_on = _gc.isenabled()
+        _gc.disable()
         try:
             with H.const_override(self.meta.overrides(self.capture_nums)), H.tail_rows(self.meta.rows_true):
                 if split:
@@ -346,6 +352,8 @@ class _StepGraph:
                         tr.optimizer.zero_grad(set_to_none=True)
                     self.graphs = [g]
         finally:
+            if gc_was_on:
+                _gc.enable()
             model._step_meta = None
             tr.optimizer.lr_device = None
             for p, v in dw:

@@ -605,8 +605,16 @@ class _BackboneGraph:
         self.graph = torch.cuda.CUDAGraph()
         # thread_local: a HIP call from another thread (a DataLoader's pin-memory thread, an eval thread) during the
         # capture -- it happens mid-training, on the third sighting of a shape -- must not abort it
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = net._forward_uint8(self.static_in, sizes, pixel_mean, pixel_std)
+        import gc
+
+        gc_was_on = gc.isenabled()  # (no cyclic collection inside a capture: see engine/trainer.py:_StepGraph._capture)
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.out = net._forward_uint8(self.static_in, sizes, pixel_mean, pixel_std)
+        finally:
+            if gc_was_on:
+                gc.enable()
 
     def __call__(self, images_u8):
         if images_u8.data_ptr() != self.static_in.data_ptr():
