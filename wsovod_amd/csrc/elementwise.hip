@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void segment_colsum_kernel(const T* __restrict
       for (int m = a + wave; m < b; m += 4) {
         const T* row = x + (long long)m * ld + n0;
         if (vec) {
-          const uint4 raw = *(const uint4*)row;
+          typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+          const u4 raw = __builtin_nontemporal_load((const u4*)row);  // read once: streaming (no L2 allocation)
           const T* e = (const T*)&raw;
 #pragma unroll
           for (int j = 0; j < V; ++j) acc[j] += to_f32(e[j]);
