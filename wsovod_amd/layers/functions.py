@@ -209,7 +209,9 @@ class _LinearGroup(Function):
         offs = [0]
         for n in Ns:
             offs.append(offs[-1] + _pad(n, 8))
-        Nt = offs[-1]
+        # (the stacked width in whole 64-column K-steps: the input-gradient GEMM contracts over it and takes the lean form
+        # of the 8-wavefront tile; the columns behind the last head stay zero)
+        Nt = _pad(offs[-1], 64)
         dA = torch.zeros((M, Nt), dtype=cd, device=x.device)
         want_db = any(ctx.has_bias[i] and ctx.needs_input_grad[3 + 2 * i] for i in range(nb))
         dbcat = torch.zeros((Nt,), dtype=torch.float32, device=x.device) if want_db else None
