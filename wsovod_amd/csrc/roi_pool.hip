@@ -166,6 +166,49 @@ __global__ __launch_bounds__(256) void max2x2_s1_nhwc(const T* __restrict__ in, 
   }
 }
 
+// The same map in STRIPS of RH rows per thread (round 5): the one-output-per-thread form re-reads every row for the row
+// above it (counters: 1.44 GB fetched for the 491-MB map at 32 images); here a thread walks RH rows of its (column, channel
+// vector), keeps the horizontal max of the previous row in registers and fetches RH + 1 rows for RH outputs.  Same
+// grouping of the four cells -- max(max(a, b), max(d, e)) -- hence the same bits.
+template <typename T, int V, int RH>
+__global__ __launch_bounds__(256) void max2x2_s1_strip_nhwc(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C,
+                                                            long long total) {
+  typedef T vec __attribute__((ext_vector_type(V)));
+  const int cv = C / V, strips = (H + RH - 1) / RH;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % cv) * V;
+    long long t = idx / cv;
+    const int w = (int)(t % W);
+    t /= W;
+    const int sp = (int)(t % strips);
+    const long long n = t / strips;
+    const int h0 = sp * RH, w1 = min(w + 1, W - 1);
+    const T* pl = in + n * H * W * C + c;
+    vec a[RH + 1], b[RH + 1];
+#pragma unroll
+    for (int r = 0; r <= RH; ++r) {
+      const int h = min(h0 + r, H - 1);
+      a[r] = *(const vec*)(pl + ((long long)h * W + w) * C);
+      b[r] = *(const vec*)(pl + ((long long)h * W + w1) * C);
+    }
+    float hm[RH + 1][V];
+#pragma unroll
+    for (int r = 0; r <= RH; ++r)
+#pragma unroll
+      for (int q = 0; q < V; ++q) hm[r][q] = fmaxf(to_f32(a[r][q]), to_f32(b[r][q]));
+#pragma unroll
+    for (int r = 0; r < RH; ++r) {
+      const int h = h0 + r;
+      if (h >= H) break;
+      vec o;
+#pragma unroll
+      for (int q = 0; q < V; ++q) o[q] = from_f32<T>(fmaxf(hm[r][q], hm[r + 1][q]));
+      *(vec*)(out + ((n * H + h) * W + w) * C + c) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // RoIPool forward, NHWC, pooled width PWT (7 on every shipped config): one WORKGROUP per
 // (roi, 64-channel group), one wavefront per pooled row ph.  The PWT bins of the row are
@@ -1257,7 +1300,18 @@ int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const fl
         const long long total_vec = (long long)N * H * W * (C / v);
         const int g2 = (int)std::min<long long>(ceil_div_ll(total_vec, 256), 256 * 64);
         wsovod::ProfScope prof2(slot2, s, 0.0, 2.0 * (double)N * C * H * W * esz);
-        if (dtype == WSOVOD_BF16)
+        // strips of 8 rows per thread (WSOVOD_ROIPOOL_M2_STRIP=0: one output per thread; A/B runs)
+        const char* ms = getenv("WSOVOD_ROIPOOL_M2_STRIP");
+        constexpr int RH = 8;
+        const long long total_strip = (long long)N * ceil_div(H, RH) * W * (C / v);
+        const int g3 = (int)std::min<long long>(ceil_div_ll(total_strip, 256), 256 * 64);
+        if (!(ms && ms[0] == '0') && dtype == WSOVOD_BF16)
+          hipLaunchKernelGGL((max2x2_s1_strip_nhwc<bf16_t, 8, RH>), dim3(g3), dim3(256), 0, s, (const bf16_t*)feat,
+                             (bf16_t*)workspace, H, W, C, total_strip);
+        else if (!(ms && ms[0] == '0'))
+          hipLaunchKernelGGL((max2x2_s1_strip_nhwc<float, 4, RH>), dim3(g3), dim3(256), 0, s, (const float*)feat,
+                             (float*)workspace, H, W, C, total_strip);
+        else if (dtype == WSOVOD_BF16)
           hipLaunchKernelGGL((max2x2_s1_nhwc<bf16_t, 8>), dim3(g2), dim3(256), 0, s, (const bf16_t*)feat, (bf16_t*)workspace,
                              H, W, C, total_vec);
         else
