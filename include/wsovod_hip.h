@@ -117,6 +117,19 @@ int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const fl
                                int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
                                int* argmax, void* out_hi, void* workspace, long long workspace_bytes,
                                wsovod_stream_t stream);
+/* Round 5 (ABI 7): the 2x2-max map of wsovod_roi_pool_forward_ws written TOGETHER with the global average pool of the same
+ * NHWC map -- the input of the data-aware head (wsovod/modeling/class_heads.py:36-53, F.adaptive_avg_pool2d of the res5
+ * map) -- in one pass over it, and the pooling on a map that is already there.  m2_out: N*H*W*C elements of `dtype`;
+ * gap_out: (N, C) fp32 means; gap_workspace: as many floats as the _workspace_floats function below returns (partial sums, added in a fixed
+ * order: run-to-run bit-identical).  wsovod_roi_pool_forward_m2 = wsovod_roi_pool_forward_ws without its own pre-pass:
+ * `m2` must hold that map of `feat` (same values as _ws bit for bit); where _ws would not use a map (argmax wanted, few
+ * rois, ...) it is ignored. */
+long long wsovod_max2x2_gap_workspace_floats(int dtype, int N, int C, int H, int W);
+int wsovod_max2x2_gap_nhwc(const void* feat, int dtype, int N, int C, int H, int W, void* m2_out, float* gap_out,
+                           float* gap_workspace, wsovod_stream_t stream);
+int wsovod_roi_pool_forward_m2(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                               int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
+                               int* argmax, void* out_hi, const void* m2, long long m2_bytes, wsovod_stream_t stream);
 /* ROILoopPool in the 3-output form of the reference's CUDA op (wsovod/layers/ROILoopPool/ROILoopPool_cuda.cu:9-204,
  * bound as `_C.roi_loop_pool_forward`, wsovod/layers/roi_loop_pool.py:9-22; context_ratio is 1.8 there): out and
  * argmax are (3R, C, ph, pw) = [region | frame | context] fp32 / int32 (NCHW order).  The matching backward is

@@ -302,3 +302,47 @@ def test_pool_kernels_cover_every_output_element(gpu, monkeypatch, C, size):
     fixed = ref_arg.clone()
     fixed[0, 0, 0, 0] = -1
     torch.testing.assert_close(gi.cpu(), O.roi_pool_backward(grad, rois, fixed, (2, C, Hh, Ww)), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,C,Hh,Ww", [(torch.float32, 512, 38, 50), (torch.float32, 2048, 9, 13), (torch.bfloat16, 512, 19, 25),
+                                         (torch.float32, 256, 8, 3)])
+def test_gap_fused_with_the_pool_prepass(gpu, dtype, C, Hh, Ww):
+    """Round 5 (ABI 7): inside hip_ops.gap_with_pool_prepass the global average pool writes the map's stride-1 2x2 maxima in
+    the same pass and the next RoI max pool on that map takes them (wsovod_max2x2_gap_nhwc + wsovod_roi_pool_forward_m2).
+    Pooled values: bit-identical to the unfused path (NaN / Inf cells included); the means: fp64 reference to 1e-6, run-to-run
+    bit-identical; another map, or a map modified in between, falls back to the pooler's own pre-pass."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(21)
+    N = 3
+    feat = torch.randn(N, C, Hh, Ww, device=gpu).to(dtype).contiguous(memory_format=torch.channels_last)
+    feat[0, 5, 2, 1] = float("nan")
+    feat[1, 7, 3, 2] = float("inf")
+    rois = random_rois(700, N, Hh * 8, Ww * 8, seed=22).to(gpu)
+    plain, _ = H.roi_pool_forward(feat, rois, 0.125, (7, 7), need_argmax=False)
+    nhwc = feat.permute(0, 2, 3, 1)
+    gap_plain = H.global_avgpool_nhwc(nhwc)
+    with H.gap_with_pool_prepass(rois.size(0), (7, 7)):
+        gap = H.global_avgpool_nhwc(nhwc)
+        assert H._M2["map"] is not None  # (700 rois on this map: the pooler's rule asks for the 2x2-max map)
+        fused, _ = H.roi_pool_forward(feat, rois, 0.125, (7, 7), need_argmax=False)
+        assert H._M2["map"] is None      # taken
+        gap2 = H.global_avgpool_nhwc(nhwc)
+        H._M2["map"] = None
+    assert torch.equal(plain.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                       fused.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
+    assert torch.equal(gap.view(torch.int32), gap2.view(torch.int32))
+    ok = torch.isfinite(gap_plain)
+    ref = feat.permute(0, 2, 3, 1).double().mean(dim=(1, 2)).float()
+    torch.testing.assert_close(gap[ok], ref[ok], rtol=2e-6 if dtype == torch.float32 else 1e-5, atol=1e-6)
+    torch.testing.assert_close(gap[ok], gap_plain[ok], rtol=2e-6 if dtype == torch.float32 else 1e-5, atol=1e-6)
+    assert torch.equal(torch.isnan(gap), torch.isnan(gap_plain)) and torch.equal(torch.isinf(gap), torch.isinf(gap_plain))
+    # a map changed in place after the GAP: the parked maxima are stale and must not be used
+    with H.gap_with_pool_prepass(rois.size(0), (7, 7)):
+        H.global_avgpool_nhwc(nhwc)
+        feat.mul_(1.5)
+        stale, _ = H.roi_pool_forward(feat, rois, 0.125, (7, 7), need_argmax=False)
+    fresh, _ = H.roi_pool_forward(feat, rois, 0.125, (7, 7), need_argmax=False)
+    assert torch.equal(stale.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                       fresh.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))

@@ -52,7 +52,7 @@ class ProfEntry(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
-ABI_VERSION = 6  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
+ABI_VERSION = 7  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
 
 # name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
 SIGNATURES = {
@@ -102,6 +102,9 @@ SIGNATURES = {
     "wsovod_grad_clip_coef": [_P, _I, _F, _F, _I, _P, _P, _P],
     "wsovod_roi_pool_workspace_bytes": [_I, _I, _I, _I, _I, _I, _I, _I, _I, _I],
     "wsovod_roi_pool_forward_ws": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _L, _P],
+    "wsovod_roi_pool_forward_m2": [_P, _I, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P, _L, _P],
+    "wsovod_max2x2_gap_workspace_floats": [_I, _I, _I, _I, _I],
+    "wsovod_max2x2_gap_nhwc": [_P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     "wsovod_pack_bf16_multi": [_P, _I, _P],
     "wsovod_sum_shards_bf16": [_P, _I, _L, _P, _P],
     "wsovod_format_rois": [_P, _P, _I, _I, _P, _P, _P, _P],
@@ -149,7 +152,8 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = C.c_int
         _lib.wsovod_last_error.restype = C.c_char_p
-        for name in ("wsovod_colsum_workspace_floats", "wsovod_grad_clip_workspace_floats", "wsovod_roi_pool_workspace_bytes"):
+        for name in ("wsovod_colsum_workspace_floats", "wsovod_grad_clip_workspace_floats", "wsovod_roi_pool_workspace_bytes",
+                     "wsovod_max2x2_gap_workspace_floats"):
             getattr(_lib, name).restype = C.c_longlong
         got = _lib.wsovod_abi_version()
         if got != ABI_VERSION:  # the structs of include/wsovod_hip.h (gemm desc, sgd tensor) changed size across versions

@@ -209,6 +209,103 @@ __global__ __launch_bounds__(256) void max2x2_s1_strip_nhwc(const T* __restrict_
   }
 }
 
+// The strip pass FUSED with the global average pool of the same map (the data-aware head's input; round 5): a workgroup
+// owns (image, strip, block of PB columns) x all channel vectors, every thread adds up the cells it loads anyway, the PB
+// columns are folded through LDS in a fixed order and one partial row per workgroup goes to `part`
+// [(image, strip, column block)][C]; max2x2_gap_finalize adds the partial rows of an image in index order.  Run-to-run
+// bit-identical (no atomics); the 2x2 maxima are the strip kernel's.
+template <typename T, int V, int RH>
+__global__ __launch_bounds__(256) void max2x2_s1_strip_gap_nhwc(const T* __restrict__ in, T* __restrict__ out, int H, int W,
+                                                                int C, int PB, int wblocks, float* __restrict__ part) {
+  typedef T vec __attribute__((ext_vector_type(V)));
+  __shared__ float red[256][V + 1];
+  const int cv = C / V, strips = (H + RH - 1) / RH;
+  const int CB = 256 / PB;  // channel vectors per pass (PB * CB = 256)
+  const int pc = threadIdx.x / CB, ci = threadIdx.x - pc * CB;
+  const int wb = blockIdx.x % wblocks;
+  const int sp = (blockIdx.x / wblocks) % strips;
+  const long long n = blockIdx.x / ((long long)wblocks * strips);
+  const int w = wb * PB + pc, h0 = sp * RH;
+  const bool wok = w < W;
+  const int wc = min(w, W - 1), w1 = min(wc + 1, W - 1);
+  for (int cp = 0; cp * CB < cv; ++cp) {
+    const int cvec = cp * CB + ci;
+    const bool ok = wok && cvec < cv;
+    const int c = min(cvec, cv - 1) * V;
+    float sum[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) sum[q] = 0.f;
+    if (ok) {
+      const T* pl = in + n * H * W * C + c;
+      vec a[RH + 1], b[RH + 1];
+#pragma unroll
+      for (int r = 0; r <= RH; ++r) {
+        const int h = min(h0 + r, H - 1);
+        a[r] = *(const vec*)(pl + ((long long)h * W + wc) * C);
+        b[r] = *(const vec*)(pl + ((long long)h * W + w1) * C);
+      }
+      float hm[RH + 1][V];
+#pragma unroll
+      for (int r = 0; r <= RH; ++r)
+#pragma unroll
+        for (int q = 0; q < V; ++q) hm[r][q] = fmaxf(to_f32(a[r][q]), to_f32(b[r][q]));
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        const int h = h0 + r;
+        if (h >= H) break;
+        vec o;
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          o[q] = from_f32<T>(fmaxf(hm[r][q], hm[r + 1][q]));
+          sum[q] += to_f32(a[r][q]);
+        }
+        *(vec*)(out + ((n * H + h) * W + wc) * C + c) = o;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) red[threadIdx.x][q] = sum[q];
+    __syncthreads();
+    if (pc == 0 && cvec < cv) {
+      float* dst = part + (long long)blockIdx.x * C + c;
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        float t = red[ci][q];
+        for (int k = 1; k < PB; ++k) t += red[k * CB + ci][q];
+        dst[q] = t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// (image, 16 channels) per workgroup: 16 groups of lanes take every 16th partial row (independent loads in flight), LDS folds
+// the groups in index order -- a fixed summation order, whatever the launch timing
+__global__ __launch_bounds__(256) void max2x2_gap_finalize(const float* __restrict__ part, int per_image, int C, float scale,
+                                                           float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int cblocks = (C + 15) / 16;
+  const int n = blockIdx.x / cblocks, c = (blockIdx.x - n * cblocks) * 16 + (threadIdx.x & 15);
+  const int g = threadIdx.x >> 4;
+  float t = 0.f;
+  if (c < C) {
+    const float* p = part + (long long)n * per_image * C + c;
+    int j = g;
+    for (; j + 48 < per_image; j += 64) {
+      const float v0 = p[(long long)j * C], v1 = p[(long long)(j + 16) * C], v2 = p[(long long)(j + 32) * C],
+                  v3 = p[(long long)(j + 48) * C];
+      t += v0; t += v1; t += v2; t += v3;
+    }
+    for (; j < per_image; j += 16) t += p[(long long)j * C];
+  }
+  red[g][threadIdx.x & 15] = t;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    float r = red[0][threadIdx.x];
+    for (int k = 1; k < 16; ++k) r += red[k][threadIdx.x];
+    out[(long long)n * C + c] = r * scale;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // RoIPool forward, NHWC, pooled width PWT (7 on every shipped config): one WORKGROUP per
 // (roi, 64-channel group), one wavefront per pooled row ph.  The PWT bins of the row are
@@ -1235,10 +1332,72 @@ long long wsovod_roi_pool_workspace_bytes(int dtype, int layout, int R, int N, i
   return (long long)N * H * W * C * (dtype == WSOVOD_BF16 ? 2 : 4);
 }
 
+static int roi_pool_forward_impl(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                                 int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
+                                 int* argmax, void* out_hi, void* workspace, long long workspace_bytes, bool m2_ready,
+                                 wsovod_stream_t stream);
+
 int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
                                int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
                                int* argmax, void* out_hi, void* workspace, long long workspace_bytes,
                                wsovod_stream_t stream) {
+  return roi_pool_forward_impl(feat, dtype, layout, rois, roi_scale, R, N, C, H, W, ph, pw, spatial_scale, out, out_dtype,
+                               argmax, out_hi, workspace, workspace_bytes, false, stream);
+}
+
+int wsovod_roi_pool_forward_m2(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                               int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
+                               int* argmax, void* out_hi, const void* m2, long long m2_bytes, wsovod_stream_t stream) {
+  WS_CHECK_ARG(m2 != nullptr, "wsovod_roi_pool_forward_m2: null map");
+  return roi_pool_forward_impl(feat, dtype, layout, rois, roi_scale, R, N, C, H, W, ph, pw, spatial_scale, out, out_dtype,
+                               argmax, out_hi, (void*)m2, m2_bytes, true, stream);
+}
+
+long long wsovod_max2x2_gap_workspace_floats(int dtype, int N, int C, int H, int W) {
+  const int v = dtype == WSOVOD_BF16 ? 8 : 4;
+  if ((dtype != WSOVOD_BF16 && dtype != WSOVOD_F32) || C % v != 0 || N <= 0 || H < 1 || W < 1) return 0;
+  const int cv = C / v;
+  int pb = 1;
+  while (pb < 256 && 256 / (pb * 2) >= cv) pb *= 2;  // PB columns x CB = 256 / PB channel vectors, CB >= cv where possible
+  return (long long)N * ceil_div(H, 8) * ceil_div(W, pb) * C;
+}
+
+int wsovod_max2x2_gap_nhwc(const void* feat, int dtype, int N, int C, int H, int W, void* m2_out, float* gap_out,
+                           float* gap_workspace, wsovod_stream_t stream) {
+  WS_CHECK_ARG(dtype == WSOVOD_BF16 || dtype == WSOVOD_F32, "wsovod_max2x2_gap_nhwc: bad dtype");
+  if (N == 0) return WSOVOD_OK;
+  const int v = dtype == WSOVOD_BF16 ? 8 : 4;
+  WS_CHECK_ARG(feat && m2_out && gap_out && gap_workspace && C > 0 && C % v == 0 && H >= 1 && W >= 1 &&
+                   (((uintptr_t)feat | (uintptr_t)m2_out) & 15) == 0,
+               "wsovod_max2x2_gap_nhwc: bad argument (NHWC map, C a multiple of %d, 16-byte aligned)", v);
+  WS_CHECK_ARG((long long)N * H * W * C * (dtype == WSOVOD_BF16 ? 2 : 4) < (1ll << 40), "wsovod_max2x2_gap_nhwc: map too large");
+  static int slot = wsovod::prof_slot("roi_pool_max2x2_map_gap");
+  hipStream_t s = (hipStream_t)stream;
+  const double esz = dtype == WSOVOD_BF16 ? 2.0 : 4.0;
+  wsovod::ProfScope prof(slot, s, 0.0, 2.0 * (double)N * C * H * W * esz);
+  constexpr int RH = 8;
+  const int cv = C / v;
+  int pb = 1;
+  while (pb < 256 && 256 / (pb * 2) >= cv) pb *= 2;
+  const int wblocks = ceil_div(W, pb), strips = ceil_div(H, RH);
+  const long long blocks = (long long)N * strips * wblocks;
+  WS_CHECK_ARG(blocks < (1ll << 31), "wsovod_max2x2_gap_nhwc: too many workgroups");
+  if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL((max2x2_s1_strip_gap_nhwc<bf16_t, 8, RH>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)feat,
+                       (bf16_t*)m2_out, H, W, C, pb, wblocks, gap_workspace);
+  else
+    hipLaunchKernelGGL((max2x2_s1_strip_gap_nhwc<float, 4, RH>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)feat,
+                       (float*)m2_out, H, W, C, pb, wblocks, gap_workspace);
+  hipLaunchKernelGGL(max2x2_gap_finalize, dim3(N * ceil_div(C, 16)), dim3(256), 0, s, gap_workspace, strips * wblocks, C,
+                     1.0f / (float)((long long)H * W), gap_out);
+  WS_CHECK_LAUNCH("wsovod_max2x2_gap_nhwc");
+  return WSOVOD_OK;
+}
+
+static int roi_pool_forward_impl(const void* feat, int dtype, int layout, const float* rois, const float* roi_scale, int R,
+                                 int N, int C, int H, int W, int ph, int pw, float spatial_scale, void* out, int out_dtype,
+                                 int* argmax, void* out_hi, void* workspace, long long workspace_bytes, bool m2_ready,
+                                 wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_pool_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
   WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
                "wsovod_roi_pool_forward_x2hi: the bf16 copy goes with a bf16x2 output");
@@ -1294,7 +1453,7 @@ int wsovod_roi_pool_forward_ws(const void* feat, int dtype, int layout, const fl
       // and cell; bf16 maps whose channel count is not a multiple of 4 keep 2 channels per lane
       const long long need = wsovod_roi_pool_workspace_bytes(dtype, layout, R, N, C, H, W, ph, pw, argmax != nullptr);
       const bool use_m2 = workspace && need > 0 && workspace_bytes >= need && (((uintptr_t)feat | (uintptr_t)workspace) & 15) == 0;
-      if (use_m2) {  // one pass over the map: its stride-1 2x2 maxima (the rows kernel then reads a quarter of the cells)
+      if (use_m2 && !m2_ready) {  // one pass over the map: its stride-1 2x2 maxima (the rows kernel then reads a quarter of the cells)
         static int slot2 = wsovod::prof_slot("roi_pool_max2x2_map");
         const int v = dtype == WSOVOD_BF16 ? 8 : 4;
         const long long total_vec = (long long)N * H * W * (C / v);

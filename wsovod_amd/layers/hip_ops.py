@@ -4,6 +4,7 @@ Every function enqueues on torch's current HIP stream and never synchronises.  T
 CPU fallback: CPU tensors or a missing library raise RuntimeError.
 """
 import ctypes as C
+import contextlib
 import os
 import threading
 
@@ -279,11 +280,13 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     # scratch for the map's 2x2 maxima (0 bytes: this shape keeps the cell scan; include/wsovod_hip.h)
     ws_bytes = int(lib().wsovod_roi_pool_workspace_bytes(dtype_code(feat.dtype), layout, R, N, Cc, H, W, ph, pw,
                                                          int(need_argmax))) if R > 0 else 0
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=feat.device) if ws_bytes > 0 else None
-    check(lib().wsovod_roi_pool_forward_ws(
+    m2 = _m2_take(feat, ws_bytes) if ws_bytes > 0 else None  # the map's 2x2 maxima written with the GAP of the same map
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=feat.device) if ws_bytes > 0 and m2 is None else None
+    entry = lib().wsovod_roi_pool_forward_ws if m2 is None else lib().wsovod_roi_pool_forward_m2
+    check(entry(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
-        C.c_float(spatial_scale), ptr(out), BF16X2P if planar else fmt_code(out_dtype), ptr(argmax), ptr(hi), ptr(ws), ws_bytes,
-        stream()), "roi_pool_forward")
+        C.c_float(spatial_scale), ptr(out), BF16X2P if planar else fmt_code(out_dtype), ptr(argmax), ptr(hi),
+        ptr(ws if m2 is None else m2), ws_bytes, stream()), "roi_pool_forward")
     if planar:
         _x2_planar_tag(out)
     return out, argmax
@@ -672,11 +675,55 @@ def _colsum_workspace(G, M, N, device):
     return torch.empty((max(1, int(lib().wsovod_colsum_workspace_floats(G, M, N))),), dtype=torch.float32, device=device)
 
 
+# ---- the global average pool FUSED with the RoIPool pre-pass (round 5) -------------------------------------------------
+# Inside `gap_with_pool_prepass(num_rois, pooled_size)` (the frozen part of the training forward, where the data-aware head's
+# GAP and the RoI max pool read the same res5 map) global_avgpool_nhwc writes the map's stride-1 2x2 maxima in the same pass
+# (wsovod_max2x2_gap_nhwc) and parks them; the next roi_pool_forward on THAT map (same storage, version and shape) takes
+# them instead of running its own pre-pass.  WSOVOD_GAP_FUSE=0 switches it off (A/B runs).
+GAP_FUSE = os.environ.get("WSOVOD_GAP_FUSE", "1") != "0"
+_M2 = {"on": None, "map": None}
+
+
+@contextlib.contextmanager
+def gap_with_pool_prepass(num_rois, pooled_size=(7, 7)):
+    prev = _M2["on"]
+    _M2["on"] = (int(num_rois), tuple(pooled_size)) if GAP_FUSE else None
+    try:
+        yield
+    finally:
+        _M2["on"], _M2["map"] = prev, None
+
+
+def _m2_key(x_nhwc_or_feat):
+    t = x_nhwc_or_feat
+    return (t.data_ptr(), t._version, t.dtype, t.numel())
+
+
+def _m2_take(feat, ws_bytes):
+    got, _M2["map"] = _M2["map"], None
+    if got is None or got[0] != _m2_key(feat) or got[1].numel() * got[1].element_size() < ws_bytes:
+        return None
+    return got[1]
+
+
 def global_avgpool_nhwc(x):
     """x: (N,H,W,C) contiguous -> (N,C) fp32."""
     require_gpu(x)
     N, H, W, Cc = x.shape
     out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+    if _M2["on"] is not None and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and N > 0:
+        R, (ph, pw) = _M2["on"]
+        code = dtype_code(x.dtype)
+        # (the pooler's own rule: enough rois to re-read the map many times over, 7 bins wide, ...)
+        if int(lib().wsovod_roi_pool_workspace_bytes(code, NHWC, R, N, Cc, H, W, ph, pw, 0)) > 0:
+            nfl = int(lib().wsovod_max2x2_gap_workspace_floats(code, N, Cc, H, W))
+            if nfl > 0:
+                m2 = torch.empty_like(x)
+                ws = torch.empty((nfl,), dtype=torch.float32, device=x.device)
+                check(lib().wsovod_max2x2_gap_nhwc(ptr(x), code, N, Cc, H, W, ptr(m2), ptr(out), ptr(ws), stream()),
+                      "max2x2_gap")
+                _M2["map"] = (_m2_key(x), m2)
+                return out
     ws = _colsum_workspace(N, N * H * W, Cc, x.device)
     check(lib().wsovod_global_avgpool_nhwc(ptr(x), dtype_code(x.dtype), N, H * W, Cc, ptr(out), ptr(ws), stream()), "gap")
     return out

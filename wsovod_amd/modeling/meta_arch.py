@@ -7,6 +7,7 @@ sub-module names (`backbone`, `data_aware_head`, `roi_heads`) so state dicts are
 The proposals-only branch (rcnn_wsovod.py:198-204) is the hot path; an RPN
 (`MODEL.PROPOSAL_GENERATOR.NAME != "PrecomputedProposals"`) is a SURVEY 8f "next" row.
 """
+import contextlib
 import logging
 from typing import Dict, List, Optional, Tuple
 
@@ -224,10 +225,16 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             return st
         features = self.backbone.forward_uint8(canvas, sizes_t, self._mean, self._std, allow_graph=True)
         st["features"] = features
-        st["gaps"] = self.data_aware_head.pooled_stats(features) if self.data_aware_head is not None else None
-        # with an RPN the box set depends on trainable weights: pooling moves to the trainable part
-        st["pooled"] = self.roi_heads.pool_features(features, st["proposals"]) if self.proposal_generator is None \
-            else None
+        pool_here = self.proposal_generator is None  # with an RPN the box set depends on trainable weights: pooling moves
+        fuse = contextlib.nullcontext()               # to the trainable part
+        if pool_here and self.data_aware_head is not None and getattr(self.roi_heads, "pooler_type", "") == "ROIPool" \
+                and st["proposals"] is not None:
+            # the GAP of the data-aware head and the RoIPool pre-pass read the same res5 map: one pass (layers/hip_ops.py)
+            res = self.roi_heads.box_pooler.output_size
+            fuse = H.gap_with_pool_prepass(sum(len(p) for p in st["proposals"]), (res, res) if isinstance(res, int) else res)
+        with fuse:
+            st["gaps"] = self.data_aware_head.pooled_stats(features) if self.data_aware_head is not None else None
+            st["pooled"] = self.roi_heads.pool_features(features, st["proposals"]) if pool_here else None
         return st
 
     def _heads_kwargs(self, st):
