@@ -448,20 +448,26 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
 // zero the output tiles [first_tile, tiles_i*tiles_j) (same tile id -> (i, j) map as the main kernel) before their
 // K slices are added into them
 __global__ __launch_bounds__(256) void tn_zero_tail_kernel(const TnArgs p) {
-  const int wg = p.full_tiles + blockIdx.x;
+  // 16 workgroups per tile (16 rows each): one workgroup per 256-KB tile took 17 us for the 32 tail tiles of fc1's dW
+  const int wg = p.full_tiles + (blockIdx.x >> 4), part = blockIdx.x & 15;
   const int group_size = p.group_m * p.tiles_j;
   const int group_id = wg / group_size;
   const int first_i = group_id * p.group_m;
   const int gm = min(p.tiles_i - first_i, p.group_m);
   const int in_group = wg - group_id * group_size;
-  const int i0 = (first_i + in_group % gm) * 256, j0 = (in_group / gm) * 256;
-  for (int e = threadIdx.x; e < 256 * 64; e += 256) {
+  const int i0 = (first_i + in_group % gm) * 256 + part * 16, j0 = (in_group / gm) * 256;
+  const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0;
+  for (int e = threadIdx.x; e < 16 * 64; e += 256) {
     const int i = i0 + (e >> 6), j = j0 + (e & 63) * 4;
     if (i >= p.NI) break;
     float* c = p.C + (long long)i * p.ldc + j;
+    if (vec && j + 3 < p.NJ) {
+      *(f32x4*)c = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (j + r < p.NJ) c[r] = 0.f;
+      for (int r = 0; r < 4; ++r)
+        if (j + r < p.NJ) c[r] = 0.f;
+    }
   }
 }
 
@@ -548,7 +554,7 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
       a.ksplit = S;
       a.slice_steps = (ceil_div(nk, S) + 1) & ~1;  // even: the kernel walks K-steps in pairs
       grid = ntiles * S;
-      if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(ntiles), dim3(256), 0, s, a);
+      if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(ntiles * 16), dim3(256), 0, s, a);
     }
   } else if (!(accumulate & 2) && ntiles > cus && tail > 0 && tail <= cus / 2 &&
              !(getenv("WSOVOD_TN_TAIL") && getenv("WSOVOD_TN_TAIL")[0] == '0')) {
@@ -558,7 +564,7 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
       a.ksplit = S;
       a.slice_steps = (ceil_div(nk, S) + 1) & ~1;
       grid = a.full_tiles + tail * S;
-      if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(tail), dim3(256), 0, s, a);
+      if (!a.accumulate) hipLaunchKernelGGL(tn_zero_tail_kernel, dim3(tail * 16), dim3(256), 0, s, a);
     }
   }
   static const int lean = getenv("WSOVOD_TN_LEAN") ? atoi(getenv("WSOVOD_TN_LEAN")) : 2;
