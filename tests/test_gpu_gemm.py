@@ -510,6 +510,57 @@ def test_gemm_split_k_matches_unsplit_tile(gpu):
     torch.testing.assert_close(b16.float(), torch.relu(A.float() @ B.float().t() + bias), rtol=2e-2, atol=0.2)
 
 
+def test_split_k_workspace_outlives_a_captured_graph(gpu):
+    """the split-K workspace grows with the shape.  A HIP graph captured on a SMALL split-K launch
+    keeps the workspace pointer it was captured with; a later, larger split-K launch must retire that block (keep it
+    allocated), never free it, and growing UNDER capture must be refused instead of calling hipMalloc inside the capture.
+    Replays after the growth (and after fresh allocations that would re-use a freed block) still give the eager result."""
+    from wsovod_amd.layers import hip_ops
+
+    torch.manual_seed(5)
+    # sizes nothing else in this process has asked for: 2 / 8 output tiles of 256 x 256 and a long K => split-K slices
+    A1 = (torch.rand(300, 16384 + 128, device=gpu) - 0.5).to(torch.bfloat16)
+    B1 = (torch.rand(260, 16384 + 128, device=gpu) - 0.5).to(torch.bfloat16)
+    want = hip_ops.gemm_nt(A1, B1, out_dtype=torch.float32)  # eager: the workspace now fits this shape
+    out = torch.empty_like(want)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        hip_ops.gemm_nt(A1, B1, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        hip_ops.gemm_nt(A1, B1, out=out)
+    out.zero_()
+    g.replay()
+    assert torch.equal(out, want)
+    # a larger split-K shape, 64 x the workspace: the block the graph points to must stay allocated
+    A2 = (torch.rand(4096, 8192, device=gpu) - 0.5).to(torch.bfloat16)
+    B2 = (torch.rand(2048, 8192, device=gpu) - 0.5).to(torch.bfloat16)
+    big = hip_ops.gemm_nt(A2, B2, out_dtype=torch.float32)
+    torch.testing.assert_close(big, A2.float() @ B2.float().t(), rtol=1e-4, atol=5e-2)
+    junk = [torch.full((1 << 20,), float("nan"), device=gpu) for _ in range(16)]  # would land in a freed block
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    del junk
+    # growing under capture is refused (the capture fails loudly; nothing is allocated inside it)
+    A3 = (torch.rand(8192, 8192, device=gpu) - 0.5).to(torch.bfloat16)
+    B3 = (torch.rand(4096, 8192, device=gpu) - 0.5).to(torch.bfloat16)
+    out3 = torch.empty(8192, 4096, device=gpu)
+    g3 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="split-K workspace"):
+        with torch.cuda.graph(g3, capture_error_mode="thread_local"):
+            hip_ops.gemm_nt(A3, B3, out=out3)
+    torch.cuda.synchronize()
+    got3 = hip_ops.gemm_nt(A3, B3, out=out3)  # eagerly it grows and runs
+    torch.testing.assert_close(got3, A3.float() @ B3.float().t(), rtol=1e-4, atol=5e-2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("k,dil", [(3, 2), (1, 1)])
 def test_conv_with_fused_projection_shortcut(gpu, dtype, tol, k, dil):

@@ -191,6 +191,60 @@ def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision
         torch.testing.assert_close(runs["1"][1][k], v, rtol=1e-5, atol=2e-6 * float(v.abs().max()) + 1e-9, msg=lambda m: f"{k}: {m}")
 
 
+@pytest.mark.parametrize("precision", ["bf16", "parity"])
+def test_mixed_dataset_model_replays_one_graph_per_source(gpu, monkeypatch, precision):
+    """BASELINE config 5's model (rcnn_wsovod_mixed_datasets.py:188-191,237-238): a batch's `dataset_id` picks the object
+    miner, the class count and the text embeddings of the step.  The step graph is keyed on (source, layout): twelve steps
+    alternating between a 20-class and an 80-class source (different miners, different K, dropout ON) with the graphs
+    against WSOVOD_STEP_GRAPH=0 -- labels / pseudo-GT indices equal step by step, losses and trained parameters (BOTH miners,
+    the shared neck and refinement head) to the eager path's jitter; the miner of the source that is NOT in the batch gets no
+    update in either run."""
+    from wsovod_amd.data import make_batch
+    from wsovod_amd.engine import HotPathTrainer, build_optimizer
+    from wsovod_amd.engine.trainer import _StepGraph
+    from wsovod_amd.layers import hip_ops as H
+    from wsovod_amd.testing import build_mixed_model
+
+    monkeypatch.setattr(H, "DETERMINISTIC", True)
+    monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", "0")
+    Ks = (20, 20, 80)
+    order = [0, 2, 0, 2, 2, 0, 0, 2, 0, 2, 2, 0]
+    batches = []
+    for s, src in enumerate(order):
+        b = make_batch(2, 64, Ks[src], H=160, W=224, seed=300 + s)
+        for x in b:
+            x["dataset_id"] = src
+        batches.append(b)
+    runs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("WSOVOD_STEP_GRAPH", flag)
+        cfg, model = build_mixed_model(seed=0, Ks=Ks, precision=precision, device="cuda:0")
+        model.train()
+        cfg.SOLVER.BASE_LR = 1e-3
+        tr = HotPathTrainer(model, build_optimizer(cfg, model))
+        hist = []
+        for b, src in zip(batches, order):
+            losses = tr.run_step(b)
+            assert model.roi_heads.num_classes == Ks[src]  # (a replay leaves the heads on its source, as an eager step does)
+            pgt = model.roi_heads._last_pgt
+            t = int(sum(len(torch.unique(x["instances"].gt_classes)) for x in b))
+            hist.append(({k: float(v.detach()) for k, v in losses.items()}, pgt["gt_classes"][:128].cpu().clone(),
+                         pgt["pgt_index"][:t].cpu().clone(), pgt["pgt_classes"][:t].cpu().clone()))
+        if flag == "1":
+            assert sorted(k[-2] for k in tr._graphs) == [0, 2] and all(type(g) is _StepGraph for g in tr._graphs.values())
+        else:
+            assert not tr._graphs
+        tr.flush()
+        runs[flag] = (hist, {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad})
+        tr.close()
+    for s, (e, g) in enumerate(zip(runs["0"][0], runs["1"][0])):
+        assert torch.equal(e[1], g[1]) and torch.equal(e[2], g[2]) and torch.equal(e[3], g[3]), s
+        for k in e[0]:
+            assert abs(e[0][k] - g[0][k]) <= 2e-5 * max(abs(e[0][k]), 1e-3), (s, k, e[0][k], g[0][k])
+    for k, v in runs["0"][1].items():
+        torch.testing.assert_close(runs["1"][1][k], v, rtol=1e-5, atol=2e-6 * float(v.abs().max()) + 1e-9, msg=lambda m: f"{k}: {m}")
+
+
 def test_step_graph_falls_back_and_respects_its_limits(gpu, monkeypatch):
     """A layout is captured on its third sighting; another total proposal count is another graph; nine images stay
     eager; state_dict() between replays sees the applied update; a failing capture leaves the layout on the eager path

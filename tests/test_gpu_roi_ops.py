@@ -325,11 +325,11 @@ def test_gap_fused_with_the_pool_prepass(gpu, dtype, C, Hh, Ww):
     gap_plain = H.global_avgpool_nhwc(nhwc)
     with H.gap_with_pool_prepass(rois.size(0), (7, 7)):
         gap = H.global_avgpool_nhwc(nhwc)
-        assert H._M2["map"] is not None  # (700 rois on this map: the pooler's rule asks for the 2x2-max map)
+        assert H._M2.map is not None  # (700 rois on this map: the pooler's rule asks for the 2x2-max map)
         fused, _ = H.roi_pool_forward(feat, rois, 0.125, (7, 7), need_argmax=False)
-        assert H._M2["map"] is None      # taken
+        assert H._M2.map is None      # taken
         gap2 = H.global_avgpool_nhwc(nhwc)
-        H._M2["map"] = None
+        H._M2.map = None
     assert torch.equal(plain.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
                        fused.view(torch.int16 if dtype == torch.bfloat16 else torch.int32))
     assert torch.equal(gap.view(torch.int32), gap2.view(torch.int32))

@@ -788,7 +788,7 @@ template <bool WREG>
 __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int tiles_x, int tiles_y, int n_tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sW = smem;                  // 9 x [64 cout][128 B]
-  char* sP = smem + C64P_W_BYTES;   // 2 x halo patch [pixel][128 B]
+  [[maybe_unused]] char* sP = smem + C64P_W_BYTES;   // 2 x halo patch [pixel][128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fq = lane >> 4;
   const int tpi = tiles_x * tiles_y;
@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
   if constexpr (!WREG) c64_load_bias(p, fq, bias4);
   const bool res_pre = c64_residual_preloadable(p);
   __syncthreads();  // weights and the first patch have landed (hipcc drains vmcnt(0) in front of the barrier)
-  u32x4 wa[WREG ? 8 : 1][2][4], wv[2][4];  // WREG: this lane's weight fragments, taps 0-7 (AGPRs) and tap 8 (VGPRs)
+  [[maybe_unused]] u32x4 wa[WREG ? 8 : 1][2][4], wv[2][4];  // WREG: this lane's weight fragments, taps 0-7 (AGPRs) and tap 8 (VGPRs)
   unsigned aoff12[4][3];
   if constexpr (WREG) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
     // `on` false) the offset is out of range and the DMA writes zeros.  About ten VALU instructions: issued one at a time
     // between the MFMA steps they hide in the matrix pipe's shadow, and the request never meets a full address FIFO
     // (44 requests of a workgroup in one burst cost each wavefront ~1.2 k cycles of issue stalls: profiles/r03_c64_wreg.md).
-    const int rq = tid >> 3, rc = tid & 7;
+    [[maybe_unused]] const int rq = tid >> 3, rc = tid & 7;
     auto stage_one = [&](const TileAt at, unsigned lds_base, int k, bool on) {
 #if defined(__HIP_DEVICE_COMPILE__)
       const int q = k * 32 + rq;
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
     TileAt at0 = tile_at(tile), at1 = tile_at(tile + stride), at2 = tile_at(tile + 2 * stride);  // tiles t, t+1, t+2
     if (tile + stride < n_tiles) stage_patch_r(at1, pb1);
     if (p.residual) load_residual(at0);
-    u32x4 fa[2][4];
+    [[maybe_unused]] u32x4 fa[2][4];
     unsigned pbase = pb0;
     C64R_RD_A(0, 0, 0, 0); C64R_RD_A(0, 1, 0, 0); C64R_RD_A(0, 2, 0, 0); C64R_RD_A(0, 3, 0, 0);
 #if (C64P_ABL & 64)
@@ -1237,7 +1237,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned pbase = ldsP + (unsigned)(cur * C64_PATCH_BYTES);
+    [[maybe_unused]] const unsigned pbase = ldsP + (unsigned)(cur * C64_PATCH_BYTES);
     bf16x8 rres[4][2];
     if (res_pre) c64_load_residual(p, img, y0, x0, wave, frow, fq, rres);
     u32x4 fa[2][4], fb[2][4];

@@ -23,6 +23,7 @@
 // Same XOR swizzle (chunk ^ ((row >> 1) & 7), applied to the DMA source address and to the read address), XCD-aware
 // grouped tile order and epilogue as gemm.hip.
 #include "gemm_common.h"
+#include <vector>
 
 namespace wsovod_gemm {
 
@@ -868,19 +869,32 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   if (allow_split && ntiles <= 128 && nk >= 32) {
     const int S = std::min(std::min(8, 256 / ntiles), nk / 16);
     if (S >= 2) {
+      // Workspace of this process (single-stream use, as the rest of the library).  A captured HIP graph keeps the
+      // pointer it was captured with, so a block is NEVER freed once handed out: when a larger one is needed the old
+      // block is retired (kept allocated; sizes double, so all retired blocks together are smaller than the live one,
+      // and the largest possible request is 8 slices x 128 tiles = 268 MB), and growing under stream capture is refused
+      // instead of calling hipMalloc inside the capture (the conv forms make `need` shape-dependent).
       static float* ws = nullptr;
       static size_t ws_bytes = 0;
+      static std::vector<float*> retired;
       const long long ldp = ((long long)a.N + 3) / 4 * 4;
       const size_t need = (size_t)S * (a.M - a.m_base) * ldp * sizeof(float);
-      if (need > ws_bytes) {  // grow-only workspace of this process (single-stream use, as the rest of the library)
-        if (ws) (void)hipFree(ws);
-        ws = nullptr;
-        ws_bytes = 0;
-        if (hipMalloc((void**)&ws, need) != hipSuccess) {
+      if (need > ws_bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+          wsovod::set_error("wsovod_gemm_nt: the split-K workspace would have to grow under stream capture; run the "
+                            "shape once outside the capture first");
+          return WSOVOD_ERR_UNSUPPORTED;
+        }
+        const size_t want = std::max(need, 2 * ws_bytes);
+        float* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, want) != hipSuccess) {
           wsovod::set_error("wsovod_gemm_nt: cannot allocate the split-K workspace");
           return WSOVOD_ERR_HIP;
         }
-        ws_bytes = need;
+        if (ws) retired.push_back(ws);
+        ws = fresh;
+        ws_bytes = want;
       }
       args.ksplit = S;
       args.slice_steps = ceil_div(nk, S);

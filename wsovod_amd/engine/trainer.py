@@ -250,6 +250,9 @@ class _StepGraph:
         nums = [len(x["proposals"]) for x in batched_inputs]
         rows = trainer.row_bucket(sum(nums))  # the graph runs on this many rows; the steps' own totals may be anything below
         self.rows = rows
+        self.source = key[-2]
+        if self.source is not None:  # mixed-dataset model: the class count of THIS graph's source sizes the label buffers
+            model.roi_heads.select_source(self.source)
         self.boxes = torch.zeros((rows, 4), dtype=torch.float32, device=dev)
         self.objectness = torch.zeros((rows,), dtype=torch.float32, device=dev)
         groups = trainer.optimizer.param_groups
@@ -359,6 +362,7 @@ class _StepGraph:
             for p, v in dw:
                 p._dw_split = v
         self.losses = {k: v.detach() for k, v in loss_dict.items()}
+        self.last_pgt = getattr(model.roi_heads, "_last_pgt", None)  # this graph's static label / pseudo-GT buffers
         del st, loss_dict
         self.fresh = True  # the Python side of this step (counters, version stamps) ran during the capture
 
@@ -394,6 +398,13 @@ class _StepGraph:
             tr._stamp_hyper()
             if not tr.overlap:
                 tr._wait_pending()
+        # the Python-side state an eager step would have left: the heads' source (mixed-dataset model) and the step's
+        # label / pseudo-GT record (with several graphs in rotation each has its own static buffers)
+        rh = tr.model.roi_heads
+        if self.source is not None:
+            rh.select_source(self.source)
+        if self.last_pgt is not None:
+            rh._last_pgt = self.last_pgt
         # fresh tensors, as the eager path returns: the static loss buffers are overwritten by the next replay
         return {k: v.clone() for k, v in self.losses.items()}
 
@@ -582,7 +593,7 @@ class HotPathTrainer:
         """Bracket, from now on, (a) the wait for the previous step's gradient exchange and (b) the frozen forward it is
         meant to hide behind with hipEvents on the compute stream (two event records per step each: no synchronisation,
         no host read until stats())."""
-        self._stats = {"wait": [], "frozen": [], "steps": 0} if on else None
+        self._stats = {"wait": [], "frozen": [], "wait_ms": 0.0, "frozen_ms": 0.0, "steps": 0} if on else None
 
     def _bracket(self, kind):
         st = self._stats
@@ -590,7 +601,11 @@ class HotPathTrainer:
             return None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        st[kind].append((e0, e1))
+        pairs = st[kind]
+        while len(pairs) >= 256 and pairs[0][1].query():  # a long run keeps running sums, not one event pair per step
+            a, b = pairs.pop(0)
+            st[kind + "_ms"] += a.elapsed_time(b)
+        pairs.append((e0, e1))
         return e1
 
     def stats(self):
@@ -610,8 +625,8 @@ class HotPathTrainer:
             else:
                 wire = sum(p.numel() for p in self.params) * 4
         return {"steps": st["steps"],
-                "exchange_wait_ms": sum(a.elapsed_time(b) for a, b in st["wait"]) / n,
-                "overlap_window_ms": sum(a.elapsed_time(b) for a, b in st["frozen"]) / n,
+                "exchange_wait_ms": (st["wait_ms"] + sum(a.elapsed_time(b) for a, b in st["wait"])) / n,
+                "overlap_window_ms": (st["frozen_ms"] + sum(a.elapsed_time(b) for a, b in st["frozen"])) / n,
                 "wire_bytes_per_step": wire, "wire": self.grad_wire if self.exchange else None,
                 "exchange": self.exchange_algo, "world": self.world,
                 # a ring moves 2 (N-1)/N of the buffer over each GPU's links, the direct form the same bytes one hop
@@ -832,16 +847,27 @@ class HotPathTrainer:
 
     def _graph_key(self, data):
         m = self.model
+        # (reduce_unused only matters where gradients are exchanged: at world = 1 the mixed-dataset model's unused miners
+        # simply have no gradient and the captured SGD launch lists the tensors that do)
         if not (self.graph_max_batch and 0 < len(data) <= self.graph_max_batch and self.iter_size == 1
-                and not self.reduce_unused and isinstance(self.optimizer, HipSGD)
+                and not (self.reduce_unused and self.exchange) and isinstance(self.optimizer, HipSGD)
                 and getattr(m, "proposal_generator", True) is None and hasattr(m, "forward_frozen")
                 and (not self.exchange or self.grad_wire == "bf16")):
             return None
         x0 = data[0]
         if "proposals" not in x0 or "instances" not in x0 or not torch.is_tensor(x0.get("image")):
             return None
-        if hasattr(m, "classifier_train") or "dataset_id" in x0:
-            return None  # mixed-dataset model: miner, class count and text embeddings change with the batch's source
+        source = None
+        if hasattr(m, "classifier_train"):
+            # mixed-dataset model (rcnn_wsovod_mixed_datasets.py:188-191,237-238): the batch's source picks the object miner,
+            # the class count and the text embeddings handed to the refinement head -- all three are STATIC per source, so
+            # the source is part of the layout: one graph per (source, layout), replayed when that source comes round again
+            ids = {int(x.get("dataset_id", 0)) for x in data}
+            if len(ids) != 1:
+                return None
+            source = ids.pop()
+            if not 0 <= source < len(m.classifier_train) or not hasattr(m.roi_heads, "num_classes_list"):
+                return None
         if getattr(getattr(m, "backbone", None), "has_trainable_stage", False):
             return None  # FREEZE_AT < 5: the stage's backward is torch autograd over MIOpen convs, not capturable launches
         shape = tuple(x0["image"].shape)
@@ -859,7 +885,8 @@ class HotPathTrainer:
         if not getattr(rh, "sampling_on", False) or rows > min(rh.batch_size_per_images[:rh.refine_K] or [0]) \
                 or any(f < 1.0 for f in rh.positive_sample_fractions[:rh.refine_K]):
             return None
-        return (len(data), shape, rows, rh.num_classes, self.exchange_algo, m.training)
+        K = rh.num_classes if source is None else rh.num_classes_list[source]
+        return (len(data), shape, rows, K, self.exchange_algo, source, m.training)
 
     @staticmethod
     def row_bucket(rows):

@@ -235,6 +235,17 @@ def x2_planar_of(x):
     return bool(b is not None and b.data_ptr() == x.data_ptr() and b.numel() == x.numel() and getattr(b, "_x2_planar", False))
 
 
+def _refuse_undeclared_planar(who, *tensors, declared=False):
+    """The planar layout changes what the BYTES of a carrier mean and is recorded on the tensor object only: a consumer that
+    reads interleaved bf16x2 must refuse a planar carrier instead of contracting garbage."""
+    if declared:
+        return
+    for t in tensors:
+        if t is not None and x2_planar_of(t):
+            raise RuntimeError(f"wsovod_hip {who}: got a PLANAR bf16x2 carrier where the interleaved layout is read "
+                               "(only the first FC layer's forward takes a_planar=True; x2_to_f32 decodes either layout)")
+
+
 def x2_to_f32(x):
     """fp32 values of a bf16x2 tensor in either layout (tests, debugging)."""
     if x2_planar_of(x):
@@ -246,7 +257,8 @@ def x2_to_f32(x):
 
 # round 5: with `want_hi` (training, "parity") the poolers write PLANAR bf16x2 instead of the interleaved layout plus a plain
 # bf16 copy (WSOVOD_X2_PLANAR=0: the round-4 form, for A/B runs)
-X2_PLANAR = os.environ.get("WSOVOD_X2_PLANAR", "1") != "0"
+# (only the LEAN two-phase tile reads the planar form: WSOVOD_G8_LEAN=0 therefore also selects the round-4 layout)
+X2_PLANAR = os.environ.get("WSOVOD_X2_PLANAR", "1") != "0" and os.environ.get("WSOVOD_G8_LEAN", "1") != "0"
 POISON_OUTPUTS = os.environ.get("WSOVOD_POISON_OUTPUTS", "0") == "1"
 POISON_BYTE = 0x7F
 
@@ -397,6 +409,7 @@ def x2_encode(src, out=None):
 def x2_decode(src):
     """bf16x2 (rows, cols) -> the fp32 values hi + lo (tests, debugging)."""
     require_gpu(src)
+    _refuse_undeclared_planar("x2_decode", src)  # (x2_to_f32 reads either layout)
     rows, cols = src.shape
     out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
     check(lib().wsovod_bf16x2_decode(ptr(src), src.stride(0), rows, cols, ptr(out), out.stride(0), stream()), "bf16x2_decode")
@@ -545,6 +558,8 @@ def gemm_nt(A, B, *, out=None, out_dtype=None, out_t=None, alpha=1.0, row_scale=
     Returns `out` (or None if want_c is False).
     """
     require_gpu(A, B, out, out_t, row_scale, bias, residual, row_group, group_add, mask_src)
+    _refuse_undeclared_planar("gemm_nt", A, declared=a_planar)
+    _refuse_undeclared_planar("gemm_nt", B, A2)
     if x2 and (A.dtype != torch.float32 or B.dtype != torch.float32):
         raise RuntimeError("wsovod_hip gemm: bf16x2 operands travel as float32-typed tensors")
     if not x2 and _X3State.active and A.dtype == torch.float32 and B.dtype == torch.float32:
@@ -681,17 +696,24 @@ def _colsum_workspace(G, M, N, device):
 # (wsovod_max2x2_gap_nhwc) and parks them; the next roi_pool_forward on THAT map (same storage, version and shape) takes
 # them instead of running its own pre-pass.  WSOVOD_GAP_FUSE=0 switches it off (A/B runs).
 GAP_FUSE = os.environ.get("WSOVOD_GAP_FUSE", "1") != "0"
-_M2 = {"on": None, "map": None}
+
+
+class _M2State(threading.local):  # per thread, as the x3 mode and the want-hi flag: an eval / TTA thread calling the GAP or
+    on = None                     # the pooler while the training thread is inside the context must not see (or steal) its map
+    map = None
+
+
+_M2 = _M2State()
 
 
 @contextlib.contextmanager
 def gap_with_pool_prepass(num_rois, pooled_size=(7, 7)):
-    prev = _M2["on"]
-    _M2["on"] = (int(num_rois), tuple(pooled_size)) if GAP_FUSE else None
+    prev = _M2.on
+    _M2.on = (int(num_rois), tuple(pooled_size)) if GAP_FUSE else None
     try:
         yield
     finally:
-        _M2["on"], _M2["map"] = prev, None
+        _M2.on, _M2.map = prev, None
 
 
 def _m2_key(x_nhwc_or_feat):
@@ -700,7 +722,7 @@ def _m2_key(x_nhwc_or_feat):
 
 
 def _m2_take(feat, ws_bytes):
-    got, _M2["map"] = _M2["map"], None
+    got, _M2.map = _M2.map, None
     if got is None or got[0] != _m2_key(feat) or got[1].numel() * got[1].element_size() < ws_bytes:
         return None
     return got[1]
@@ -711,8 +733,8 @@ def global_avgpool_nhwc(x):
     require_gpu(x)
     N, H, W, Cc = x.shape
     out = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
-    if _M2["on"] is not None and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and N > 0:
-        R, (ph, pw) = _M2["on"]
+    if _M2.on is not None and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and N > 0:
+        R, (ph, pw) = _M2.on
         code = dtype_code(x.dtype)
         # (the pooler's own rule: enough rois to re-read the map many times over, 7 bins wide, ...)
         if int(lib().wsovod_roi_pool_workspace_bytes(code, NHWC, R, N, Cc, H, W, ph, pw, 0)) > 0:
@@ -722,7 +744,7 @@ def global_avgpool_nhwc(x):
                 ws = torch.empty((nfl,), dtype=torch.float32, device=x.device)
                 check(lib().wsovod_max2x2_gap_nhwc(ptr(x), code, N, Cc, H, W, ptr(m2), ptr(out), ptr(ws), stream()),
                       "max2x2_gap")
-                _M2["map"] = (_m2_key(x), m2)
+                _M2.map = (_m2_key(x), m2)
                 return out
     ws = _colsum_workspace(N, N * H * W, Cc, x.device)
     check(lib().wsovod_global_avgpool_nhwc(ptr(x), dtype_code(x.dtype), N, H * W, Cc, ptr(out), ptr(ws), stream()), "gap")
@@ -1092,6 +1114,7 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=F
     contraction over the operands' slow index, no transposed copies (transposed LDS reads).
     split_tail=False keeps a partial last round of tiles unsplit (fixed summation order, bit-reproducible)."""
     require_gpu(P, Q, out)
+    _refuse_undeclared_planar("gemm_tn", P, Q)  # (the hi plane of a planar carrier is passed as its own bf16 view)
     split_tail = split_tail and not DETERMINISTIC
     # q_x2: Q is a bf16x2 matrix (fp32-typed carrier); the kernel reads the hi halves = Q rounded to bf16
     assert P.dtype == torch.bfloat16 and Q.dtype == (torch.float32 if q_x2 else torch.bfloat16) and P.shape[0] == Q.shape[0]

@@ -16,6 +16,7 @@ re-evaluated from its saved input with torch's GPU convolution (MIOpen) under au
 the stage's weights and of its input.  Never a CPU path; tests/test_gpu_freeze_at.py pins it to the reference (G19).
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -358,9 +359,24 @@ def _torch_block(block, x):
     return out
 
 
+_WARNED_TRAINABLE = set()
+
+
+def _warn_trainable_stage_once(name):
+    if name not in _WARNED_TRAINABLE:
+        _WARNED_TRAINABLE.add(name)
+        warnings.warn(f"wsovod_amd: backbone stage {name} is trainable (MODEL.BACKBONE.FREEZE_AT < 5): its backward re-evaluates "
+                      "the stage in fp32 torch ops (MIOpen) and the step leaves the optimised path -- no frozen-forward "
+                      "overlap, no step graph, no backbone graph (DESIGN.md section 7)", stacklevel=3)
+
+
 class _TrainableStage(torch.autograd.Function):
     """One backbone stage with trainable weights.  forward: the HIP kernels (as for a frozen stage).  backward: the
-    stage re-evaluated from its saved input in fp32 torch ops on the GPU under autograd -> d input, d weights."""
+    stage re-evaluated from its saved input in fp32 torch ops on the GPU under autograd -> d input, d weights.
+    The re-evaluation is fp32 while the forward that produced the loss ran in the model's precision (bf16 / bf16x2): a ReLU
+    mask or max-pool winner of the recomputation can differ from the forward's where two candidates lie within the
+    forward's rounding, so the gradient is that of a slightly different function (bf16: up to ~15 % on single elements,
+    tests/test_gpu_freeze_at.py; fp32 / parity: at the oracle's tolerance)."""
 
     @staticmethod
     def forward(ctx, stage, x3, x, *params):
@@ -458,13 +474,21 @@ class ResNet(nn.Module):
             cached = self._params_cache = list(self.parameters())
         return cached
 
+    def _stage_params(self, stage):
+        cache = self.__dict__.setdefault("_stage_params_cache", {})
+        got = cache.get(id(stage))
+        if got is None:  # (fixed after construction, as _param_list)
+            got = cache[id(stage)] = list(stage.parameters())
+        return got
+
     def _run(self, x):
         outputs = {}
         if "stem" in self._out_features:
             outputs["stem"] = x.permute(0, 3, 1, 2)
         for name, stage in zip(self.stage_names, self.stages):
-            params = [p for p in stage.parameters()]
+            params = self._stage_params(stage)
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                _warn_trainable_stage_once(name)
                 x = _TrainableStage.apply(stage, H.x3_active(), x, *params)
             else:
                 with torch.no_grad():
