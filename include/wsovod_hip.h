@@ -413,6 +413,25 @@ int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, i
  * activations its forward pass left in bf16x2, without a cast pass. */
 int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
                       float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
+/* The weight-gradient contraction FUSED with the optimizer step of that weight (round 6): the tile's gradient
+ *   g = alpha * sum_m P[m][i] * Q[m][j] * grad_scale
+ * never goes to memory; the epilogue applies torch.optim.SGD's update (momentum, weight decay, dampening 0 -- the arithmetic
+ * of wsovod_sgd_momentum_multi, engine/defaults.py:274-318 of the reference) to param (NI, NJ) fp32 contiguous in place:
+ *   buf = momentum * buf + (g + weight_decay * param);  param -= lr * buf;  shadow refreshed (bf16 or bf16x2 copy).
+ * Replaces, for ONE large weight at small batches, the pair (dW = dY^T X under autograd, box_head.py:60-75) + (the
+ * optimizer's pass over that tensor, engine/trainer.py:72-84): 16 - 20 bytes per parameter instead of 28 - 32.  Whole tiles
+ * only (no reduction slices: fixed summation order).  The caller owns the schedule: no clipping, no accumulation
+ * (ITER_SIZE 1), no gradient exchange may be pending on this tensor (HotPathTrainer installs it at world = 1 only). */
+typedef struct wsovod_tn_sgd {
+  float* param;
+  float* momentum_buf;
+  void* shadow;          /* optional bf16 / bf16x2 copy of param (NULL = none) */
+  int shadow_is_bf16x2;
+  float lr, weight_decay, momentum, grad_scale;
+  const float* lr_dev;   /* optional DEVICE scalar read instead of lr (captured step graphs) */
+} wsovod_tn_sgd;
+int wsovod_gemm_tn_sgd(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
+                       float alpha, const wsovod_tn_sgd* update, wsovod_stream_t stream);
 
 /* Greedy non-maximum suppression over G independent segments of boxes that are already sorted by
  * descending score inside each segment.  Replaces torchvision.ops.nms / batched_nms (un-vendored; SURVEY

@@ -510,55 +510,66 @@ def test_gemm_split_k_matches_unsplit_tile(gpu):
     torch.testing.assert_close(b16.float(), torch.relu(A.float() @ B.float().t() + bias), rtol=2e-2, atol=0.2)
 
 
+_WS_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from wsovod_amd.layers import hip_ops
+gpu = torch.device("cuda", 0)
+torch.manual_seed(5)
+# 2 x 2 output tiles of 256 x 256 and a long K => split-K slices; a FRESH process: the workspace starts empty
+A1 = (torch.rand(300, 16384 + 128, device=gpu) - 0.5).to(torch.bfloat16)
+B1 = (torch.rand(260, 16384 + 128, device=gpu) - 0.5).to(torch.bfloat16)
+want = hip_ops.gemm_nt(A1, B1, out_dtype=torch.float32)  # eager: the workspace now fits this shape (2.5 MB)
+out = torch.empty_like(want)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    hip_ops.gemm_nt(A1, B1, out=out)
+torch.cuda.current_stream().wait_stream(side)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    hip_ops.gemm_nt(A1, B1, out=out)
+out.zero_(); g.replay()
+assert torch.equal(out, want), "replay != eager"
+# a larger split-K shape (128 tiles x 2 slices = 67 MB of partial sums): growing UNDER capture is refused ...
+A2 = (torch.rand(4096, 8192, device=gpu) - 0.5).to(torch.bfloat16)
+B2 = (torch.rand(2048, 8192, device=gpu) - 0.5).to(torch.bfloat16)
+out2 = torch.empty(4096, 2048, device=gpu)
+g2 = torch.cuda.CUDAGraph()
+try:
+    with torch.cuda.graph(g2, capture_error_mode="thread_local"):
+        hip_ops.gemm_nt(A2, B2, out=out2)
+    raise SystemExit("growing the workspace under capture was not refused")
+except RuntimeError as e:
+    assert "split-K workspace" in str(e), str(e)
+torch.cuda.synchronize()
+# ... eagerly it grows: the block the first graph points to must stay allocated (retired, never freed)
+big = hip_ops.gemm_nt(A2, B2, out=out2)
+torch.testing.assert_close(big, A2.float() @ B2.float().t(), rtol=1e-4, atol=5e-2)
+junk = [torch.full((1 << 20,), float("nan"), device=gpu) for _ in range(16)]  # would land in a freed block
+out.zero_(); g.replay(); torch.cuda.synchronize()
+assert torch.equal(out, want), "replay after the growth != eager"
+g3 = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g3):  # the grown workspace serves the capture now
+    hip_ops.gemm_nt(A2, B2, out=out2)
+out2.zero_(); g3.replay(); g.replay(); torch.cuda.synchronize()
+assert torch.equal(out2, big) and torch.equal(out, want)
+print("WS_OK")
+"""
+
+
 def test_split_k_workspace_outlives_a_captured_graph(gpu):
     """the split-K workspace grows with the shape.  A HIP graph captured on a SMALL split-K launch
     keeps the workspace pointer it was captured with; a later, larger split-K launch must retire that block (keep it
     allocated), never free it, and growing UNDER capture must be refused instead of calling hipMalloc inside the capture.
-    Replays after the growth (and after fresh allocations that would re-use a freed block) still give the eager result."""
-    from wsovod_amd.layers import hip_ops
+    Runs in a fresh process (the workspace is process-wide and other tests may already have grown it to its maximum)."""
+    import os
+    import subprocess
+    import sys
 
-    torch.manual_seed(5)
-    # sizes nothing else in this process has asked for: 2 / 8 output tiles of 256 x 256 and a long K => split-K slices
-    A1 = (torch.rand(300, 16384 + 128, device=gpu) - 0.5).to(torch.bfloat16)
-    B1 = (torch.rand(260, 16384 + 128, device=gpu) - 0.5).to(torch.bfloat16)
-    want = hip_ops.gemm_nt(A1, B1, out_dtype=torch.float32)  # eager: the workspace now fits this shape
-    out = torch.empty_like(want)
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        hip_ops.gemm_nt(A1, B1, out=out)
-    torch.cuda.current_stream().wait_stream(side)
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        hip_ops.gemm_nt(A1, B1, out=out)
-    out.zero_()
-    g.replay()
-    assert torch.equal(out, want)
-    # a larger split-K shape, 64 x the workspace: the block the graph points to must stay allocated
-    A2 = (torch.rand(4096, 8192, device=gpu) - 0.5).to(torch.bfloat16)
-    B2 = (torch.rand(2048, 8192, device=gpu) - 0.5).to(torch.bfloat16)
-    big = hip_ops.gemm_nt(A2, B2, out_dtype=torch.float32)
-    torch.testing.assert_close(big, A2.float() @ B2.float().t(), rtol=1e-4, atol=5e-2)
-    junk = [torch.full((1 << 20,), float("nan"), device=gpu) for _ in range(16)]  # would land in a freed block
-    out.zero_()
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(out, want)
-    del junk
-    # growing under capture is refused (the capture fails loudly; nothing is allocated inside it)
-    A3 = (torch.rand(8192, 8192, device=gpu) - 0.5).to(torch.bfloat16)
-    B3 = (torch.rand(4096, 8192, device=gpu) - 0.5).to(torch.bfloat16)
-    out3 = torch.empty(8192, 4096, device=gpu)
-    g3 = torch.cuda.CUDAGraph()
-    with pytest.raises(RuntimeError, match="split-K workspace"):
-        with torch.cuda.graph(g3, capture_error_mode="thread_local"):
-            hip_ops.gemm_nt(A3, B3, out=out3)
-    torch.cuda.synchronize()
-    got3 = hip_ops.gemm_nt(A3, B3, out=out3)  # eagerly it grows and runs
-    torch.testing.assert_close(got3, A3.float() @ B3.float().t(), rtol=1e-4, atol=5e-2)
-    g.replay()
-    torch.cuda.synchronize()
-    assert torch.equal(out, want)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "WS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])

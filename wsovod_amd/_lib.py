@@ -52,7 +52,7 @@ class ProfEntry(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
-ABI_VERSION = 7  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
+ABI_VERSION = 8  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
 
 # name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
 SIGNATURES = {
@@ -110,6 +110,7 @@ SIGNATURES = {
     "wsovod_format_rois": [_P, _P, _I, _I, _P, _P, _P, _P],
     "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_gemm_tn_ex": [_P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _F, _I, _P],
+    "wsovod_gemm_tn_sgd": [_P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _P],
     "wsovod_mask_transpose_ex": [_P, _L, _I, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P, _P],
     "wsovod_bf16x2_encode": [_P, _L, _I, _I, _P, _L, _P],
     "wsovod_bf16x2_decode": [_P, _L, _I, _I, _P, _L, _P],
@@ -126,6 +127,13 @@ class SgdTensor(C.Structure):
                 ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
                 ("shadow_is_bf16x2", C.c_int), ("used_flag", C.c_void_p), ("grad_coef", C.c_void_p),
                 ("clip_value", C.c_float), ("lr_dev", C.c_void_p)]
+
+
+class TnSgd(C.Structure):
+    """wsovod_tn_sgd (include/wsovod_hip.h)."""
+    _fields_ = [("param", C.c_void_p), ("momentum_buf", C.c_void_p), ("shadow", C.c_void_p), ("shadow_is_bf16x2", C.c_int),
+                ("lr", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float), ("grad_scale", C.c_float),
+                ("lr_dev", C.c_void_p)]
 
 
 class PackTensor(C.Structure):

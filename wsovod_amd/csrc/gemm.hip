@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64p_kernel(const GemmArgs p, int
     if (tile + stride < n_tiles) stage_patch_r(at1, pb1);
     if (p.residual) load_residual(at0);
     [[maybe_unused]] u32x4 fa[2][4];
-    unsigned pbase = pb0;
+    [[maybe_unused]] unsigned pbase = pb0;
     C64R_RD_A(0, 0, 0, 0); C64R_RD_A(0, 1, 0, 0); C64R_RD_A(0, 2, 0, 0); C64R_RD_A(0, 3, 0, 0);
 #if (C64P_ABL & 64)
     long long tph[5] = {0, 0, 0, 0, 0}, tmark = (long long)__builtin_amdgcn_s_memtime();

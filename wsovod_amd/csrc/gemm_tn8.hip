@@ -43,6 +43,12 @@ struct TnArgs {
 #endif
   int q_x2;  // Q is a bf16x2 matrix (include/wsovod_hip.h): only the hi halves of its values are read, column k at bf16
              // slot 64 (k / 32) + k % 32 of the row; ldq is then counted in bf16 slots (2 per value)
+  // SGD form (wsovod_gemm_tn_sgd): C is the PARAMETER itself; the tile's gradient never goes to memory
+  float* mom;            // momentum buffer, the parameter's shape
+  bf16_t* shadow;        // optional bf16 / bf16x2 operand copy of the parameter, refreshed in the same pass
+  int shadow_x2;
+  float lr, wd, mu, gscale;
+  const float* lr_dev;   // optional device scalar read instead of lr
 };
 
 // LEAN = 1 (round 5): the same schedule with the per-phase address arithmetic removed from the half of a phase that the
@@ -60,7 +66,7 @@ __device__ __forceinline__ void tr_read_imm(__attribute__((ext_vector_type(2))) 
 #endif
 }
 
-template <int LEAN>
+template <int LEAN, bool SGD = false>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   constexpr int BI = 256, BJ = 256, BK = 64;
   constexpr int OP_BYTES = 2 * BK * 256;        // one operand of one K-step: 2 sub-images x 64 rows x 256 B
@@ -420,6 +426,62 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
     }
     return;
   }
+  if constexpr (SGD) {
+    // ---- the momentum-SGD update of this tile applied from the accumulators (torch.optim.SGD, dampening 0, as
+    // sgd_momentum_multi_kernel spells it): g = alpha * acc * gscale; buf = mu * buf + (g + wd * p); p -= lr * buf; the
+    // bf16 / bf16x2 operand copy refreshed.  Per element 8 B read + 12 / 16 B written instead of 4 B (dW) + 12 B read +
+    // 12 / 16 B written by the two-kernel form.  The launcher guarantees whole quads (NJ % 8 == 0), ldc == NJ rows, no
+    // K slices.  The wavefront's 128 x 64 block goes through the (idle) staging buffers so that one instruction touches
+    // whole 256-byte row pieces (4 rows x 64 floats), as the sliced path's atomics do.
+    constexpr int SROW = 64;
+    float* stg = (float*)smem + wave * (64 * SROW);
+    const float lr = p.lr_dev ? *p.lr_dev : p.lr;
+    const float ag = p.alpha, gs = p.gscale, mu = p.mu, wd = p.wd;
+    const int cbase = j0 + wc * 64;
+    const int rsub = lane >> 4, c4 = (lane & 15) << 2;  // lane -> (row it * 4 + rsub, 4 consecutive columns c4 ..)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *(f32x4*)(stg + (i * 16 + frow) * SROW + (((j * 4 + fq) ^ frow) << 2)) = acc[half * 4 + i][j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int rbase = i0 + wr * 128 + half * 64;
+      if (cbase + c4 < p.NJ) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+          const int row = it * 4 + rsub;
+          if (rbase + row >= p.NI) break;
+          f32x4 gv = *(const f32x4*)(stg + row * SROW + ((((c4 >> 2)) ^ (row & 15)) << 2));
+          const long long e = (long long)(rbase + row) * p.ldc + cbase + c4;
+          f32x4 pv = __builtin_nontemporal_load((const f32x4*)(p.C + e));
+          f32x4 bv = __builtin_nontemporal_load((const f32x4*)(p.mom + e));
+          gv = gv * ag;
+          gv = gv * gs;
+          bv = mu * bv + (gv + wd * pv);
+          pv -= lr * bv;
+          __builtin_nontemporal_store(bv, (f32x4*)(p.mom + e));
+          __builtin_nontemporal_store(pv, (f32x4*)(p.C + e));
+          if (p.shadow) {
+            const bf16x4 hi = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+            if (p.shadow_x2) {
+              bf16_t* q = p.shadow + ((e >> 5) << 6) + (e & 31);
+              *(bf16x4*)q = hi;
+              *(bf16x4*)(q + 32) = bf16x4{(bf16_t)(pv[0] - (float)hi[0]), (bf16_t)(pv[1] - (float)hi[1]),
+                                          (bf16_t)(pv[2] - (float)hi[2]), (bf16_t)(pv[3] - (float)hi[3])};
+            } else {
+              *(bf16x4*)(p.shadow + e) = hi;
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
   const bool vec = (p.ldc & 3) == 0 && ((uintptr_t)p.C & 15) == 0 && j0 + BJ <= p.NJ;
 #define WS_TN_ROW(I)                                                                                      \
   {                                                                                                       \
@@ -474,16 +536,31 @@ __global__ __launch_bounds__(256) void tn_zero_tail_kernel(const TnArgs p) {
 }  // namespace
 }  // namespace wsovod_gemm
 
+static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
+                     float* C, long long ldc, float alpha, int accumulate, const wsovod_tn_sgd* upd, wsovod_stream_t stream);
+
 extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI,
-                                 int NJ, float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream);
+                                 int NJ, float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream) {
+  return tn_launch(P, ldp, Q, ldq, q_dtype, Mred, NI, NJ, C, ldc, alpha, accumulate, nullptr, stream);
+}
+
+extern "C" int wsovod_gemm_tn_sgd(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI,
+                                  int NJ, float alpha, const wsovod_tn_sgd* upd, wsovod_stream_t stream) {
+  WS_CHECK_ARG(upd && upd->param && upd->momentum_buf, "wsovod_gemm_tn_sgd: null parameter / momentum buffer");
+  WS_CHECK_ARG((((uintptr_t)upd->param | (uintptr_t)upd->momentum_buf) & 15) == 0 && ((uintptr_t)upd->shadow & 7) == 0,
+               "wsovod_gemm_tn_sgd: parameter / momentum buffer must be 16-byte aligned (shadow: 8)");
+  WS_CHECK_ARG(!upd->shadow || !upd->shadow_is_bf16x2 || NJ % 32 == 0,
+               "wsovod_gemm_tn_sgd: a bf16x2 shadow needs rows of whole 32-value groups");
+  return tn_launch(P, ldp, Q, ldq, q_dtype, Mred, NI, NJ, upd->param, NJ, alpha, 2, upd, stream);
+}
 
 extern "C" int wsovod_gemm_tn(const void* P, long long ldp, const void* Q, long long ldq, int Mred, int NI, int NJ,
                               float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream) {
   return wsovod_gemm_tn_ex(P, ldp, Q, ldq, WSOVOD_BF16, Mred, NI, NJ, C, ldc, alpha, accumulate, stream);
 }
 
-extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI,
-                                 int NJ, float* C, long long ldc, float alpha, int accumulate, wsovod_stream_t stream) {
+static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
+                     float* C, long long ldc, float alpha, int accumulate, const wsovod_tn_sgd* upd, wsovod_stream_t stream) {
   using namespace wsovod_gemm;
   WS_CHECK_ARG(q_dtype == WSOVOD_BF16 || q_dtype == WSOVOD_BF16X2, "wsovod_gemm_tn: Q must be bf16 or bf16x2");
   const bool q_x2 = q_dtype == WSOVOD_BF16X2;
@@ -510,6 +587,22 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
   a.alpha = alpha;
   a.accumulate = accumulate & 1;
   a.q_x2 = q_x2 ? 1 : 0;
+  a.mom = nullptr;
+  a.shadow = nullptr;
+  a.shadow_x2 = 0;
+  a.lr = a.wd = a.mu = 0.f;
+  a.gscale = 1.f;
+  a.lr_dev = nullptr;
+  if (upd) {
+    a.mom = upd->momentum_buf;
+    a.shadow = (bf16_t*)upd->shadow;
+    a.shadow_x2 = upd->shadow_is_bf16x2;
+    a.lr = upd->lr;
+    a.wd = upd->weight_decay;
+    a.mu = upd->momentum;
+    a.gscale = upd->grad_scale;
+    a.lr_dev = upd->lr_dev;
+  }
 #if defined(TN_STAMPS)
   a.dbg = getenv("WSOVOD_TN_DEBUG_PTR") ? (float*)strtoull(getenv("WSOVOD_TN_DEBUG_PTR"), nullptr, 16) : nullptr;
 #endif
@@ -522,18 +615,21 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
     // near-square CONCURRENT set per XCD (32 workgroups), see gemm8.hip; fc1 dW shape: group 4/8/14/16 -> 1197/1207/1154/1172
     a.group_m = std::max(1, std::min(std::min(g, 8), a.tiles_i));
   }
-  static int slot = wsovod::prof_slot("gemm_tn_bf16_256x256_tr");
+  static int slot_plain = wsovod::prof_slot("gemm_tn_bf16_256x256_tr");
+  static int slot_sgd = wsovod::prof_slot("gemm_tn_bf16_256x256_tr_sgd");
+  const int slot = upd ? slot_sgd : slot_plain;
   static bool attr_set = false;
   constexpr int lds_bytes = 2 * 2 * 2 * 64 * 256;  // 2 K-steps x (P, Q) x 2 sub-images x 64 rows x 256 B = 128 KiB
   if (!attr_set) {
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "wsovod_gemm_tn: LDS opt-in (160 KiB)");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "wsovod_gemm_tn_sgd: LDS opt-in (160 KiB)");
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * Mred * NI * NJ;
-  const double bytes = 2.0 * Mred * ((double)NI + NJ) + 4.0 * NI * NJ;
+  const double bytes = 2.0 * Mred * ((double)NI + NJ) + (upd ? (upd->shadow ? (upd->shadow_is_bf16x2 ? 20.0 : 18.0) : 16.0) : 4.0) * NI * NJ;
   wsovod::ProfScope prof(slot, s, flops, bytes);
   // Tail split: with more than one round of tiles on the 256 CUs, a last round that fills less than half of them is cut
   // along K so that it fills the chip (fc1 dW: 1568 tiles = 6 rounds + 32 tiles -> 32 x 8 slices; one round of a 7-round
@@ -568,7 +664,9 @@ extern "C" int wsovod_gemm_tn_ex(const void* P, long long ldp, const void* Q, lo
     }
   }
   static const int lean = getenv("WSOVOD_TN_LEAN") ? atoi(getenv("WSOVOD_TN_LEAN")) : 2;
-  if (lean == 2)
+  if (upd)  // (accumulate = 2 above: whole tiles only -- the update needs the finished sum of a tile in one place)
+    hipLaunchKernelGGL((gemm_tn8_kernel<2, true>), dim3(grid), dim3(512), 160 * 1024, s, a);
+  else if (lean == 2)
     hipLaunchKernelGGL(gemm_tn8_kernel<2>, dim3(grid), dim3(512), 160 * 1024, s, a);
   else if (lean == 1)
     hipLaunchKernelGGL(gemm_tn8_kernel<1>, dim3(grid), dim3(512), lds_bytes, s, a);

@@ -71,6 +71,50 @@ class HipSGD(torch.optim.Optimizer):
                     p._hip_shadow = (shadow, p._version)
 
 
+class _FusedUpdate:
+    """The optimizer step of ONE large weight applied from inside its weight-gradient kernel (wsovod_gemm_tn_sgd; installed
+    by HotPathTrainer on the weight as `_fused_update`, called by layers/functions.py:_Linear.backward).  At the reference's
+    own batch (1 - 2 images per GPU) the step is dominated by the bytes of fc1: its gradient (411 MB fp32 for WSR_18) was
+    written by one kernel and read back by the optimizer's; fused, an element costs 20 bytes instead of 32.  The arithmetic
+    is HipSGD's (same formula, same order); what changes is WHEN this tensor's update lands: inside backward instead of
+    with the other tensors -- nothing reads the weight in between (the input gradient of the layer is taken first).
+    Only without gradient exchange, accumulation or clipping, and only up to `max_rows` reduction rows: the fused kernel
+    keeps a partly filled last round of tiles whole, which costs more than the saved bytes at large batches."""
+
+    def __init__(self, optimizer, param, max_rows):
+        self.opt = weakref.proxy(optimizer)
+        self.param = weakref.ref(param)
+        self.max_rows = int(max_rows)
+        self.group = next(g for g in optimizer.param_groups if any(q is param for q in g["params"]))
+        self.calls = 0
+
+    def wants(self, rows):
+        p = self.param()
+        return p is not None and rows <= self.max_rows and p.grad is None and getattr(p, "_wire_grad", None) is None \
+            and self.opt.clip is None and getattr(p, "_used_flag", None) is None
+
+    def __call__(self, dA, x, q_x2):
+        p, opt, g = self.param(), self.opt, self.group
+        state = opt.state[p]
+        if "momentum_buffer" not in state:
+            state["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        sh = getattr(p, "_hip_shadow", None)
+        shadow = sh[0] if (sh is not None and sh[1] == p._version and sh[0].dtype == torch.bfloat16) else None
+        xe = getattr(p, "_x2_enc", None)
+        if xe is not None and xe[0] == (p._version, p.data_ptr(), None) and p.numel() % 32 == 0:
+            shadow = xe[1]
+        lr = g["lr"] if opt.lr_device is None else opt.lr_device[p]
+        H.gemm_tn_sgd(dA, x, p.data, state["momentum_buffer"], shadow, lr, g["weight_decay"], g["momentum"],
+                      grad_scale=opt.grad_scale, q_x2=q_x2)
+        torch.autograd.graph.increment_version(p)  # (as HipSGD.step: caches keyed on the version are rebuilt ...
+        if shadow is not None and shadow.dtype == torch.float32:  # ... and the refreshed operand copy is re-stamped)
+            p._x2_enc = ((p._version, p.data_ptr(), None), shadow)
+        elif shadow is not None:
+            p._hip_shadow = (shadow, p._version)
+        self.calls += 1
+        return True
+
+
 def build_optimizer(cfg, model):
     """engine/defaults.py:274-318: every trainable tensor is its own group with BASE_LR / WEIGHT_DECAY."""
     params, memo = [], set()
@@ -509,6 +553,15 @@ class HotPathTrainer:
             p._wire_grad = None
         if self.exchange and grad_wire == "bf16" and self.params and self.iter_size == 1:
             self._setup_early_exchange()  # (with accumulation the early block would miss the earlier micro-steps)
+        # round 6: without a gradient exchange, the optimizer step of the largest weight rides in its weight-gradient kernel
+        # at small batches (WSOVOD_FUSED_SGD=0 switches it off; WSOVOD_FUSED_SGD_ROWS = the largest reduction it takes)
+        self._fused = None
+        if (not self.exchange and self.iter_size == 1 and isinstance(optimizer, HipSGD) and optimizer.clip is None
+                and self.params and os.environ.get("WSOVOD_FUSED_SGD", "1") != "0"):
+            big = max(self.params, key=lambda q: q.numel())
+            if big.dim() == 2 and big.is_cuda and big.is_contiguous() and big.numel() >= (1 << 24) and big.shape[1] % 32 == 0:
+                self._fused = big
+                big._fused_update = _FusedUpdate(optimizer, big, int(os.environ.get("WSOVOD_FUSED_SGD_ROWS", "2048")))
         self._hooks = []
         if hasattr(model, "register_state_dict_pre_hook"):
             self._hooks.append(model.register_state_dict_pre_hook(lambda *_a, **_k: self.synchronize()))
@@ -544,6 +597,9 @@ class HotPathTrainer:
             bb.graph_max_batch = 0
             bb.__dict__.pop("_graphs", None)
         self._graphs.clear()
+        if getattr(self, "_fused", None) is not None:
+            self._fused.__dict__.pop("_fused_update", None)
+            self._fused = None
         if getattr(self.model, "_pre_inference", None) is getattr(self, "_pre_inference_hook", None):
             self.model._pre_inference = None
 

@@ -3,6 +3,7 @@
 `once_differentiable`) extended to every op on the hot path.  Forward AND backward run on the
 C-ABI kernels; torch only carries tensors, streams and the autograd graph.
 """
+import contextlib
 import os
 import threading
 
@@ -54,6 +55,36 @@ def _x2_mode():
     return H.x3_active() == "x2"
 
 
+class _BwdSplitState(threading.local):
+    on = False
+
+
+_BWD_SPLIT = _BwdSplitState()
+
+
+@contextlib.contextmanager
+def backward_split(on=True):
+    """MODEL.HIP.PRECISION = "parity_train": Functions created inside keep the hi/lo split in their BACKWARD contractions
+    too (three bf16 MFMA products on fp32 gradients, decoded bf16x2 activations and fp32 master weights -- the arithmetic
+    of the "bf16x3" mode's backward) instead of plain bf16 products on the hi halves.  The "parity" forward is unchanged;
+    what changes is the trained trajectory (tests/test_gpu_full_size.py: five optimizer steps against the oracle).
+    WSOVOD_PT_SPLIT = "dw" / "dx" restricts the split to the weight-gradient / input-gradient contractions (ablation)."""
+    prev = _BWD_SPLIT.on
+    _BWD_SPLIT.on = bool(on)
+    try:
+        yield
+    finally:
+        _BWD_SPLIT.on = prev
+
+
+def _bwd_split():
+    """-> frozenset of {"dw", "dx"}: which backward contractions of a Function created now keep the split."""
+    if not _BWD_SPLIT.on:
+        return frozenset()
+    which = os.environ.get("WSOVOD_PT_SPLIT", "dw,dx")
+    return frozenset(w for w in which.split(",") if w in ("dw", "dx"))
+
+
 def _no_split(x3):
     """The x3 state a backward pass runs under: the forward-only modes ("fwd", "x2") contract in plain bf16."""
     return x3 if x3 not in ("fwd", "x2") else False
@@ -79,6 +110,9 @@ class _Linear(Function):
             y = H.gemm_nt(x, wq, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed, dropout_seed_add=seed_add,
                           out_dtype=out_dtype)
         ctx.relu, ctx.dropout_p = relu, dropout_p
+        ctx.bwd = _bwd_split() if ctx.x2 else frozenset()
+        if "dw" in ctx.bwd:
+            x_hi = None  # the split weight gradient reads hi AND lo: the carrier itself is kept (either layout)
         ctx.save_for_backward(x if x_hi is None else x_hi.view(x.shape), weight, y if (relu or dropout_p > 0) else None)
         ctx.x_is_hi = x_hi is not None
         ctx.has_bias = bias is not None
@@ -95,7 +129,53 @@ class _Linear(Function):
             return _Linear._backward(ctx, dy)
 
     @staticmethod
+    def _backward_split(ctx, dy):
+        """"parity_train": dW = dA^T X and / or dX = dA W with the hi/lo split kept -- fp32 dA (mask applied, not rounded),
+        the saved bf16x2 input decoded to fp32, the fp32 master weight; the contractions are the "bf16x3" mode's (three bf16
+        MFMA products per value pair, operands split on the fly).  A contraction not named in ctx.bwd runs as in "parity"."""
+        x, weight, y = ctx.saved_tensors
+        M, K = x.shape
+        N = weight.size(0)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_db = ctx.has_bias and ctx.needs_input_grad[2]
+        s_dw, s_dx = need_dw and "dw" in ctx.bwd, need_dx and "dx" in ctx.bwd
+        dy = _contig2d(dy)
+        scale = 1.0 / (1.0 - ctx.dropout_p) if ctx.dropout_p > 0 else 1.0
+        Mp, Np = _pad(M, 64), _pad(N, 8)
+        y_x2 = ctx.y_x2
+        db = torch.zeros((N,), dtype=torch.float32, device=dy.device) if need_db else None
+        dA32 = dAt32 = dA16 = None
+        if s_dw or s_dx:
+            dA32, dAt32 = H.mask_transpose(dy, y, scale, torch.float32, want_plain=s_dx, want_t=s_dw, ld_t=Mp, ld_plain=Np,
+                                           colsum=db, y_x2=y_x2)
+        if (need_dw and not s_dw) or (need_dx and not s_dx) or (db is not None and dA32 is None and dAt32 is None):
+            dA16, _ = H.mask_transpose(dy, y, scale, torch.bfloat16, want_plain=True, want_t=False, ld_plain=Np,
+                                       colsum=db if (dA32 is None and dAt32 is None) else None, y_x2=y_x2)
+        dx = dw = None
+        if s_dw:
+            xt = H.transpose_cast(H.x2_to_f32(x), torch.float32, ld_dst=Mp)  # (K, Mp)
+            with H.x3_mode("full"):
+                dw = H.gemm_nt(dAt32, xt, out_dtype=torch.float32)  # (N, K)
+            del xt
+        elif need_dw:
+            # (x is the pooler's plain bf16 copy when it wrote one -- ctx.x_is_hi --, else the interleaved bf16x2 carrier)
+            dw = H.gemm_tn(dA16, x, q_x2=not ctx.x_is_hi)
+            if Np != N:
+                dw = dw[:N]
+        if dw is not None and ctx.dw_split is not None and 0 < ctx.dw_split[0] < N and ctx.dw_split[0] % 8 == 0:
+            ctx.dw_split[1](dw[:ctx.dw_split[0]])  # (a data-parallel trainer's early block: handed over late, still first)
+        if s_dx:
+            wt = H.transpose_cast(weight, torch.float32, ld_dst=Np)  # (K, Np)
+            with H.x3_mode("full"):
+                dx = H.gemm_nt(dA32, wt, out_dtype=torch.float32)  # (M, K)
+        elif need_dx:
+            dx = H.gemm_nt(dA16, H.transpose_cast(weight, torch.bfloat16, ld_dst=Np), out_dtype=torch.float32)
+        return dx, dw, db, None, None, None, None, None
+
+    @staticmethod
     def _backward(ctx, dy):
+        if ctx.bwd:
+            return _Linear._backward_split(ctx, dy)
         x, weight, y = ctx.saved_tensors
         in_dtype = torch.float32 if ctx.x_is_hi else x.dtype
         if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
@@ -117,6 +197,16 @@ class _Linear(Function):
         dA, dAt = H.mask_transpose(dy, y, scale, cd, want_plain=need_dx or tn, want_t=need_dw and not tn,
                                    ld_t=Mp, ld_plain=Np, colsum=db, y_x2=ctx.x2 and ctx.y_x2)
         dx = dw = None
+        # round 6: the trainer may have put a fused update on ONE large weight (engine/trainer.py:_FusedUpdate): dW and the
+        # optimizer step of that tensor are then one kernel and no gradient is returned (the optimizer skips `grad is None`).
+        # The input gradient reads the weights BEFORE the update, so it is taken first.
+        fused = getattr(weight, "_fused_update", None) if (tn and need_dw and Np == N and ctx.dw_split is None) else None
+        if fused is not None and fused.wants(M):
+            if need_dx:
+                dx = H.gemm_nt(dA, H.transpose_cast(weight, cd, ld_dst=Np), out_dtype=in_dtype)
+            if fused(dA, x, q_x2):
+                return dx, None, db, None, None, None, None, None
+            need_dx = need_dx and dx is None
         if tn:
             split = ctx.dw_split
             if split is not None and Np == N and 0 < split[0] < N and split[0] % 8 == 0:
@@ -132,7 +222,7 @@ class _Linear(Function):
         elif need_dw:
             xt = H.transpose_cast(x, cd, ld_dst=Mp)  # (K, Mp)
             dw = H.gemm_nt(dAt, xt, out_dtype=torch.float32)  # (N,K) = dA^T X, reduction over proposals
-        if need_dx:
+        if need_dx and dx is None:
             wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
             dx = H.gemm_nt(dA, wt, out_dtype=in_dtype)  # (M,K)
         return dx, dw, db, None, None, None, None, None
@@ -183,6 +273,7 @@ class _LinearGroup(Function):
                 ys[h] = y if len(run) == 1 else y[:, col:col + n]
                 col += n
         ctx.heads, ctx.first = heads, first
+        ctx.bwd = _bwd_split() if ctx.x2 else frozenset()
         ctx.save_for_backward(x, *ws, *[y if heads[h][0] else None for h, y in enumerate(ys)])
         ctx.has_bias = [b is not None for b in bs]
         ctx.x3 = H.x3_active()
@@ -204,6 +295,11 @@ class _LinearGroup(Function):
         if ctx.x3 == "fwd":  # bf16x3f: plain bf16 backward on a cast of the saved fp32 input
             x = H.cast(x, torch.bfloat16)
         cd = torch.bfloat16 if ctx.x2 else x.dtype
+        # "parity_train": fp32 masked gradients, decoded input, fp32 weights -- the generic path below under the bf16x3 split
+        # (WSOVOD_PT_SPLIT names one of the two contractions only: the whole group then follows the weight gradient's choice)
+        split = ctx.x2 and bool(ctx.bwd)
+        if split:
+            cd = torch.float32
         M, K = x.shape
         Ns = [sum(ws[i].size(0) for i in range(first[h], first[h + 1])) for h in range(nh)]
         offs = [0]
@@ -221,6 +317,7 @@ class _LinearGroup(Function):
                                  out_plain=dA[:, offs[h]:offs[h] + Ns[h]],
                                  colsum=dbcat[offs[h]:offs[h] + Ns[h]] if want_db else None,
                                  y_x2=ctx.x2 and heads[h][1] == H.X2)
+        xs = H.x3_mode("full") if split else contextlib.nullcontext()
         need_dx = ctx.needs_input_grad[0]
         need_dw = any(ctx.needs_input_grad[2 + 2 * i] for i in range(nb))
         rows = []  # (row block i, first row in the stacked layout)
@@ -234,10 +331,16 @@ class _LinearGroup(Function):
             wcat = torch.zeros((Nt, K), dtype=cd, device=x.device)
             for i, r in rows:
                 wcat[r:r + ws[i].size(0)] = ws[i]
-            dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=in_dtype)  # (M,K) = dA_cat @ W_cat
+            with xs:
+                dx = H.gemm_nt(dA, H.transpose_cast(wcat, cd), out_dtype=in_dtype)  # (M,K) = dA_cat @ W_cat
         grads = [None] * (2 * nb)
         if need_dw:
-            if ctx.x2:
+            if split:
+                Mp = _pad(M, 64)
+                with xs:
+                    dwcat = H.gemm_nt(H.transpose_cast(dA, cd, ld_dst=Mp), H.transpose_cast(H.x2_to_f32(x), cd, ld_dst=Mp),
+                                      out_dtype=torch.float32)
+            elif ctx.x2:
                 dwcat = H.gemm_tn(dA, x, q_x2=True)
             elif _USE_TN and cd == torch.bfloat16 and K % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 \
                     and ((Nt + 255) // 256) * ((K + 255) // 256) >= 64:
@@ -382,6 +485,7 @@ class _CosineLogits(Function):
         ctx.save_for_backward(z, wnT)
         ctx.cfg = (temperature, normalize, bias_vec is not None)
         ctx.x3 = H.x3_active()
+        ctx.bwd = _bwd_split() if ctx.x3 == "x2" else frozenset()
         return logits
 
     @staticmethod
@@ -395,13 +499,15 @@ class _CosineLogits(Function):
         z, wnT = ctx.saved_tensors
         temperature, normalize, has_bias = ctx.cfg
         cd = z.dtype
-        if ctx.x3 in ("fwd", "x2") and wnT.dtype == torch.float32:  # forward-only split: the backward class matrix in bf16
+        split = "dx" in ctx.bwd and wnT.dtype == torch.float32  # "parity_train": the input gradient keeps the split
+        if ctx.x3 in ("fwd", "x2") and wnT.dtype == torch.float32 and not split:  # forward-only split: the backward class matrix in bf16
             wnT = H.cast(wnT, torch.bfloat16)
             cd = torch.bfloat16
         dl = _contig2d(dl)
         M, K1 = dl.shape
         dA, _ = H.mask_transpose(dl, None, 1.0, cd, want_plain=True, want_t=False, ld_plain=wnT.size(1))
-        u = H.gemm_nt(dA, wnT, out_dtype=torch.float32)  # (M,D) = dL/d(zn)
+        with (H.x3_mode("full") if split else contextlib.nullcontext()):
+            u = H.gemm_nt(dA, wnT, out_dtype=torch.float32)  # (M,D) = dL/d(zn)
         dz = H.row_l2norm_backward(z, u, temperature, relu_mask=False) if normalize else u
         if z.dtype != torch.float32:
             dz = H.cast(dz, z.dtype)

@@ -1133,6 +1133,38 @@ def gemm_tn(P, Q, out=None, alpha=1.0, accumulate=False, split_tail=True, q_x2=F
     return out
 
 
+def gemm_tn_sgd(P, Q, param, momentum_buf, shadow, lr, weight_decay, momentum, grad_scale=1.0, alpha=1.0, q_x2=False):
+    """The weight-gradient contraction alpha * P^T @ Q FUSED with the momentum-SGD update of `param` (NI, NJ) it is the
+    gradient of (wsovod_gemm_tn_sgd): the gradient never goes to memory.  shadow: None, the bf16 copy or the bf16x2
+    (float32-typed) copy of param, refreshed in the same pass; lr: a float or a 1-element fp32 DEVICE tensor."""
+    from .._lib import TnSgd
+
+    require_gpu(P, Q, param, momentum_buf, shadow)
+    _refuse_undeclared_planar("gemm_tn_sgd", P, Q)
+    assert P.dtype == torch.bfloat16 and Q.dtype == (torch.float32 if q_x2 else torch.bfloat16) and P.shape[0] == Q.shape[0]
+    Mred, NI, NJ = P.shape[0], P.shape[1], Q.shape[1]
+    if tuple(param.shape) != (NI, NJ) or not param.is_contiguous() or param.dtype != torch.float32 \
+            or momentum_buf.shape != param.shape or not momentum_buf.is_contiguous() or momentum_buf.dtype != torch.float32:
+        raise RuntimeError("wsovod_hip gemm_tn_sgd: param / momentum buffer must be contiguous fp32 (NI, NJ)")
+    if 2 * Mred * max(_ld(P), _ld(Q) * (2 if q_x2 else 1)) >= GEMM_TN_MAX_OPERAND_BYTES:
+        raise RuntimeError("wsovod_hip gemm_tn_sgd: the reduction does not fit one launch (the fused update needs the "
+                           "finished sum of a tile)")
+    u = TnSgd()
+    u.param, u.momentum_buf = param.data_ptr(), momentum_buf.data_ptr()
+    u.shadow = shadow.data_ptr() if shadow is not None else None
+    u.shadow_is_bf16x2 = int(shadow is not None and shadow.dtype == torch.float32)
+    if shadow is not None and (shadow.numel() != param.numel() or not shadow.is_contiguous()):
+        raise RuntimeError("wsovod_hip gemm_tn_sgd: the shadow must be a contiguous copy of the parameter")
+    if torch.is_tensor(lr):
+        require_gpu(lr)
+        u.lr, u.lr_dev = 0.0, lr.data_ptr()
+    else:
+        u.lr, u.lr_dev = float(lr), None
+    u.weight_decay, u.momentum, u.grad_scale = float(weight_decay), float(momentum), float(grad_scale)
+    check(lib().wsovod_gemm_tn_sgd(ptr(P), _ld(P), ptr(Q), _ld(Q), BF16X2 if q_x2 else BF16, Mred, NI, NJ, C.c_float(alpha),
+                                   C.byref(u), stream()), "gemm_tn_sgd")
+
+
 def sgd_momentum_multi(entries, momentum, grad_scale=1.0, clip=None):
     """entries: list of (param, grad fp32 or bf16, momentum_buf, bf16_shadow or None, lr, weight_decay[, used_flag]);
     one launch per 32.  used_flag: optional 1-element fp32 device tensor, 0 = leave the tensor untouched.

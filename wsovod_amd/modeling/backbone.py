@@ -359,6 +359,12 @@ def _torch_block(block, x):
     return out
 
 
+def forward_precision(name):
+    """MODEL.HIP.PRECISION "parity_train" = the "parity" forward (bf16x2 activations, three products) + a backward that
+    keeps the split too (layers/functions.py:backward_split): every module sees "parity", the meta-arch sets the flag."""
+    return "parity" if name == "parity_train" else name
+
+
 _WARNED_TRAINABLE = set()
 
 
@@ -693,4 +699,4 @@ def build_wsl_resnet_backbone(cfg, input_shape):
         out_channels *= 2
         bottleneck_channels *= 2
     return ResNet(stem, stages, out_features=out_features, freeze_at=freeze_at,
-                  precision=cfg.MODEL.HIP.PRECISION)
+                  precision=forward_precision(cfg.MODEL.HIP.PRECISION))

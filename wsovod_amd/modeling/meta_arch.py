@@ -68,6 +68,8 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         self._mean, self._std = [float(v) for v in pixel_mean], [float(v) for v in pixel_std]
         self.logger = logging.getLogger(__name__)
         self.classifier = None
+        # MODEL.HIP.PRECISION = "parity_train": the heads' backward keeps the hi/lo split (layers/functions.py)
+        self.backward_split = bool(cfg is not None and cfg.MODEL.HIP.PRECISION == "parity_train")
 
     @classmethod
     def from_config(cls, cfg):
@@ -190,7 +192,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
             return self._forward_frozen(batched_inputs)
 
     def forward_trainable(self, st):
-        with H.x3_mode(self.x3):
+        from ..layers.functions import backward_split
+
+        with H.x3_mode(self.x3), backward_split(self.backward_split):
             return self._forward_trainable(st)
 
     @torch.no_grad()

@@ -211,7 +211,7 @@ class WSOVODROIHeads(ROIHeads):
             "positive_sample_fractions": cfg.WSOVOD.SAMPLING.POSITIVE_FRACTION,
             "cls_agnostic_bbox_known": cfg.WSOVOD.CLS_AGNOSTIC_BBOX_KNOWN, "pooler_type": pooler_type,
             "rpn_on": cfg.MODEL.PROPOSAL_GENERATOR.NAME != "PrecomputedProposals", "metadata": None,
-            "precision": cfg.MODEL.HIP.PRECISION,
+            "precision": "parity" if cfg.MODEL.HIP.PRECISION == "parity_train" else cfg.MODEL.HIP.PRECISION,
         }
 
     # ------------------------------------------------------------------------------
