@@ -622,8 +622,9 @@ def side_measurements(args, dev):
         # parity of the line: MEASURED against the oracle for this configuration (one comparison per distinct model /
         # precision / pooler / shape; lines that differ only in images per step or in where the inputs live share it)
         # (round 6: on the line's OWN images per step up to 8 -- the tile / split-K rules of a small batch are the ones the
-        # comparison runs; larger steps share the 8-image comparison, the headline's 32 are compared in `parity.at_timed_batch`)
-        pimg = max(1, min(int(cfgv["batch_size"]), 8)) if not cfgv.get("depth") == 50 else min(int(cfgv["batch_size"]), 2)
+        # comparison runs; larger steps share a 2-image comparison, the headline's 32 are compared in `parity.at_timed_batch`)
+        b_ = int(cfgv["batch_size"])
+        pimg = (b_ if b_ <= 8 else 2) if not cfgv.get("depth") == 50 else min(b_, 2)
         pkey = (cfgv["precision"], cfgv["pooler"], cfgv.get("depth"), cfgv.get("proposals"), cfgv.get("classes"),
                 cfgv.get("embed_dim"), bool(cfgv.get("mixed")), pimg)
         if args.no_parity:

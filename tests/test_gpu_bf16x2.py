@@ -346,6 +346,47 @@ def test_conv_x2_split_k_at_few_tiles(gpu, case, monkeypatch):
     assert float((outs[0] - outs[2256256]).abs().max()) < 1e-5 * scale
 
 
+@pytest.mark.parametrize("case", ["res3", "res4_residual", "res5_shortcut_dilated", "fc2"])
+def test_deep_dma_small_tiles_equal_the_two_stage_tiles(gpu, case):
+    """Round 6: at 1 - 2 images per step the 128x64 / 64x64 grids run behind a deep LDS-DMA pipeline (three / four stages in
+    flight: tiles 3128064 / 3064064) instead of one DMA round trip per K-step.  Same products in the same order: bit-identical
+    to the two-stage tiles 1128064 / 64064 -- conv with residual, conv with the fused 1x1 shortcut under dilation (K range
+    ends inside the shortcut), ragged rows / columns, a plain GEMM with bias + ReLU.  (The dispatcher picks the deep forms
+    wherever it used to pick the two-stage ones; WSOVOD_X2_DEEP=0 restores those.)"""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(8)
+    if case == "fc2":
+        M, N, K = 520, 1000 - 8, 4096
+        A, B = H.x2_encode(torch.randn(M, K, device=gpu)), H.x2_encode(torch.randn(N, K, device=gpu) * 0.02)
+        kw = dict(x2=True, bias=torch.randn(N, device=gpu), relu=True, out_dtype=torch.float32)
+        run = lambda tile: H.gemm_nt(A, B, tile_hint=tile, **kw)
+        pairs = [(3128064, 1128064)]
+    else:
+        if case == "res3":
+            n, Hh, Ww, C1, Co, dil, C2, res_on = 1, 75, 100, 128, 128, 1, 0, True
+        elif case == "res4_residual":
+            n, Hh, Ww, C1, Co, dil, C2, res_on = 1, 38, 50, 256, 256, 2, 0, True
+        else:
+            n, Hh, Ww, C1, Co, dil, C2, res_on = 1, 30, 41, 512, 512, 2, 256, False
+        enc = lambda t, c: H.x2_encode(t.reshape(-1, c).contiguous().to(gpu)).view(n, Hh, Ww, c)
+        h = enc(torch.randn(n, Hh, Ww, C1) * 0.5, C1)
+        wcat = H.x2_encode((torch.randn(Co, 9 * C1 + C2) * 0.03).to(gpu))
+        conv = dict(n_img=n, H=Hh, W=Ww, Cin=C1, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=dil, dil=dil)
+        kw = dict(conv=conv, x2=True, bias=torch.randn(Co, device=gpu), relu=True, out_dtype=H.X2)
+        if C2:
+            kw["A2"] = enc(torch.randn(n, Hh, Ww, C2) * 0.5, C2)
+        if res_on:
+            kw.update(residual=H.x2_encode(torch.randn(n * Hh * Ww, Co, device=gpu)), residual_x2=True)
+        run = lambda tile: H.gemm_nt(h, wcat, tile_hint=tile, **kw)
+        pairs = [(3128064, 1128064), (3064064, 64064)]
+    for deep, base in pairs:
+        a, b = run(deep), run(base)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), (case, deep)
+        assert bool(torch.isfinite(H.x2_decode(a) if a.dtype == torch.float32 and kw.get("out_dtype") == H.X2 else a).all())
+
+
 def test_res3_convs_on_the_512x128_tile_equal_the_256x128_tile(gpu):
     """Round 5: from ~14 images per step the 128-channel convs of res3 run on 512 x 128 tiles (16 wavefronts as 8 x 2, 160 KiB
     of LDS).  Same products in the same order per output element as the 256 x 128 tile: bit-identical outputs -- stride 2

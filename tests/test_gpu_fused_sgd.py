@@ -124,8 +124,20 @@ def test_fused_update_steps_aside_for_clipping_accumulation_and_large_batches(gp
     monkeypatch.setenv("WSOVOD_FUSED_SGD_ROWS", "100")
     tr = HotPathTrainer(model, build_optimizer(cfg, model))
     fu = tr._fused._fused_update
+    assert not fu.wants(64)  # not inside the trainer's own backward: a caller's loss.backward() gets a gradient
+    fu.armed = True
     assert fu.wants(64) and not fu.wants(128)
     tr._fused.grad = torch.zeros_like(tr._fused)
     assert not fu.wants(64)  # somebody left a gradient on the tensor: it goes through the optimizer
     tr._fused.grad = None
+    fu.armed = False
+    # a plain forward + backward on the model while the trainer is attached leaves the weight alone and fills .grad
+    from wsovod_amd.data import make_batch
+
+    b = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
+          "height": x["height"], "width": x["width"]} for x in make_batch(1, 64, 20, H=160, W=224, seed=5)]
+    before = tr._fused.detach().clone()
+    sum(model(b).values()).backward()
+    assert tr._fused.grad is not None and torch.equal(tr._fused.detach(), before) and fu.calls == 0
+    model.zero_grad(set_to_none=True)
     tr.close()

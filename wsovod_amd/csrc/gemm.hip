@@ -29,7 +29,8 @@ namespace wsovod_gemm {
 // K-step computes b_hi*a_hi + b_lo*a_hi + b_hi*a_lo from the two fragment reads the bf16 form makes (see gemm8.hip).
 template <typename T, int BM, int BN, bool CONV, int WM = 2, int WN = 2, bool DMA = false, int STAGES = 2, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p) {
-  static_assert(!X3 || (sizeof(T) == 2 && STAGES == 2), "X3 is a bf16, two-stage variant");
+  static_assert(!X3 || sizeof(T) == 2, "X3 is a bf16 variant");
+  static_assert(!X3 || STAGES == 2 || DMA, "the deep X3 pipeline stages by LDS-DMA");
   constexpr int EPC = Traits<T>::EPC;
   constexpr int BKE = Traits<T>::BKE;
   constexpr int NT = 64 * WM * WN;       // threads: WM x WN wavefronts
@@ -256,7 +257,58 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
   auto compute = [&](int cur) {
     const char* cA = sA + cur * BM * 128 + (wm * (BM / WM)) * 128;
     const char* cB = sB + cur * BN * 128 + (wn * (BN / WN)) * 128;
-    if constexpr (X3) {
+    if constexpr (X3 && DMA && STAGES >= 3) {
+      // round 6, small batches: the X3 products behind the DEEP LDS-DMA pipeline (STAGES - 1 K-steps in flight).  At 1 - 2
+      // images per step the 128x64 / 64x64 grids are one round of workgroups whose K-steps each wait out a whole DMA
+      // round trip (res5 of one image: 144 K-steps x 0.86 us with 0.18 us of MFMAs in each); with two K-steps in flight
+      // the trip is shared.  Fragment reads are asm (hipcc must not see them: it would drain the ring with vmcnt(0)),
+      // retired by an explicit lgkmcnt(0) that the reads' destinations are tied to; same products in the same order as
+      // the two-stage form (bit-identical results).
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef __attribute__((address_space(3))) const char lds_cchar;
+      const unsigned baseA = (unsigned)(size_t)(lds_cchar*)cA, baseB = (unsigned)(size_t)(lds_cchar*)cB;
+      u32x4 af[TM], bfr[TN];
+      auto rd = [&](u32x4& dst, unsigned base, int row, int chunk) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));
+      };
+      // all four fragment sets of the K-step are requested up front (one LDS round trip per K-step instead of three: at two
+      // wavefronts per SIMD nothing else hides them); the 16-wavefront tiles cannot afford the registers, these can
+      u32x4 al[TM], bh[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rd(af[i], baseA, i * 16 + frow, fq);        // a_hi
+#pragma unroll
+      for (int j = 0; j < TN; ++j) rd(bfr[j], baseB, j * 16 + frow, fq + 4);   // b_lo
+#pragma unroll
+      for (int j = 0; j < TN; ++j) rd(bh[j], baseB, j * 16 + frow, fq);        // b_hi
+#pragma unroll
+      for (int i = 0; i < TM; ++i) rd(al[i], baseA, i * 16 + frow, fq + 4);    // a_lo
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "+v"(af[i]), "+v"(al[i]));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bfr[j]), "+v"(bh[j]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)  // b_lo * a_hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
+                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)  // b_hi * a_hi
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                              __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)  // b_hi * a_lo
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bh[j]),
+                                                              __builtin_bit_cast(bf16x8, al[i]), acc[i][j], 0, 0, 0);
+#endif
+    }
+    else if constexpr (X3) {
       // Two fragment sets live at a time (a third costs the 16-wavefront tile spills at its 128-register budget): b_lo and
       // a_hi first, then b_hi takes b_lo's registers, then a_lo takes a_hi's.
       u32x4 af[TM], bfr[TN];
@@ -298,8 +350,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
         for (int j = 0; j < TN; ++j)  // b_hi * a_lo
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bfr[j]),
                                                               __builtin_bit_cast(bf16x8, af[i]), acc[i][j], 0, 0, 0);
-      return;
-    }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int chunk = fq + 4 * ks;
@@ -322,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
           const int row = j * 16 + frow;
           asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[j]) : "v"(baseB + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)));
         }
-        static_assert(TM == 4 && TN == 4, "the lgkmcnt wait statement names 8 fragment registers");
+        static_assert(X3 || (TM == 4 && TN == 4), "the lgkmcnt wait statement names 8 fragment registers");
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]),
                        "+v"(bfr[3]));
@@ -358,6 +409,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_nt_kernel(const GemmArgs p)
                   __builtin_bit_cast(f32x4, bfr[j])[e], __builtin_bit_cast(f32x4, af[i])[e], acc[i][j], 0, 0, 0);
       }
     }
+    }  // (!X3)
   };
 
   if constexpr (DMA && STAGES >= 3) {
@@ -1891,6 +1943,21 @@ int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, d
     case 1128064:
       return launch<bf16_t, 128, 64, CONV, 2, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64" : "gemm_nt_bf16x2_128x64",
                                                               flops, bytes);
+    case 3128064:  // round 6: three DMA stages (72 KiB: still two workgroups per CU)
+      return launch<bf16_t, 128, 64, CONV, 2, 2, true, 3, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64_s3" : "gemm_nt_bf16x2_128x64_s3",
+                                                              flops, bytes);
+    case 4128064:  // (experiment) eight wavefronts of 32 x 32, three stages
+      return launch<bf16_t, 128, 64, CONV, 4, 2, true, 3, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64_w8s3" : "gemm_nt_bf16x2_128x64_w8s3",
+                                                              flops, bytes);
+    case 5128064:  // (experiment) eight wavefronts of 32 x 32, four stages (96 KiB: one workgroup per CU)
+      return launch<bf16_t, 128, 64, CONV, 4, 2, true, 4, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64_w8s4" : "gemm_nt_bf16x2_128x64_w8s4",
+                                                              flops, bytes);
+    case 3128128:  // (experiment) 128 x 128, eight wavefronts of 32 x 64, three stages (96 KiB)
+      return launch<bf16_t, 128, 128, CONV, 4, 2, true, 3, true>(a, s, CONV ? "conv_igemm_bf16x2_128x128_w8s3" : "gemm_nt_bf16x2_128x128_w8s3",
+                                                               flops, bytes);
+    case 3064064:  // round 6: the 64x64 tile by LDS-DMA, four stages (64 KiB: two workgroups per CU)
+      return launch<bf16_t, 64, 64, CONV, 2, 2, true, 4, true>(a, s, CONV ? "conv_igemm_bf16x2_64x64_s4" : "gemm_nt_bf16x2_64x64_s4",
+                                                             flops, bytes);
     case 1128128:
     case 128128:
       return launch<bf16_t, 128, 128, CONV, 2, 2, true, 2, true>(a, s, CONV ? "conv_igemm_bf16x2_128x128" : "gemm_nt_bf16x2_128x128",
@@ -2196,6 +2263,13 @@ extern "C" int wsovod_gemm_nt(const wsovod_gemm_desc* d, wsovod_stream_t stream)
     if (!d->tile_hint && d->conv && getenv("WSOVOD_CONV_SPLITK") && getenv("WSOVOD_CONV_SPLITK")[0] == '1' && d->M >= 256 &&
         d->N >= 256 && d->K >= 2048 && (long long)ceil_div(d->M, 256) * ceil_div(d->N, 256) <= 128)
       tile = 2256256;
+    // round 6: the small grids of 1 - 2 images per step behind a deep LDS-DMA pipeline (their K-steps were one DMA round
+    // trip each); WSOVOD_X2_DEEP=0: the two-stage forms (A/B runs, bit-identical results)
+    static const bool deep = !(getenv("WSOVOD_X2_DEEP") && getenv("WSOVOD_X2_DEEP")[0] == '0');
+    if (!d->tile_hint && deep) {
+      if (tile == 1128064) tile = 3128064;
+      else if (tile == 64064 && d->conv && d->K >= 1024 && d->M >= 1024) tile = 3064064;
+    }
     if (planar) {  // the planar A operand exists in the lean two-phase tile (split-K included)
       WS_CHECK_ARG(!d->tile_hint || d->tile_hint == 2256256, "wsovod_gemm_nt: a planar A operand takes tile 2256256 only");
       tile = 2256256;

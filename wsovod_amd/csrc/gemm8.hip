@@ -65,8 +65,8 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   constexpr int BM = 256, BN = 256, BKE = 64, EPC = 8, esz = 2;
   constexpr int LR = 64;  // rows staged per DMA pass (512 threads x 16 B = 64 rows x 128 B)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* sA = smem;                  // 2 x [256][128 B]
-  char* sB = smem + 2 * BM * 128;   // 2 x [256][128 B]
+  [[maybe_unused]] char* sA = smem;                  // 2 x [256][128 B]
+  [[maybe_unused]] char* sB = smem + 2 * BM * 128;   // 2 x [256][128 B]
 
   const int nwg = p.tiles_m * p.tiles_n;
   int wg;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = kt + 1 < nk, more2 = kt + 2 < nk;
-    const unsigned bA = ldsA + cur * (BM * 128) + offA, bB = ldsB + cur * (BN * 128) + offB;
+    [[maybe_unused]] const unsigned bA = ldsA + cur * (BM * 128) + offA, bB = ldsB + cur * (BN * 128) + offB;
     if constexpr (PH == 2) {
       // ---- phase A: A rows 0-63 x all 64 columns of this wavefront (16 fragment reads)
       G8_STAMP0();
@@ -867,7 +867,8 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   // (round 5: also the implicit-GEMM convs at 1 - 4 images per step -- res5 of ONE 800x600 image is 30 x 2 tiles --
   // where the alternative was a 128x128 / 64x64 grid at 0.12 - 0.25 of peak)
   if (allow_split && ntiles <= 128 && nk >= 32) {
-    const int S = std::min(std::min(8, 256 / ntiles), nk / 16);
+    int S = std::min(std::min(8, 256 / ntiles), nk / 16);
+    if (const char* fs = getenv("WSOVOD_SPLITK_S")) S = std::max(1, std::min(atoi(fs), nk / 4));  // (experiments)
     if (S >= 2) {
       // Workspace of this process (single-stream use, as the rest of the library).  A captured HIP graph keeps the
       // pointer it was captured with, so a block is NEVER freed once handed out: when a larger one is needed the old
@@ -903,6 +904,8 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
       grid = ntiles * S;
     }
   }
+  static int slot_fin = wsovod::prof_slot("splitk_finalize");
+  {
   wsovod::ProfScope prof(x3 ? (conv ? slot_c3 : slot_g3) : (conv ? slot_c : slot_g), s, flops, bytes);
 #define WS_L8(C, X, P) hipLaunchKernelGGL((gemm256_8ph_kernel<C, X, P>), dim3(grid), dim3(512), lds_bytes, s, args)
 #define WS_L8L(C, X) hipLaunchKernelGGL((gemm256_8ph_kernel<C, X, 2, true>), dim3(grid), dim3(512), lds_bytes, s, args)
@@ -934,8 +937,10 @@ int launch_gemm256_8ph(const GemmArgs& a, bool conv, hipStream_t s, double flops
   }
 #undef WS_L8
 #undef WS_L8L
+  }
   if (args.ksplit > 1) {
     const long long quads = (long long)(a.M - a.m_base) * ((a.N + 3) / 4);
+    wsovod::ProfScope prof(slot_fin, s, 0.0, (double)quads * 16.0 * (args.ksplit + 1));
     hipLaunchKernelGGL(splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, args);
   }
   WS_CHECK_LAUNCH("wsovod_gemm_nt(256x256 8-phase)");

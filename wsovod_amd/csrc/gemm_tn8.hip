@@ -363,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
       const bool more = kt + 1 < nk;
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
-        const unsigned base = lds0 + cur * STEP_BYTES + half * (32 * 256);
+        [[maybe_unused]] const unsigned base = lds0 + cur * STEP_BYTES + half * (32 * 256);
         TN_STAMP0();
 #pragma unroll
         for (int t = 0; t < 4; ++t) {

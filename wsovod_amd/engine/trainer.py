@@ -87,10 +87,12 @@ class _FusedUpdate:
         self.max_rows = int(max_rows)
         self.group = next(g for g in optimizer.param_groups if any(q is param for q in g["params"]))
         self.calls = 0
+        self.armed = False  # only inside the trainer's OWN backward: a caller's loss.backward() on the model gets gradients
 
     def wants(self, rows):
         p = self.param()
-        return p is not None and rows <= self.max_rows and p.grad is None and getattr(p, "_wire_grad", None) is None \
+        return self.armed and p is not None and rows <= self.max_rows and p.grad is None \
+            and getattr(p, "_wire_grad", None) is None \
             and self.opt.clip is None and getattr(p, "_used_flag", None) is None
 
     def __call__(self, dA, x, q_x2):
@@ -561,7 +563,9 @@ class HotPathTrainer:
             big = max(self.params, key=lambda q: q.numel())
             if big.dim() == 2 and big.is_cuda and big.is_contiguous() and big.numel() >= (1 << 24) and big.shape[1] % 32 == 0:
                 self._fused = big
-                big._fused_update = _FusedUpdate(optimizer, big, int(os.environ.get("WSOVOD_FUSED_SGD_ROWS", "2048")))
+                # (measured, WSR_18 x 512 proposals: 1 image 2.71 -> 2.59 ms per step, 8 images 7.55 -> 7.46; beyond 8 images the
+                # split tile-round tail of the two-kernel form is worth more than the bytes: profiles/HISTORY.md, round 6)
+                big._fused_update = _FusedUpdate(optimizer, big, int(os.environ.get("WSOVOD_FUSED_SGD_ROWS", "4096")))
         self._hooks = []
         if hasattr(model, "register_state_dict_pre_hook"):
             self._hooks.append(model.register_state_dict_pre_hook(lambda *_a, **_k: self.synchronize()))
@@ -889,12 +893,19 @@ class HotPathTrainer:
         seed = self._seed
         if seed is None or seed.device != roots[0].device or seed.dtype != roots[0].dtype:
             seed = self._seed = torch.full((), 1.0 / self.iter_size, dtype=roots[0].dtype, device=roots[0].device)
-        if capturing:
-            grads = torch.autograd.grad(roots, self.params, [seed.expand_as(r) for r in roots], allow_unused=True)
-            for p, g in zip(self.params, grads):
-                p.grad = g
-            return
-        torch.autograd.backward(roots, [seed.expand_as(r) for r in roots])
+        fused = self._fused._fused_update if getattr(self, "_fused", None) is not None else None
+        if fused is not None:
+            fused.armed = True  # (this backward is followed by this trainer's optimizer step: the fused update IS that step)
+        try:
+            if capturing:
+                grads = torch.autograd.grad(roots, self.params, [seed.expand_as(r) for r in roots], allow_unused=True)
+                for p, g in zip(self.params, grads):
+                    p.grad = g
+                return
+            torch.autograd.backward(roots, [seed.expand_as(r) for r in roots])
+        finally:
+            if fused is not None:
+                fused.armed = False
 
     # ---- whole-step HIP graphs (small batches) ----
     GRAPH_AFTER = 3  # eager steps with a layout before it is captured (the first ones fill caches and allocator pools)

@@ -68,7 +68,12 @@ def backward_split(on=True):
     too (three bf16 MFMA products on fp32 gradients, decoded bf16x2 activations and fp32 master weights -- the arithmetic
     of the "bf16x3" mode's backward) instead of plain bf16 products on the hi halves.  The "parity" forward is unchanged;
     what changes is the trained trajectory (tests/test_gpu_full_size.py: five optimizer steps against the oracle).
-    WSOVOD_PT_SPLIT = "dw" / "dx" restricts the split to the weight-gradient / input-gradient contractions (ablation)."""
+    Which contractions keep it (WSOVOD_PT_SPLIT, default "dx"): the ablation of round 6 (tools/parity_train_ablation.py,
+    profiles/r06_parity_train_ablation.json) shows that the trajectory error of the plain-bf16 backward comes from the
+    INPUT-gradient contractions dX = dA W -- their rounding is inherited by every layer further back -- and not from the
+    weight gradients dW = dA^T X, whose rounding is independent noise per element: after five optimizer steps the logits are
+    6.7e-3 from the oracle's with neither, 7.1e-3 with the split in dW only, 4.0e-4 with the split in dX only, 4.2e-4 with
+    both.  "dw,dx" keeps both (the "bf16x3" mode's backward, ~+35 % step time instead of ~+11 %)."""
     prev = _BWD_SPLIT.on
     _BWD_SPLIT.on = bool(on)
     try:
@@ -81,7 +86,7 @@ def _bwd_split():
     """-> frozenset of {"dw", "dx"}: which backward contractions of a Function created now keep the split."""
     if not _BWD_SPLIT.on:
         return frozenset()
-    which = os.environ.get("WSOVOD_PT_SPLIT", "dw,dx")
+    which = os.environ.get("WSOVOD_PT_SPLIT", "dx")
     return frozenset(w for w in which.split(",") if w in ("dw", "dx"))
 
 
