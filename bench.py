@@ -33,8 +33,10 @@ sys.path.insert(0, ROOT)
 DTYPE = {"parity": "bf16 (bf16x2 hi/lo activations, three MFMA products per value pair forward; plain bf16 backward; fp32 "
                    "accumulation, master weights, losses and optimizer)",
          "bf16": "bf16", "fp32": "f32", "bf16x3": "bf16 (hi/lo split operands, forward and backward)",
-         "bf16x3f": "bf16 (hi/lo split operands forward, plain bf16 backward)"}
-PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "bf16x3f": 2500.0, "parity": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md); x3 runs bf16 MFMAs
+         "bf16x3f": "bf16 (hi/lo split operands forward, plain bf16 backward)",
+         "parity_train": "bf16 (the parity forward; the input-gradient contractions of the backward keep the hi/lo split: "
+                         "three bf16 MFMA products on fp32 gradients and fp32 master weights)"}
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "bf16x3f": 2500.0, "parity": 2500.0, "parity_train": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md); x3 runs bf16 MFMAs
 HBM_PEAK_GBS = 8000.0
 
 
@@ -101,7 +103,7 @@ def pmc_traffic(kernel_name, args):
 
     path = None
     prec = args.precision
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):  # newest committed PMC pass of this workload (written by tools/collect_profiles.sh)
         cand = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_b{args.batch}_{prec}.json")
         if os.path.exists(cand):
             path = cand
@@ -454,7 +456,7 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     # the reported final losses stay meaningful: tests/test_gpu_model_parity.py::test_training_on_a_fixed_batch_...)
     cfg.SOLVER.BASE_LR = 1e-3
     optimizer = build_optimizer(cfg, model)
-    wire = ("bf16" if precision in ("bf16", "parity", "bf16x3f") else "fp32") if args.grad_wire == "auto" else args.grad_wire
+    wire = ("bf16" if precision in ("bf16", "parity", "parity_train", "bf16x3f") else "fp32") if args.grad_wire == "auto" else args.grad_wire
     # asynchronous gradient exchange behind the next step's frozen forward.  At N > 1 with --exchange auto both forms are
     # timed below and the faster one carries the headline: the trainer starts on the ring (RCCL's own all-reduce)
     ab = world > 1 and wire == "bf16" and args.exchange == "auto"

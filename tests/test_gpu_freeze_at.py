@@ -1,6 +1,7 @@
 """GPU: MODEL.BACKBONE.FREEZE_AT < 5 (reference: backbone/resnet_wsl.py:530-552).  The trainable stages run their FORWARD
-on the HIP kernels; their backward is the torch-autograd re-evaluation of `modeling/backbone.py:_TrainableStage` (MIOpen
-convs on the GPU -- no conv dgrad / wgrad kernel exists, the shipped configs freeze all five stages).  Pinned to the
+on the HIP kernels; their backward (`modeling/backbone.py:_TrainableStage`) too since round 6 for the stages without a tail
+pool (res4 / res5: mask passes, input gradients as implicit-GEMM convs on the rotated weights, weight gradients as the
+transposed-read contraction over im2col rows); res2 / res3 keep the torch-autograd re-evaluation (MIOpen).  Pinned to the
 REFERENCE's own step at FREEZE_AT = 4 (tests/golden/g19_freeze_at_4.npz, make_golden.py:golden_trainable_stage): the
 gradient runs through the HIP RoIPool backward (argmax scatter) and the GAP of the data-aware head into res5."""
 import numpy as np
@@ -62,6 +63,30 @@ def test_res5_trainable_step_matches_reference_golden(gpu, precision):
         if precision == "fp32":
             ref = g["gradsample/" + k]
             assert (gen.strided_sample(gr, 1024) - ref).abs().max() <= 5e-3 * ref.abs().max() + 1e-8, k
+
+
+@pytest.mark.parametrize("precision,freeze_at,tol", [("fp32", 3, 2e-3), ("parity", 3, 2e-2), ("bf16", 4, 0.1)])
+def test_hip_conv_backward_agrees_with_the_torch_re_evaluation(gpu, monkeypatch, precision, freeze_at, tol):
+    """Round 6: the HIP dgrad / wgrad path of the trainable stages against the torch (MIOpen, fp32) re-evaluation it replaces
+    (WSOVOD_HIP_CONV_BACKWARD=0), same model, same batch: every trainable tensor's gradient -- res4 AND res5 at
+    FREEZE_AT = 3, i.e. the input gradient crosses a stage boundary, blocks with a projection shortcut fused into their last
+    conv and blocks with an identity shortcut -- agrees in norm and element-wise to the precision's backward grade."""
+    batch = to_inputs(gen.seeded_batch(2, 24, 20, 160, 208, seed=13))
+    grads = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WSOVOD_HIP_CONV_BACKWARD", flag)
+        cfg, model = _model(precision, freeze_at)
+        sum(model(batch).values()).backward()
+        torch.cuda.synchronize()
+        grads[flag] = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.requires_grad}
+        del model
+    bb = [k for k in grads["1"] if k.startswith("backbone.")]
+    assert len(bb) == (10 if freeze_at == 3 else 5)  # R18: res4 = 2 blocks (4 convs + 1 shortcut), res5 likewise
+    for k in grads["1"]:
+        a, b = grads["1"][k], grads["0"][k]
+        assert bool(torch.isfinite(a).all()), k
+        assert abs(float(a.norm()) - float(b.norm())) <= tol * float(b.norm()) + 1e-9, (k, float(a.norm()), float(b.norm()))
+        assert float((a - b).abs().max()) <= 4 * tol * float(b.abs().max()) + 1e-9, k
 
 
 def test_trainer_and_optimizer_with_a_trainable_stage(gpu):

@@ -365,15 +365,142 @@ def forward_precision(name):
     return "parity" if name == "parity_train" else name
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# round 6: the backward of a trainable stage on the HIP kernels themselves (blocks without a tail pool: res4 / res5, i.e.
+# MODEL.BACKBONE.FREEZE_AT = 3 / 4; reference: resnet_wsl.py:94-110,221-241 under autograd, :530-552)
+#   mask          dL/d(pre-activation) = dL/d(out) * [out > 0]              wsovod_mask_transpose
+#   input grad    a k x k, stride-1, same-size conv IS a conv of the output gradient with the kernel rotated by 180 deg and
+#                 its channel roles swapped ([Cin][kh'][kw'][Cout]): the implicit-GEMM kernel of the forward pass; 1x1: a GEMM
+#   weight grad   dW'[co][tap][ci] = sum_p g[p][co] * x[p + tap][ci] = g^T @ im2col(x): the transposed-read contraction
+#                 (wsovod_gemm_tn) over patch rows (wsovod_im2col_rows); FrozenBN folds w' = w * scale[co], so dw = dW' * scale
+# Arithmetic: the precision's backward grade -- plain bf16 MFMA products with fp32 accumulation for "bf16" / "parity" (on
+# the hi halves of bf16x2 maps), exact-fp32 MFMA for "fp32".  The stage's activations are RE-COMPUTED by the same forward
+# kernels (bit-identical to the forward that produced the loss: the ReLU masks are the forward's own -- the fp32 torch
+# re-evaluation this replaces could pick other winners where two candidates lie within the forward's rounding).
+# ---------------------------------------------------------------------------------------------------------------
+def _hip_backward_ok(stage, x3):
+    if os.environ.get("WSOVOD_HIP_CONV_BACKWARD", "1") == "0" or x3 in ("full", "fwd"):
+        return False  # (the bf16x3 modes keep their operands in fp32 tensors and split on the fly: torch re-evaluation)
+    for b in stage.children():
+        if not isinstance(b, (BasicBlock, BottleneckBlock)) or b.has_pool:
+            return False
+        for c in (b.conv1, b.conv2, getattr(b, "conv3", None), b.shortcut):
+            if c is not None and (c.stride != 1 or c.bias is not None or 2 * c.padding != c.dilation * (c.kernel_size - 1)
+                                  or c.in_channels % 64 or c.out_channels % 64):
+                return False
+    return True
+
+
+def _masked(dy, y, cd):
+    """dL/d(pre-activation) of y = relu(.): (P, C) in the compute dtype `cd` (dy fp32, y the forward's own output map)."""
+    C = dy.shape[-1]
+    P = dy.numel() // C
+    if y.dtype == torch.bfloat16 and dy.dtype != torch.bfloat16:
+        dy = dy.to(torch.bfloat16)  # (the mask kernel takes dy in y's dtype; "bf16" precision: bf16 gradients anyway)
+    return H.mask_transpose(dy.reshape(P, C), y.reshape(P, C), 1.0, cd, want_plain=True, want_t=False,
+                            y_x2=(y.dtype == torch.float32 and _is_x2_map(y, C)))[0]
+
+
+def _is_x2_map(t, channels):
+    """A bf16x2 carrier and a real fp32 map have the same dtype and shape; the blocks tag what they emit."""
+    return bool(getattr(t, "_x2_map", False))
+
+
+def _conv_dgrad(g2d, conv, N, Hh, Ww, cd):
+    """g2d: (N*H*W, Cout) in cd -> dL/d(input) (N*H*W, Cin) fp32."""
+    k, d = conv.kernel_size, conv.dilation
+    w, _ = conv.folded(torch.float32)  # [Cout][kh*kw*Cin]
+    Co, Ci = conv.out_channels, conv.in_channels
+    if k == 1:
+        return H.gemm_nt(g2d, w.t().contiguous().to(cd), out_dtype=torch.float32)
+    wt = w.view(Co, k, k, Ci).flip(1, 2).permute(3, 1, 2, 0).reshape(Ci, k * k * Co).contiguous().to(cd)
+    geom = dict(n_img=N, H=Hh, W=Ww, Cin=Co, Ho=Hh, Wo=Ww, KH=k, KW=k, stride=1, pad=conv.padding, dil=d)
+    return H.gemm_nt(g2d.view(N, Hh, Ww, Co), wt, conv=geom, out_dtype=torch.float32)
+
+
+def _conv_wgrad(g2d, xin, conv, cd):
+    """g2d (P, Cout) in cd; xin: the conv's NHWC input as the forward left it (bf16 / fp32 / bf16x2 carrier) -> dL/dw in
+    the parameter's own layout (Cout, Cin, kh, kw), FrozenBN scale applied."""
+    k = conv.kernel_size
+    N, Hh, Ww, Ci = xin.shape
+    P = N * Hh * Ww
+    x2 = _is_x2_map(xin, Ci)
+    if k == 1:
+        patches = xin.reshape(P, Ci)
+    else:
+        rows = torch.arange(P, dtype=torch.int64, device=xin.device)
+        patches = H.im2col_rows(xin, rows, k, 1, conv.padding, conv.dilation)  # (P, k*k*Ci), tap-major then channel
+    if cd == torch.float32:
+        Pp = (P + 63) // 64 * 64
+        dw = H.gemm_nt(H.transpose_cast(g2d, torch.float32, ld_dst=Pp), H.transpose_cast(patches, torch.float32, ld_dst=Pp),
+                       out_dtype=torch.float32)
+    else:
+        dw = H.gemm_tn(g2d, patches, q_x2=x2)  # (Cout, k*k*Ci); of a bf16x2 map the hi halves are read
+    dw = dw.view(conv.out_channels, k, k, Ci).permute(0, 3, 1, 2)
+    if conv.norm is not None:
+        dw = dw * conv.norm.scale_shift()[0].view(-1, 1, 1, 1)
+    return dw.contiguous()
+
+
+def _block_forward_saving(block, x):
+    """The block's forward on the HIP kernels (exactly BasicBlock.forward / BottleneckBlock.forward), keeping what the
+    backward reads: -> (out, [inputs of conv1, conv2(, conv3)])."""
+    last = getattr(block, "_emits_fp32", False) and not block.has_pool
+    tag = lambda t, real_fp32=False: (setattr(t, "_x2_map", _x2() and not real_fp32) or t)
+    tag(x)
+    h = tag(hip_conv(x, block.conv1, relu=True))
+    ins = [x, h]
+    tail = block.conv2
+    if isinstance(block, BottleneckBlock):
+        h = tag(hip_conv(h, block.conv2, relu=True))
+        ins.append(h)
+        tail = block.conv3
+    if _fusable_shortcut(block.shortcut, x) and h.shape[:3] == x.shape[:3]:
+        out = hip_conv(h, tail, relu=True, shortcut=(x, block.shortcut), out_fp32=last)
+    else:
+        sc = hip_conv(x, block.shortcut) if block.shortcut is not None else x
+        out = hip_conv(h, tail, relu=True, residual=sc, out_fp32=last)
+    return tag(out, real_fp32=last), ins
+
+
+def _block_backward(block, ins, out, dy, cd, need_dx):
+    """dy: dL/d(out) (N,H,W,C) fp32 -> (dL/d(block input) (N,H,W,Cin) fp32 or None, {conv module: dL/dw})."""
+    N, Hh, Ww, _ = out.shape
+    convs = [block.conv1, block.conv2] + ([block.conv3] if isinstance(block, BottleneckBlock) else [])
+    grads = {}
+    g = _masked(dy.contiguous(), out, cd)  # through the block's last ReLU: gradient of conv_tail(h) + shortcut(x)
+    g_tail = g
+    for i in range(len(convs) - 1, -1, -1):
+        conv, xin = convs[i], ins[i]
+        if conv.weight.requires_grad:
+            grads[conv] = _conv_wgrad(g, xin, conv, cd)
+        if i == 0 and not need_dx:
+            dx = None
+            break
+        dx = _conv_dgrad(g, conv, N, Hh, Ww, cd)  # fp32 (P, Cin of this conv)
+        if i > 0:
+            g = _masked(dx.view(N, Hh, Ww, -1), xin, cd)  # through the ReLU that produced this conv's input
+    sc = block.shortcut
+    if sc is not None:
+        if sc.weight.requires_grad:
+            grads[sc] = _conv_wgrad(g_tail, ins[0], sc, cd)
+        if need_dx:
+            dx = dx + _conv_dgrad(g_tail, sc, N, Hh, Ww, cd)
+    elif need_dx:
+        dx = dx + (g_tail.float() if g_tail.dtype != torch.float32 else g_tail)
+    return (dx.view(N, Hh, Ww, -1) if dx is not None else None), grads
+
+
 _WARNED_TRAINABLE = set()
 
 
 def _warn_trainable_stage_once(name):
     if name not in _WARNED_TRAINABLE:
         _WARNED_TRAINABLE.add(name)
-        warnings.warn(f"wsovod_amd: backbone stage {name} is trainable (MODEL.BACKBONE.FREEZE_AT < 5): its backward re-evaluates "
-                      "the stage in fp32 torch ops (MIOpen) and the step leaves the optimised path -- no frozen-forward "
-                      "overlap, no step graph, no backbone graph (DESIGN.md section 7)", stacklevel=3)
+        warnings.warn(f"wsovod_amd: backbone stage {name} is trainable (MODEL.BACKBONE.FREEZE_AT < 5): the step leaves the "
+                      "optimised path -- no frozen-forward overlap, no step graph, no backbone graph; stages with a tail pool "
+                      "(res2 / res3) take their backward from a torch (MIOpen) re-evaluation of the stage, res4 / res5 run "
+                      "it on the HIP kernels (DESIGN.md section 7)", stacklevel=3)
 
 
 class _TrainableStage(torch.autograd.Function):
@@ -395,6 +522,8 @@ class _TrainableStage(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, *params = ctx.saved_tensors
+        if _hip_backward_ok(ctx.stage, ctx.x3):
+            return _TrainableStage._backward_hip(ctx, dy, x, params)
         with torch.no_grad():  # the saved map in its on-device format (bf16x2 carrier / bf16 / fp32 NHWC) -> fp32 NCHW
             x32 = H.x2_decode(x.reshape(-1, x.shape[-1])).view(x.shape) if ctx.x3 == "x2" else x.float()
             x32 = x32.permute(0, 3, 1, 2).contiguous()
@@ -409,6 +538,34 @@ class _TrainableStage(torch.autograd.Function):
         dx = grads.pop(0).permute(0, 2, 3, 1).contiguous().to(x.dtype if ctx.x3 != "x2" else torch.float32) if need_dx else None
         it = iter(grads)
         return (None, None, dx, *[next(it) if p.requires_grad else None for p in params])
+
+
+def _stage_backward_hip(ctx, dy, x, params):
+    stage = ctx.stage
+    cd = torch.float32 if (ctx.x3 is False and x.dtype == torch.float32) else torch.bfloat16
+    blocks = list(stage.children())
+    with torch.no_grad():
+        with H.x3_mode(ctx.x3):  # the forward's own kernels again: bit-identical activations, hence the forward's own masks
+            acts, cur = [], x
+            for b in blocks:
+                out, ins = _block_forward_saving(b, cur)
+                acts.append((ins, out))
+                cur = out
+        grads = {}
+        g = dy.float() if dy.dtype != torch.float32 else dy
+        with H.x3_mode(False):
+            for bi in range(len(blocks) - 1, -1, -1):
+                ins, out = acts[bi]
+                need_dx = bi > 0 or ctx.needs_input_grad[2]
+                g, gb = _block_backward(blocks[bi], ins, out, g, cd, need_dx)
+                grads.update({id(c.weight): v for c, v in gb.items()})
+    dx = None
+    if ctx.needs_input_grad[2] and g is not None:
+        dx = g if x.dtype == torch.float32 else g.to(x.dtype)
+    return (None, None, dx, *[grads.get(id(p)) if p.requires_grad else None for p in params])
+
+
+_TrainableStage._backward_hip = staticmethod(_stage_backward_hip)
 
 
 class ResNet(nn.Module):
