@@ -268,6 +268,12 @@ int wsovod_stem_conv1(const unsigned char* img, const int* sizes, const float* m
  * resnet_wsl.py:85-92,408. */
 int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C, int stride,
                            int zero_pad_br, void* out, wsovod_stream_t stream);
+/* Its backward (round 6; a trainable res2 / res3 stage, resnet_wsl.py:85-92,530-552 under autograd): din (N,H,W,C) fp32 =
+ * the gradient dout (N,Ho,Wo,C) fp32 routed to the FIRST maximum of every window in torch's scan order ((0,0), (0,1), (1,0),
+ * (1,1), strict '>'); the padded zero cells take part in the comparison and drop their share.  `in` is the pool's input as
+ * the forward saw it (dtype fp32 / bf16 / WSOVOD_BF16X2: hi + lo is compared). */
+int wsovod_maxpool2x2_nhwc_backward(const void* in, int dtype, int N, int H, int W, int C, int stride, int zero_pad_br,
+                                    const float* dout, float* din, wsovod_stream_t stream);
 /* AdaptiveAvgPool2d(1) over NHWC -> (N,C) fp32 (data_aware_features_head.py:62,124).  workspace: caller-owned fp32
  * scratch sized by wsovod_colsum_workspace_floats for (G, M, N) = (N, N*HW, C) (see wsovod_segment_colsum). */
 int wsovod_global_avgpool_nhwc(const void* in, int dtype, int N, int HW, int C, float* out, float* workspace,

@@ -65,12 +65,15 @@ def test_res5_trainable_step_matches_reference_golden(gpu, precision):
             assert (gen.strided_sample(gr, 1024) - ref).abs().max() <= 5e-3 * ref.abs().max() + 1e-8, k
 
 
-@pytest.mark.parametrize("precision,freeze_at,tol", [("fp32", 3, 2e-3), ("parity", 3, 2e-2), ("bf16", 4, 0.1)])
+@pytest.mark.parametrize("precision,freeze_at,tol", [("fp32", 3, 2e-3), ("parity", 3, 2e-2), ("bf16", 4, 0.1),
+                                                     ("fp32", 1, 2e-3), ("parity", 1, 3e-2), ("bf16", 2, 0.15)])
 def test_hip_conv_backward_agrees_with_the_torch_re_evaluation(gpu, monkeypatch, precision, freeze_at, tol):
     """Round 6: the HIP dgrad / wgrad path of the trainable stages against the torch (MIOpen, fp32) re-evaluation it replaces
     (WSOVOD_HIP_CONV_BACKWARD=0), same model, same batch: every trainable tensor's gradient -- res4 AND res5 at
     FREEZE_AT = 3, i.e. the input gradient crosses a stage boundary, blocks with a projection shortcut fused into their last
-    conv and blocks with an identity shortcut -- agrees in norm and element-wise to the precision's backward grade."""
+    conv and blocks with an identity shortcut; at FREEZE_AT = 1 / 2 also the stages with a tail pool (res2: stride 2, fused
+    into the 64-channel conv in the forward pass; res3: ZeroPad2d + stride 1) through the pool-backward kernel -- agrees in
+    norm and element-wise to the precision's backward grade."""
     batch = to_inputs(gen.seeded_batch(2, 24, 20, 160, 208, seed=13))
     grads = {}
     for flag in ("1", "0"):
@@ -81,7 +84,8 @@ def test_hip_conv_backward_agrees_with_the_torch_re_evaluation(gpu, monkeypatch,
         grads[flag] = {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.requires_grad}
         del model
     bb = [k for k in grads["1"] if k.startswith("backbone.")]
-    assert len(bb) == (10 if freeze_at == 3 else 5)  # R18: res4 = 2 blocks (4 convs + 1 shortcut), res5 likewise
+    # R18: res2 = 2 blocks x 2 convs; res3 / res4 / res5 = 2 blocks (4 convs + 1 projection shortcut) each
+    assert len(bb) == {1: 19, 2: 15, 3: 10, 4: 5}[freeze_at]
     for k in grads["1"]:
         a, b = grads["1"][k], grads["0"][k]
         assert bool(torch.isfinite(a).all()), k
@@ -126,3 +130,33 @@ def test_trainable_stem_is_refused(gpu):
     model.train()
     with pytest.raises(NotImplementedError, match="FREEZE_AT = 0"):
         model(to_inputs(gen.seeded_batch(2, 16, 20, 96, 128, seed=1)))
+
+
+@pytest.mark.parametrize("stride,pad", [(2, False), (1, True)])
+@pytest.mark.parametrize("fmt", ["fp32", "bf16", "x2"])
+def test_maxpool_backward_routes_to_torchs_first_maximum(gpu, stride, pad, fmt):
+    """wsovod_maxpool2x2_nhwc_backward against torch's max_pool2d backward (resnet_wsl.py:85-92 under autograd) on maps with
+    MANY ties (post-ReLU zeros; quantised values): the gradient goes to the first maximum in scan order, the zero cells of
+    ZeroPad2d((0,1,0,1)) take part and swallow their share; odd sizes (a last row / column no stride-2 window covers)."""
+    import torch.nn.functional as F
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(3)
+    N, Hh, Ww, C = 2, 13, 11, 64
+    x = torch.relu(torch.randn(N, Hh, Ww, C, device=gpu)).mul(4).round().div(4)  # ties and zeros
+    if fmt == "bf16":
+        xin = x.to(torch.bfloat16)
+    elif fmt == "x2":
+        xin = H.x2_encode(x.view(-1, C)).view(N, Hh, Ww, C)
+    else:
+        xin = x
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = F.max_pool2d(F.pad(xr, (0, 1, 0, 1)), 2, 1) if pad else F.max_pool2d(xr, 2, stride)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    want = xr.grad.permute(0, 2, 3, 1)
+    got = H.maxpool2x2_nhwc_backward(xin.contiguous(), dy.permute(0, 2, 3, 1).contiguous(), stride, zero_pad_br=pad, x2=fmt == "x2")
+    torch.testing.assert_close(got, want, rtol=0, atol=0)
+    fwd = H.maxpool2x2_nhwc(xin.contiguous(), stride, zero_pad_br=pad, x2=fmt == "x2")
+    fwd32 = H.x2_to_f32(fwd) if fmt == "x2" else fwd.float()
+    torch.testing.assert_close(fwd32, y.detach().permute(0, 2, 3, 1), rtol=0, atol=0)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "wsovod_stem_im2col": [_P, _P, _P, _P, _I, _I, _I, _P, _I, _P],
     "wsovod_stem_conv1": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "wsovod_maxpool2x2_nhwc": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
+    "wsovod_maxpool2x2_nhwc_backward": [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "wsovod_global_avgpool_nhwc": [_P, _I, _I, _I, _I, _P, _P, _P],
     "wsovod_transpose_cast": [_P, _I, _L, _I, _I, _P, _I, _L, _P],
     "wsovod_cast": [_P, _I, _P, _I, _L, _P],

@@ -110,6 +110,70 @@ __global__ void maxpool2x2_nhwc_kernel(const T* __restrict__ in, int N, int H, i
 }
 
 // ---------------------------------------------------------------------------------
+// 2x2 max pool backward (round 6; trainable res2 / res3 stages, resnet_wsl.py:85-92 under autograd): gather form -- every
+// input position adds the output gradients of the windows whose FIRST maximum (scan order (0,0), (0,1), (1,0), (1,1), strict
+// '>': torch's max_pool2d index rule; the zero cells of ZeroPad2d((0,1,0,1)) take part and swallow their share) it is.
+// X2: `in` is a bf16x2 map (value = hi + lo, as the forward pool compares them).  Gradients fp32.
+// ---------------------------------------------------------------------------------
+template <typename T, bool X2>
+__global__ void maxpool2x2_bwd_kernel(const T* __restrict__ in, int N, int H, int W, int C, int Ho, int Wo, int stride,
+                                      int zero_pad, const float* __restrict__ dout, float* __restrict__ din) {
+  constexpr int V = 4;
+  const int cv = C / V;
+  const long long total = (long long)N * H * W * cv;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cv) * V;
+    const int w = (int)((i / cv) % W);
+    const int h = (int)((i / ((long long)cv * W)) % H);
+    const int n = (int)(i / ((long long)cv * W * H));
+    auto cell = [&](int hh, int ww, float (&v)[V]) -> bool {  // false: the cell does not exist (no padding)
+      if (hh < H && ww < W) {
+        const long long pix = ((long long)n * H + hh) * W + ww;
+        if constexpr (X2) {
+          const bf16_t* q = (const bf16_t*)in + pix * 2 * C + ((c >> 5) << 6) + (c & 31);
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[j] = (float)q[j] + (float)q[32 + j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) v[j] = to_f32(in[pix * C + c + j]);
+        }
+        return true;
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) v[j] = 0.f;
+      return zero_pad != 0;
+    };
+    float acc[V] = {0.f, 0.f, 0.f, 0.f};
+    const int ho_lo = stride == 2 ? (h >> 1) : max(h - 1, 0), ho_hi = stride == 2 ? (h >> 1) : h;
+    const int wo_lo = stride == 2 ? (w >> 1) : max(w - 1, 0), wo_hi = stride == 2 ? (w >> 1) : w;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        if (ho >= Ho || wo >= Wo) continue;
+        const int me = (h - ho * stride) * 2 + (w - wo * stride);  // this position's index in the window's scan
+        float best[V];
+        int arg[V] = {-1, -1, -1, -1};
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v[V];
+          if (!cell(ho * stride + (k >> 1), wo * stride + (k & 1), v)) continue;
+#pragma unroll
+          for (int j = 0; j < V; ++j)
+            if (!any || v[j] > best[j]) { best[j] = v[j]; arg[j] = k; }
+          any = true;
+        }
+        const float* g = dout + (((long long)n * Ho + ho) * Wo + wo) * C + c;
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+          if (arg[j] == me) acc[j] += g[j];
+      }
+    float* d = din + (((long long)n * H + h) * W + w) * C + c;
+#pragma unroll
+    for (int j = 0; j < V; ++j) d[j] = acc[j];
+  }
+}
+
+// ---------------------------------------------------------------------------------
 // transpose + cast: dst[c][r] = src[r][c]  (64x64 LDS tile; 8 elements = 16/32 B per lane on both
 // the load and the store side), and plain cast.
 // ---------------------------------------------------------------------------------
@@ -939,6 +1003,33 @@ int wsovod_maxpool2x2_nhwc(const void* in, int dtype, int N, int H, int W, int C
     hipLaunchKernelGGL(maxpool2x2_nhwc_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)in, N,
                        H, W, C, Ho, Wo, stride, zero_pad_br, (float*)out);
   WS_CHECK_LAUNCH("wsovod_maxpool2x2_nhwc");
+  return WSOVOD_OK;
+}
+
+int wsovod_maxpool2x2_nhwc_backward(const void* in, int dtype, int N, int H, int W, int C, int stride, int zero_pad_br,
+                                    const float* dout, float* din, wsovod_stream_t stream) {
+  WS_CHECK_ARG(dtype == WSOVOD_F32 || dtype == WSOVOD_BF16 || dtype == WSOVOD_BF16X2, "wsovod_maxpool2x2_nhwc_backward: bad dtype");
+  WS_CHECK_ARG(stride == 1 || stride == 2, "wsovod_maxpool2x2_nhwc_backward: stride must be 1 or 2");
+  WS_CHECK_ARG(C % (dtype == WSOVOD_BF16X2 ? 32 : 4) == 0, "wsovod_maxpool2x2_nhwc_backward: C=%d must be a multiple of 4 (bf16x2: 32)", C);
+  const int Hin = H + (zero_pad_br ? 1 : 0), Win = W + (zero_pad_br ? 1 : 0);
+  const int Ho = (Hin - 2) / stride + 1, Wo = (Win - 2) / stride + 1;
+  if (N == 0 || H == 0 || W == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(in && dout && din, "wsovod_maxpool2x2_nhwc_backward: null pointer");
+  static int slot = wsovod::prof_slot("maxpool2x2_nhwc_bwd");
+  hipStream_t s = (hipStream_t)stream;
+  const long long total = (long long)N * H * W * (C / 4);
+  wsovod::ProfScope prof(slot, s, 0.0, (double)N * H * W * C * 12.0);
+  const dim3 grid(grid_for(total, 256));
+  if (dtype == WSOVOD_BF16X2)
+    hipLaunchKernelGGL((maxpool2x2_bwd_kernel<bf16_t, true>), grid, dim3(256), 0, s, (const bf16_t*)in, N, H, W, C, Ho, Wo, stride,
+                       zero_pad_br, dout, din);
+  else if (dtype == WSOVOD_BF16)
+    hipLaunchKernelGGL((maxpool2x2_bwd_kernel<bf16_t, false>), grid, dim3(256), 0, s, (const bf16_t*)in, N, H, W, C, Ho, Wo, stride,
+                       zero_pad_br, dout, din);
+  else
+    hipLaunchKernelGGL((maxpool2x2_bwd_kernel<float, false>), grid, dim3(256), 0, s, (const float*)in, N, H, W, C, Ho, Wo, stride,
+                       zero_pad_br, dout, din);
+  WS_CHECK_LAUNCH("wsovod_maxpool2x2_nhwc_backward");
   return WSOVOD_OK;
 }
 

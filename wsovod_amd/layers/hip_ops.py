@@ -684,6 +684,19 @@ def maxpool2x2_nhwc(x, stride, zero_pad_br=False, x2=False):
     return out
 
 
+def maxpool2x2_nhwc_backward(x, dout, stride, zero_pad_br=False, x2=False):
+    """x: the pool's input (N,H,W,C) as the forward saw it; dout (N,Ho,Wo,C) fp32 -> din (N,H,W,C) fp32 (first-maximum
+    routing, torch's max_pool2d rule)."""
+    require_gpu(x, dout)
+    N, H, W, Cc = x.shape
+    dout = dout.contiguous()
+    assert dout.dtype == torch.float32 and x.is_contiguous()
+    din = torch.empty((N, H, W, Cc), dtype=torch.float32, device=x.device)
+    check(lib().wsovod_maxpool2x2_nhwc_backward(ptr(x), BF16X2 if x2 else dtype_code(x.dtype), N, H, W, Cc, stride,
+                                                int(zero_pad_br), ptr(dout), ptr(din), stream()), "maxpool2x2_nhwc_backward")
+    return din
+
+
 def _colsum_workspace(G, M, N, device):
     """fp32 scratch of the two-stage column sums (one partial per 128-row chunk and column): allocated per call from
     torch's caching allocator, so it belongs to the calling stream like any other temporary."""

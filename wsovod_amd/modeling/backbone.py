@@ -366,8 +366,9 @@ def forward_precision(name):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# round 6: the backward of a trainable stage on the HIP kernels themselves (blocks without a tail pool: res4 / res5, i.e.
-# MODEL.BACKBONE.FREEZE_AT = 3 / 4; reference: resnet_wsl.py:94-110,221-241 under autograd, :530-552)
+# round 6: the backward of a trainable stage on the HIP kernels themselves (MODEL.BACKBONE.FREEZE_AT = 1 .. 4; reference:
+# resnet_wsl.py:94-110,221-241 under autograd, :530-552)
+#   tail pool     res2 / res3: the gradient goes to the first maximum of every 2x2 window      wsovod_maxpool2x2_nhwc_backward
 #   mask          dL/d(pre-activation) = dL/d(out) * [out > 0]              wsovod_mask_transpose
 #   input grad    a k x k, stride-1, same-size conv IS a conv of the output gradient with the kernel rotated by 180 deg and
 #                 its channel roles swapped ([Cin][kh'][kw'][Cout]): the implicit-GEMM kernel of the forward pass; 1x1: a GEMM
@@ -382,7 +383,7 @@ def _hip_backward_ok(stage, x3):
     if os.environ.get("WSOVOD_HIP_CONV_BACKWARD", "1") == "0" or x3 in ("full", "fwd"):
         return False  # (the bf16x3 modes keep their operands in fp32 tensors and split on the fly: torch re-evaluation)
     for b in stage.children():
-        if not isinstance(b, (BasicBlock, BottleneckBlock)) or b.has_pool:
+        if not isinstance(b, (BasicBlock, BottleneckBlock)):
             return False
         for c in (b.conv1, b.conv2, getattr(b, "conv3", None), b.shortcut):
             if c is not None and (c.stride != 1 or c.bias is not None or 2 * c.padding != c.dilation * (c.kernel_size - 1)
@@ -455,12 +456,18 @@ def _block_forward_saving(block, x):
         h = tag(hip_conv(h, block.conv2, relu=True))
         ins.append(h)
         tail = block.conv3
-    if _fusable_shortcut(block.shortcut, x) and h.shape[:3] == x.shape[:3]:
+    if _fusable_shortcut(block.shortcut, x) and h.shape[:3] == x.shape[:3] and \
+            not (isinstance(block, BasicBlock) and block.has_pool and block.pool_stride == 2):  # (the forwards' own rules)
         out = hip_conv(h, tail, relu=True, shortcut=(x, block.shortcut), out_fp32=last)
     else:
         sc = hip_conv(x, block.shortcut) if block.shortcut is not None else x
         out = hip_conv(h, tail, relu=True, residual=sc, out_fp32=last)
-    return tag(out, real_fp32=last), ins
+    tag(out, real_fp32=last)
+    if block.has_pool:
+        # the map the tail pool reads (the forward's fused 64-channel conv + pool never writes it: same bits, gemm.hip) and
+        # the pooled map the next block takes
+        return tag(block._pool(out)), ins, out
+    return out, ins, out
 
 
 def _block_backward(block, ins, out, dy, cd, need_dx):
@@ -468,6 +475,9 @@ def _block_backward(block, ins, out, dy, cd, need_dx):
     N, Hh, Ww, _ = out.shape
     convs = [block.conv1, block.conv2] + ([block.conv3] if isinstance(block, BottleneckBlock) else [])
     grads = {}
+    if block.has_pool:  # `out` is the map the tail pool read: route dy back through the pool first
+        dy = H.maxpool2x2_nhwc_backward(out, dy.contiguous(), block.pool_stride, zero_pad_br=block.pool_stride == 1,
+                                        x2=_is_x2_map(out, out.shape[-1]))
     g = _masked(dy.contiguous(), out, cd)  # through the block's last ReLU: gradient of conv_tail(h) + shortcut(x)
     g_tail = g
     for i in range(len(convs) - 1, -1, -1):
@@ -498,9 +508,9 @@ def _warn_trainable_stage_once(name):
     if name not in _WARNED_TRAINABLE:
         _WARNED_TRAINABLE.add(name)
         warnings.warn(f"wsovod_amd: backbone stage {name} is trainable (MODEL.BACKBONE.FREEZE_AT < 5): the step leaves the "
-                      "optimised path -- no frozen-forward overlap, no step graph, no backbone graph; stages with a tail pool "
-                      "(res2 / res3) take their backward from a torch (MIOpen) re-evaluation of the stage, res4 / res5 run "
-                      "it on the HIP kernels (DESIGN.md section 7)", stacklevel=3)
+                      "optimised path -- no frozen-forward overlap, no step graph, no backbone graph; its backward runs on "
+                      "the HIP kernels too (the bf16x3 modes: a torch re-evaluation of the stage; DESIGN.md section 7)",
+                      stacklevel=3)
 
 
 class _TrainableStage(torch.autograd.Function):
@@ -548,9 +558,9 @@ def _stage_backward_hip(ctx, dy, x, params):
         with H.x3_mode(ctx.x3):  # the forward's own kernels again: bit-identical activations, hence the forward's own masks
             acts, cur = [], x
             for b in blocks:
-                out, ins = _block_forward_saving(b, cur)
+                nxt, ins, out = _block_forward_saving(b, cur)
                 acts.append((ins, out))
-                cur = out
+                cur = nxt
         grads = {}
         g = dy.float() if dy.dtype != torch.float32 else dy
         with H.x3_mode(False):
