@@ -123,13 +123,46 @@ def test_trainer_and_optimizer_with_a_trainable_stage(gpu):
     tr.close()
 
 
-def test_trainable_stem_is_refused(gpu):
-    from wsovod_amd.testing import build_hot_path_model
+def test_trainable_stem_matches_the_oracle(gpu):
+    """MODEL.BACKBONE.FREEZE_AT = 0 (round 6; reference: resnet_wsl.py:530-552 with nothing frozen): the whole backbone
+    trains -- the stem's conv1 is fused with the uint8 normalisation in the forward pass and takes its weight gradient from
+    the normalised im2col rows of the image.  fp32 against the ORACLE's autograd (oracle/wsovod_ref.py with the gradient
+    running through its differentiable RoIPool into res5 ... stem.conv1): every trainable tensor's gradient norm within 3e-3,
+    sampled elements within 1 %; the parity precision against the fp32 run at its backward grade."""
+    from oracle import wsovod_ref as R
 
-    cfg, model = build_hot_path_model(seed=0, precision="fp32", device="cuda:0", freeze_at=0)
-    model.train()
+    host = gen.seeded_batch(2, 16, 20, 96, 128, seed=21)
+    grads = {}
+    for precision in ("fp32", "parity"):
+        cfg, model = _model(precision, 0)
+        train = [k for k, p in model.named_parameters() if p.requires_grad]
+        assert "backbone.stem.conv1.weight" in train and len([k for k in train if k.startswith("backbone.")]) == 22
+        sum(model(to_inputs(host)).values()).backward()
+        torch.cuda.synchronize()
+        grads[precision] = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters() if p.requires_grad}
+        if precision == "fp32":
+            sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+        del model
+    for k in train:
+        sd[k].requires_grad_(True)
+    losses, _ = R.train_forward(sd, host, depth=18, num_classes=20, pixel_std=tuple(gen.PIXEL_STD),
+                                backbone_grad=True)
+    want = dict(zip(train, torch.autograd.grad(sum(losses.values()), [sd[k] for k in train], allow_unused=True)))
+    top = max(float(g.norm()) for g in want.values() if g is not None)
+    for k in train:
+        w, g32, gp = want[k], grads["fp32"][k], grads["parity"][k]
+        if w is None or float(w.norm()) < 1e-6 * top:
+            continue
+        assert abs(float(g32.norm()) - float(w.norm())) <= 3e-3 * float(w.norm()), (k, float(g32.norm()), float(w.norm()))
+        assert float((g32 - w).abs().max()) <= 1e-2 * float(w.abs().max()) + 1e-9, k
+        assert abs(float(gp.norm()) - float(w.norm())) <= 3e-2 * float(w.norm()), (k, float(gp.norm()), float(w.norm()))
+
+
+def test_float_entry_with_a_trainable_stem_is_refused(gpu):
+    """ResNet.forward(x) (the generic float entry) has no trainable-stem path; it says so instead of silently freezing."""
+    cfg, model = _model("fp32", 0)
     with pytest.raises(NotImplementedError, match="FREEZE_AT = 0"):
-        model(to_inputs(gen.seeded_batch(2, 16, 20, 96, 128, seed=1)))
+        model.backbone(torch.randn(1, 3, 64, 96, device=gpu))
 
 
 @pytest.mark.parametrize("stride,pad", [(2, False), (1, True)])

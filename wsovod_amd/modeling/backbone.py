@@ -550,6 +550,57 @@ class _TrainableStage(torch.autograd.Function):
         return (None, None, dx, *[next(it) if p.requires_grad else None for p in params])
 
 
+class _TrainableStem(torch.autograd.Function):
+    """MODEL.BACKBONE.FREEZE_AT = 0 (round 6): the stem with trainable weights.  forward: the fused uint8 -> conv1 kernel and
+    the 64-channel convs as for a frozen stem.  backward: the stem's activations recomputed by the same kernels, then pool
+    backward -> mask -> weight / input gradients of conv3 and conv2 as in the residual stages -> conv1's weight gradient as
+    g^T @ (normalised im2col rows of the image, wsovod_stem_im2col); the image itself takes no gradient."""
+
+    @staticmethod
+    def forward(ctx, net, x3, images_u8, sizes, mean, std, *params):
+        with torch.no_grad(), H.x3_mode(x3):
+            out = net._stem_uint8(images_u8, sizes, mean, std)
+        ctx.net, ctx.x3, ctx.norm = net, x3, (mean, std)
+        ctx.save_for_backward(images_u8, sizes, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        images_u8, sizes, *params = ctx.saved_tensors
+        net, stem = ctx.net, ctx.net.stem
+        mean, std = ctx.norm
+        cd = torch.float32 if (ctx.x3 is False and net.compute_dtype == torch.float32) else torch.bfloat16
+        tag = lambda t, on: (setattr(t, "_x2_map", on) or t)
+        with torch.no_grad():
+            with H.x3_mode(ctx.x3):
+                x2 = _x2()
+                a1 = tag(net._stem_conv1(images_u8, sizes, mean, std), x2)
+                a2 = tag(hip_conv(a1, stem.conv2, relu=True), x2)
+                a3 = tag(hip_conv(a2, stem.conv3, relu=True), x2)  # (the forward pools in this conv's epilogue: same bits)
+            grads = {}
+            with H.x3_mode(False):
+                N, Hh, Ww, _ = a3.shape
+                g = H.maxpool2x2_nhwc_backward(a3, (dy.float() if dy.dtype != torch.float32 else dy).contiguous(), 2, x2=x2)
+                g = _masked(g, a3, cd)
+                for conv, xin, yin in ((stem.conv3, a2, a2), (stem.conv2, a1, a1)):
+                    if conv.weight.requires_grad:
+                        grads[id(conv.weight)] = _conv_wgrad(g, xin, conv, cd)
+                    g = _masked(_conv_dgrad(g, conv, N, Hh, Ww, cd).view(N, Hh, Ww, -1), yin, cd)
+                if stem.conv1.weight.requires_grad:
+                    patches, _, _ = H.stem_im2col(images_u8, sizes, mean, std, cd)  # (P, 32): [kh][kw][cin] + 5 zero columns
+                    if cd == torch.float32:
+                        Pp = (patches.size(0) + 63) // 64 * 64
+                        dw = H.gemm_nt(H.transpose_cast(g, torch.float32, ld_dst=Pp),
+                                       H.transpose_cast(patches, torch.float32, ld_dst=Pp), out_dtype=torch.float32)
+                    else:
+                        dw = H.gemm_tn(g, patches)
+                    dw = dw[:, :27].reshape(stem.conv1.out_channels, 3, 3, 3).permute(0, 3, 1, 2)
+                    if stem.conv1.norm is not None:
+                        dw = dw * stem.conv1.norm.scale_shift()[0].view(-1, 1, 1, 1)
+                    grads[id(stem.conv1.weight)] = dw.contiguous()
+        return (None, None, None, None, None, None, *[grads.get(id(p)) if p.requires_grad else None for p in params])
+
+
 def _stage_backward_hip(ctx, dy, x, params):
     stage = ctx.stage
     cd = torch.float32 if (ctx.x3 is False and x.dtype == torch.float32) else torch.bfloat16
@@ -628,12 +679,12 @@ class ResNet(nn.Module):
         return torch.bfloat16 if self.precision == "bf16" else torch.float32  # "fp32" and "bf16x3" carry fp32 tensors
 
     def _check_frozen(self):
-        """The stem's first conv is fused with the image normalisation (no weight gradient there): a trainable STEM
-        (FREEZE_AT = 0) stays unsupported; trainable stages res2 - res5 go through _TrainableStage."""
-        if any(p.requires_grad for p in self.stem.parameters()):
+        """The generic float entry (`forward(x)`, a normalised float image) has no trainable-stem path: the stem's first conv
+        trains through the fused uint8 entry (`forward_uint8`, what the meta-arch calls; _TrainableStem)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.stem.parameters()):
             raise NotImplementedError(
-                "wsovod_amd: MODEL.BACKBONE.FREEZE_AT = 0 (a trainable stem) is not supported: the stem runs fused with the "
-                "uint8 normalisation, forward only; FREEZE_AT >= 1 trains the residual stages through the torch fallback")
+                "wsovod_amd: MODEL.BACKBONE.FREEZE_AT = 0 (a trainable stem) trains through ResNet.forward_uint8 (the uint8 "
+                "entry the meta-arch uses); the float entry ResNet.forward(x) runs the stem forward-only")
 
     @property
     def has_trainable_stage(self):
@@ -744,15 +795,39 @@ class ResNet(nn.Module):
             cache[key] = g
         return g or None
 
+    def _stem_conv1(self, images_u8, sizes, pixel_mean, pixel_std):
+        """relu(conv1 (normalised image)) as the stem's forward produces it."""
+        stem = self.stem
+        if (self.compute_dtype == torch.bfloat16 or _x2()) and stem.out_channels == 64 and stem.in_channels == 3:
+            if _x2():
+                w32, b = stem._im2col_weight(torch.float32)
+                return H.stem_conv1_x2(images_u8, sizes, pixel_mean, pixel_std, H.x2_cached(w32), b)
+            w32, b = stem._im2col_weight(torch.bfloat16)
+            return H.stem_conv1(images_u8, sizes, pixel_mean, pixel_std, w32, b)
+        a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
+        w32, b = stem._im2col_weight(a.dtype)
+        return H.gemm_nt(a, w32, bias=b, relu=True, out_dtype=a.dtype).view(images_u8.size(0), ho, wo, stem.out_channels)
+
+    def _stem_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
+        if (self.compute_dtype == torch.bfloat16 or _x2()) and self.stem.out_channels == 64 and self.stem.in_channels == 3:
+            # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)
+            return self.stem.forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
+        a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
+        return self.stem.forward_im2col(a, images_u8.size(0), ho, wo)
+
     def _forward_uint8(self, images_u8, sizes, pixel_mean, pixel_std):
-        self._check_frozen()
-        with torch.no_grad():
-            if (self.compute_dtype == torch.bfloat16 or _x2()) and self.stem.out_channels == 64 and self.stem.in_channels == 3:
-                # bf16: one kernel from the uint8 canvas to relu(conv1) (bit-identical to im2col + GEMM, no operand pass)
-                xs = self.stem.forward_uint8(images_u8, sizes, pixel_mean, pixel_std)
-            else:
-                a, ho, wo = H.stem_im2col(images_u8, sizes, pixel_mean, pixel_std, self.compute_dtype)
-                xs = self.stem.forward_im2col(a, images_u8.size(0), ho, wo)
+        stem_params = self._stage_params(self.stem)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in stem_params):
+            # MODEL.BACKBONE.FREEZE_AT = 0: the stem trains too (its backward on the HIP kernels, _TrainableStem)
+            x3 = H.x3_active()
+            if x3 in ("full", "fwd") or not (self.stem.out_channels == 64 and self.stem.in_channels == 3):
+                raise NotImplementedError("wsovod_amd: MODEL.BACKBONE.FREEZE_AT = 0 (a trainable stem) is supported in the "
+                                          "bf16 / fp32 / parity precisions on the 3 -> 64 stem")
+            _warn_trainable_stage_once("stem")
+            xs = _TrainableStem.apply(self, x3, images_u8, sizes, pixel_mean, pixel_std, *stem_params)
+        else:
+            with torch.no_grad():
+                xs = self._stem_uint8(images_u8, sizes, pixel_mean, pixel_std)
         return self._run(xs)
 
     def output_shape(self):
