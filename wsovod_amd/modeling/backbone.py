@@ -10,10 +10,13 @@ feature map is logically NCHW but stored NHWC (torch.channels_last), which the R
 directly.
 
 Scope: every shipped WSR config freezes the whole backbone (FREEZE_AT: 5): the HIP kernels are the
-FORWARD of every conv.  A trainable stage (FREEZE_AT < 5, resnet_wsl.py:530-552) still runs its forward on those kernels;
-its backward -- outside the benchmarked path, no conv dgrad / wgrad kernel exists -- is `_TrainableStage`: the stage is
-re-evaluated from its saved input with torch's GPU convolution (MIOpen) under autograd, which yields the gradients of
-the stage's weights and of its input.  Never a CPU path; tests/test_gpu_freeze_at.py pins it to the reference (G19).
+FORWARD of every conv.  A trainable stage (FREEZE_AT < 5, resnet_wsl.py:530-552) runs its forward on those kernels and --
+since round 6 -- its BACKWARD too (`_TrainableStage`, `_TrainableStem`): the stage's activations are recomputed by the
+forward kernels, ReLU masks and pool routing come from those bits, input gradients are implicit-GEMM convs on the rotated
+weights, weight gradients the transposed-read contraction over im2col rows (stem conv1: over the normalised im2col rows of
+the image).  The "bf16x3" modes keep the earlier form (the stage re-evaluated with torch's GPU convolution under autograd).
+Never a CPU path; tests/test_gpu_freeze_at.py pins it to the reference (G19), to the oracle (FREEZE_AT = 0) and to the
+torch re-evaluation (FREEZE_AT 1 - 4).
 """
 import os
 import warnings
