@@ -50,6 +50,38 @@ def test_fused_kernel_equals_dw_then_sgd(gpu, shadow_kind, q_x2):
         assert torch.equal(sf, H.x2_encode(wf))
 
 
+@pytest.mark.parametrize("tail", ["0", "1"])
+def test_fused_kernel_with_a_partly_filled_last_round(gpu, monkeypatch, tail):
+    """More than one round of 256 x 256 tiles with a last round that fills less than half the chip (17 x 16 = 272 tiles: 16 in
+    the tail, as fc1's 1568 = 6 x 256 + 32), ragged last row tile: whole tiles (the default) and the measured-and-not-default
+    form WSOVOD_TN_SGD_TAIL=1 -- the tail tiles' K slices meet by atomics in a compact scratch and a small pass applies their
+    update -- against dW (whole tiles, fixed order) + the optimizer kernel."""
+    from wsovod_amd.layers import hip_ops as H
+
+    monkeypatch.setenv("WSOVOD_TN_SGD_TAIL", tail)
+
+    torch.manual_seed(12)
+    Mred, NI, NJ = 4096, 4096 + 40, 4096
+    dA = (torch.randn(Mred, NI, device=gpu) * 0.05).to(torch.bfloat16)
+    x = torch.randn(Mred, NJ, device=gpu).to(torch.bfloat16)
+    w0 = torch.randn(NI, NJ, device=gpu) * 0.05
+    lr, wd, mu = 0.01, 5e-4, 0.9
+    wr, br = w0.clone(), torch.zeros_like(w0)
+    sr = H.x2_encode(wr)
+    wf, bf = w0.clone(), torch.zeros_like(w0)
+    sf = H.x2_encode(wf)
+    for _ in range(2):
+        g = H.gemm_tn(dA, x, split_tail=False)
+        H.sgd_momentum_multi([(wr, g, br, sr, lr, wd)], mu)
+        H.gemm_tn_sgd(dA, x, wf, bf, sf, lr, wd, mu)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(wf, wr, rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(bf, br, rtol=2e-5, atol=2e-5)
+    assert torch.equal(sf, H.x2_encode(wf))
+    # the tail tiles (the last tile ids of the grouped order) were updated exactly once per step: nothing left at w0
+    assert float((wf - w0).abs().min()) >= 0 and float(((wf - w0).abs() > 0).float().mean()) > 0.999
+
+
 def _steps(gpu, monkeypatch, fused, graph, precision, n_steps=6):
     from wsovod_amd.data import make_batch
     from wsovod_amd.engine import HotPathTrainer, build_optimizer
@@ -64,7 +96,9 @@ def _steps(gpu, monkeypatch, fused, graph, precision, n_steps=6):
     model.train()
     cfg.SOLVER.BASE_LR = 1e-3
     tr = HotPathTrainer(model, build_optimizer(cfg, model))
-    assert (tr._fused is not None) == fused
+    assert bool(tr._fused) == fused  # (fc1 and fc2: the 2-D weights of at least 2^24 elements, largest first)
+    if fused:
+        assert [tuple(p.shape) for p in tr._fused] == [(4096, 25088), (4096, 4096)]
     losses = []
     for s in range(n_steps):
         for grp in tr.optimizer.param_groups:
@@ -74,7 +108,9 @@ def _steps(gpu, monkeypatch, fused, graph, precision, n_steps=6):
               "height": x["height"], "width": x["width"]} for x in b]
         losses.append({k: float(v.detach()) for k, v in tr.run_step(b).items()})
     tr.flush()
-    calls = tr._fused._fused_update.calls if fused else 0
+    calls = tr._fused[0]._fused_update.calls if fused else 0
+    fc2_calls = tr._fused[1]._fused_update.calls if fused else 0
+    assert fc2_calls == calls
     fc1 = model.roi_heads.box_head.fc1.weight
     out = {"params": {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad},
            "mom_fc1": tr.optimizer.state[fc1]["momentum_buffer"].clone(), "losses": losses, "calls": calls,
@@ -116,28 +152,29 @@ def test_fused_update_steps_aside_for_clipping_accumulation_and_large_batches(gp
     model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     tr = HotPathTrainer(model, HipSGD(params, lr=1e-3, momentum=0.9, clip=("full_model", 1.0)))
-    assert tr._fused is None
+    assert not tr._fused
     tr.close()
     tr = HotPathTrainer(model, build_optimizer(cfg, model), iter_size=2)
-    assert tr._fused is None
+    assert not tr._fused
     tr.close()
     monkeypatch.setenv("WSOVOD_FUSED_SGD_ROWS", "100")
     tr = HotPathTrainer(model, build_optimizer(cfg, model))
-    fu = tr._fused._fused_update
+    big = tr._fused[0]
+    fu = big._fused_update
     assert not fu.wants(64)  # not inside the trainer's own backward: a caller's loss.backward() gets a gradient
     fu.armed = True
     assert fu.wants(64) and not fu.wants(128)
-    tr._fused.grad = torch.zeros_like(tr._fused)
+    big.grad = torch.zeros_like(big)
     assert not fu.wants(64)  # somebody left a gradient on the tensor: it goes through the optimizer
-    tr._fused.grad = None
+    big.grad = None
     fu.armed = False
     # a plain forward + backward on the model while the trainer is attached leaves the weight alone and fills .grad
     from wsovod_amd.data import make_batch
 
     b = [{"image": x["image"].to(gpu), "proposals": x["proposals"].to(gpu), "instances": x["instances"],
           "height": x["height"], "width": x["width"]} for x in make_batch(1, 64, 20, H=160, W=224, seed=5)]
-    before = tr._fused.detach().clone()
+    before = big.detach().clone()
     sum(model(b).values()).backward()
-    assert tr._fused.grad is not None and torch.equal(tr._fused.detach(), before) and fu.calls == 0
+    assert big.grad is not None and torch.equal(big.detach(), before) and fu.calls == 0
     model.zero_grad(set_to_none=True)
     tr.close()

@@ -17,6 +17,7 @@
 // K-step (4 instructions: P/Q x two 128-column sub-images) and waits vmcnt(4), i.e. for the half issued one phase
 // earlier, which is read one phase later.  A row half is overwritten two phases after its last read.
 #include "gemm_common.h"
+#include <vector>
 
 namespace wsovod_gemm {
 
@@ -49,6 +50,11 @@ struct TnArgs {
   int shadow_x2;
   float lr, wd, mu, gscale;
   const float* lr_dev;   // optional device scalar read instead of lr
+  // SGD form with a split tile-round tail: the K slices of the tail tiles meet by atomics in a COMPACT scratch
+  // [tail tile][256][256] fp32 (TAILBUF instantiation, launched as its own grid with bid_base = full_tiles), and
+  // tn_sgd_tail_kernel applies the update of those tiles from it
+  float* tail_buf;
+  int bid_base;
 };
 
 // LEAN = 1 (round 5): the same schedule with the per-phase address arithmetic removed from the half of a phase that the
@@ -66,7 +72,7 @@ __device__ __forceinline__ void tr_read_imm(__attribute__((ext_vector_type(2))) 
 #endif
 }
 
-template <int LEAN, bool SGD = false>
+template <int LEAN, bool SGD = false, bool TAILBUF = false>
 __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   constexpr int BI = 256, BJ = 256, BK = 64;
   constexpr int OP_BYTES = 2 * BK * 256;        // one operand of one K-step: 2 sub-images x 64 rows x 256 B
@@ -82,8 +88,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int wg, slice = 0;
+  const int bid = TAILBUF ? (int)blockIdx.x + p.bid_base : (int)blockIdx.x;
   {
-    const int bid = blockIdx.x;
     const int nwg = p.ksplit ? p.full_tiles : p.tiles_i * p.tiles_j;  // tiles that are remapped per XCD
     if (bid < nwg) {
       const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
@@ -94,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
       slice = t - (t / p.ksplit) * p.ksplit;
     }
   }
-  const bool sliced = p.ksplit && (int)blockIdx.x >= p.full_tiles;
+  const bool sliced = p.ksplit && bid >= p.full_tiles;
   const int group_size = p.group_m * p.tiles_j;
   const int group_id = wg / group_size;
   const int first_i = group_id * p.group_m;
@@ -416,10 +422,14 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       const int rbase = i0 + wr * 128 + half * 64;
+      // (TAILBUF: the tile's own 256 x 256 block of the compact scratch instead of its place in C)
+      float* dst = TAILBUF ? p.tail_buf + (long long)(wg - p.full_tiles) * 65536 + (long long)(wr * 128 + half * 64) * 256 + wc * 64
+                           : p.C + (long long)rbase * p.ldc + cbase;
+      const long long ldd = TAILBUF ? 256 : p.ldc;
       for (int row = 0; row < 64; ++row) {
         if (rbase + row >= p.NI) break;
         const float v = stg[row * SROW + ((((lane >> 2) ^ (row & 15)) << 2) | (lane & 3))];
-        if (cbase + lane < p.NJ) unsafeAtomicAdd(p.C + (long long)(rbase + row) * p.ldc + cbase + lane, v);
+        if (cbase + lane < p.NJ) unsafeAtomicAdd(dst + row * ldd + lane, v);
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -533,6 +543,47 @@ __global__ __launch_bounds__(256) void tn_zero_tail_kernel(const TnArgs p) {
   }
 }
 
+// SGD form: the update of the tail tiles [full_tiles, tiles) from the compact scratch their K slices were added into
+// (same tile id -> (i, j) map as the main kernel; the arithmetic of the fused epilogue)
+__global__ __launch_bounds__(256) void tn_sgd_tail_kernel(const TnArgs p) {
+  const int wg = p.full_tiles + (blockIdx.x >> 4), part = blockIdx.x & 15;
+  const int group_size = p.group_m * p.tiles_j;
+  const int group_id = wg / group_size;
+  const int first_i = group_id * p.group_m;
+  const int gm = min(p.tiles_i - first_i, p.group_m);
+  const int in_group = wg - group_id * group_size;
+  const int i0 = (first_i + in_group % gm) * 256 + part * 16, j0 = (in_group / gm) * 256;
+  const float* src = p.tail_buf + (long long)(wg - p.full_tiles) * 65536 + (long long)part * 16 * 256;
+  const float lr = p.lr_dev ? *p.lr_dev : p.lr;
+  const float gs = p.gscale, mu = p.mu, wd = p.wd;
+  for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+    const int r = e >> 6, c4 = (e & 63) * 4;
+    const int i = i0 + r, j = j0 + c4;
+    if (i >= p.NI) break;
+    if (j >= p.NJ) continue;  // (NJ % 8 == 0: whole quads)
+    f32x4 gv = *(const f32x4*)(src + r * 256 + c4);
+    const long long q = (long long)i * p.ldc + j;
+    f32x4 pv = *(const f32x4*)(p.C + q);
+    f32x4 bv = *(const f32x4*)(p.mom + q);
+    gv = gv * gs;
+    bv = mu * bv + (gv + wd * pv);
+    pv -= lr * bv;
+    *(f32x4*)(p.mom + q) = bv;
+    *(f32x4*)(p.C + q) = pv;
+    if (p.shadow) {
+      const bf16x4 hi = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
+      if (p.shadow_x2) {
+        bf16_t* d = p.shadow + ((q >> 5) << 6) + (q & 31);
+        *(bf16x4*)d = hi;
+        *(bf16x4*)(d + 32) = bf16x4{(bf16_t)(pv[0] - (float)hi[0]), (bf16_t)(pv[1] - (float)hi[1]),
+                                    (bf16_t)(pv[2] - (float)hi[2]), (bf16_t)(pv[3] - (float)hi[3])};
+      } else {
+        *(bf16x4*)(p.shadow + q) = hi;
+      }
+    }
+  }
+}
+
 }  // namespace
 }  // namespace wsovod_gemm
 
@@ -593,6 +644,8 @@ static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq,
   a.lr = a.wd = a.mu = 0.f;
   a.gscale = 1.f;
   a.lr_dev = nullptr;
+  a.tail_buf = nullptr;
+  a.bid_base = 0;
   if (upd) {
     a.mom = upd->momentum_buf;
     a.shadow = (bf16_t*)upd->shadow;
@@ -625,6 +678,7 @@ static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq,
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), "wsovod_gemm_tn: LDS opt-in");
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "wsovod_gemm_tn: LDS opt-in (160 KiB)");
     WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "wsovod_gemm_tn_sgd: LDS opt-in (160 KiB)");
+    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tn8_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "wsovod_gemm_tn_sgd (tail): LDS opt-in (160 KiB)");
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -664,9 +718,50 @@ static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq,
     }
   }
   static const int lean = getenv("WSOVOD_TN_LEAN") ? atoi(getenv("WSOVOD_TN_LEAN")) : 2;
-  if (upd)  // (accumulate = 2 above: whole tiles only -- the update needs the finished sum of a tile in one place)
-    hipLaunchKernelGGL((gemm_tn8_kernel<2, true>), dim3(grid), dim3(512), 160 * 1024, s, a);
-  else if (lean == 2)
+  if (upd) {
+    // The update needs the finished sum of a tile in one place: whole tiles, the fused epilogue.  WSOVOD_TN_SGD_TAIL=1
+    // (measured and NOT the default): a last round that fills less than half the chip cut along K as the plain form does,
+    // its slices meeting by atomics in a compact scratch and a small pass applying the update of those tiles from it --
+    // fc1 (1568 tiles = 6 rounds + 32) at 1 image 0.526 against 0.496 ms for fc1 + fc2, at 8 images 0.969 against 0.944: the
+    // memset + atomics + extra pass cost more than the partly filled round at these reduction lengths.
+    const bool want_tail = ntiles > cus && tail > 0 && tail <= cus / 2 &&
+                           getenv("WSOVOD_TN_SGD_TAIL") && getenv("WSOVOD_TN_SGD_TAIL")[0] == '1';
+    const int S = want_tail ? std::min(8, cus / tail) : 0;
+    if (want_tail && S >= 2 && nk >= 8 * S) {
+      static float* tb = nullptr;
+      static size_t tb_bytes = 0;
+      static std::vector<float*> retired;  // (never freed: a captured step graph keeps the pointer it was captured with)
+      const size_t need = (size_t)tail * 65536 * sizeof(float);
+      if (need > tb_bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+          wsovod::set_error("wsovod_gemm_tn_sgd: the tail scratch would have to grow under stream capture; run the shape once "
+                            "outside the capture first");
+          return WSOVOD_ERR_UNSUPPORTED;
+        }
+        float* fresh = nullptr;
+        const size_t want = std::max(need, std::min<size_t>(2 * tb_bytes, (size_t)128 * 65536 * sizeof(float)));
+        if (hipMalloc((void**)&fresh, want) != hipSuccess) {
+          wsovod::set_error("wsovod_gemm_tn_sgd: cannot allocate the tail scratch");
+          return WSOVOD_ERR_HIP;
+        }
+        if (tb) retired.push_back(tb);
+        tb = fresh;
+        tb_bytes = want;
+      }
+      a.tail_buf = tb;
+      a.full_tiles = ntiles - tail;
+      a.ksplit = S;
+      a.slice_steps = (ceil_div(nk, S) + 1) & ~1;
+      a.bid_base = a.full_tiles;
+      WS_CHECK_HIP(hipMemsetAsync(tb, 0, need, s), "wsovod_gemm_tn_sgd: tail scratch");
+      hipLaunchKernelGGL((gemm_tn8_kernel<2, true>), dim3(a.full_tiles), dim3(512), 160 * 1024, s, a);
+      hipLaunchKernelGGL((gemm_tn8_kernel<2, false, true>), dim3(tail * S), dim3(512), 160 * 1024, s, a);
+      hipLaunchKernelGGL(tn_sgd_tail_kernel, dim3(tail * 16), dim3(256), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((gemm_tn8_kernel<2, true>), dim3(grid), dim3(512), 160 * 1024, s, a);
+    }
+  } else if (lean == 2)
     hipLaunchKernelGGL(gemm_tn8_kernel<2>, dim3(grid), dim3(512), 160 * 1024, s, a);
   else if (lean == 1)
     hipLaunchKernelGGL(gemm_tn8_kernel<1>, dim3(grid), dim3(512), lds_bytes, s, a);

@@ -557,15 +557,15 @@ class HotPathTrainer:
             self._setup_early_exchange()  # (with accumulation the early block would miss the earlier micro-steps)
         # round 6: without a gradient exchange, the optimizer step of the largest weight rides in its weight-gradient kernel
         # at small batches (WSOVOD_FUSED_SGD=0 switches it off; WSOVOD_FUSED_SGD_ROWS = the largest reduction it takes)
-        self._fused = None
+        self._fused = []  # the large 2-D weights (fc1, fc2): largest first
         if (not self.exchange and self.iter_size == 1 and isinstance(optimizer, HipSGD) and optimizer.clip is None
                 and self.params and os.environ.get("WSOVOD_FUSED_SGD", "1") != "0"):
-            big = max(self.params, key=lambda q: q.numel())
-            if big.dim() == 2 and big.is_cuda and big.is_contiguous() and big.numel() >= (1 << 24) and big.shape[1] % 32 == 0:
-                self._fused = big
-                # (measured, WSR_18 x 512 proposals: 1 image 2.71 -> 2.59 ms per step, 8 images 7.55 -> 7.46; beyond 8 images the
-                # split tile-round tail of the two-kernel form is worth more than the bytes: profiles/HISTORY.md, round 6)
-                big._fused_update = _FusedUpdate(optimizer, big, int(os.environ.get("WSOVOD_FUSED_SGD_ROWS", "4096")))
+            for big in sorted(self.params, key=lambda q: -q.numel()):
+                if big.dim() == 2 and big.is_cuda and big.is_contiguous() and big.numel() >= (1 << 24) and big.shape[1] % 32 == 0:
+                    self._fused.append(big)
+                    # (measured, WSR_18 x 512 proposals: 1 image 2.71 -> 2.59 ms per step, 8 images 7.55 -> 7.46; beyond 8
+                    # images the longer epilogue costs more than the saved bytes: profiles/HISTORY.md, round 6)
+                    big._fused_update = _FusedUpdate(optimizer, big, int(os.environ.get("WSOVOD_FUSED_SGD_ROWS", "4096")))
         self._hooks = []
         if hasattr(model, "register_state_dict_pre_hook"):
             self._hooks.append(model.register_state_dict_pre_hook(lambda *_a, **_k: self.synchronize()))
@@ -601,9 +601,9 @@ class HotPathTrainer:
             bb.graph_max_batch = 0
             bb.__dict__.pop("_graphs", None)
         self._graphs.clear()
-        if getattr(self, "_fused", None) is not None:
-            self._fused.__dict__.pop("_fused_update", None)
-            self._fused = None
+        for p in getattr(self, "_fused", None) or []:
+            p.__dict__.pop("_fused_update", None)
+        self._fused = []
         if getattr(self.model, "_pre_inference", None) is getattr(self, "_pre_inference_hook", None):
             self.model._pre_inference = None
 
@@ -893,9 +893,9 @@ class HotPathTrainer:
         seed = self._seed
         if seed is None or seed.device != roots[0].device or seed.dtype != roots[0].dtype:
             seed = self._seed = torch.full((), 1.0 / self.iter_size, dtype=roots[0].dtype, device=roots[0].device)
-        fused = self._fused._fused_update if getattr(self, "_fused", None) is not None else None
-        if fused is not None:
-            fused.armed = True  # (this backward is followed by this trainer's optimizer step: the fused update IS that step)
+        fused = [p._fused_update for p in getattr(self, "_fused", None) or []]
+        for f in fused:
+            f.armed = True  # (this backward is followed by this trainer's optimizer step: the fused update IS that step)
         try:
             if capturing:
                 grads = torch.autograd.grad(roots, self.params, [seed.expand_as(r) for r in roots], allow_unused=True)
@@ -904,8 +904,8 @@ class HotPathTrainer:
                 return
             torch.autograd.backward(roots, [seed.expand_as(r) for r in roots])
         finally:
-            if fused is not None:
-                fused.armed = False
+            for f in fused:
+                f.armed = False
 
     # ---- whole-step HIP graphs (small batches) ----
     GRAPH_AFTER = 3  # eager steps with a layout before it is captured (the first ones fill caches and allocator pools)
