@@ -74,7 +74,11 @@ def test_hip_conv_backward_agrees_with_the_torch_re_evaluation(gpu, monkeypatch,
     conv and blocks with an identity shortcut; at FREEZE_AT = 1 / 2 also the stages with a tail pool (res2: stride 2, fused
     into the 64-channel conv in the forward pass; res3: ZeroPad2d + stride 1) through the pool-backward kernel -- agrees in
     norm and element-wise to the precision's backward grade."""
+    from wsovod_amd.modeling import backbone as BB
+
     batch = to_inputs(gen.seeded_batch(2, 24, 20, 160, 208, seed=13))
+    if freeze_at == 1:  # the weight gradients in several row blocks of patch rows (accumulated), as at large batches
+        monkeypatch.setattr(BB, "WGRAD_PATCH_BYTES", 1 << 20)
     grads = {}
     for flag in ("1", "0"):
         monkeypatch.setenv("WSOVOD_HIP_CONV_BACKWARD", flag)

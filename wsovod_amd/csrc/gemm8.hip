@@ -295,6 +295,36 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
   const unsigned ldsA = 0, ldsB = 0;
 #endif
 
+#if defined(G8_MXPROBE) && defined(__HIP_DEVICE_COMPILE__)
+  // TIMING PROBE ONLY (round 6, tools/mx_rate_probe.py; never part of the product library): the MFMA block of a plain-bf16
+  // phase replaced by the instruction mix a block-scaled cross-term format would issue on the SAME fragments / LDS image /
+  // DMA schedule -- per 32x32 output tile two fp16 32x32x16 products (hi x hi) and ONE v_mfma_scale_f32_32x32x64_f8f6f4
+  // (both cross terms as 64 MX-e4m3 values): 12 MFMAs = 512 matrix-pipe cycles per phase instead of 32 x 16.  The bits in
+  // the fragments are whatever the bf16 operands hold: RESULTS ARE MEANINGLESS, the time is the point.
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  f32x16 pacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pacc[i][e] = 0.f;
+  const int mx_scale = 0x7f7f7f7f;  // E8M0 2^0 in every byte
+  auto mx_cat = [](const u32x4 a, const u32x4 b) {
+    return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+  };
+#define WS_MFMA_QUAD(I0, BREG, J0)                                                                                    \
+  _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
+    f32x16& c_ = pacc[(I0) + 2 * t + ((J0) >> 1)];                                                                    \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, BREG[0][0]),                                \
+                                                __builtin_bit_cast(f16x8, af[2 * t][0]), c_, 0, 0, 0);                \
+    c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, BREG[0][1]),                                \
+                                                __builtin_bit_cast(f16x8, af[2 * t][1]), c_, 0, 0, 0);                \
+    c_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_cat(BREG[1][0], BREG[1][1]),                              \
+                                                         mx_cat(af[2 * t + 1][0], af[2 * t + 1][1]), c_, 0, 0, 0,     \
+                                                         mx_scale, 0, mx_scale);                                      \
+  }
+#else
   // bf16: k-halves (0,0), (1,1).  X3: (b_lo, a_hi), (b_hi, a_hi), (b_hi, a_lo) -- the order of gemm.hip's X3 tiles (bit-
   // identical results); the lo*lo term (2^-16 of a product) is dropped
 #define WS_MFMA_QUAD(I0, BREG, J0)                                                                                   \
@@ -302,6 +332,7 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
       _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[(I0) + i][(J0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
           __builtin_bit_cast(bf16x8, BREG[j][X3 ? (ks == 0) : ks]), __builtin_bit_cast(bf16x8, af[i][X3 ? (ks == 2) : ks]), \
           acc[(I0) + i][(J0) + j], 0, 0, 0)
+#endif
 
   // ---- DMA schedule (two instructions per phase; the LDS rows a pass overwrites were last read >= 2 phases ago):
   //   phase 1 (kt): B passes 0,1 of kt+1      phase 2 (kt): B passes 2,3 of kt+1, then vmcnt -> A_hi(kt) landed
@@ -628,6 +659,12 @@ __global__ __launch_bounds__(512) void gemm256_8ph_kernel(const GemmArgs p) {
     if (CONV) { t1 = t2; t2 = tap_next(t2); }
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
+#if defined(G8_MXPROBE) && defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] += f32x4{pacc[i][4 * j], pacc[i][4 * j + 1], pacc[i][4 * j + 2], pacc[i][4 * j + 3]};
+#endif
 #if defined(G8_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
   const unsigned long long st_loop1 = __builtin_amdgcn_s_memtime();
   if (p.partial && lane == 0 && p.ksplit <= 1) {

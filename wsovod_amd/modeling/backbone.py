@@ -395,6 +395,9 @@ def _hip_backward_ok(stage, x3):
     return True
 
 
+WGRAD_PATCH_BYTES = 1 << 30  # (tests lower it to exercise the row blocks)
+
+
 def _masked(dy, y, cd):
     """dL/d(pre-activation) of y = relu(.): (P, C) in the compute dtype `cd` (dy fp32, y the forward's own output map)."""
     C = dy.shape[-1]
@@ -429,17 +432,25 @@ def _conv_wgrad(g2d, xin, conv, cd):
     N, Hh, Ww, Ci = xin.shape
     P = N * Hh * Ww
     x2 = _is_x2_map(xin, Ci)
-    if k == 1:
-        patches = xin.reshape(P, Ci)
-    else:
-        rows = torch.arange(P, dtype=torch.int64, device=xin.device)
-        patches = H.im2col_rows(xin, rows, k, 1, conv.padding, conv.dilation)  # (P, k*k*Ci), tap-major then channel
-    if cd == torch.float32:
-        Pp = (P + 63) // 64 * 64
-        dw = H.gemm_nt(H.transpose_cast(g2d, torch.float32, ld_dst=Pp), H.transpose_cast(patches, torch.float32, ld_dst=Pp),
-                       out_dtype=torch.float32)
-    else:
-        dw = H.gemm_tn(g2d, patches, q_x2=x2)  # (Cout, k*k*Ci); of a bf16x2 map the hi halves are read
+    # patch rows are materialised in blocks of at most ~1 GiB (the stem's 64-channel convs at 32 images would be 8.8 GB at
+    # once): the blocks' contributions accumulate into dW
+    step = P if k == 1 else max(64, (WGRAD_PATCH_BYTES // (k * k * Ci * xin.element_size())) // 64 * 64)
+    dw = torch.empty((conv.out_channels, k * k * Ci), dtype=torch.float32, device=xin.device)
+    for a in range(0, P, step):
+        b = min(P, a + step)
+        if k == 1:
+            patches = xin.reshape(P, Ci)
+        else:
+            rows = torch.arange(a, b, dtype=torch.int64, device=xin.device)
+            patches = H.im2col_rows(xin, rows, k, 1, conv.padding, conv.dilation)  # (b - a, k*k*Ci), tap-major then channel
+        gb = g2d[a:b]
+        if cd == torch.float32:
+            Pp = (b - a + 63) // 64 * 64
+            H.gemm_nt(H.transpose_cast(gb, torch.float32, ld_dst=Pp), H.transpose_cast(patches, torch.float32, ld_dst=Pp),
+                      out=dw, accumulate=a > 0)
+        else:
+            H.gemm_tn(gb, patches, out=dw, accumulate=a > 0, q_x2=x2)  # of a bf16x2 map the hi halves are read
+        del patches
     dw = dw.view(conv.out_channels, k, k, Ci).permute(0, 3, 1, 2)
     if conv.norm is not None:
         dw = dw * conv.norm.scale_shift()[0].view(-1, 1, 1, 1)
