@@ -11,7 +11,7 @@ from wsovod_amd.layers import hip_ops as H
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-TILES = [0, 2256256, 256128, 1128128, 1128064, 3128064, 4128064, 5128064, 3128128, 64064, 3064064]
+TILES = [0, 2256256, 256128, 1128128, 1128064, 3128064, 64064, 3064064]
 
 
 def bench(fns, rounds=5, inner=10):

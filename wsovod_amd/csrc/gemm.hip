@@ -1946,15 +1946,6 @@ int dispatch_tile_x3(const GemmArgs& a, int tile, hipStream_t s, double flops, d
     case 3128064:  // round 6: three DMA stages (72 KiB: still two workgroups per CU)
       return launch<bf16_t, 128, 64, CONV, 2, 2, true, 3, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64_s3" : "gemm_nt_bf16x2_128x64_s3",
                                                               flops, bytes);
-    case 4128064:  // (experiment) eight wavefronts of 32 x 32, three stages
-      return launch<bf16_t, 128, 64, CONV, 4, 2, true, 3, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64_w8s3" : "gemm_nt_bf16x2_128x64_w8s3",
-                                                              flops, bytes);
-    case 5128064:  // (experiment) eight wavefronts of 32 x 32, four stages (96 KiB: one workgroup per CU)
-      return launch<bf16_t, 128, 64, CONV, 4, 2, true, 4, true>(a, s, CONV ? "conv_igemm_bf16x2_128x64_w8s4" : "gemm_nt_bf16x2_128x64_w8s4",
-                                                              flops, bytes);
-    case 3128128:  // (experiment) 128 x 128, eight wavefronts of 32 x 64, three stages (96 KiB)
-      return launch<bf16_t, 128, 128, CONV, 4, 2, true, 3, true>(a, s, CONV ? "conv_igemm_bf16x2_128x128_w8s3" : "gemm_nt_bf16x2_128x128_w8s3",
-                                                               flops, bytes);
     case 3064064:  // round 6: the 64x64 tile by LDS-DMA, four stages (64 KiB: two workgroups per CU)
       return launch<bf16_t, 64, 64, CONV, 2, 2, true, 4, true>(a, s, CONV ? "conv_igemm_bf16x2_64x64_s4" : "gemm_nt_bf16x2_64x64_s4",
                                                              flops, bytes);

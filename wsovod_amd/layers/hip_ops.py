@@ -229,6 +229,8 @@ def _x2_planar_tag(out):
 
 def x2_planar_of(x):
     """True when `x` (or the tensor it is a whole view of) is a planar bf16x2 carrier."""
+    if x is None or x.dtype != torch.float32:
+        return False  # (a carrier is float32-typed: the bf16 view of its hi plane is a plain bf16 matrix)
     if getattr(x, "_x2_planar", False):
         return True
     b = getattr(x, "_base", None)
