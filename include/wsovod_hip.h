@@ -49,7 +49,7 @@ typedef enum {
  * INPUT format of wsovod_gemm_nt's A operand (wsovod_gemm_desc.a_plane_bytes): the pooled tensor feeds the first FC layer's
  * three-product forward (hi and lo planes) AND its bf16 weight-gradient contraction (the hi plane alone, a plain bf16
  * matrix), which in the interleaved format needed a second, plain-bf16 copy of every pooled value (822 MB per 32 images). */
-typedef enum { WSOVOD_F32 = 0, WSOVOD_BF16 = 1, WSOVOD_BF16X2 = 2, WSOVOD_BF16X2P = 3 } wsovod_dtype;
+typedef enum { WSOVOD_F32 = 0, WSOVOD_BF16 = 1, WSOVOD_BF16X2 = 2, WSOVOD_BF16X2P = 3, WSOVOD_F16MX = 4 } wsovod_dtype;
 /* Feature-map layout.  NCHW is the reference's layout; NHWC is what the HIP backbone
  * produces (torch.channels_last memory format on the Python side). */
 typedef enum { WSOVOD_NCHW = 0, WSOVOD_NHWC = 1 } wsovod_layout;
@@ -438,6 +438,31 @@ typedef struct wsovod_tn_sgd {
 } wsovod_tn_sgd;
 int wsovod_gemm_tn_sgd(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
                        float alpha, const wsovod_tn_sgd* update, wsovod_stream_t stream);
+
+/* Round 6 ("parity_mx" precision): the forward contractions of the big layers -- the two FC layers of the box head
+ * (box_head.py:60-75, F.linear) and the res4 / res5 convolutions (resnet_wsl.py:94-110) -- with the two cross terms of the
+ * three-product forward on gfx950's block-scaled matrix instruction.  Operand format WSOVOD_F16MX ("f16mx"): rows of groups of
+ * 32 values = 128 bytes [32 x fp16 hi | 32 x OCP e4m3 q | 32 x e4m3 ql] (4 bytes per value, leading dimensions in VALUES as
+ * for WSOVOD_BF16X2),
+ *   q = e4m3(x / 2^s),  ql = e4m3((x - hi) / 2^(s - 11))   (saturating at +-448; hi = fp16(x)).
+ * ACTIVATIONS carry no scale (s = 0, "unit scale": what wsovod_gemm_f16mx writes with dtype_c = WSOVOD_F16MX, the RoI poolers
+ * with out_dtype = WSOVOD_F16MX, wsovod_f16mx_from_bf16x2, and wsovod_f16mx_encode with scales = NULL); WEIGHTS one E8M0 byte
+ * per ROW SEGMENT in scales[row][nseg] (nseg equal segments of the row), s = floor(log2(max |hi| of the segment)) - 7,
+ * byte = s + 127 (wsovod_f16mx_encode; cols a multiple of 32 * nseg).
+ * wsovod_gemm_f16mx: C = epilogue(A B^T) for f16mx A (M, K) -- a_scale NULL = unit scale -- and B (N, K); a scale segment is the
+ * whole row or a multiple of 6 groups of 32; `d` as for wsovod_gemm_nt (dtype_in ignored) with the epilogue alpha / bias /
+ * residual (fp32, bf16, bf16x2 or unit-scale f16mx) / ReLU / counter dropout and C in fp32, bf16, bf16x2 (N a multiple of 4) or
+ * unit-scale f16mx (N a multiple of 16); c_bf16 (may be NULL): a plain bf16 copy of C, the operand of the next layer's weight
+ * gradient and the mask source of this layer's backward.  d->conv = 1: the implicit-GEMM convolution of wsovod_gemm_nt on an
+ * NHWC unit-scale f16mx map (Cin a multiple of 32; A2 / Cin2: the fused 1x1 projection shortcut, also f16mx).  Per product
+ * hi_a hi_b + q_a ql_b + ql_a q_b  (two v_mfma_f32_32x32x16_f16 + one v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile). */
+int wsovod_f16mx_encode(const float* src, long long ld_src, int rows, int cols, int nseg, void* dst, long long ld_dst,
+                        unsigned char* scales, wsovod_stream_t stream);
+/* n values (whole groups of 32) of an interleaved bf16x2 tensor -> unit-scale f16mx (the map that crosses from the bf16x2
+ * layers, res3, to the f16mx ones, res4). */
+int wsovod_f16mx_from_bf16x2(const void* src, void* dst, long long n, wsovod_stream_t stream);
+int wsovod_gemm_f16mx(const wsovod_gemm_desc* d, const unsigned char* a_scale, int a_segments, const unsigned char* b_scale,
+                      int b_segments, void* c_bf16, long long ld_c_bf16, wsovod_stream_t stream);
 
 /* Greedy non-maximum suppression over G independent segments of boxes that are already sorted by
  * descending score inside each segment.  Replaces torchvision.ops.nms / batched_nms (un-vendored; SURVEY

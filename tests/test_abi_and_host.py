@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         args = m.group(1).strip()
         n = 0 if args in ("void", "") else args.count(",") + 1
         assert n == len(_lib.SIGNATURES[name]), (name, n)
-    assert L.wsovod_abi_version() == _lib.ABI_VERSION == 8
+    assert L.wsovod_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_error_convention_without_gpu():

@@ -93,7 +93,39 @@ def q_tied(x, h, dim):
     return undo(q), undo(ql)
 
 
-def planes(x, dim):
+def q_row(x, h, dim):
+    """ONE power-of-two scale per ROW of the operand (the whole reduction length): derived from the row's largest fp16 hi value,
+    the lo plane's scale tied 2^-11 below -- the block scales become loop constants of the kernel; e4m3's own exponent (17.8
+    binades down from the row maximum) carries the dynamic range inside the row."""
+    hm = h.movedim(dim, -1)
+    amax = hm.abs().amax(dim=-1, keepdim=True).clamp(min=2.0 ** -14)
+    sq = torch.exp2(torch.floor(torch.log2(amax)) - 7)
+    xm, lm = x.movedim(dim, -1), (x - h).movedim(dim, -1)
+    q = (xm / sq).to(torch.float8_e4m3fn).float() * sq
+    sl = sq * 2.0 ** -11
+    ql = (lm / sl).to(torch.float8_e4m3fn).float() * sl
+    return q.movedim(-1, dim).contiguous(), ql.movedim(-1, dim).contiguous()
+
+
+def q_unit(x, h):
+    """What the kernels of round 6 write for ACTIVATIONS (include/wsovod_hip.h, WSOVOD_F16MX): no scale at all -- q = e4m3(x),
+    ql = e4m3((x - hi) 2^11) 2^-11, saturating at +-448 -- so that a producing epilogue needs no row maximum."""
+    q = x.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float()
+    ql = ((x - h) * 2048.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float() / 2048.0
+    return q, ql
+
+
+def q_rowall(x, h):
+    """Weights: ONE tied power-of-two scale per output row (dim 0; all of the reduction, also a conv's taps)."""
+    amax = h.abs().flatten(1).amax(dim=1).clamp(min=2.0 ** -14).view(-1, *([1] * (x.dim() - 1)))
+    sq = torch.exp2(torch.floor(torch.log2(amax)) - 7)
+    q = (x / sq).to(torch.float8_e4m3fn).float() * sq
+    sl = sq * 2.0 ** -11
+    ql = ((x - h) / sl).to(torch.float8_e4m3fn).float() * sl
+    return q, ql
+
+
+def planes(x, dim, role="a"):
     """-> list of (a_plane) per product term for operand a, and the same for b by the caller."""
     fmt = MODE["fmt"]
     if fmt == "bf16x2":
@@ -111,12 +143,18 @@ def planes(x, dim):
     if elem == "e4m3t":
         q, ql = q_tied(x, h, dim)
         return h, q, ql
+    if elem == "e4m3r":
+        q, ql = q_row(x, h, dim)
+        return h, q, ql
+    if elem == "e4m3u":  # the build: unit-scale activations (operand a), row-scaled weights (operand b, rows = dim 0)
+        q, ql = q_unit(x, h) if role == "a" else q_rowall(x, h)
+        return h, q, ql
     return h, q_mx(x, dim, elem), q_mx(x - h, dim, elem)
 
 
 def three(contract, a, b, adim, bdim):
-    ah, aq, al = planes(a, adim)
-    bh, bq, bl = planes(b, bdim)
+    ah, aq, al = planes(a, adim, "a")
+    bh, bq, bl = planes(b, bdim, "b")
     out = contract(ah, bh)
     if aq is not None:
         out = out + contract(aq, bl) + contract(al, bq)
@@ -138,7 +176,11 @@ def in_scope(k, big):
     if s == "all":
         return True
     if s == "big":  # res4 / res5 convs + fc1 / fc2 / projection: the two lean-tile kernel families (17 of 26 ms)
-        return big
+        return bool(big)
+    if s == "fc":
+        return big in ("fc", "fc2")
+    if s == "build":  # what round 6 builds: the res4 / res5 convs (with their fused shortcuts) and fc1 / fc2
+        return big in (True, "fc2")
     raise ValueError(s)
 
 
@@ -156,7 +198,7 @@ def conv2d(x, w, bias=None, stride=1, padding=0, dilation=1, groups=1):
 
 def linear(x, w, bias=None):
     xg, wg = x.detach().to(DEV), w.detach().to(DEV)
-    if not in_scope(w.shape[1], w.shape[1] >= 1024 and w.shape[0] >= 512):
+    if not in_scope(w.shape[1], ("fc2" if w.shape[0] >= 4096 else "fc") if (w.shape[1] >= 1024 and w.shape[0] >= 512) else False):
         out = xg @ wg.t()
     else:
         out = three(lambda a, b: a @ b.t(), xg, wg, 1, 1)
@@ -215,20 +257,35 @@ def main():
             g["operand_ranges"] = MODE["stats"]
         return g
 
-    out = {"workload": f"{n} x 800x600 images x 512 proposals, WSR_18, K = {K}, forward pass of the ORACLE with its "
+    rows = {"workload": f"{n} x 800x600 images x 512 proposals, WSR_18, K = {K}, forward pass of the ORACLE with its "
                        "contractions replaced by fp32 contractions of dequantised operand planes; vs the plain oracle",
            "gate": {"logits": 3e-4, "scores": 1e-4, "labels_exact": True, "pgt_exact": True},
-           "emulator_fp32_on_gpu (no quantisation: the floor of the method)": run(None),
-           "bf16x2 (today's parity arithmetic, emulated: calibration)": run("bf16x2", stats=True),
-           "f16 hi only (one product)": run("f16"),
-           "f16x2 (fp16 hi + fp16 lo, three 16-bit products)": run("f16x2"),
-           "f16 + MX e4m3 cross terms, every contraction with K >= 64": run("f16+e4m3"),
-           "f16 + MX e4m3 cross terms, res4-5 + fc1 / fc2 / projection only": run("f16+e4m3", "big"),
+           "emulator_fp32_on_gpu (no quantisation: the floor of the method)": lambda: run(None),
+           "bf16x2 (today's parity arithmetic, emulated: calibration)": lambda: run("bf16x2", stats=True),
+           "f16 hi only (one product)": lambda: run("f16"),
+           "f16x2 (fp16 hi + fp16 lo, three 16-bit products)": lambda: run("f16x2"),
+           "f16 + MX e4m3 cross terms, every contraction with K >= 64": lambda: run("f16+e4m3"),
+           "f16 + MX e4m3 cross terms, res4-5 + fc1 / fc2 / projection only": lambda: run("f16+e4m3", "big"),
            "f16 + MX e4m3, scale from the block's fp16 exponent, lo scale tied 2^-11 below (no scale array); K >= 64":
-               run("f16+e4m3t"),
-           "same, res4-5 + fc1 / fc2 / projection only": run("f16+e4m3t", "big"),
-           "f16 + MX e2m3 cross terms, every contraction with K >= 64": run("f16+e2m3"),
-           "f16 + MX e2m3 cross terms, res4-5 + fc1 / fc2 / projection only": run("f16+e2m3", "big")}
+               lambda: run("f16+e4m3t"),
+           "same, res4-5 + fc1 / fc2 / projection only": lambda: run("f16+e4m3t", "big"),
+           "f16 + e4m3 with ONE tied scale per operand ROW (loop-constant scales), FC layers only (fc1 / fc2 / projection)":
+               lambda: run("f16+e4m3r", "fc"),
+           "f16 + MX e4m3 (tied block scales), FC layers only": lambda: run("f16+e4m3t", "fc"),
+           "THE BUILD: unit-scale e4m3 activations, row-scaled e4m3 weights; res4 / res5 convs + fc1 / fc2":
+               lambda: run("f16+e4m3u", "build"),
+           "the same, fc1 / fc2 only": lambda: run("f16+e4m3u", "fc"),
+           "the same, every conv with Cout >= 256 + fc1 / fc2 / projection": lambda: run("f16+e4m3u", "big"),
+           "f16 + MX e2m3 cross terms, every contraction with K >= 64": lambda: run("f16+e2m3"),
+           "f16 + MX e2m3 cross terms, res4-5 + fc1 / fc2 / projection only": lambda: run("f16+e2m3", "big")}
+    only = os.environ.get("MX_EMU_ONLY")  # substring filter of the row names (the calibration rows always run)
+    out = {}
+    for k, v in rows.items():
+        if callable(v):
+            if only and only not in k and "calibration" not in k and "floor" not in k:
+                continue
+            v = v()
+        out[k] = v
     print(json.dumps(out, indent=1))
 
 

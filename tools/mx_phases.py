@@ -1,0 +1,35 @@
+"""Where a K-step of the f16mx two-phase tile (gemm8mx.hip) spends its cycles: instrumented build
+`hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -DMX_STAMPS -c wsovod_amd/csrc/gemm8mx.hip -o /tmp/mx_st.o &&
+ hipcc --offload-arch=gfx950 -shared -fPIC -o wsovod_amd/lib/abl/libmx.so /tmp/mx_st.o $(ls wsovod_amd/csrc/build/*.o | grep -v "/gemm8mx.o")`,
+then `WSOVOD_LIB=$PWD/wsovod_amd/lib/abl/libmx.so python tools/mx_phases.py` on the box."""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import wsovod_amd._lib as _L
+if os.environ.get("WSOVOD_LIB"):
+    _L.LIB_PATH = os.environ["WSOVOD_LIB"]
+from wsovod_amd.layers import hip_ops as H
+dbg = torch.zeros(32, device="cuda")
+os.environ["WSOVOD_MX_DEBUG_PTR"] = hex(dbg.data_ptr())
+names = os.environ.get("MX_STAMP_NAMES", "A: reads landed|A: 4 DMA issued|A: lgkm|A: barrier 1|A: 12 MFMA|A: barrier 2|"
+                       "B: reads + 4 DMA + vmcnt(8) + lgkm|B: barrier + 12 MFMA + barrier").split("|")
+def report(tag, fl, run):
+    run(); torch.cuda.synchronize(); dbg.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        run()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    d = dbg.view(2, 16).cpu()
+    print(f"{tag}: {ms:.3f} ms ({fl / ms / 1e9:.0f} TF algorithmic, instrumented)")
+    for g in range(2):
+        n = float(d[g, 8])
+        if n:
+            print(f"  group {g}: ticks per K-step: " + ", ".join(f"{nm} {float(d[g, k]) / n:.0f}" for k, nm in enumerate(names)) +
+                  f"; total {float(d[g, :8].sum()) / n:.0f}", flush=True)
+for M, N, K in ((16384, 4096, 25088), (16384, 4096, 4096)):
+    a, sa = H.mx_encode(torch.randn(M, K, device="cuda")); b, sb = H.mx_encode(torch.randn(N, K, device="cuda") * 0.01)
+    bias = torch.randn(N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    report(f"f16mx {M}x{N}x{K}", 2.0 * M * N * K, lambda: H.gemm_mx(a, sa, b, sb, bias=bias, relu=True, out=out, out_dtype=H.X2))
+    del a, b

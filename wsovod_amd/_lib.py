@@ -13,7 +13,7 @@ import torch  # must be imported first: the library resolves libamdhip64.so.7 to
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libwsovod_hip.so")
 
-F32, BF16, BF16X2, BF16X2P = 0, 1, 2, 3  # wsovod_dtype (bf16x2 / its planar form: include/wsovod_hip.h)
+F32, BF16, BF16X2, BF16X2P, F16MX = 0, 1, 2, 3, 4  # wsovod_dtype (bf16x2 / its planar form / f16mx: include/wsovod_hip.h)
 NCHW, NHWC = 0, 1
 
 
@@ -52,7 +52,7 @@ class ProfEntry(C.Structure):
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
-ABI_VERSION = 8  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
+ABI_VERSION = 9  # == wsovod_abi_version() of the library this file's struct layouts and signatures were written for
 
 # name -> argtypes; must list every symbol include/wsovod_hip.h declares (tests check this).
 SIGNATURES = {
@@ -112,6 +112,9 @@ SIGNATURES = {
     "wsovod_gemm_tn": [_P, _L, _P, _L, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_gemm_tn_ex": [_P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_gemm_tn_sgd": [_P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _P],
+    "wsovod_f16mx_encode": [_P, _L, _I, _I, _I, _P, _L, _P, _P],
+    "wsovod_f16mx_from_bf16x2": [_P, _P, _L, _P],
+    "wsovod_gemm_f16mx": [_P, _P, _I, _P, _I, _P, _L, _P],
     "wsovod_mask_transpose_ex": [_P, _L, _I, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P, _P],
     "wsovod_bf16x2_encode": [_P, _L, _I, _I, _P, _L, _P],
     "wsovod_bf16x2_decode": [_P, _L, _I, _I, _P, _L, _P],

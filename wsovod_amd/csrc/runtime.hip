@@ -90,7 +90,7 @@ static void drain_pending() {
 extern "C" {
 
 const char* wsovod_last_error(void) { return wsovod::g_err; }
-int wsovod_abi_version(void) { return 8; }
+int wsovod_abi_version(void) { return 9; }
 
 int wsovod_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(wsovod::g_mu);

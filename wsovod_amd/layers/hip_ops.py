@@ -11,7 +11,7 @@ import threading
 import torch
 
 from .. import _lib
-from .._lib import BF16, BF16X2, BF16X2P, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
+from .._lib import BF16, BF16X2, BF16X2P, F16MX, F32, NCHW, NHWC, GemmDesc, check, dtype_code, lib, ptr, require_gpu, stream
 
 
 _CONST_CACHE = {}
@@ -389,11 +389,11 @@ X2 = "bf16x2"  # format tag accepted wherever a kernel front takes an `out_dtype
 
 
 def storage_dtype(fmt):
-    return torch.float32 if fmt == X2 else fmt
+    return torch.float32 if fmt in (X2, "f16mx") else fmt
 
 
 def fmt_code(fmt):
-    return BF16X2 if fmt == X2 else dtype_code(fmt)
+    return BF16X2 if fmt == X2 else F16MX if fmt == "f16mx" else dtype_code(fmt)
 
 
 def x2_encode(src, out=None):
@@ -415,6 +415,121 @@ def x2_decode(src):
     rows, cols = src.shape
     out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
     check(lib().wsovod_bf16x2_decode(ptr(src), src.stride(0), rows, cols, ptr(out), out.stride(0), stream()), "bf16x2_decode")
+    return out
+
+
+MX = "f16mx"  # format tag of the block-scaled parity format (include/wsovod_hip.h: WSOVOD_F16MX); carriers are float32-typed
+
+
+def mx_encode(src, nseg=1, unit=False):
+    """fp32 (rows, cols), cols % (32 nseg) == 0 -> (f16mx carrier (rows, cols) float32-typed, scales (rows, nseg) uint8: one
+    tied E8M0 scale per row segment): include/wsovod_hip.h, wsovod_f16mx_encode.  unit: the activations' form, no scales
+    (-> (carrier, None))."""
+    require_gpu(src)
+    src = src.contiguous()
+    rows, cols = src.shape
+    out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
+    scales = None if unit else torch.empty((rows, nseg), dtype=torch.uint8, device=src.device)
+    check(lib().wsovod_f16mx_encode(ptr(src), src.stride(0), rows, cols, int(nseg), ptr(out), out.stride(0), ptr(scales),
+                                    stream()), "f16mx_encode")
+    return out, scales
+
+
+def mx_decode(carrier, scales=None):
+    """(tests, tools) the three planes of an f16mx carrier as fp32: hi, q * 2^s, ql * 2^(s - 11); scales None = unit scale."""
+    shape = carrier.shape
+    carrier = carrier.reshape(-1, shape[-1])
+    rows, cols = carrier.shape
+    raw = carrier.contiguous().view(torch.uint8).view(rows, cols // 32, 128)
+    hi = raw[:, :, :64].contiguous().view(torch.float16).float().view(rows, cols)
+    nseg = 1 if scales is None else scales.shape[1]
+    q = raw[:, :, 64:96].contiguous().view(torch.float8_e4m3fn).float().view(rows, nseg, -1)
+    ql = raw[:, :, 96:].contiguous().view(torch.float8_e4m3fn).float().view(rows, nseg, -1)
+    s = 1.0 if scales is None else torch.exp2(scales.float() - 127.0).unsqueeze(-1)
+    return hi.view(shape), (q * s).view(shape), (ql * s * 2.0 ** -11).view(shape)
+
+
+def mx_to_f32(carrier):
+    """The values a unit-scale f16mx tensor stands for: hi + ql 2^-11 (tests, debugging)."""
+    hi, _, ql = mx_decode(carrier)
+    return hi + ql
+
+
+def mx_from_x2(src):
+    """interleaved bf16x2 tensor -> unit-scale f16mx tensor of the same shape (wsovod_f16mx_from_bf16x2)."""
+    require_gpu(src)
+    _refuse_undeclared_planar("mx_from_x2", src)
+    assert src.dtype == torch.float32 and src.is_contiguous() and src.shape[-1] % 32 == 0
+    out = torch.empty_like(src)
+    check(lib().wsovod_f16mx_from_bf16x2(ptr(src), ptr(out), src.numel(), stream()), "f16mx_from_bf16x2")
+    return out
+
+
+def gemm_mx(A, a_scale, B, b_scale, *, bias=None, relu=False, dropout_p=0.0, dropout_seed=0, dropout_seed_add=None,
+            alpha=1.0, out=None, out_dtype=torch.float32, out_bf16=None, residual=None, residual_fmt=None, conv=None, A2=None):
+    """C = epilogue(A B^T) on f16mx operands (mx_encode): wsovod_gemm_f16mx.  a_scale None: A is a unit-scale (activation)
+    carrier.  out_dtype: float32, bfloat16, X2 or MX (unit-scale f16mx); out_bf16: an optional (M, N) bfloat16 tensor that
+    receives the plain bf16 copy of C.  residual (+ residual_fmt = X2 / MX for carriers).  conv: the geometry dict of gemm_nt
+    on an NHWC unit-scale f16mx map (A2: the fused projection shortcut's input)."""
+    require_gpu(A, a_scale, B, b_scale, bias, out, out_bf16, residual, A2)
+    assert b_scale.dtype == torch.uint8 and b_scale.is_contiguous() and (a_scale is None or (a_scale.dtype == torch.uint8 and a_scale.is_contiguous()))
+    d = GemmDesc()
+    d.dtype_in = F16MX
+    d.N, d.K = B.size(0), B.size(1)
+    d.B, d.ldb = B.data_ptr(), _ld(B)
+    if conv is not None:
+        g = d.geom
+        for k, v in conv.items():
+            setattr(g, k, int(v))
+        d.conv = 1
+        d.M = g.n_img * g.Ho * g.Wo
+        d.A, d.lda = A.data_ptr(), g.Cin
+        if not A.is_contiguous():
+            raise RuntimeError("wsovod_hip gemm_mx: the conv input must be NHWC-contiguous")
+        if A2 is not None:
+            if not A2.is_contiguous() or A2.numel() != d.M * A2.shape[-1]:
+                raise RuntimeError("wsovod_hip gemm_mx: the fused shortcut input must be NHWC-contiguous (n_img, Ho, Wo, Cin2)")
+            d.A2, d.Cin2 = A2.data_ptr(), int(A2.shape[-1])
+    else:
+        d.M = A.size(0)
+        d.A, d.lda = A.data_ptr(), _ld(A)
+    if out is None:
+        out = torch.empty((d.M, d.N), dtype=storage_dtype(out_dtype), device=A.device)
+    d.C, d.ldc = out.data_ptr(), _ld(out)
+    d.dtype_c = fmt_code(out_dtype)
+    d.alpha = alpha
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    if residual is not None:
+        d.residual, d.ldr = residual.data_ptr(), _ld(residual)
+        d.dtype_r = fmt_code(residual_fmt) if residual_fmt is not None else dtype_code(residual.dtype)
+    d.relu = int(bool(relu))
+    d.dropout_p = float(dropout_p)
+    d.dropout_seed = int(dropout_seed)
+    if dropout_seed_add is not None:
+        require_gpu(dropout_seed_add)
+        d.dropout_seed_add = dropout_seed_add.data_ptr()
+    if out_bf16 is not None:
+        assert out_bf16.dtype == torch.bfloat16 and out_bf16.shape == (d.M, d.N)
+    check(lib().wsovod_gemm_f16mx(C.byref(d), ptr(a_scale), 1 if a_scale is None else int(a_scale.shape[1]), ptr(b_scale),
+                                  int(b_scale.shape[1]), ptr(out_bf16), 0 if out_bf16 is None else _ld(out_bf16), stream()),
+          "gemm_f16mx")
+    return out
+
+
+def mx_cached(t, view_rows_cols=None):
+    """f16mx encoding (carrier, per-row scales) of a weight, cached on the tensor object and keyed by its version counter (one
+    re-encode per optimizer step at most; frozen backbone weights once)."""
+    key = (t._version, t.data_ptr(), view_rows_cols)
+    c = getattr(t, "_mx_enc", None)
+    if c is not None and c[0] == key:
+        return c[1]
+    src = t.detach()
+    out = mx_encode(src.reshape(view_rows_cols) if view_rows_cols is not None else src)
+    try:
+        t._mx_enc = (key, out)
+    except AttributeError:
+        pass
     return out
 
 
