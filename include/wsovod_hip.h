@@ -560,8 +560,9 @@ int wsovod_mask_transpose(const void* dy, long long lddy, const void* y, long lo
 int wsovod_mask_transpose_colsum(const void* dy, long long lddy, const void* y, long long ldy, int in_dtype,
                                  int M, int N, float scale, void* dA, long long ldda, void* dAt, long long ldt,
                                  int out_dtype, float* colsum, wsovod_stream_t stream);
-/* General form: dy in `dy_dtype` (fp32 / bf16), the mask source y in `y_dtype` = dy_dtype or WSOVOD_BF16X2 (the layer's
- * own output as the "parity" forward pass left it; ldy in values), colsum optional (NULL = none). */
+/* General form: dy in `dy_dtype` (fp32 / bf16), the mask source y in `y_dtype` = dy_dtype, WSOVOD_BF16X2 (the layer's
+ * own output as the "parity" forward pass left it; ldy in values) or -- next to an fp32 dy -- WSOVOD_BF16 (the plain bf16
+ * rounding that wsovod_gemm_f16mx writes beside an f16mx output; round 6), colsum optional (NULL = none). */
 int wsovod_mask_transpose_ex(const void* dy, long long lddy, int dy_dtype, const void* y, long long ldy, int y_dtype, int M,
                              int N, float scale, void* dA, long long ldda, void* dAt, long long ldt, int out_dtype,
                              float* colsum, wsovod_stream_t stream);

@@ -190,6 +190,16 @@ def test_parity_mode_matches_the_oracle_at_full_size(gpu):
     _assert_parity_mode(rep)
 
 
+@pytest.mark.parametrize("pooler", ["ROIPool", "ROIAlignV2"])
+def test_parity_mx_mode_matches_the_oracle_at_full_size(gpu, pooler):
+    """MODEL.HIP.PRECISION = "parity_mx" (round 6): the parity forward with the res4 / res5 convs and fc1 / fc2 on the
+    block-scaled f16mx kernels (fp16 hi*hi + e4m3 cross terms; csrc/gemm8mx.hip) -- the same bar as "parity": forward
+    quantities inside the north star's bound against the oracle at the headline size, indices exact, gradients of the bf16
+    grade (the backward is the parity mode's, on the plain bf16 copies the f16mx producers write)."""
+    rep = _oracle_vs_hip(gpu, "parity_mx", n_images=2, proposals=512, classes=20, pooler=pooler)
+    _assert_parity_mode(rep)
+
+
 def _assert_parity_mode(rep, elem_tol=3e-2):
     """The "parity" precision's bar: forward quantities inside the north star's bound, indices exact; the backward runs
     in plain bf16 on the hi halves, so its gradients carry bf16's grade -- every tensor's norm within 1 % of the oracle's

@@ -870,8 +870,14 @@ static int mask_transpose_impl(const void* dy, long long lddy, const void* y, lo
     else if (out_dtype == WSOVOD_BF16) MTX(bf16_t);
     else { wsovod::set_error("wsovod_mask_transpose: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
 #undef MTX
+  } else if (y && y_dtype == WSOVOD_BF16 && in_dtype == WSOVOD_F32) {  // (round 6: the plain bf16 rounding of an f16mx output)
+#define MTB(TO) hipLaunchKernelGGL((mask_transpose_kernel<float, TO, bf16_t, false>), grid, dim3(256), 0, s, (const float*)dy, lddy, (const bf16_t*)y, ldy, M, N, scale, (TO*)dA, ldda, (TO*)dAt, ldt, colsum)
+    if (out_dtype == WSOVOD_F32) MTB(float);
+    else if (out_dtype == WSOVOD_BF16) MTB(bf16_t);
+    else { wsovod::set_error("wsovod_mask_transpose: bad dtype"); return WSOVOD_ERR_INVALID_ARGUMENT; }
+#undef MTB
   } else if (y && y_dtype != in_dtype) {
-    wsovod::set_error("wsovod_mask_transpose: y must have dy's dtype or be bf16x2");
+    wsovod::set_error("wsovod_mask_transpose: y must have dy's dtype, be bf16 next to an fp32 dy, or be bf16x2");
     return WSOVOD_ERR_INVALID_ARGUMENT;
   } else if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_F32) MT(float, float);
   else if (in_dtype == WSOVOD_F32 && out_dtype == WSOVOD_BF16) MT(float, bf16_t);

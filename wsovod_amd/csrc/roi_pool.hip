@@ -16,6 +16,7 @@
 #include <float.h>
 
 #include "common.h"
+#include "f16mx.h"
 #include <type_traits>
 
 // Index results (bins, keep sets, labels) must match the reference bit for bit: no mul+add fusion anywhere in this
@@ -501,6 +502,26 @@ __global__ void roi_pool_fwd_nhwc_rows(const T* __restrict__ feat, const float* 
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
     else
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+  } else if (out_dtype == WSOVOD_F16MX) {
+    // unit-scale f16mx (include/wsovod_hip.h, round 6): 8 values per lane = 16 B of fp16 hi + 8 B of e4m3 q + 8 B of e4m3 ql of
+    // one 128-byte group, and -- `out_hi` -- the plain bf16 rounding, the operand of the first FC layer's weight gradient
+    char* o = (char*)out;
+    for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
+      wsovod_mx::f16x4 h0, h1;
+      int q0, q1, l0, l1;
+      const f32x4 v0 = *(const f32x4*)(sval + i), v1 = *(const f32x4*)(sval + i + 4);
+      wsovod_mx::mx_enc4_unit(v0, h0, q0, l0);
+      wsovod_mx::mx_enc4_unit(v1, h1, q1, l1);
+      const long long k = obase + i;
+      char* d = o + wsovod_mx::mx_group(k);
+      const int w = (int)(k & 31);
+      __builtin_nontemporal_store(wsovod_mx::f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}, (wsovod_mx::f16x8*)(d + 2 * w));
+      __builtin_nontemporal_store(wsovod_mx::i32x2{q0, q1}, (wsovod_mx::i32x2*)(d + 64 + w));
+      __builtin_nontemporal_store(wsovod_mx::i32x2{l0, l1}, (wsovod_mx::i32x2*)(d + 96 + w));
+      if (out_hi)
+        __builtin_nontemporal_store(bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1],
+                                           (bf16_t)v1[2], (bf16_t)v1[3]}, (bf16x8*)((bf16_t*)out_hi + k));
+    }
   } else if (out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P) {
     // bf16x2 (include/wsovod_hip.h): the run [obase, obase + nvalid) covers whole 32-value groups (launcher); 8 values per
     // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form.  PLANAR (round 5): hi to the
@@ -1138,6 +1159,26 @@ __global__ __launch_bounds__(512, WPE) void roi_align_fwd_nhwc_rows(const T* __r
       for (int i = tid * 4; i < nvalid; i += nthreads * 4) *(float4*)(o + i) = *(const float4*)(sval + i);
     else
       for (int i = tid; i < nvalid; i += nthreads) o[i] = sval[i];
+  } else if (out_dtype == WSOVOD_F16MX) {
+    // unit-scale f16mx (include/wsovod_hip.h, round 6): 8 values per lane = 16 B of fp16 hi + 8 B of e4m3 q + 8 B of e4m3 ql of
+    // one 128-byte group, and -- `out_hi` -- the plain bf16 rounding, the operand of the first FC layer's weight gradient
+    char* o = (char*)out;
+    for (int i = tid * 8; i < nvalid; i += nthreads * 8) {
+      wsovod_mx::f16x4 h0, h1;
+      int q0, q1, l0, l1;
+      const f32x4 v0 = *(const f32x4*)(sval + i), v1 = *(const f32x4*)(sval + i + 4);
+      wsovod_mx::mx_enc4_unit(v0, h0, q0, l0);
+      wsovod_mx::mx_enc4_unit(v1, h1, q1, l1);
+      const long long k = obase + i;
+      char* d = o + wsovod_mx::mx_group(k);
+      const int w = (int)(k & 31);
+      __builtin_nontemporal_store(wsovod_mx::f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]}, (wsovod_mx::f16x8*)(d + 2 * w));
+      __builtin_nontemporal_store(wsovod_mx::i32x2{q0, q1}, (wsovod_mx::i32x2*)(d + 64 + w));
+      __builtin_nontemporal_store(wsovod_mx::i32x2{l0, l1}, (wsovod_mx::i32x2*)(d + 96 + w));
+      if (out_hi)
+        __builtin_nontemporal_store(bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3], (bf16_t)v1[0], (bf16_t)v1[1],
+                                           (bf16_t)v1[2], (bf16_t)v1[3]}, (bf16x8*)((bf16_t*)out_hi + k));
+    }
   } else if (out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P) {
     // bf16x2 (include/wsovod_hip.h): the run [obase, obase + nvalid) covers whole 32-value groups (launcher); 8 values per
     // lane = 16 B of hi and 16 B of lo half a line further, streamed past L2 like the bf16 form.  PLANAR (round 5): hi to the
@@ -1399,11 +1440,11 @@ static int roi_pool_forward_impl(const void* feat, int dtype, int layout, const 
                                  int* argmax, void* out_hi, void* workspace, long long workspace_bytes, bool m2_ready,
                                  wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_pool_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
-  WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
-               "wsovod_roi_pool_forward_x2hi: the bf16 copy goes with a bf16x2 output");
+  WS_CHECK_ARG(!out_hi || ((out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_F16MX) && ((uintptr_t)out_hi & 15) == 0),
+               "wsovod_roi_pool_forward_x2hi: the bf16 copy goes with a bf16x2 / f16mx output");
   if (rc) return rc;
-  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P,
-               "wsovod_roi_pool_forward: bad out_dtype");
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P ||
+                   out_dtype == WSOVOD_F16MX, "wsovod_roi_pool_forward: bad out_dtype");
   const bool planar_out = out_dtype == WSOVOD_BF16X2P;  // same constraints as the interleaved form; lo plane behind the hi plane
   if (planar_out) {
     WS_CHECK_ARG(((long long)R * C * ph * pw) % 8 == 0, "wsovod_roi_pool_forward: planar bf16x2 output needs 16-byte aligned planes");
@@ -1411,7 +1452,7 @@ static int roi_pool_forward_impl(const void* feat, int dtype, int layout, const 
   }
   // bf16x2 output: the wavefront-per-pooled-row kernel only (NHWC, 7 bins wide), whole 128-channel groups, so that every
   // workgroup's run of outputs is whole 32-value groups
-  WS_CHECK_ARG((out_dtype != WSOVOD_BF16X2 && !planar_out) || (layout == WSOVOD_NHWC && pw == 7 && ph <= 16 && C % 256 == 0 &&
+  WS_CHECK_ARG((out_dtype != WSOVOD_BF16X2 && out_dtype != WSOVOD_F16MX && !planar_out) || (layout == WSOVOD_NHWC && pw == 7 && ph <= 16 && C % 256 == 0 &&
                                               (C * ph * pw) % 32 == 0 && ((uintptr_t)feat & 7) == 0 && ((uintptr_t)out & 15) == 0),
                "wsovod_roi_pool_forward: bf16x2 output needs NHWC, pw = 7, C a multiple of 256");
   if (R == 0) return WSOVOD_OK;
@@ -1625,17 +1666,17 @@ int wsovod_roi_align_forward_x2hi(const void* feat, int dtype, int layout, const
                                   int N, int C, int H, int W, int ph, int pw, float spatial_scale, int sampling_ratio,
                                   int aligned, void* out, int out_dtype, void* out_hi, wsovod_stream_t stream) {
   int rc = check_common("wsovod_roi_align_forward", feat, dtype, layout, rois, R, N, C, H, W, ph, pw, out);
-  WS_CHECK_ARG(!out_hi || (out_dtype == WSOVOD_BF16X2 && ((uintptr_t)out_hi & 15) == 0),
-               "wsovod_roi_align_forward_x2hi: the bf16 copy goes with a bf16x2 output");
+  WS_CHECK_ARG(!out_hi || ((out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_F16MX) && ((uintptr_t)out_hi & 15) == 0),
+               "wsovod_roi_align_forward_x2hi: the bf16 copy goes with a bf16x2 / f16mx output");
   if (rc) return rc;
-  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P,
-               "wsovod_roi_align_forward: bad out_dtype");
+  WS_CHECK_ARG(out_dtype == WSOVOD_F32 || out_dtype == WSOVOD_BF16 || out_dtype == WSOVOD_BF16X2 || out_dtype == WSOVOD_BF16X2P ||
+                   out_dtype == WSOVOD_F16MX, "wsovod_roi_align_forward: bad out_dtype");
   const bool planar_out = out_dtype == WSOVOD_BF16X2P;
   if (planar_out) {
     WS_CHECK_ARG(((long long)R * C * ph * pw) % 8 == 0, "wsovod_roi_align_forward: planar bf16x2 output needs 16-byte aligned planes");
     out_hi = (char*)out + (long long)R * C * ph * pw * 2;
   }
-  WS_CHECK_ARG((out_dtype != WSOVOD_BF16X2 && !planar_out) || (layout == WSOVOD_NHWC && pw == 7 && ph >= 7 && ph <= 8 && C % 256 == 0 &&
+  WS_CHECK_ARG((out_dtype != WSOVOD_BF16X2 && out_dtype != WSOVOD_F16MX && !planar_out) || (layout == WSOVOD_NHWC && pw == 7 && ph >= 7 && ph <= 8 && C % 256 == 0 &&
                                               (C * ph * pw) % 32 == 0 && ((uintptr_t)feat & 7) == 0 && ((uintptr_t)out & 15) == 0),
                "wsovod_roi_align_forward: bf16x2 output needs NHWC, 7x7 / 8x7 bins, C a multiple of 256");
   if (R == 0) return WSOVOD_OK;

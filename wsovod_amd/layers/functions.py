@@ -105,8 +105,27 @@ class _Linear(Function):
     def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype, seed_add=None):
         ctx.x2 = _x2_mode()
         ctx.y_x2 = out_dtype == H.X2
-        x_hi = None
-        if ctx.x2:
+        x_hi = y_mask = None
+        if ctx.x2 and H.mx_of(x):
+            # "parity_mx": x is a unit-scale f16mx carrier (the pooler's, or the previous FC layer's); the products are
+            # fp16 hi*hi + block-scaled e4m3 cross terms on the f16mx weight (one re-encode per optimizer step).  An f16mx
+            # output comes with its plain bf16 rounding: the mask source of this layer's backward and the operand of the
+            # NEXT layer's weight gradient
+            wq, wscale = H.mx_cached(weight)
+            y_bf16 = None
+            if out_dtype == H.MX and any(ctx.needs_input_grad):  # (grad mode is off inside Function.forward)
+                y_bf16 = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.bfloat16, device=x.device)
+            y = H.gemm_mx(x, None, wq, wscale, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
+                          dropout_seed_add=seed_add, out_dtype=out_dtype, out_bf16=y_bf16)
+            if out_dtype == H.MX:
+                y._mx = True
+                if y_bf16 is not None:
+                    y._x2_hi = y_mask = y_bf16
+            x_hi = H.x2_hi_pop(x)
+            if x_hi is None and ctx.needs_input_grad[1]:
+                raise RuntimeError("wsovod_hip linear: an f16mx input needs its plain bf16 copy for the weight gradient "
+                                   "(the pooler / the previous layer writes it in training mode)")
+        elif ctx.x2:
             y = H.gemm_nt(x, H.x2_cached(weight), x2=True, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
                           dropout_seed_add=seed_add, out_dtype=out_dtype, a_planar=H.x2_planar_of(x))
             x_hi = H.x2_hi_pop(x)  # the pooler's plain bf16 copy of x, if it wrote one: the operand of dW
@@ -116,9 +135,14 @@ class _Linear(Function):
                           out_dtype=out_dtype)
         ctx.relu, ctx.dropout_p = relu, dropout_p
         ctx.bwd = _bwd_split() if ctx.x2 else frozenset()
+        if ctx.bwd and H.mx_of(x):
+            raise NotImplementedError('"parity_train" (a backward that keeps the hi/lo split) is not combined with f16mx activations')
         if "dw" in ctx.bwd:
             x_hi = None  # the split weight gradient reads hi AND lo: the carrier itself is kept (either layout)
-        ctx.save_for_backward(x if x_hi is None else x_hi.view(x.shape), weight, y if (relu or dropout_p > 0) else None)
+        if y_mask is not None:
+            ctx.y_x2 = False  # (the mask is read from the plain bf16 rounding of the f16mx output)
+        ctx.save_for_backward(x if x_hi is None else x_hi.view(x.shape), weight,
+                              (y if y_mask is None else y_mask) if (relu or dropout_p > 0) else None)
         ctx.x_is_hi = x_hi is not None
         ctx.has_bias = bias is not None
         # (rows, callback) set by a data-parallel trainer on ONE large weight: its gradient is produced in two row
@@ -408,7 +432,7 @@ class _RoIPool(Function):
         need_grad = feat.requires_grad
         out, argmax = H.roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=roi_scale,
                                          out_dtype=out_dtype, need_argmax=need_grad,
-                                         want_hi=out_dtype == H.X2 and _WANT_HI.on)
+                                         want_hi=out_dtype in (H.X2, H.MX) and _WANT_HI.on)
         ctx.shape = tuple(feat.shape)
         ctx.cl = not feat.is_contiguous()
         ctx.in_dtype = feat.dtype
@@ -457,7 +481,7 @@ class _RoIAlign(Function):
     @staticmethod
     def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned, roi_scale, out_dtype):
         out = H.roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, aligned,
-                                  roi_scale=roi_scale, out_dtype=out_dtype, want_hi=out_dtype == H.X2 and _WANT_HI.on)
+                                  roi_scale=roi_scale, out_dtype=out_dtype, want_hi=out_dtype in (H.X2, H.MX) and _WANT_HI.on)
         ctx.cfg = (tuple(feat.shape), not feat.is_contiguous(), spatial_scale, sampling_ratio, aligned, feat.dtype)
         ctx.save_for_backward(rois, roi_scale)
         return out

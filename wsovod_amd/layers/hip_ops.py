@@ -260,6 +260,19 @@ def x2_to_f32(x):
 # round 5: with `want_hi` (training, "parity") the poolers write PLANAR bf16x2 instead of the interleaved layout plus a plain
 # bf16 copy (WSOVOD_X2_PLANAR=0: the round-4 form, for A/B runs)
 # (only the LEAN two-phase tile reads the planar form: WSOVOD_G8_LEAN=0 therefore also selects the round-4 layout)
+MX = "f16mx"  # format tag of the block-scaled parity format (include/wsovod_hip.h: WSOVOD_F16MX); carriers are float32-typed
+
+
+def mx_of(x):
+    """True when `x` (or the tensor it is a whole view of) was written as a unit-scale f16mx carrier."""
+    if x is None or x.dtype != torch.float32:
+        return False
+    if getattr(x, "_mx", False):
+        return True
+    b = getattr(x, "_base", None)
+    return bool(b is not None and b.data_ptr() == x.data_ptr() and b.numel() == x.numel() and getattr(b, "_mx", False))
+
+
 X2_PLANAR = os.environ.get("WSOVOD_X2_PLANAR", "1") != "0" and os.environ.get("WSOVOD_G8_LEAN", "1") != "0"
 POISON_OUTPUTS = os.environ.get("WSOVOD_POISON_OUTPUTS", "0") == "1"
 POISON_BYTE = 0x7F
@@ -290,7 +303,9 @@ def roi_pool_forward(feat, rois, spatial_scale, output_size, roi_scale=None, out
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     planar = bool(want_hi and out_dtype == X2 and R > 0 and _x2_planar_ok(R, Cc * ph * pw))
-    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0 and not planar) else None
+    hi = _x2_hi_alloc(out) if (want_hi and out_dtype in (X2, MX) and R > 0 and not planar) else None
+    if out_dtype == MX:
+        out._mx = True  # a unit-scale f16mx carrier (with, in training, its plain bf16 rounding for fc1's weight gradient)
     # scratch for the map's 2x2 maxima (0 bytes: this shape keeps the cell scan; include/wsovod_hip.h)
     ws_bytes = int(lib().wsovod_roi_pool_workspace_bytes(dtype_code(feat.dtype), layout, R, N, Cc, H, W, ph, pw,
                                                          int(need_argmax))) if R > 0 else 0
@@ -353,7 +368,9 @@ def roi_align_forward(feat, rois, spatial_scale, output_size, sampling_ratio, al
     if roi_scale is not None:
         roi_scale = roi_scale.to(torch.float32).contiguous()
     planar = bool(want_hi and out_dtype == X2 and R > 0 and _x2_planar_ok(R, Cc * ph * pw))
-    hi = _x2_hi_alloc(out) if (want_hi and out_dtype == X2 and R > 0 and not planar) else None
+    hi = _x2_hi_alloc(out) if (want_hi and out_dtype in (X2, MX) and R > 0 and not planar) else None
+    if out_dtype == MX:
+        out._mx = True
     check(lib().wsovod_roi_align_forward_x2hi(
         ptr(feat), dtype_code(feat.dtype), layout, ptr(rois), ptr(roi_scale), R, N, Cc, H, W, ph, pw,
         C.c_float(spatial_scale), int(sampling_ratio), int(bool(aligned)), ptr(out),
@@ -416,9 +433,6 @@ def x2_decode(src):
     out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
     check(lib().wsovod_bf16x2_decode(ptr(src), src.stride(0), rows, cols, ptr(out), out.stride(0), stream()), "bf16x2_decode")
     return out
-
-
-MX = "f16mx"  # format tag of the block-scaled parity format (include/wsovod_hip.h: WSOVOD_F16MX); carriers are float32-typed
 
 
 def mx_encode(src, nseg=1, unit=False):
@@ -596,6 +610,35 @@ class x3_mode:
     def __exit__(self, *exc):
         _X3State.active = self.prev
         return False
+
+
+class _MxStateT(threading.local):
+    on = False
+
+
+_MxState = _MxStateT()
+
+
+class mx_mode:
+    """Context manager (MODEL.HIP.PRECISION = "parity_mx"): inside the "x2" (parity) mode, the big forward contractions -- the
+    res4 / res5 convs and the box head's FC layers -- take the block-scaled f16mx kernels (wsovod_gemm_f16mx) and the tensors
+    between them travel as unit-scale f16mx carriers instead of bf16x2."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _MxState.on
+        _MxState.on = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _MxState.on = self.prev
+        return False
+
+
+def mx_active():
+    return bool(_MxState.on) and x3_active() == "x2"
 
 
 def x3_active():
@@ -1094,9 +1137,10 @@ def mask_transpose(dy, y, scale, out_dtype, want_plain=True, want_t=True, ld_t=N
         dAt = (torch.zeros if ld != M else torch.empty)((N, ld), dtype=out_dtype, device=dy.device)
     if colsum is not None:
         assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
-    if y_x2 and y is not None:  # the mask source is the layer's bf16x2 output: its hi halves carry the sign
+    if y is not None and (y_x2 or y.dtype != dy.dtype):
+        # the mask source is the layer's bf16x2 output (its hi halves carry the sign) or -- f16mx outputs -- its plain bf16 rounding
         check(lib().wsovod_mask_transpose_ex(
-            ptr(dy), _ld(dy), dtype_code(dy.dtype), ptr(y), _ld(y), BF16X2, M, N, C.c_float(scale), ptr(dA), ldp, ptr(dAt),
+            ptr(dy), _ld(dy), dtype_code(dy.dtype), ptr(y), _ld(y), BF16X2 if y_x2 else dtype_code(y.dtype), M, N, C.c_float(scale), ptr(dA), ldp, ptr(dAt),
             _ld(dAt) if want_t else 0, dtype_code(out_dtype), ptr(colsum), stream()), "mask_transpose_ex")
         return dA, dAt
     if colsum is not None:

@@ -146,6 +146,29 @@ def hip_conv(x, conv, relu=False, residual=None, pool2=False, shortcut=None, out
                                   out_fp32=out_fp32))
         return torch.cat(parts)
     geom = dict(n_img=N, H=Hh, W=Ww, Cin=Cin, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=s, pad=p, dil=d)
+    if _x2() and H.mx_of(x):
+        # "parity_mx": x (and residual / shortcut input) are unit-scale f16mx maps; fp16 hi*hi + block-scaled e4m3 cross terms
+        # on the f16mx weights (per-row scales, encoded once: the stages are frozen or re-encoded per optimizer step); the
+        # output is f16mx again, or real fp32 for the map that leaves the backbone
+        assert not pool2
+        fmt = torch.float32 if out_fp32 else H.MX
+        if shortcut is not None:
+            x2in, sc = shortcut
+            assert residual is None and H.mx_of(x2in) and x2in.shape[:3] == (N, Ho, Wo) and x2in.shape[3] == sc.in_channels
+            wq, b = _folded_with_shortcut(conv, sc, torch.float32)
+            wm, ws = H.mx_cached(wq)
+            out = H.gemm_mx(x, None, wm, ws, conv=geom, A2=x2in, bias=b, relu=relu, out_dtype=fmt)
+        else:
+            wq, b = conv.folded(torch.float32, cin_pad=Cin)
+            wm, ws = H.mx_cached(wq)
+            res2d = residual.view(N * Ho * Wo, conv.out_channels) if residual is not None else None
+            assert res2d is None or H.mx_of(residual)
+            out = H.gemm_mx(x, None, wm, ws, conv=geom, bias=b, relu=relu, residual=res2d,
+                            residual_fmt=H.MX if res2d is not None else None, out_dtype=fmt)
+        out = out.view(N, Ho, Wo, conv.out_channels)
+        if not out_fp32:
+            out._mx = True
+        return out
     if _x2():
         # x (and residual / shortcut input) are bf16x2 maps; three-MFMA products on the bf16x2 weights; the output is
         # bf16x2 again, or real fp32 for the map that leaves the backbone (out_fp32)
@@ -364,8 +387,9 @@ def _torch_block(block, x):
 
 def forward_precision(name):
     """MODEL.HIP.PRECISION "parity_train" = the "parity" forward (bf16x2 activations, three products) + a backward that
-    keeps the split too (layers/functions.py:backward_split): every module sees "parity", the meta-arch sets the flag."""
-    return "parity" if name == "parity_train" else name
+    keeps the split too (layers/functions.py:backward_split): every module sees "parity", the meta-arch sets the flag.
+    "parity_mx" likewise: the parity forward with its big contractions on the f16mx kernels (hip_ops.mx_mode)."""
+    return "parity" if name in ("parity_train", "parity_mx") else name
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -719,12 +743,32 @@ class ResNet(nn.Module):
             got = cache[id(stage)] = list(stage.parameters())
         return got
 
+    def _mx_from(self):
+        """"parity_mx": index of the first stage that runs on the f16mx kernels -- the trailing run of FROZEN stages of
+        BasicBlocks without pools whose convs are at least 256 channels wide (res4 / res5 of WSR_18: what the numerics gate
+        covered, profiles/r06_mx_gate.md); len(stages) = none."""
+        first = len(self.stages)
+        for i in range(len(self.stages) - 1, -1, -1):
+            stage = self.stages[i]
+            ok = all(isinstance(b, BasicBlock) and not b.has_pool and b.in_channels % 32 == 0 and b.out_channels % 32 == 0
+                     and b.out_channels >= 256 and (b.shortcut is None or (b.shortcut.kernel_size == 1 and b.shortcut.stride == 1))
+                     for b in stage.children())
+            if not ok or any(p.requires_grad for p in self._stage_params(stage)):
+                break
+            first = i
+        return first
+
     def _run(self, x):
         outputs = {}
         if "stem" in self._out_features:
             outputs["stem"] = x.permute(0, 3, 1, 2)
-        for name, stage in zip(self.stage_names, self.stages):
+        mx_from = self._mx_from() if (H.mx_active() and list(self._out_features) == [self.stage_names[-1]]) else len(self.stages)
+        for si, (name, stage) in enumerate(zip(self.stage_names, self.stages)):
             params = self._stage_params(stage)
+            if si == mx_from and si > 0:  # the map that crosses from the bf16x2 layers to the f16mx ones
+                with torch.no_grad():
+                    x = H.mx_from_x2(x)
+                    x._mx = True
             if torch.is_grad_enabled() and any(p.requires_grad for p in params):
                 _warn_trainable_stage_once(name)
                 x = _TrainableStage.apply(stage, H.x3_active(), x, *params)
@@ -785,7 +829,7 @@ class ResNet(nn.Module):
         cache = self.__dict__.setdefault("_graphs", {})
         if any(v and v.fingerprint != fp for v in cache.values()):
             cache.clear()  # a weight changed (load_state_dict, broadcast): the folded copies the graphs point at are stale
-        key = (tuple(images_u8.shape), sizes.data_ptr(), tuple(pixel_mean), tuple(pixel_std), H.x3_active())
+        key = (tuple(images_u8.shape), sizes.data_ptr(), tuple(pixel_mean), tuple(pixel_std), H.x3_active(), H.mx_active())
         g = cache.get(key)
         if g is None:
             # capture on the third call with a shape: with multi-scale inputs most shapes never repeat, and a capture

@@ -97,9 +97,13 @@ class DiscriminativeAdaptationNeck(nn.Sequential):
                 seed = (self._base_seed() * 1000003 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
             else:
                 seed = (self._base_seed() * 1000003 + self._step * 16 + k) & 0x7FFFFFFFFFFFFFFF if p > 0 else 0
-            # "parity" precision: x arrives as bf16x2 (the pooler wrote it) and every FC hands bf16x2 on
-            x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed,
-                          out_dtype=H.X2 if H.x3_active() == "x2" else None, seed_add=step_term if p > 0 else None)
+            # "parity" precision: x arrives as bf16x2 (the pooler wrote it) and every FC hands bf16x2 on; "parity_mx": x arrives
+            # as f16mx, the FC layers hand f16mx on among themselves and the last one bf16x2 to the heads
+            fmt = None
+            if H.x3_active() == "x2":
+                fmt = H.MX if (H.mx_of(x) and k + 1 < len(self.fcs)) else H.X2
+            x = Fn.linear(x, fc.weight, fc.bias, relu=True, dropout_p=p, seed=seed, out_dtype=fmt,
+                          seed_add=step_term if p > 0 else None)
         return x
 
     @property

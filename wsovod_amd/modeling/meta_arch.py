@@ -70,6 +70,9 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         self.classifier = None
         # MODEL.HIP.PRECISION = "parity_train": the heads' backward keeps the hi/lo split (layers/functions.py)
         self.backward_split = bool(cfg is not None and cfg.MODEL.HIP.PRECISION == "parity_train")
+        # "parity_mx" (round 6): the parity forward with the res4 / res5 convs and the box head's FC layers on the block-scaled
+        # f16mx kernels (layers/hip_ops.py:mx_mode); every module sees "parity", this flag selects the kernels
+        self.mx = bool(cfg is not None and cfg.MODEL.HIP.PRECISION == "parity_mx")
 
     @classmethod
     def from_config(cls, cfg):
@@ -188,13 +191,13 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
 
     @torch.no_grad()
     def forward_frozen(self, batched_inputs):
-        with H.x3_mode(self.x3):
+        with H.x3_mode(self.x3), H.mx_mode(getattr(self, "mx", False)):
             return self._forward_frozen(batched_inputs)
 
     def forward_trainable(self, st):
         from ..layers.functions import backward_split
 
-        with H.x3_mode(self.x3), backward_split(self.backward_split):
+        with H.x3_mode(self.x3), backward_split(self.backward_split), H.mx_mode(getattr(self, "mx", False)):
             return self._forward_trainable(st)
 
     @torch.no_grad()
@@ -202,7 +205,7 @@ class GeneralizedRCNN_WSOVOD(nn.Module):
         pre = getattr(self, "_pre_inference", None)  # an overlapped trainer applies its pending update first (eval / TTA
         if pre is not None:                          # hooks between steps must see the weights after optimizer.step())
             pre()
-        with H.x3_mode(self.x3):
+        with H.x3_mode(self.x3), H.mx_mode(getattr(self, "mx", False)):
             return self._inference(batched_inputs, detected_instances, do_postprocess, classifier)
 
     def _forward_frozen(self, batched_inputs):

@@ -157,7 +157,10 @@ class WSOVODROIHeads(ROIHeads):
 
     @property
     def pool_dtype(self):
-        """What the pooler writes: the compute dtype, or bf16x2 (hip_ops.X2) under the "parity" precision."""
+        """What the pooler writes: the compute dtype, bf16x2 (hip_ops.X2) under the "parity" precision, unit-scale f16mx
+        (hip_ops.MX) under "parity_mx"."""
+        if H.mx_active() and self.pooler_type in ("ROIPool", "ROIAlignV2", "ROIAlign"):
+            return H.MX
         return H.X2 if H.x3_active() == "x2" else self.compute_dtype
 
     @classmethod
@@ -211,7 +214,7 @@ class WSOVODROIHeads(ROIHeads):
             "positive_sample_fractions": cfg.WSOVOD.SAMPLING.POSITIVE_FRACTION,
             "cls_agnostic_bbox_known": cfg.WSOVOD.CLS_AGNOSTIC_BBOX_KNOWN, "pooler_type": pooler_type,
             "rpn_on": cfg.MODEL.PROPOSAL_GENERATOR.NAME != "PrecomputedProposals", "metadata": None,
-            "precision": "parity" if cfg.MODEL.HIP.PRECISION == "parity_train" else cfg.MODEL.HIP.PRECISION,
+            "precision": "parity" if cfg.MODEL.HIP.PRECISION in ("parity_train", "parity_mx") else cfg.MODEL.HIP.PRECISION,
         }
 
     # ------------------------------------------------------------------------------
