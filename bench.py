@@ -34,9 +34,14 @@ DTYPE = {"parity": "bf16 (bf16x2 hi/lo activations, three MFMA products per valu
                    "accumulation, master weights, losses and optimizer)",
          "bf16": "bf16", "fp32": "f32", "bf16x3": "bf16 (hi/lo split operands, forward and backward)",
          "bf16x3f": "bf16 (hi/lo split operands forward, plain bf16 backward)",
+         "parity_mx": "bf16 / fp16 + MX fp8 (the parity forward with the res4 / res5 convs and fc1 / fc2 on fp16 hi*hi + block-scaled "
+                      "e4m3 cross terms -- two v_mfma_f32_32x32x16_f16 + one v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32x32 tile --, "
+                      "bf16x2 three-product forward elsewhere; plain bf16 backward; fp32 accumulation, master weights, losses "
+                      "and optimizer)",
          "parity_train": "bf16 (the parity forward; the input-gradient contractions of the backward keep the hi/lo split: "
                          "three bf16 MFMA products on fp32 gradients and fp32 master weights)"}
-PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "bf16x3f": 2500.0, "parity": 2500.0, "parity_train": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md); x3 runs bf16 MFMAs
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0, "bf16x3f": 2500.0, "parity": 2500.0, "parity_train": 2500.0,
+        "parity_mx": 2500.0}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md); x3 runs bf16 MFMAs
 HBM_PEAK_GBS = 8000.0
 
 
@@ -49,7 +54,7 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
-    ap.add_argument("--precision", default="parity", choices=["parity", "parity_train", "bf16", "fp32", "bf16x3", "bf16x3f"],
+    ap.add_argument("--precision", default="parity", choices=["parity", "parity_mx", "parity_train", "bf16", "fp32", "bf16x3", "bf16x3f"],
                     help="parity (default, the headline) = the mode that MEETS the north star's 1e-3 logit bound with exact "
                          "proposal indexing: bf16 MFMA arithmetic on bf16x2 (hi, lo) activations, three products per value "
                          "pair in the forward pass, plain bf16 backward; bf16 = plain bf16 MFMA (BASELINE config 2's dtype, "
@@ -466,7 +471,7 @@ def run_config(args, dev, rank, world, *, precision, batch_size, pooler, steps, 
     # the reported final losses stay meaningful: tests/test_gpu_model_parity.py::test_training_on_a_fixed_batch_...)
     cfg.SOLVER.BASE_LR = 1e-3
     optimizer = build_optimizer(cfg, model)
-    wire = ("bf16" if precision in ("bf16", "parity", "parity_train", "bf16x3f") else "fp32") if args.grad_wire == "auto" else args.grad_wire
+    wire = ("bf16" if precision in ("bf16", "parity", "parity_mx", "parity_train", "bf16x3f") else "fp32") if args.grad_wire == "auto" else args.grad_wire
     # asynchronous gradient exchange behind the next step's frozen forward.  At N > 1 with --exchange auto both forms are
     # timed below and the faster one carries the headline: the trainer starts on the ring (RCCL's own all-reduce)
     ab = world > 1 and wire == "bf16" and args.exchange == "auto"

@@ -213,12 +213,13 @@ def _assert_parity_mode(rep, elem_tol=3e-2):
     assert elem_tol is None or rep["max_rel_grad_elem_err"] < elem_tol, rep
 
 
-@pytest.mark.parametrize("precision", ["parity", "fp32"])
+@pytest.mark.parametrize("precision", ["parity", "parity_mx", "fp32"])
 def test_benchmarked_batch_of_32_images_matches_the_oracle(gpu, precision):
     """The bench's own step -- 32 x 800x600 images x 512 proposals, one training step -- against the oracle on the same
     weights (~1 min of CPU for the oracle's step, shared by the two precisions): fc1 at M = 16384 rows (64 row tiles,
     split-K tails of the small layers' dW at this batch), 512-row MIL segments x 32, the backbone on 32 images, the
-    transposed-read dW over 16384 proposals.  parity: the headline precision; fp32: the exact mode."""
+    transposed-read dW over 16384 proposals.  parity / parity_mx: the headline precisions (round 6: the f16mx kernels at their
+    full tile counts -- 1876 conv tiles, 1024 FC tiles); fp32: the exact mode."""
     rep = _oracle_vs_hip(gpu, precision, n_images=32, proposals=512, classes=20)
     if precision == "fp32":
         _assert_parity(rep, 2e-3)

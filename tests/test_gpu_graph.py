@@ -141,7 +141,7 @@ def _varying_batches(n_steps, nums_list, K=20, H=320, W=416):
     return out
 
 
-@pytest.mark.parametrize("precision", ["bf16", "parity"])
+@pytest.mark.parametrize("precision", ["bf16", "parity", "parity_mx"])
 def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision):
     """HotPathTrainer at 2 images per step, dropout ON, eight steps on eight different batches whose per-image proposal
     counts AND totals change from step to step (inside one row bucket): with the whole-step HIP graph (captured on the third step, replayed
