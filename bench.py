@@ -10,10 +10,11 @@ instance refinement (cosine-similarity head) -> losses -> backward -> fused SGD 
   python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0.  `value` = images/sec over all N GPUs (weak scaling: per-GPU batch fixed).
-The default precision is "parity" -- the mode that meets the north star's bound (MIL-head logits within 1e-3 of the
-reference path, proposal indexing bit-exact): at N = 1 the line carries that comparison, made with the oracle on the timed
-batch itself (the oracle is the checker here, never the thing measured), `roofline.frac` counts ALGORITHMIC flops (the
-executed rate of the three-MFMA products travels as `executed_frac`), and plain bf16 is a `side` line.
+The default precision is "parity_mx" (round 6) -- the "parity" mode, which meets the north star's bound (MIL-head logits
+within 1e-3 of the reference path, proposal indexing bit-exact), with its big forward contractions (res4 / res5 convs, fc1 /
+fc2) on the block-scaled f16mx kernels: at N = 1 the line carries that comparison, made with the oracle on the timed batch
+itself (the oracle is the checker here, never the thing measured), `roofline.frac` counts ALGORITHMIC flops (the executed
+matrix-pipe work travels as `executed_frac`), and "parity" (bf16x2 everywhere) and plain bf16 are `side` lines.
 """
 import argparse
 import json
@@ -54,8 +55,10 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for debugging)")
     ap.add_argument("--share-device", action="store_true",
                     help="debug: every rank uses cuda:0 (lets the N>1 code path run on a 1-GPU box with --backend gloo)")
-    ap.add_argument("--precision", default="parity", choices=["parity", "parity_mx", "parity_train", "bf16", "fp32", "bf16x3", "bf16x3f"],
-                    help="parity (default, the headline) = the mode that MEETS the north star's 1e-3 logit bound with exact "
+    ap.add_argument("--precision", default="parity_mx", choices=["parity", "parity_mx", "parity_train", "bf16", "fp32", "bf16x3", "bf16x3f"],
+                    help="parity_mx (default, the headline since round 6) = parity with the res4 / res5 convs and fc1 / fc2 on the "
+                         "block-scaled f16mx kernels (fp16 hi*hi + MX-e4m3 cross terms: two thirds of the matrix-pipe cycles); "
+                         "parity = the mode that MEETS the north star's 1e-3 logit bound with exact "
                          "proposal indexing: bf16 MFMA arithmetic on bf16x2 (hi, lo) activations, three products per value "
                          "pair in the forward pass, plain bf16 backward; bf16 = plain bf16 MFMA (BASELINE config 2's dtype, "
                          "misses the bound: a side line); fp32 = exact-fp32 MFMA; bf16x3 / bf16x3f = round 2's split forms")
@@ -113,15 +116,17 @@ def pmc_traffic(kernel_name, args):
         if os.path.exists(cand):
             path = cand
             break
-    if not (path and prec in ("bf16", "parity") and args.depth == 18 and args.proposals == 512):
+    if not (path and prec in ("bf16", "parity", "parity_mx") and args.depth == 18 and args.proposals == 512):
         return None, None
     if getattr(args, "rpn", False) or args.pooler != "ROIPool" or args.h2d:
         return None, None
-    m = re.match(r"(gemm_nt|conv_igemm)_(bf16x2|bf16|f32)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
+    m = re.match(r"(gemm_nt|conv_igemm)_(bf16x2|bf16|f32|f16mx)_(\d+)x(\d+)(_dma|_8ph)?$", kernel_name)
     if not m:
         return None, None
     conv, x3 = m.group(1) == "conv_igemm", m.group(2) == "bf16x2"
-    if m.group(5) == "_8ph":  # rocprofv3 prints this one demangled: gemm256_8ph_kernel<CONV, X3, PH, LEAN>
+    if m.group(2) == "f16mx":  # csrc/gemm8mx.hip: gemm256_mx_kernel<CONV>
+        tags = ("gemm256_mx_kernel<%s>" % ("true" if conv else "false"),)
+    elif m.group(5) == "_8ph":  # rocprofv3 prints this one demangled: gemm256_8ph_kernel<CONV, X3, PH, LEAN>
         c, x = ("true" if conv else "false"), ("true" if x3 else "false")
         tags = (f"gemm256_8ph_kernel<{c}, {x},", f"gemm256_8ph_kernel<{c}>") if not x3 else (f"gemm256_8ph_kernel<{c}, {x},",)
     else:
@@ -868,11 +873,17 @@ def main():
                                  "gbs": (e["bytes"] / (e["ms"] * 1e-3) / 1e9) if e["bytes"] and e["ms"] else None}
                                 for e in table[:16]]}
         if mfma:
-            ex = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+            # (f16mx operands: per 32x32x32 block two fp16 MFMAs + one block-scaled fp8 MFMA of the same pipe time = the cycles
+            # of FOUR bf16-rate MFMA units of 32x32x16, i.e. twice the cycles of a plain 16-bit contraction)
+            exf = 2.0 if "f16mx" in top["name"] else 1.0
+            ex = exf * top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
             roofline["executed_achieved"], roofline["executed_frac"] = ex, ex / peak
             roofline["executed_note"] = ("bf16x2 operands: three bf16 MFMA products per value pair (hi*hi + hi*lo + lo*hi), the "
                                          "price of the 1e-3 logit bound on a 16-bit matrix pipe; `frac` counts the "
-                                         "algorithmic 2*M*N*K only") if "bf16x2" in top["name"] else None
+                                         "algorithmic 2*M*N*K only") if "bf16x2" in top["name"] else (
+                "f16mx operands: hi*hi as two fp16 MFMAs + both cross terms as ONE block-scaled e4m3 MFMA per 32x32x32 block "
+                "= the matrix-pipe cycles of two 16-bit products per value pair (three with bf16x2); `executed` prices those "
+                "cycles at the 16-bit rate, `frac` counts the algorithmic 2*M*N*K only") if "f16mx" in top["name"] else None
         # end to end: SURVEY 8d's algorithmic FLOP per image x images per step / step time, against the same MFMA peak
         gf_img = {(18, 512): 469.2, (50, 1024): 2199.4}.get((args.depth, args.proposals))
         if gf_img is not None and not args.rpn:
@@ -940,7 +951,7 @@ def main():
                 out["parity_checked_on_images"] = pm.get("images", args.parity_images)
                 out["gradient_grade"] = ("forward quantities of fp32 grade (the bound above); the backward pass runs in plain "
                                          "bf16 on the hi halves: gradient norms / elements carry bf16's grade (fields above)"
-                                         if args.precision in ("parity", "bf16x3f") else None)
+                                         if args.precision in ("parity", "parity_mx", "bf16x3f") else None)
             if not args.no_side:
                 out["side"] = side_measurements(args, dev)
                 # the reference's own operating points (1 and 8 images per GPU) as top-level keys

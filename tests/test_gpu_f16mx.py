@@ -180,3 +180,48 @@ def test_conv_equals_the_three_plane_convolution(gpu, n, Hh, Ww, Cin, Cout, k, d
     want = torch.relu(want + bias.double())
     scale = float(want.abs().max())
     assert float((got.double() - want).abs().max()) < 1e-5 * scale
+
+
+@pytest.mark.parametrize("form", ["gemm", "conv", "conv_shortcut_f16mx_out"])
+def test_last_round_of_tiles_as_split_k_slices(gpu, form, monkeypatch):
+    """More tiles than CUs with a partly filled last round: the rows of that round go to a second launch of the kernel as S
+    copies of the grid over slices of K + a finalize pass (fp32 workspace, the same epilogue chain and output formats).
+    Against the single launch (WSOVOD_MX_TAIL=0) to fp32 summation-order error, output bytes of the f16mx form included
+    up to that error."""
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(7)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if form == "gemm":
+        M, N, K = (cus + 18) * 256 - 100, 256, 1536
+        a = torch.relu(torch.randn(M, K, device=gpu))
+        b = torch.randn(N, K, device=gpu) * 0.03
+        bias = torch.randn(N, device=gpu)
+        A, _ = H.mx_encode(a, unit=True)
+        B, sb = H.mx_encode(b)
+        run = lambda: H.gemm_mx(A, None, B, sb, bias=bias, relu=True, dropout_p=0.5, dropout_seed=11)
+    else:
+        n, Hh, Ww, Cin, Cout = (cus * 256) // 7500 + 4, 75, 100, 128, 256
+        x = torch.relu(torch.randn(n * Hh * Ww, Cin, device=gpu))
+        Cin2 = 64 if form != "conv" else 0
+        w = torch.randn(Cout, 9 * Cin + Cin2, device=gpu) * 0.03
+        bias = torch.randn(Cout, device=gpu)
+        X = H.mx_encode(x, unit=True)[0].view(n, Hh, Ww, Cin)
+        X2 = H.mx_encode(torch.randn(n * Hh * Ww, Cin2, device=gpu), unit=True)[0].view(n, Hh, Ww, Cin2) if Cin2 else None
+        res = None if Cin2 else H.mx_encode(torch.randn(n * Hh * Ww, Cout, device=gpu), unit=True)[0]
+        W, sw = H.mx_encode(w)
+        geom = dict(n_img=n, H=Hh, W=Ww, Cin=Cin, Ho=Hh, Wo=Ww, KH=3, KW=3, stride=1, pad=2, dil=2)
+        fmt = H.MX if Cin2 else torch.float32
+        run = lambda: H.gemm_mx(X, None, W, sw, conv=geom, A2=X2, bias=bias, relu=True, residual=res,
+                                residual_fmt=H.MX if res is not None else None, out_dtype=fmt)
+    got = run()
+    monkeypatch.setenv("WSOVOD_MX_TAIL", "0")
+    want = run()
+    if form == "conv_shortcut_f16mx_out":
+        got, want = H.mx_to_f32(got), H.mx_to_f32(want)
+        tol = 2.0 ** -13  # (a last-bit difference of the fp32 sum can move an e4m3 rounding of the lo plane)
+    else:
+        tol = 2e-6
+    assert not torch.equal(got[: got.shape[0] // 2], torch.zeros_like(got[: got.shape[0] // 2]))
+    assert float((got - want).abs().max()) <= tol * float(want.abs().max())
+    assert torch.equal(got == 0, want == 0) or form != "gemm"  # the same ReLU / dropout pattern

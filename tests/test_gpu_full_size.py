@@ -191,11 +191,17 @@ def test_parity_mode_matches_the_oracle_at_full_size(gpu):
 
 
 @pytest.mark.parametrize("pooler", ["ROIPool", "ROIAlignV2"])
-def test_parity_mx_mode_matches_the_oracle_at_full_size(gpu, pooler):
+def test_parity_mx_mode_matches_the_oracle_at_full_size(gpu, pooler, monkeypatch):
     """MODEL.HIP.PRECISION = "parity_mx" (round 6): the parity forward with the res4 / res5 convs and fc1 / fc2 on the
     block-scaled f16mx kernels (fp16 hi*hi + e4m3 cross terms; csrc/gemm8mx.hip) -- the same bar as "parity": forward
     quantities inside the north star's bound against the oracle at the headline size, indices exact, gradients of the bf16
-    grade (the backward is the parity mode's, on the plain bf16 copies the f16mx producers write)."""
+    grade (the backward is the parity mode's, on the plain bf16 copies the f16mx producers write).  (The mode hands layers with
+    fewer than ~200 tiles to the bf16x2 kernels; the thresholds are lowered here so that two images take the f16mx ones.)"""
+    from wsovod_amd.modeling.backbone import ResNet
+    from wsovod_amd.modeling.roi_heads import WSOVODROIHeads
+
+    monkeypatch.setattr(ResNet, "MX_MIN_TILES", 1)
+    monkeypatch.setattr(WSOVODROIHeads, "MX_MIN_ROWS", 1)
     rep = _oracle_vs_hip(gpu, "parity_mx", n_images=2, proposals=512, classes=20, pooler=pooler)
     _assert_parity_mode(rep)
 

@@ -155,6 +155,12 @@ def test_whole_step_graph_reproduces_the_eager_steps(gpu, monkeypatch, precision
 
     monkeypatch.setattr(H, "DETERMINISTIC", True)
     monkeypatch.setenv("WSOVOD_BACKBONE_GRAPH", "0")
+    if precision == "parity_mx":  # (two small images: below the mode's tile-count thresholds -- lowered, the f16mx kernels run)
+        from wsovod_amd.modeling.backbone import ResNet
+        from wsovod_amd.modeling.roi_heads import WSOVODROIHeads
+
+        monkeypatch.setattr(ResNet, "MX_MIN_TILES", 1)
+        monkeypatch.setattr(WSOVODROIHeads, "MX_MIN_ROWS", 1)
     # totals 128 / 120 / 113 / 97: one bucket of 128 rows (trainer.row_bucket) -- the graph runs the short steps with
     # padding rows behind the last image (an empty box, label -1, zero gradient, the box loss normalised by the real count)
     batches = _varying_batches(8, [(64, 64), (60, 60), (70, 43), (33, 64)])

@@ -2,11 +2,11 @@
 # Runs ON THE GPU BOX (via gpurun): the round's bench line, the rocprofv3 kernel-trace summary of the same command and
 # the PMC passes behind roofline.traffic and the MFMA-utilisation table.  Counters are collected in their own runs with
 # --kernel-trace only (no sys/hip/hsa trace domains).  Everything lands under gpurun_out/final/ (copy to profiles/).
-#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh'                     (the headline: parity, 32 images / step)
+#   gpurun --timeout 1800 -- 'bash tools/collect_profiles.sh'                     (the headline: parity_mx, 32 images / step)
 #   gpurun --timeout 1800 -- 'PREC=bf16 bash tools/collect_profiles.sh'           (plain bf16, the side line)
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-PREC=${PREC:-parity}
+PREC=${PREC:-parity_mx}
 BATCH=${BATCH:-32}
 TAG=b${BATCH}_${PREC}
 OUT=$ROOT/gpurun_out/final
@@ -15,7 +15,7 @@ cd /tmp && export TMPDIR=/tmp
 COMMON="--precision $PREC --batch $BATCH"
 SHORT="$COMMON --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-side --no-parity"
 FULL=""
-if [ "$PREC" != "parity" ]; then FULL="--no-side --no-parity --no-cpu-baseline"; fi
+if [ "$PREC" != "parity_mx" ]; then FULL="--no-side --no-parity --no-cpu-baseline"; fi
 python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 5 $FULL > "$OUT/bench_$TAG.json" 2> "$OUT/bench_$TAG.err"
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- \
     python3 "$ROOT/bench.py" $COMMON --steps 20 --warmup 5 --no-cpu-baseline --no-side --no-parity > "$OUT/bench_${TAG}_under_rocprof.json" 2> "$OUT/rocprof_$TAG.err"

@@ -45,12 +45,16 @@ for name, Cin, Cout, Cin2, cnt in (("res4.0.conv1", 128, 256, 0, 1), ("res4.0.co
     o1 = torch.empty(n * Hi * Wi, Cout, device="cuda")
     o2 = torch.empty(n * Hi * Wi, Cout, device="cuda")
     t_x2 = t(lambda: H.gemm_nt(xx, wx, conv=geom, x2=True, bias=bias, relu=True, out=o1, out_dtype=H.X2, A2=a2x))
+    os.environ["WSOVOD_MX_TAIL"] = "0"
+    t_mx1 = t(lambda: H.gemm_mx(xm, None, wm, sw, conv=geom, A2=a2m, bias=bias, relu=True, out=o2, out_dtype=H.MX))
+    os.environ["WSOVOD_MX_TAIL"] = "1"
     t_mx = t(lambda: H.gemm_mx(xm, None, wm, sw, conv=geom, A2=a2m, bias=bias, relu=True, out=o2, out_dtype=H.MX))
+    tot_one = globals().get("tot_one", 0.0) + cnt * t_mx1
     fl = 2.0 * n * Hi * Wi * Cout * (9 * Cin + Cin2)
     d1, d2 = H.x2_decode(o1), H.mx_to_f32(o2)
     err = float((d1 - d2).abs().max() / d1.abs().max())
     tot_x2 += cnt * t_x2
     tot_mx += cnt * t_mx
     print(f"{name} ({Cin}->{Cout}, x{cnt}): bf16x2 {t_x2:.3f} ms ({fl / t_x2 / 1e9:.0f} TF algorithmic)   f16mx {t_mx:.3f} ms "
-          f"({fl / t_mx / 1e9:.0f} TF)   x{t_x2 / t_mx:.3f}   max |diff| / max = {err:.2e}", flush=True)
-print(f"per step (8 convs): bf16x2 {tot_x2:.3f} ms   f16mx {tot_mx:.3f} ms   x{tot_x2 / tot_mx:.3f}")
+          f"({fl / t_mx / 1e9:.0f} TF; one launch, no split-K tail: {t_mx1:.3f} ms)   x{t_x2 / t_mx:.3f}   max |diff| / max = {err:.2e}", flush=True)
+print(f"per step (8 convs): bf16x2 {tot_x2:.3f} ms   f16mx {tot_mx:.3f} ms (single launches: {tot_one:.3f})   x{tot_x2 / tot_mx:.3f}")

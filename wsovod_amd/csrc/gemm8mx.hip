@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace wsovod_gemm {
 namespace {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const int nwg = p.tiles_m * p.tiles_n;
   int wg;
   {
-    const int bid = (int)blockIdx.x;
+    const int bid = p.ksplit > 1 ? (int)(blockIdx.x % (unsigned)nwg) : (int)blockIdx.x;  // split-K: slice-major copies of the grid
     const int qq = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     wg = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (bid >> 3);
   }
@@ -88,7 +89,11 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const int in_group = wg - group_id * group_size;
   const int tile_m = first_m + in_group % gm;
   const int tile_n = in_group / gm;
-  [[maybe_unused]] const int m0 = tile_m * BM, n0 = tile_n * BN;
+  [[maybe_unused]] const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;  // (m_base: a launch may cover rows [m_base, M) only)
+  // split-K (the last, partly filled round of tiles of a launch: wsovod_gemm_f16mx): slice z of the grid reduces K-steps
+  // [z * slice_steps, (z + 1) * slice_steps) and stores its raw fp32 sums; mx_splitk_finalize_kernel adds them
+  const int kslice = p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;
+  [[maybe_unused]] const int kt_base = kslice * p.slice_steps;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   [[maybe_unused]] const int wr = wave >> 2, wc = wave & 3;
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const int passB = (int)(LR * p.ldb * esz);  // (scalar; < 2^31: launcher)
   typedef __attribute__((address_space(3))) void lds_void;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int nk = p.K / BKE;  // (launcher: K a whole number of K-steps)
+  const int nk = p.ksplit > 1 ? max(0, min(p.K / BKE - kt_base, p.slice_steps)) : p.K / BKE;  // (launcher: K = whole K-steps)
 
   // ---- conv: the four rows a lane stages (pass i: tile row lrow + 64 i) as pixels -- offset of the pixel with the filter at
   // its top-left tap, one validity bit per tap, the output pixel in the shortcut's input
@@ -177,12 +182,12 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   };
   // scalar byte offsets of a K-step: into the A operand (conv: the tap's displacement + channel chunk) and the B rows
   auto soff_a = [&](int kt, const Tap t) -> int {
-    if (!CONV) return kt * (BKE * esz);
+    if (!CONV) return (kt + kt_base) * (BKE * esz);
     if (t.c0 >= p.Cin) return (t.c0 - p.Cin) * esz;
     return (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;
   };
   auto soff_b = [&](int kt, const Tap t) -> int {
-    if (!CONV) return kt * (BKE * esz);
+    if (!CONV) return (kt + kt_base) * (BKE * esz);
     return (t.c0 >= p.Cin ? p.KH * p.KW * p.Cin + (t.c0 - p.Cin) : (t.r * p.KW + t.q) * p.Cin + t.c0) * esz;
   };
   auto dma_a = [&](int stage, int i, int so, bool second) {
@@ -200,6 +205,17 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   };
   // K-steps 0 and 1 (the loop keeps two K-steps in flight: the pieces of K-step kt + 2 are requested during K-step kt)
   Tap t2{0, 0, 0};  // (conv) the tap of the K-step requested next
+  if (CONV && kt_base > 0) {  // split-K slice of a conv: the (filter tap, channel chunk) of its first K-step
+    const int taps = p.KH * p.KW, nk_main = taps * (p.Cin / BKE);
+    if (kt_base >= nk_main) {
+      t2.c0 = p.Cin + (kt_base - nk_main) * BKE;
+    } else {
+      const int chunk = kt_base / taps, tap = kt_base - chunk * taps;
+      t2.r = tap / p.KW;
+      t2.q = tap - t2.r * p.KW;
+      t2.c0 = chunk * BKE;
+    }
+  }
   {
     const int sb0 = soff_b(0, t2);
     dma_b(0, 0, sb0); dma_b(0, 1, sb0); dma_b(0, 2, sb0); dma_b(0, 3, sb0);
@@ -455,6 +471,21 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
 
   // ---- epilogue: tile T = 2 t + u holds row m0 + wr*128 + 32 t + r32 and, in registers 4 g .. 4 g + 3, the columns
   // n0 + wc*64 + 32 u + 16 h + 4 g ..  (the B-row permutation above): 16 consecutive columns per lane, tile and row
+  if (p.ksplit > 1) {  // split-K: raw partial sums of this K slice (rows counted from m_base)
+    float* part = p.partial + ((long long)kslice * (p.M - p.m_base) - p.m_base) * p.partial_ld;
+    auto part_tile = [&](const f32x16& a, const int T) {
+      const int m = m0 + wr * 128 + 32 * (T >> 1) + r32;
+      const int nb0 = n0 + wc * 64 + 32 * (T & 1) + 16 * hh;
+      if (m >= p.M) return;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (nb0 + 4 * g < p.N)
+          *(f32x4*)(part + (long long)m * p.partial_ld + nb0 + 4 * g) = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]};
+    };
+    part_tile(acc[0], 0); part_tile(acc[1], 1); part_tile(acc[2], 2); part_tile(acc[3], 3);
+    part_tile(acc[4], 4); part_tile(acc[5], 5); part_tile(acc[6], 6); part_tile(acc[7], 7);
+    return;
+  }
   const float keep_scale = p.dropout_p > 0.f ? 1.0f / (1.0f - p.dropout_p) : 1.0f;
   const unsigned long long dseed = p.dropout_p > 0.f ? WS_DROPOUT_SEED(p) : 0ull;
   const unsigned dthr = dropout_threshold(p.dropout_p);
@@ -516,6 +547,40 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   };
   emit_tile(acc[0], 0); emit_tile(acc[1], 1); emit_tile(acc[2], 2); emit_tile(acc[3], 3);
   emit_tile(acc[4], 4); emit_tile(acc[5], 5); emit_tile(acc[6], 6); emit_tile(acc[7], 7);
+#endif
+}
+
+// split-K finalize: C[m][n] = epilogue(sum over the K slices) for 4 consecutive columns per thread -- the same chain and the
+// same output formats as the tile kernel's epilogue
+__global__ __launch_bounds__(256) void mx_splitk_finalize_kernel(const MxArgs q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const GemmArgs& p = q.g;
+  const int n4 = p.N >> 2;  // (launcher: N a multiple of 4)
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int rows = p.M - p.m_base;
+  if (idx >= (long long)rows * n4) return;
+  const int mr = (int)(idx / n4), nb = (int)(idx - (long long)mr * n4) * 4, m = p.m_base + mr;
+  f32x4 x = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.ksplit; ++z) x += *(const f32x4*)(p.partial + ((long long)z * rows + mr) * p.partial_ld + nb);
+  x = x * p.alpha;
+  if (p.bias) x += *(const f32x4*)(p.bias + nb);
+  if (p.residual) {
+    if (p.dtype_r == WSOVOD_F16MX) x += mx_load4_unit((const char*)p.residual + (long long)m * p.ldr * 4, nb);
+    else x += load4_as_f32(p.residual, m, p.ldr, nb, p.dtype_r);
+  }
+  const float lo = p.relu ? 0.f : -__builtin_inff();
+  x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};
+  if (p.dropout_p > 0.f) {
+    const float keep_scale = 1.0f / (1.0f - p.dropout_p);
+    const unsigned long long dz = dropout_quad(WS_DROPOUT_SEED(p), m, p.N, nb);
+    const unsigned dthr = dropout_threshold(p.dropout_p);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = dropout_keep(dz, r, dthr) ? x[r] * keep_scale : 0.f;
+  }
+  if (p.dtype_c == WSOVOD_F16MX) mx_store4_unit((char*)p.C + (long long)m * p.ldc * 4, nb, x);
+  else store4_from_f32(p.C, m, p.ldc, nb, p.dtype_c, x);
+  if (q.c_bf16)
+    *(bf16x4*)((bf16_t*)q.c_bf16 + (long long)m * q.ld_cb + nb) = bf16x4{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
 #endif
 }
 
@@ -736,9 +801,93 @@ extern "C" int wsovod_gemm_f16mx(const wsovod_gemm_desc* d, const unsigned char*
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
+  // ---- the last, partly filled round of tiles.  One 256 x 256 tile per CU and launch round: a launch of T tiles costs
+  // ceil(T / CUs) tile times -- res5 of 32 images is 1876 tiles = 7.33 rounds.  The rows of the last round go to a SECOND
+  // launch of the same kernel whose grid is S copies of those tiles, copy z reducing a slice of the K-steps into an fp32
+  // workspace, and a finalize pass adds the slices and applies the epilogue: S is chosen so that the copies fill whole rounds
+  // again (res5: 84 tiles x 3 = 252).  Measured (tools/mx_conv_ab.py, 32 images): res5 1.833 -> 1.780 ms per conv; a last
+  // round that is more than half full (res4: 170 tiles) is left alone -- its slices' workspace traffic and shorter K loops cost
+  // more than the idle CUs, which the chip gives back as clock under its power limit (0.509 -> 0.560 ms with 170 x 3).
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) n_cu = 256;
+    else n_cu = std::max(1, prop.multiProcessorCount);
+    (void)hipGetLastError();
+  }
+  const int ntiles = a.tiles_m * a.tiles_n, nk_all = a.K / 64;
+  int tail_mt = 0, S = 1;
+  {
+    const char* ts = getenv("WSOVOD_MX_TAIL");  // (A/B runs: 0 = one launch)
+    const bool on = !(ts && ts[0] == '0') && q.nseg_a == 1 && q.nseg_b == 1 && n_cu % a.tiles_n == 0 && nk_all >= 24;
+    const int rem = ntiles % n_cu;
+    if (on && ntiles > n_cu && rem != 0 && rem % a.tiles_n == 0 && 2 * rem <= n_cu) {
+      double best = 1.0 + 0.02;
+      for (int c = 2; c <= 8 && nk_all / c >= 12; ++c) {
+        const double cost = (double)((rem * c + n_cu - 1) / n_cu) / c + 0.02 * c;
+        if (cost < best - 1e-9) best = cost, S = c;
+      }
+      if (S > 1) tail_mt = rem / a.tiles_n;
+    }
+  }
+  if (tail_mt > 0) {
+    // workspace of this process (single-stream use, as the rest of the library): never freed once handed out -- a captured
+    // HIP graph keeps the pointer --, growing under stream capture is refused (the policy of gemm8.hip's split-K workspace)
+    static float* ws = nullptr;
+    static size_t ws_bytes = 0;
+    static std::vector<float*> retired;
+    const int m_base = (a.tiles_m - tail_mt) * 256;
+    const long long ldp = ((long long)d->N + 3) / 4 * 4;
+    const size_t need = (size_t)S * (d->M - m_base) * ldp * sizeof(float);
+    if (need > ws_bytes) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      const bool capturing = s && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+      float* fresh = nullptr;
+      const size_t want = std::max(need, 2 * ws_bytes);
+      if (capturing || hipMalloc((void**)&fresh, want) != hipSuccess) {
+        (void)hipGetLastError();
+        tail_mt = 0;  // (no workspace: the single launch)
+      } else {
+        if (ws) retired.push_back(ws);
+        ws = fresh;
+        ws_bytes = want;
+      }
+    }
+    if (tail_mt > 0) {
+      a.partial = ws;
+      a.partial_ld = ldp;
+    }
+  }
   wsovod::ProfScope prof(d->conv ? slot_c : slot_g, s, 2.0 * d->M * (double)d->N * d->K, bytes);
-  if (d->conv) hipLaunchKernelGGL(gemm256_mx_kernel<true>, dim3(a.tiles_m * a.tiles_n), dim3(512), lds_bytes, s, q);
-  else hipLaunchKernelGGL(gemm256_mx_kernel<false>, dim3(a.tiles_m * a.tiles_n), dim3(512), lds_bytes, s, q);
+  auto launch = [&](const MxArgs& qq, int grid) {
+    if (d->conv) hipLaunchKernelGGL(gemm256_mx_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, qq);
+    else hipLaunchKernelGGL(gemm256_mx_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, qq);
+  };
+  if (tail_mt == 0) {
+    launch(q, ntiles);
+  } else {
+    MxArgs qm = q;  // whole rounds: rows [0, m_base)
+    const int m_base = (a.tiles_m - tail_mt) * 256;
+    qm.g.M = m_base;
+    qm.g.tiles_m = a.tiles_m - tail_mt;
+    qm.g.partial = nullptr;
+    launch(qm, qm.g.tiles_m * a.tiles_n);
+    MxArgs qt = q;  // the last round's rows [m_base, M), S slices of K
+    qt.g.m_base = m_base;
+    qt.g.tiles_m = tail_mt;
+    qt.g.ksplit = S;
+    qt.g.slice_steps = (nk_all + S - 1) / S;
+    {
+      const int run = std::max(1, tail_mt * a.tiles_n / 8);
+      int g = 1;
+      while ((g + 1) * (g + 1) <= run) ++g;
+      qt.g.group_m = std::max(1, std::min(std::min(g, 4), tail_mt));
+    }
+    launch(qt, tail_mt * a.tiles_n * S);
+    const long long quads = (long long)(d->M - m_base) * (d->N / 4);
+    hipLaunchKernelGGL(mx_splitk_finalize_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, qt);
+  }
   WS_CHECK_LAUNCH("wsovod_gemm_f16mx");
   return WSOVOD_OK;
 }

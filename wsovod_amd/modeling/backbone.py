@@ -743,10 +743,14 @@ class ResNet(nn.Module):
             got = cache[id(stage)] = list(stage.parameters())
         return got
 
+    MX_MIN_TILES = int(os.environ.get("WSOVOD_MX_MIN_TILES", "200"))
+
     def _mx_from(self):
         """"parity_mx": index of the first stage that runs on the f16mx kernels -- the trailing run of FROZEN stages of
         BasicBlocks without pools whose convs are at least 256 channels wide (res4 / res5 of WSR_18: what the numerics gate
-        covered, profiles/r06_mx_gate.md); len(stages) = none."""
+        covered, profiles/r06_mx_gate.md); len(stages) = none.  The f16mx kernel has ONE tile shape (256 x 256, a workgroup per
+        CU): below ~200 tiles per conv (fewer than 8 images of 800 x 600) the bf16x2 path's smaller tiles / split-K forms win
+        and the stages stay on it -- same precision mode, same bound (both formats were gated alone and together)."""
         first = len(self.stages)
         for i in range(len(self.stages) - 1, -1, -1):
             stage = self.stages[i]
@@ -765,7 +769,8 @@ class ResNet(nn.Module):
         mx_from = self._mx_from() if (H.mx_active() and list(self._out_features) == [self.stage_names[-1]]) else len(self.stages)
         for si, (name, stage) in enumerate(zip(self.stage_names, self.stages)):
             params = self._stage_params(stage)
-            if si == mx_from and si > 0:  # the map that crosses from the bf16x2 layers to the f16mx ones
+            if si == mx_from and si > 0 and -(-(x.shape[0] * x.shape[1] * x.shape[2]) // 256) >= self.MX_MIN_TILES:
+                # the map that crosses from the bf16x2 layers to the f16mx ones (enough 256-row tiles: see _mx_from)
                 with torch.no_grad():
                     x = H.mx_from_x2(x)
                     x._mx = True

@@ -159,9 +159,17 @@ class WSOVODROIHeads(ROIHeads):
     def pool_dtype(self):
         """What the pooler writes: the compute dtype, bf16x2 (hip_ops.X2) under the "parity" precision, unit-scale f16mx
         (hip_ops.MX) under "parity_mx"."""
-        if H.mx_active() and self.pooler_type in ("ROIPool", "ROIAlignV2", "ROIAlign"):
-            return H.MX
         return H.X2 if H.x3_active() == "x2" else self.compute_dtype
+
+    MX_MIN_ROWS = int(os.environ.get("WSOVOD_MX_MIN_ROWS", "4096"))
+
+    def _pool_dtype_for(self, rows):
+        """"parity_mx": the box head's FC layers take the f16mx kernel (one 256 x 256 tile shape) from 4096 pooled rows up --
+        16 row tiles x 16 column tiles = one workgroup per CU; below, the bf16x2 path's split-K forms win (same mode, same
+        bound)."""
+        if H.mx_active() and self.pooler_type in ("ROIPool", "ROIAlignV2", "ROIAlign") and rows >= self.MX_MIN_ROWS:
+            return H.MX
+        return self.pool_dtype
 
     @classmethod
     def from_config(cls, cfg, input_shape):
@@ -270,7 +278,7 @@ class WSOVODROIHeads(ROIHeads):
         Fn._WANT_HI.on = self.training and os.environ.get("WSOVOD_X2_HI", "1") != "0"  # (bf16x2 pooling only) a plain bf16 copy for fc1's dW
         try:
             return self.box_pooler(feats, [x.proposal_boxes for x in proposals], roi_scale=roi_scale,
-                                   out_dtype=self.pool_dtype, rois=rois)
+                                   out_dtype=self._pool_dtype_for(int(rois.shape[0])), rois=rois)
         finally:
             Fn._WANT_HI.on = False
 
