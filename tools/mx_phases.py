@@ -33,3 +33,13 @@ for M, N, K in ((16384, 4096, 25088), (16384, 4096, 4096)):
     out = torch.empty(M, N, device="cuda")
     report(f"f16mx {M}x{N}x{K}", 2.0 * M * N * K, lambda: H.gemm_mx(a, sa, b, sb, bias=bias, relu=True, out=out, out_dtype=H.X2))
     del a, b
+for name, n, Cin, Cout in (("res5 conv 512->512, 16 images", 16, 512, 512), ("res4 conv 256->256, 32 images", 32, 256, 256)):
+    Hi, Wi = 75, 100
+    x = H.mx_encode(torch.relu(torch.randn(n * Hi * Wi, Cin, device="cuda")), unit=True)[0].view(n, Hi, Wi, Cin)
+    w, sw = H.mx_encode(torch.randn(Cout, 9 * Cin, device="cuda") * 0.02)
+    bias = torch.randn(Cout, device="cuda")
+    geom = dict(n_img=n, H=Hi, W=Wi, Cin=Cin, Ho=Hi, Wo=Wi, KH=3, KW=3, stride=1, pad=2, dil=2)
+    out = torch.empty(n * Hi * Wi, Cout, device="cuda")
+    os.environ["WSOVOD_MX_TAIL"] = "0"
+    report(f"f16mx {name}", 2.0 * n * Hi * Wi * Cout * 9 * Cin, lambda: H.gemm_mx(x, None, w, sw, conv=geom, bias=bias, relu=True, out=out, out_dtype=H.MX))
+    del x, w

@@ -161,37 +161,46 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       vmask[i] = mk;
     }
   }
-  auto tap_next = [&](Tap t) {  // (channel chunk, tap) order with the tap innermost: the taps of a chunk re-read the same
-    if (t.c0 >= p.Cin) { t.c0 += BKE; return t; }  // input pixels while they are still in L2
-    if (++t.q >= p.KW) {
-      t.q = 0;
-      if (++t.r >= p.KH) { t.r = 0; t.c0 += BKE; }
-    }
-    return t;
+  // (channel chunk, tap) order with the tap innermost: the taps of a chunk re-read the same input pixels while they are still
+  // in L2.  Branch-free on purpose (scalar selects): as `if`s hipcc turned the tap state into a web of scalar branches
+  // through the K loop, one of them in the middle of the products of phase B (tools/mx_phases.py: +450 cycles per K-step)
+  auto tap_next = [&](const Tap t) {
+    const bool sec = t.c0 >= p.Cin;
+    const int q1 = t.q + 1;
+    const bool wq = q1 >= p.KW;
+    const int r1 = t.r + (wq ? 1 : 0);
+    const bool wrp = r1 >= p.KH;
+    Tap n;
+    n.q = sec ? t.q : (wq ? 0 : q1);
+    n.r = sec ? t.r : (wrp ? 0 : r1);
+    n.c0 = t.c0 + ((sec || (wq && wrp)) ? BKE : 0);
+    return n;
   };
   // per-lane offsets of tap t for this lane's four rows -- the pixel offset where the tap lies inside the image, out of
   // range where it does not; the tap's own displacement is the scalar offset.  Branch-free
   [[maybe_unused]] auto conv_va = [&](const Tap t) {
     const bool sec = t.c0 >= p.Cin;
-    const unsigned tapbit = sec ? 0u : (1u << (t.r * p.KW + t.q));
+    const unsigned secm = sec ? 0xffffffffu : 0u;                    // (scalar masks instead of a uniform branch)
+    const unsigned tapbit = (1u << (t.r * p.KW + t.q)) & ~secm;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const unsigned alt = sec ? pix2v[i] : OOB;
+      const unsigned alt = (pix2v[i] & secm) | (OOB & ~secm);
       va[i] = (vmask[i] & tapbit) ? pixb[i] : alt;
     }
   };
   // scalar byte offsets of a K-step: into the A operand (conv: the tap's displacement + channel chunk) and the B rows
   auto soff_a = [&](int kt, const Tap t) -> int {
     if (!CONV) return (kt + kt_base) * (BKE * esz);
-    if (t.c0 >= p.Cin) return (t.c0 - p.Cin) * esz;
-    return (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz;
+    const int main_off = (((t.r * p.W + t.q) * p.dil) * p.Cin + t.c0) * esz, sec_off = (t.c0 - p.Cin) * esz;
+    return t.c0 >= p.Cin ? sec_off : main_off;
   };
   auto soff_b = [&](int kt, const Tap t) -> int {
     if (!CONV) return (kt + kt_base) * (BKE * esz);
-    return (t.c0 >= p.Cin ? p.KH * p.KW * p.Cin + (t.c0 - p.Cin) : (t.r * p.KW + t.q) * p.Cin + t.c0) * esz;
+    const int main_k = (t.r * p.KW + t.q) * p.Cin + t.c0, sec_k = p.KH * p.KW * p.Cin + (t.c0 - p.Cin);
+    return (t.c0 >= p.Cin ? sec_k : main_k) * esz;
   };
-  auto dma_a = [&](int stage, int i, int so, bool second) {
-    char* dA = sA + stage * BM * 128 + wave_u * 1024 + LR * i * 128;
+  auto dma_a = [&](int stage_off, int i, int so, bool second) {  // stage_off: byte offset of the ring stage (scalar)
+    char* dA = sA + stage_off + wave_u * 1024 + LR * i * 128;
     if constexpr (CONV) {
       if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA2, (lds_void*)dA, 16, (int)va[i], so, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, (int)va[i], so, 0, 0);
@@ -199,8 +208,8 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)dA, 16, (int)va0, so + i * passA, 0, 0);
     }
   };
-  auto dma_b = [&](int buf, int i, int so) {
-    char* dB = sB + buf * BN * 128 + wave_u * 1024 + LR * i * 128;
+  auto dma_b = [&](int buf_off, int i, int so) {
+    char* dB = sB + buf_off + wave_u * 1024 + LR * i * 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16, (int)vb0, so + i * passB, 0, 0);
   };
   // K-steps 0 and 1 (the loop keeps two K-steps in flight: the pieces of K-step kt + 2 are requested during K-step kt)
@@ -227,11 +236,12 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   if (nk > 1) {
     if constexpr (CONV) t2 = tap_next(t2);
     const int sb1 = soff_b(1, t2);
-    dma_b(1, 0, sb1); dma_b(1, 1, sb1); dma_b(1, 2, sb1); dma_b(1, 3, sb1);
+    constexpr int ST = BM * 128;
+    dma_b(ST, 0, sb1); dma_b(ST, 1, sb1); dma_b(ST, 2, sb1); dma_b(ST, 3, sb1);
     if constexpr (CONV) conv_va(t2);
     const int sa1 = soff_a(1, t2);
     const bool sec = CONV && t2.c0 >= p.Cin;
-    dma_a(1, 0, sa1, sec); dma_a(1, 2, sa1, sec); dma_a(1, 1, sa1, sec); dma_a(1, 3, sa1, sec);
+    dma_a(ST, 0, sa1, sec); dma_a(ST, 2, sa1, sec); dma_a(ST, 1, sa1, sec); dma_a(ST, 3, sa1, sec);
   }
   if constexpr (CONV) {
     t2 = tap_next(t2);
@@ -273,7 +283,6 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const unsigned rowA = ldsA + (unsigned)((wr * 128 + r32) * 128), rowB = ldsB + (unsigned)((wc * 64 + r32) * 128);
   const unsigned cA0 = rowA + (((unsigned)(2 * hh) ^ sw) << 4), cA1 = rowA + (((unsigned)(2 * hh + 1) ^ sw) << 4);
   const unsigned cA2 = rowA + (((unsigned)(4 + 2 * hh) ^ sw) << 4), cA3 = rowA + (((unsigned)(5 + 2 * hh) ^ sw) << 4);
-  const unsigned cA0x = cA0 + 65536u, cA1x = cA1 + 65536u, cA2x = cA2 + 65536u, cA3x = cA3 + 65536u;  // ring stage 2
   const unsigned cB0 = rowB + (((unsigned)(2 * hh) ^ sw) << 4), cB1 = rowB + (((unsigned)(2 * hh + 1) ^ sw) << 4);
   const unsigned cB2 = rowB + (((unsigned)(6 - 2 * hh) ^ sw) << 4), cB3 = rowB + (((unsigned)(7 - 2 * hh) ^ sw) << 4);
 
@@ -301,14 +310,20 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                                       \
                : "+v"(af[0][0]), "+v"(af[0][1]), "+v"(af[1][0]), "+v"(af[1][1]), "+{" MX_RA0L "}"(a8l[0]),                 \
                  "+{" MX_RA0H "}"(a8h[0]), "+{" MX_RA1L "}"(a8l[1]), "+{" MX_RA1H "}"(a8h[1]))
-  // one 32x32 tile: acc[T] += hi_b x hi_a (two fp16 steps) + [ql_b | q_b] x [q_a | ql_a] (one block-scaled step)
-#define MX_TILE(T, TA, U, SA, SB)                                                                                           \
-  acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[U][0]), __builtin_bit_cast(f16x8, af[TA][0]), \
-                                                  acc[T], 0, 0, 0);                                                         \
-  acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[U][1]), __builtin_bit_cast(f16x8, af[TA][1]), \
-                                                  acc[T], 0, 0, 0);                                                         \
+  // one 32x32 tile: acc[T] += hi_b x hi_a (two fp16 steps) + [ql_b | q_b] x [q_a | ql_a] (one block-scaled step); a phase
+  // issues the three steps tile-interleaved (four independent accumulators between two products into the same one)
+#define MX_H0(T, TA, U) \
+  acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[U][0]), __builtin_bit_cast(f16x8, af[TA][0]), acc[T], 0, 0, 0)
+#define MX_H1(T, TA, U) \
+  acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, bf[U][1]), __builtin_bit_cast(f16x8, af[TA][1]), acc[T], 0, 0, 0)
+#define MX_SC(T, TA, U, SA, SB)                                                                                             \
   acc[T] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(mx_cat(b8l[U], b8h[U]), mx_cat(a8l[TA], a8h[TA]), acc[T], 0, 0,  \
                                                            0, (int)(SB), 0, (int)(SA))
+#define MX_PHASE(T0, S0, S1)                                                                          \
+  MX_H0(T0, 0, 0); MX_H0(T0 + 1, 0, 1); MX_H0(T0 + 2, 1, 0); MX_H0(T0 + 3, 1, 1);                     \
+  MX_H1(T0, 0, 0); MX_H1(T0 + 1, 0, 1); MX_H1(T0 + 2, 1, 0); MX_H1(T0 + 3, 1, 1);                     \
+  MX_SC(T0, 0, 0, S0, sb_c[0]); MX_SC(T0 + 1, 0, 1, S0, sb_c[1]); MX_SC(T0 + 2, 1, 0, S1, sb_c[0]);   \
+  MX_SC(T0 + 3, 1, 1, S1, sb_c[1])
 
   MX_VMCNT(0);  // (K-steps 0 and 1, and the scale bytes requested behind them)
   __builtin_amdgcn_s_barrier();
@@ -336,25 +351,30 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   //                 whoever passes that barrier -- also the staggered group -- may overwrite the rows);
   //   phase B (kt): the four B passes of kt + 2 -> buffer SB, whose only reads (phase A of kt, fragments kept in registers
   //                 through phase B) ended one phase ago; then vmcnt(8) -> everything of K-step kt + 1 has landed.
-  auto kstep = [&](auto sa_c_, auto sb_c_, int kt) {
-    constexpr int SA = decltype(sa_c_)::value, SB = decltype(sb_c_)::value;
-    constexpr int IA = (SA == 2 ? 0 : SA) * (BM * 128), IB = SB * (BN * 128);
-    constexpr int NA = (SA + 2) % 3;
-    const unsigned a0 = SA == 2 ? cA0x : cA0, a1 = SA == 2 ? cA1x : cA1, a2 = SA == 2 ? cA2x : cA2, a3 = SA == 2 ? cA3x : cA3;
+  // The ring stage / buffer of a K-step is RUNTIME state (scalar byte offsets added to the eight per-lane read addresses at
+  // the top of the K-step, 8 VALU instructions): with the stages as template constants the loop was six K-steps long (+ five
+  // for the tail) and, in the conv form, ~100 KB of code.
+  int offA = 0, offB = 0;  // ring stage of K-step kt (A: 0 / 32 KiB / 64 KiB), buffer (B: 0 / 32 KiB)
+  auto kstep = [&](int kt) {
+    constexpr int IA = 0, IB = 0, ST = BM * 128;
+    const int NA = offA >= ST ? offA - ST : offA + 2 * ST;  // stage of K-step kt + 2 = (stage + 2) % 3
+    const int SB = offB;
+    const unsigned a0 = cA0 + (unsigned)offA, a1 = cA1 + (unsigned)offA, a2 = cA2 + (unsigned)offA, a3 = cA3 + (unsigned)offA;
+    const unsigned b0 = cB0 + (unsigned)offB, b1 = cB1 + (unsigned)offB, b2 = cB2 + (unsigned)offB, b3 = cB3 + (unsigned)offB;
     const bool more2 = kt + 2 < nk;
     const int soa = soff_a(kt + 2, t2), sob = soff_b(kt + 2, t2);  // (scalar)
     const bool sec2 = CONV && t2.c0 >= p.Cin;
     // ---- phase A: A rows 0-63 (tiles 0, 1) x all 64 columns (tiles 0, 1) of this wavefront: 16 fragment reads
     MX_STAMP0();
 #if !defined(MX_ABL_NOREAD)
-    mx_read<IB + 0 * 4096>(bf[0][0], cB0); mx_read<IB + 0 * 4096>(bf[0][1], cB1);
-    MX_READ_P(MX_RB0L, b8l[0], IB + 0 * 4096, cB2); MX_READ_P(MX_RB0H, b8h[0], IB + 0 * 4096, cB3);
+    mx_read<IB + 0 * 4096>(bf[0][0], b0); mx_read<IB + 0 * 4096>(bf[0][1], b1);
+    MX_READ_P(MX_RB0L, b8l[0], IB + 0 * 4096, b2); MX_READ_P(MX_RB0H, b8h[0], IB + 0 * 4096, b3);
     mx_read<IA + 0 * 4096>(af[0][0], a0); mx_read<IA + 0 * 4096>(af[0][1], a1);
     MX_READ_P(MX_RA0L, a8l[0], IA + 0 * 4096, a2); MX_READ_P(MX_RA0H, a8h[0], IA + 0 * 4096, a3);
     mx_read<IA + 1 * 4096>(af[1][0], a0); mx_read<IA + 1 * 4096>(af[1][1], a1);
     MX_READ_P(MX_RA1L, a8l[1], IA + 1 * 4096, a2); MX_READ_P(MX_RA1H, a8h[1], IA + 1 * 4096, a3);
-    mx_read<IB + 1 * 4096>(bf[1][0], cB0); mx_read<IB + 1 * 4096>(bf[1][1], cB1);
-    MX_READ_P(MX_RB1L, b8l[1], IB + 1 * 4096, cB2); MX_READ_P(MX_RB1H, b8h[1], IB + 1 * 4096, cB3);
+    mx_read<IB + 1 * 4096>(bf[1][0], b0); mx_read<IB + 1 * 4096>(bf[1][1], b1);
+    MX_READ_P(MX_RB1L, b8l[1], IB + 1 * 4096, b2); MX_READ_P(MX_RB1H, b8h[1], IB + 1 * 4096, b3);
 #endif
     MX_STAMP(0);
 #if !defined(MX_ABL_NODMA)
@@ -367,8 +387,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     MX_STAMP(3);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    MX_TILE(0, 0, 0, sa_c[0], sb_c[0]); MX_TILE(1, 0, 1, sa_c[0], sb_c[1]);
-    MX_TILE(2, 1, 0, sa_c[1], sb_c[0]); MX_TILE(3, 1, 1, sa_c[1], sb_c[1]);
+    MX_PHASE(0, sa_c[0], sa_c[1]);
     // (the empty asm pins the products HERE: they are pure register operations for every pass before the scheduler, which
     // otherwise sinks them past the barriers into the next phase and keeps copies of their operands alive)
     asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
@@ -397,8 +416,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
-    MX_TILE(4, 0, 0, sa_c[2], sb_c[0]); MX_TILE(5, 0, 1, sa_c[2], sb_c[1]);
-    MX_TILE(6, 1, 0, sa_c[3], sb_c[0]); MX_TILE(7, 1, 1, sa_c[3], sb_c[1]);
+    MX_PHASE(4, sa_c[2], sa_c[3]);
     if constexpr (CONV) {
       // the tap after next and its per-lane offsets, one instruction at a time behind the products: they issue in the
       // matrix pipe's shadow (the empty asm pins the results HERE: hipcc otherwise sinks the selects to their use, in front
@@ -419,12 +437,13 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     MX_STAMP(7);
+    offA = offA >= 2 * ST ? 0 : offA + ST;
+    offB ^= ST;
   };
-  // K-steps six at a time (ring stage x buffer); the block scales of an operand change only at such a boundary (launcher:
-  // a scale segment is a whole row or a multiple of six K-steps)
-  using std::integral_constant;
-  int kt = 0, next_a = seg_a, next_b = seg_b;
-  for (; kt + 5 < nk; kt += 6) {
+  // (the block scales of an operand change at segment boundaries only: launcher -- whole rows, or multiples of 6 K-steps)
+  int next_a = seg_a, next_b = seg_b;
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
     if (kt == next_a) {  // (the empty asm: the bytes are waited for HERE, not in front of the first product)
       load_scales_a(kt / seg_a); next_a += seg_a;
       asm volatile("" : "+v"(sa_c[0]), "+v"(sa_c[1]), "+v"(sa_c[2]), "+v"(sa_c[3]));
@@ -433,27 +452,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       load_scales_b(kt / seg_b); next_b += seg_b;
       asm volatile("" : "+v"(sb_c[0]), "+v"(sb_c[1]));
     }
-    kstep(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
-    kstep(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
-    kstep(integral_constant<int, 2>{}, integral_constant<int, 0>{}, kt + 2);
-    kstep(integral_constant<int, 0>{}, integral_constant<int, 1>{}, kt + 3);
-    kstep(integral_constant<int, 1>{}, integral_constant<int, 0>{}, kt + 4);
-    kstep(integral_constant<int, 2>{}, integral_constant<int, 1>{}, kt + 5);
-  }
-  if (kt < nk) {  // (the last, shorter group: at most five K-steps)
-    if (kt == next_a) {
-      load_scales_a(kt / seg_a);
-      asm volatile("" : "+v"(sa_c[0]), "+v"(sa_c[1]), "+v"(sa_c[2]), "+v"(sa_c[3]));
-    }
-    if (kt == next_b) {
-      load_scales_b(kt / seg_b);
-      asm volatile("" : "+v"(sb_c[0]), "+v"(sb_c[1]));
-    }
-    kstep(integral_constant<int, 0>{}, integral_constant<int, 0>{}, kt);
-    if (kt + 1 < nk) kstep(integral_constant<int, 1>{}, integral_constant<int, 1>{}, kt + 1);
-    if (kt + 2 < nk) kstep(integral_constant<int, 2>{}, integral_constant<int, 0>{}, kt + 2);
-    if (kt + 3 < nk) kstep(integral_constant<int, 0>{}, integral_constant<int, 1>{}, kt + 3);
-    if (kt + 4 < nk) kstep(integral_constant<int, 1>{}, integral_constant<int, 0>{}, kt + 4);
+    kstep(kt);
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
 #if defined(MX_STAMPS)
@@ -463,7 +462,10 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     atomicAdd(q.dbg + wr * 16 + 8, (float)nk);
   }
 #endif
-#undef MX_TILE
+#undef MX_PHASE
+#undef MX_H0
+#undef MX_H1
+#undef MX_SC
 #undef MX_READ_P
 #undef MX_LGKM_ALL
 #undef MX_LGKM_A
