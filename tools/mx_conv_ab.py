@@ -6,6 +6,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+import wsovod_amd._lib as _L
+
+if os.environ.get("WSOVOD_LIB"):  # (timing ablations: an alternative build of the library)
+    _L.LIB_PATH = os.environ["WSOVOD_LIB"]
 from wsovod_amd.layers import hip_ops as H
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32

@@ -27,6 +27,11 @@ def report(tag, fl, run):
         if n:
             print(f"  group {g}: ticks per K-step: " + ", ".join(f"{nm} {float(d[g, k]) / n:.0f}" for k, nm in enumerate(names)) +
                   f"; total {float(d[g, :8].sum()) / n:.0f}", flush=True)
+            w = float(d[g, 11])
+            if w:
+                print(f"    per tile: setup + K-steps 0 / 1 requested {float(d[g, 9]) / w:.0f}, their data + barriers {float(d[g, 12]) / w:.0f}, "
+                      f"loop {float(d[g, 10]) / w:.0f}, epilogue issue {float(d[g, 13]) / w:.0f}, store drain {float(d[g, 14]) / w:.0f} ticks",
+                      flush=True)
 for M, N, K in ((16384, 4096, 25088), (16384, 4096, 4096)):
     a, sa = H.mx_encode(torch.randn(M, K, device="cuda")); b, sb = H.mx_encode(torch.randn(N, K, device="cuda") * 0.01)
     bias = torch.randn(N, device="cuda")

@@ -95,6 +95,9 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const int kslice = p.ksplit > 1 ? (int)(blockIdx.x / (unsigned)nwg) : 0;
   [[maybe_unused]] const int kt_base = kslice * p.slice_steps;
 
+#if defined(MX_STAMPS)
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();  // (tile level: prologue / first data / loop / epilogue / drain)
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   [[maybe_unused]] const int wr = wave >> 2, wc = wave & 3;
   const int lrow = tid >> 3;
@@ -139,28 +142,6 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   // its top-left tap, one validity bit per tap, the output pixel in the shortcut's input
   struct Tap { int r, q, c0; };  // c0 >= Cin: the K-steps of the fused 1x1 shortcut (second input at channel c0 - Cin)
   [[maybe_unused]] unsigned pixb[4], pix2v[4], vmask[4], va[4];
-  if constexpr (CONV) {
-    const int hw = p.Ho * p.Wo;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + lrow + LR * i;
-      const bool ok = m < p.M;
-      const int mm = ok ? m : 0;
-      const int img = mm / hw, rem = mm - img * hw;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      const int hi0 = ok ? ho * p.stride - p.pad : -(1 << 28), wi0 = wo * p.stride - p.pad;
-      const int a_img = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
-      pixb[i] = ok ? (unsigned)(a_img + ((hi0 * p.W + wi0) * p.Cin) * esz + cbias) : 0u;
-      pix2v[i] = (ok && p.A2) ? (unsigned)((((img * p.Ho + ho) * p.Wo + wo) * p.Cin2 + lchunk * EPC) * esz) : OOB;
-      // branch-free, KH + KW steps: valid filter rows x valid filter columns (a row past M: hi0 = -2^28)
-      unsigned rowm = 0, colm = 0;
-      for (int r = 0; r < p.KH; ++r) rowm |= (unsigned)((unsigned)(hi0 + r * p.dil) < (unsigned)p.H) << r;
-      for (int c = 0; c < p.KW; ++c) colm |= (unsigned)((unsigned)(wi0 + c * p.dil) < (unsigned)p.W) << c;
-      unsigned mk = 0;
-      for (int r = 0; r < p.KH; ++r) mk |= ((rowm >> r) & 1u) ? (colm << (r * p.KW)) : 0u;
-      vmask[i] = mk;
-    }
-  }
   // (channel chunk, tap) order with the tap innermost: the taps of a chunk re-read the same input pixels while they are still
   // in L2.  Branch-free on purpose (scalar selects): as `if`s hipcc turned the tap state into a web of scalar branches
   // through the K loop, one of them in the middle of the products of phase B (tools/mx_phases.py: +450 cycles per K-step)
@@ -212,7 +193,8 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     char* dB = sB + buf_off + wave_u * 1024 + LR * i * 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)dB, 16, (int)vb0, so + i * passB, 0, 0);
   };
-  // K-steps 0 and 1 (the loop keeps two K-steps in flight: the pieces of K-step kt + 2 are requested during K-step kt)
+  // K-steps 0 and 1 (the loop keeps two K-steps in flight: the pieces of K-step kt + 2 are requested during K-step kt).  Their
+  // B rows first: they are in flight while the conv form decodes its pixels (4 integer divisions per lane, the tap masks)
   Tap t2{0, 0, 0};  // (conv) the tap of the K-step requested next
   if (CONV && kt_base > 0) {  // split-K slice of a conv: the (filter tap, channel chunk) of its first K-step
     const int taps = p.KH * p.KW, nk_main = taps * (p.Cin / BKE);
@@ -225,19 +207,44 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       t2.c0 = chunk * BKE;
     }
   }
+  const Tap t1 = CONV ? tap_next(t2) : t2;
   {
-    const int sb0 = soff_b(0, t2);
+    constexpr int ST = BM * 128;
+    const int sb0 = soff_b(0, t2), sb1 = soff_b(1, t1);
     dma_b(0, 0, sb0); dma_b(0, 1, sb0); dma_b(0, 2, sb0); dma_b(0, 3, sb0);
+    if (nk > 1) { dma_b(ST, 0, sb1); dma_b(ST, 1, sb1); dma_b(ST, 2, sb1); dma_b(ST, 3, sb1); }
+  }
+  if constexpr (CONV) {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + lrow + LR * i;
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
+      const int img = mm / hw, rem = mm - img * hw;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      const int hi0 = ok ? ho * p.stride - p.pad : -(1 << 28), wi0 = wo * p.stride - p.pad;
+      const int a_img = (img * p.H * p.W * p.Cin + lchunk * EPC) * esz;
+      pixb[i] = ok ? (unsigned)(a_img + ((hi0 * p.W + wi0) * p.Cin) * esz + cbias) : 0u;
+      pix2v[i] = (ok && p.A2) ? (unsigned)((((img * p.Ho + ho) * p.Wo + wo) * p.Cin2 + lchunk * EPC) * esz) : OOB;
+      // branch-free, KH + KW steps: valid filter rows x valid filter columns (a row past M: hi0 = -2^28)
+      unsigned rowm = 0, colm = 0;
+      for (int r = 0; r < p.KH; ++r) rowm |= (unsigned)((unsigned)(hi0 + r * p.dil) < (unsigned)p.H) << r;
+      for (int c = 0; c < p.KW; ++c) colm |= (unsigned)((unsigned)(wi0 + c * p.dil) < (unsigned)p.W) << c;
+      unsigned mk = 0;
+      for (int r = 0; r < p.KH; ++r) mk |= ((rowm >> r) & 1u) ? (colm << (r * p.KW)) : 0u;
+      vmask[i] = mk;
+    }
+  }
+  {
     if constexpr (CONV) conv_va(t2);
     const int sa0 = soff_a(0, t2);
     const bool sec = CONV && t2.c0 >= p.Cin;
     dma_a(0, 0, sa0, sec); dma_a(0, 2, sa0, sec); dma_a(0, 1, sa0, sec); dma_a(0, 3, sa0, sec);
   }
+  if constexpr (CONV) t2 = t1;
   if (nk > 1) {
-    if constexpr (CONV) t2 = tap_next(t2);
-    const int sb1 = soff_b(1, t2);
     constexpr int ST = BM * 128;
-    dma_b(ST, 0, sb1); dma_b(ST, 1, sb1); dma_b(ST, 2, sb1); dma_b(ST, 3, sb1);
     if constexpr (CONV) conv_va(t2);
     const int sa1 = soff_a(1, t2);
     const bool sec = CONV && t2.c0 >= p.Cin;
@@ -325,9 +332,15 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   MX_SC(T0, 0, 0, S0, sb_c[0]); MX_SC(T0 + 1, 0, 1, S0, sb_c[1]); MX_SC(T0 + 2, 1, 0, S1, sb_c[0]);   \
   MX_SC(T0 + 3, 1, 1, S1, sb_c[1])
 
+#if defined(MX_STAMPS)
+  const unsigned long long st_setup = __builtin_amdgcn_s_memtime();
+#endif
   MX_VMCNT(0);  // (K-steps 0 and 1, and the scale bytes requested behind them)
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second M-half runs one barrier behind
+#if defined(MX_STAMPS)
+  const unsigned long long st_loop0 = __builtin_amdgcn_s_memtime();
+#endif
 
 #if defined(MX_STAMPS)
   // instrumented builds only (tools/mx_phases.py): s_memtime ticks per section of the two-phase K-step
@@ -456,11 +469,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   }
   if (wr == 0) __builtin_amdgcn_s_barrier();  // balance the stagger barrier
 #if defined(MX_STAMPS)
-  if (q.dbg && lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(q.dbg + wr * 16 + k, (float)st_acc[k]);
-    atomicAdd(q.dbg + wr * 16 + 8, (float)nk);
-  }
+  const unsigned long long st_loop1 = __builtin_amdgcn_s_memtime();
 #endif
 #undef MX_PHASE
 #undef MX_H0
@@ -493,31 +502,85 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const unsigned dthr = dropout_threshold(p.dropout_p);
   const float lo = p.relu ? 0.f : -__builtin_inff();
   // (launcher: alpha / bias / residual / ReLU / dropout epilogue, vector-aligned rows, N a multiple of 4 -- of 16 for f16mx)
-  auto emit_tile = [&](const f32x16& a, const int T) {
+  // Loads FIRST: the output may alias anything as far as hipcc knows, so a load behind a store waits for nothing but is never
+  // hoisted above it -- eight tiles of [bias load, residual load, compute, store] were eight memory round trips in a row
+  // (~30 us of a 120-us res4 tile).  The bias quads of this lane's 2 x 16 columns are loaded once, an f16mx residual (the conv
+  // chain's) for four tiles at a time, before the first store of those tiles.
+#if defined(MX_ABL_NOEPI)
+  if (p.M > 0) return;  // (timing ablation: the tile without its epilogue)
+#endif
+  asm volatile("" ::: "memory");  // (the epilogue's loads stay behind the K loop: hoisted above it they would live through it)
+  f32x4 bv[2][4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb = n0 + wc * 64 + 32 * u + 16 * hh + 4 * g;
+      bv[u][g] = (p.bias && nb < p.N) ? *(const f32x4*)(p.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const bool res_mx = p.residual && p.dtype_r == WSOVOD_F16MX;
+  // 4-byte-per-value outputs of whole 64-column wavefront blocks leave through a row image in LDS (free behind the K loop:
+  // every fragment read was waited for in front of the last barrier each wavefront passed)
+  constexpr int IMG_LD = 256 + 16;  // (+16: the 8 rows of a ds_write_b128 lane group fall on different banks)
+  const bool via_lds = p.N % 64 == 0 && (p.dtype_c == WSOVOD_F16MX || p.dtype_c == WSOVOD_BF16X2 || p.dtype_c == WSOVOD_F32);
+  char* img = smem + wave_u * (32 * IMG_LD);
+  auto emit_tile = [&](const f32x16& a, auto T_c, const f16x8 rh0, const f16x8 rh1, const i32x4 rl) {
+    constexpr int T = decltype(T_c)::value;  // (a compile-time tile index: a runtime one would index bv[] in scratch)
     const int m = m0 + wr * 128 + 32 * (T >> 1) + r32;
     const int nb0 = n0 + wc * 64 + 32 * (T & 1) + 16 * hh;
-    if (m >= p.M || nb0 >= p.N) return;
+    if (!via_lds && (m >= p.M || nb0 >= p.N)) return;
+    const int mc = min(m, p.M - 1);  // (staged form: every lane fills its slot of the row image; rows past M are not stored)
     f32x4 y[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int nb = nb0 + 4 * g;
       f32x4 x = f32x4{a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]} * p.alpha;
       if (nb < p.N) {
-        if (p.bias) x += *(const f32x4*)(p.bias + nb);
-        if (p.residual) {
-          if (p.dtype_r == WSOVOD_F16MX) x += mx_load4_unit((const char*)p.residual + (long long)m * p.ldr * 4, nb);
-          else x += load4_as_f32(p.residual, m, p.ldr, nb, p.dtype_r);
+        x += bv[T & 1][g];
+        if (res_mx) {
+          const f16x8 h = g < 2 ? rh0 : rh1;
+          const int o = 4 * (g & 1);
+          x += mx_dec4_unit(f16x4{h[o], h[o + 1], h[o + 2], h[o + 3]}, rl[g]);
+        } else if (p.residual) {
+          x += load4_as_f32(p.residual, mc, p.ldr, nb, p.dtype_r);
         }
         x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};
         if (p.dropout_p > 0.f) {
-          const unsigned long long dz = dropout_quad(dseed, m, p.N, nb);
+          const unsigned long long dz = dropout_quad(dseed, mc, p.N, nb);
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = dropout_keep(dz, r, dthr) ? x[r] * keep_scale : 0.f;
         }
       }
       y[g] = x;
     }
-    if (p.dtype_c == WSOVOD_F16MX) {  // 16 values = half a group: 32 B of hi, 16 B of q, 16 B of ql
+    if (via_lds) {
+      // the lane's 16 values as the bytes of the output format, into the wavefront's row image [32 rows][256 B + 16]: the
+      // stores then leave as whole 256-byte row segments (emit_pair) instead of 64 separate 16-byte pieces per instruction
+      char* slot = img + r32 * IMG_LD + (T & 1) * 128;
+      if (p.dtype_c == WSOVOD_F16MX) {
+        f16x4 h[4];
+        int qv[4], lv[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mx_enc4_unit(y[g], h[g], qv[g], lv[g]);
+        *(f16x8*)(slot + 32 * hh) = f16x8{h[0][0], h[0][1], h[0][2], h[0][3], h[1][0], h[1][1], h[1][2], h[1][3]};
+        *(f16x8*)(slot + 32 * hh + 16) = f16x8{h[2][0], h[2][1], h[2][2], h[2][3], h[3][0], h[3][1], h[3][2], h[3][3]};
+        *(i32x4*)(slot + 64 + 16 * hh) = i32x4{qv[0], qv[1], qv[2], qv[3]};
+        *(i32x4*)(slot + 96 + 16 * hh) = i32x4{lv[0], lv[1], lv[2], lv[3]};
+      } else if (p.dtype_c == WSOVOD_BF16X2) {
+        bf16x8 hi0, hi1, lo0, lo1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v0 = y[e >> 2][e & 3], v1 = y[2 + (e >> 2)][e & 3];
+          hi0[e] = (bf16_t)v0; hi1[e] = (bf16_t)v1;
+          lo0[e] = x2_lo(v0, hi0[e]); lo1[e] = x2_lo(v1, hi1[e]);
+        }
+        *(bf16x8*)(slot + 32 * hh) = hi0; *(bf16x8*)(slot + 32 * hh + 16) = hi1;
+        *(bf16x8*)(slot + 64 + 32 * hh) = lo0; *(bf16x8*)(slot + 64 + 32 * hh + 16) = lo1;
+      } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(f32x4*)(slot + 64 * hh + 16 * g) = y[g];
+      }
+    } else if (p.dtype_c == WSOVOD_F16MX) {  // 16 values = half a group: 32 B of hi, 16 B of q, 16 B of ql
       f16x4 h[4];
       int qv[4], lv[4];
 #pragma unroll
@@ -533,7 +596,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       for (int g = 0; g < 4; ++g)
         if (nb0 + 4 * g < p.N) store4_from_f32(p.C, m, p.ldc, nb0 + 4 * g, p.dtype_c, y[g]);
     }
-    if (q.c_bf16) {
+    if (q.c_bf16 && m < p.M && nb0 < p.N) {
       bf16_t* cb = (bf16_t*)q.c_bf16 + (long long)m * q.ld_cb + nb0;
       if (nb0 + 16 <= p.N) {
         *(bf16x8*)cb = bf16x8{(bf16_t)y[0][0], (bf16_t)y[0][1], (bf16_t)y[0][2], (bf16_t)y[0][3],
@@ -547,8 +610,63 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       }
     }
   };
-  emit_tile(acc[0], 0); emit_tile(acc[1], 1); emit_tile(acc[2], 2); emit_tile(acc[3], 3);
-  emit_tile(acc[4], 4); emit_tile(acc[5], 5); emit_tile(acc[6], 6); emit_tile(acc[7], 7);
+  // the f16mx residual pieces of TWO tiles at a time (one row, both column halves: 24 registers next to the accumulators)
+  auto emit_pair = [&](auto T0_c, const f32x16& a0, const f32x16& a1) {
+    constexpr int T0 = decltype(T0_c)::value;
+    f16x8 rh0[2], rh1[2];
+    i32x4 rl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      rh0[k] = rh1[k] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      rl[k] = i32x4{0, 0, 0, 0};
+      const int T = T0 + k;
+      const int m = m0 + wr * 128 + 32 * (T >> 1) + r32;
+      const int nb0 = n0 + wc * 64 + 32 * (T & 1) + 16 * hh;
+      if (res_mx && m < p.M && nb0 < p.N) {  // (launcher: N a multiple of 16 with an f16mx residual)
+        const char* grp = (const char*)p.residual + (long long)m * p.ldr * 4 + mx_group(nb0);
+        const int w = nb0 & 31;
+        rh0[k] = *(const f16x8*)(grp + 2 * w);
+        rh1[k] = *(const f16x8*)(grp + 2 * w + 16);
+        rl[k] = *(const i32x4*)(grp + 96 + w);
+      }
+    }
+    emit_tile(a0, std::integral_constant<int, T0>{}, rh0[0], rh1[0], rl[0]);
+    emit_tile(a1, std::integral_constant<int, T0 + 1>{}, rh0[1], rh1[1], rl[1]);
+    if (via_lds) {  // 32 rows x 256 B: an instruction stores four whole row segments (16 lanes x 16 B each)
+      const int mrow = m0 + wr * 128 + 32 * (T0 >> 1);
+      char* cbase = (char*)p.C + ((long long)(n0 + wc * 64) << 2) + (lane & 15) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = 4 * j + (lane >> 4);
+        const u32x4 v = *(const u32x4*)(img + row * IMG_LD + (lane & 15) * 16);
+        if (mrow + row < p.M && n0 + wc * 64 < p.N) *(u32x4*)(cbase + (long long)(mrow + row) * p.ldc * 4) = v;
+      }
+    }
+  };
+  emit_pair(std::integral_constant<int, 0>{}, acc[0], acc[1]);
+  emit_pair(std::integral_constant<int, 2>{}, acc[2], acc[3]);
+  emit_pair(std::integral_constant<int, 4>{}, acc[4], acc[5]);
+  emit_pair(std::integral_constant<int, 6>{}, acc[6], acc[7]);
+#if defined(MX_STAMPS)
+  {
+    const unsigned long long st_e0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_e1 = __builtin_amdgcn_s_memtime();
+    if (q.dbg && lane == 0) {  // (all atomics behind the last stamp: 512 workgroups adding to the same floats take ~50 us)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) atomicAdd(q.dbg + wr * 16 + k, (float)st_acc[k]);
+      atomicAdd(q.dbg + wr * 16 + 8, (float)nk);
+    }
+    if (q.dbg && lane == 0 && (wave == 0 || wave == 4)) {
+      atomicAdd(q.dbg + wr * 16 + 9, (float)(st_setup - st_begin));
+      atomicAdd(q.dbg + wr * 16 + 12, (float)(st_loop0 - st_setup));
+      atomicAdd(q.dbg + wr * 16 + 10, (float)(st_loop1 - st_loop0));
+      atomicAdd(q.dbg + wr * 16 + 13, (float)(st_e0 - st_loop1));
+      atomicAdd(q.dbg + wr * 16 + 14, (float)(st_e1 - st_e0));
+      atomicAdd(q.dbg + wr * 16 + 11, 1.0f);
+    }
+  }
+#endif
 #endif
 }
 
@@ -722,6 +840,7 @@ extern "C" int wsovod_gemm_f16mx(const wsovod_gemm_desc* d, const unsigned char*
                                 : d->dtype_r == WSOVOD_BF16 ? (d->ldr % 4 == 0 && ((uintptr_t)d->residual & 7) == 0)
                                                             : (d->dtype_r == WSOVOD_F32 && d->ldr % 4 == 0 && ((uintptr_t)d->residual & 15) == 0)),
                "wsovod_gemm_f16mx: residual rows must be vector-aligned");
+  WS_CHECK_ARG(!d->residual || d->dtype_r != WSOVOD_F16MX || d->N % 16 == 0, "wsovod_gemm_f16mx: an f16mx residual needs N a multiple of 16");
 
   MxArgs q;
   memset(&q, 0, sizeof(q));
