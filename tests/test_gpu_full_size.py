@@ -206,6 +206,19 @@ def test_parity_mx_mode_matches_the_oracle_at_full_size(gpu, pooler, monkeypatch
     _assert_parity_mode(rep)
 
 
+def test_parity_mx_wsr50_bottleneck_stages_match_the_oracle_at_full_size(gpu, monkeypatch):
+    """BASELINE config 3 / 4's backbone under "parity_mx": the BottleneckBlocks of res4 / res5 (1x1 -> 3x3 dilated -> 1x1 + the
+    fused projection shortcut, 256 - 2048 channels) and fc1 / fc2 at 1024 proposals on the f16mx kernels, against the oracle
+    (thresholds lowered: one image takes the f16mx kernels)."""
+    from wsovod_amd.modeling.backbone import ResNet
+    from wsovod_amd.modeling.roi_heads import WSOVODROIHeads
+
+    monkeypatch.setattr(ResNet, "MX_MIN_TILES", 1)
+    monkeypatch.setattr(WSOVODROIHeads, "MX_MIN_ROWS", 1)
+    rep = _oracle_vs_hip(gpu, "parity_mx", n_images=1, proposals=1024, classes=80, depth=50)
+    _assert_parity_mode(rep, elem_tol=None)
+
+
 def _assert_parity_mode(rep, elem_tol=3e-2):
     """The "parity" precision's bar: forward quantities inside the north star's bound, indices exact; the backward runs
     in plain bf16 on the hi halves, so its gradients carry bf16's grade -- every tensor's norm within 1 % of the oracle's

@@ -748,15 +748,22 @@ class ResNet(nn.Module):
     def _mx_from(self):
         """"parity_mx": index of the first stage that runs on the f16mx kernels -- the trailing run of FROZEN stages of
         BasicBlocks without pools whose convs are at least 256 channels wide (res4 / res5 of WSR_18: what the numerics gate
-        covered, profiles/r06_mx_gate.md); len(stages) = none.  The f16mx kernel has ONE tile shape (256 x 256, a workgroup per
+        covered, profiles/r06_mx_gate.md; the BottleneckBlocks of WSR_50's res4 / res5 -- 1x1 / 3x3 / 1x1, 256 - 2048 channels -- are
+        the same contractions and take the same kernel: tests/test_gpu_full_size.py holds them to the same bar); len(stages) = none.  The f16mx kernel has ONE tile shape (256 x 256, a workgroup per
         CU): below ~200 tiles per conv (fewer than 8 images of 800 x 600) the bf16x2 path's smaller tiles / split-K forms win
         and the stages stay on it -- same precision mode, same bound (both formats were gated alone and together)."""
         first = len(self.stages)
         for i in range(len(self.stages) - 1, -1, -1):
             stage = self.stages[i]
-            ok = all(isinstance(b, BasicBlock) and not b.has_pool and b.in_channels % 32 == 0 and b.out_channels % 32 == 0
-                     and b.out_channels >= 256 and (b.shortcut is None or (b.shortcut.kernel_size == 1 and b.shortcut.stride == 1))
-                     for b in stage.children())
+            def block_ok(b):  # every conv of the block at least 256 wide, whole 32-value groups, no pool, a 1x1 / stride-1 shortcut
+                if not isinstance(b, (BasicBlock, BottleneckBlock)) or b.has_pool:
+                    return False
+                convs = [c for c in (b.conv1, b.conv2, getattr(b, "conv3", None)) if c is not None]
+                return (all(c.in_channels % 32 == 0 and c.out_channels % 32 == 0 and c.out_channels >= 256 and c.stride == 1
+                            for c in convs)
+                        and (b.shortcut is None or (b.shortcut.kernel_size == 1 and b.shortcut.stride == 1)))
+
+            ok = all(block_ok(b) for b in stage.children())
             if not ok or any(p.requires_grad for p in self._stage_params(stage)):
                 break
             first = i
