@@ -994,11 +994,24 @@ def test_backbone_in_image_blocks_equals_the_single_launch(gpu, depth, monkeypat
 # ---------------------------------------------------------------------------------------------------------------
 # MODEL.HIP.PRECISION = "parity" (bf16x2 activations, three-MFMA forward products) on the paths beside the headline step
 # ---------------------------------------------------------------------------------------------------------------
-def test_parity_mode_step_matches_reference_golden(gpu):
-    """The reference's golden step (g8) in the parity precision: forward quantities inside the north star's bound, labels
+def _lower_mx_thresholds(monkeypatch, precision):
+    """"parity_mx" hands layers with fewer than ~200 tiles / 4096 rows to the bf16x2 kernels: the small golden cases lower the
+    thresholds so that the f16mx kernels (csrc/gemm8mx.hip) are what runs."""
+    if precision == "parity_mx":
+        from wsovod_amd.modeling.backbone import ResNet
+        from wsovod_amd.modeling.roi_heads import WSOVODROIHeads
+
+        monkeypatch.setattr(ResNet, "MX_MIN_TILES", 1)
+        monkeypatch.setattr(WSOVODROIHeads, "MX_MIN_ROWS", 1)
+
+
+@pytest.mark.parametrize("precision", ["parity", "parity_mx"])
+def test_parity_mode_step_matches_reference_golden(gpu, precision, monkeypatch):
+    """The reference's golden step (g8) in the parity precisions: forward quantities inside the north star's bound, labels
     and pseudo-GT exact, losses 1e-3, gradients of the bf16 grade (the backward is plain bf16)."""
     g = load_golden("g8_train_step_r18_k20")
-    cfg, model, sd = build_seeded_hip_model("parity")
+    _lower_mx_thresholds(monkeypatch, precision)
+    cfg, model, sd = build_seeded_hip_model(precision)
     batch = gen.seeded_batch(4, 64, 20, 320, 416, seed=2)
     losses, cap, pgt = _run(model, batch)
     scores, logits = cap["miner"][0].detach().cpu(), cap["refine"][0].detach().cpu()
@@ -1016,11 +1029,13 @@ def test_parity_mode_step_matches_reference_golden(gpu):
             assert abs(float(p.grad.double().norm()) - ref) <= 0.15 * ref + 1e-6, k
 
 
-def test_parity_mode_inference_matches_reference_golden(gpu):
-    """G14's per-proposal scores / boxes from the HIP model in the parity precision (eval branch: the per-module Linear
-    calls instead of the grouped heads, per-call class embeddings)."""
+@pytest.mark.parametrize("precision", ["parity", "parity_mx"])
+def test_parity_mode_inference_matches_reference_golden(gpu, precision, monkeypatch):
+    """G14's per-proposal scores / boxes from the HIP model in the parity precisions (eval branch: the per-module Linear
+    calls instead of the grouped heads, per-call class embeddings; parity_mx: f16mx carriers without their bf16 copies)."""
     g = load_golden("g14_eval_tail")
-    cfg, model, sd = build_seeded_hip_model("parity")
+    _lower_mx_thresholds(monkeypatch, precision)
+    cfg, model, sd = build_seeded_hip_model(precision)
     model.eval()
     batch = gen.seeded_batch(3, 200, 20, 256, 352, seed=15)
     inputs = to_inputs(batch)

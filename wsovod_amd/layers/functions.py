@@ -102,7 +102,7 @@ class _Linear(Function):
     kernel straight from the bf16x2 x)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype, seed_add=None):
+    def forward(ctx, x, weight, bias, relu, dropout_p, seed, out_dtype, seed_add=None, grad_on=True):
         ctx.x2 = _x2_mode()
         ctx.y_x2 = out_dtype == H.X2
         x_hi = y_mask = None
@@ -113,7 +113,8 @@ class _Linear(Function):
             # NEXT layer's weight gradient
             wq, wscale = H.mx_cached(weight)
             y_bf16 = None
-            if out_dtype == H.MX and any(ctx.needs_input_grad):  # (grad mode is off inside Function.forward)
+            # (grad_on: the caller's grad mode -- it is off inside Function.forward, and needs_input_grad ignores no_grad)
+            if out_dtype == H.MX and grad_on and any(ctx.needs_input_grad):
                 y_bf16 = torch.empty((x.shape[0], weight.shape[0]), dtype=torch.bfloat16, device=x.device)
             y = H.gemm_mx(x, None, wq, wscale, bias=bias, relu=relu, dropout_p=dropout_p, dropout_seed=seed,
                           dropout_seed_add=seed_add, out_dtype=out_dtype, out_bf16=y_bf16)
@@ -122,7 +123,7 @@ class _Linear(Function):
                 if y_bf16 is not None:
                     y._x2_hi = y_mask = y_bf16
             x_hi = H.x2_hi_pop(x)
-            if x_hi is None and ctx.needs_input_grad[1]:
+            if x_hi is None and grad_on and ctx.needs_input_grad[1]:
                 raise RuntimeError("wsovod_hip linear: an f16mx input needs its plain bf16 copy for the weight gradient "
                                    "(the pooler / the previous layer writes it in training mode)")
         elif ctx.x2:
@@ -199,7 +200,7 @@ class _Linear(Function):
                 dx = H.gemm_nt(dA32, wt, out_dtype=torch.float32)  # (M, K)
         elif need_dx:
             dx = H.gemm_nt(dA16, H.transpose_cast(weight, torch.bfloat16, ld_dst=Np), out_dtype=torch.float32)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
     @staticmethod
     def _backward(ctx, dy):
@@ -234,7 +235,7 @@ class _Linear(Function):
             if need_dx:
                 dx = H.gemm_nt(dA, H.transpose_cast(weight, cd, ld_dst=Np), out_dtype=in_dtype)
             if fused(dA, x, q_x2):
-                return dx, None, db, None, None, None, None, None
+                return dx, None, db, None, None, None, None, None, None
             need_dx = need_dx and dx is None
         if tn:
             split = ctx.dw_split
@@ -254,14 +255,15 @@ class _Linear(Function):
         if need_dx and dx is None:
             wt = H.transpose_cast(weight, cd, ld_dst=Np)  # (K, Np) shadow of W^T
             dx = H.gemm_nt(dA, wt, out_dtype=in_dtype)  # (M,K)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
 def linear(x, weight, bias=None, relu=False, dropout_p=0.0, seed=0, out_dtype=None, seed_add=None):
     """out_dtype: a torch dtype, or hip_ops.X2 for a bf16x2 output ("parity" precision; the default there is fp32).
     seed_add: optional 1-element int64 DEVICE tensor added to `seed` inside the kernel (the per-step term of the dropout
     seed kept in memory, so that a captured HIP graph draws a fresh mask at every replay)."""
-    return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype, seed_add)
+    return _Linear.apply(x, weight, bias, relu, float(dropout_p), int(seed), out_dtype or x.dtype, seed_add,
+                         torch.is_grad_enabled())
 
 
 class _LinearGroup(Function):
