@@ -334,6 +334,10 @@ typedef struct wsovod_sgd_tensor {
   const float* lr_dev;    /* optional DEVICE scalar read instead of `lr`: the learning rate of a captured step graph lives
                            * in memory, so that a scheduler (detectron2's WarmupMultiStepLR changes it every iteration of
                            * the warm-up, engine/defaults.py build_lr_scheduler) takes effect at the next replay */
+  const unsigned char* mx_scale; /* shadow_is_bf16x2 == 2 (round 6): `bf16_shadow` is an f16mx copy of the parameter (numel a
+                           * multiple of 32) encoded with ONE power-of-two scale for the whole tensor, the E8M0 byte this
+                           * DEVICE pointer names (wsovod_f16mx_encode_with): the "parity_mx" weight operand refreshed in the
+                           * update pass.  NULL otherwise */
 } wsovod_sgd_tensor;
 int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float momentum, float grad_scale,
                               wsovod_stream_t stream);
@@ -435,6 +439,8 @@ typedef struct wsovod_tn_sgd {
   int shadow_is_bf16x2;
   float lr, weight_decay, momentum, grad_scale;
   const float* lr_dev;   /* optional DEVICE scalar read instead of lr (captured step graphs) */
+  const unsigned char* mx_scale; /* shadow_is_bf16x2 == 2: an f16mx shadow with this per-tensor E8M0 byte (DEVICE), as in
+                          * wsovod_sgd_tensor */
 } wsovod_tn_sgd;
 int wsovod_gemm_tn_sgd(const void* P, long long ldp, const void* Q, long long ldq, int q_dtype, int Mred, int NI, int NJ,
                        float alpha, const wsovod_tn_sgd* update, wsovod_stream_t stream);
@@ -458,6 +464,12 @@ int wsovod_gemm_tn_sgd(const void* P, long long ldp, const void* Q, long long ld
  * hi_a hi_b + q_a ql_b + ql_a q_b  (two v_mfma_f32_32x32x16_f16 + one v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile). */
 int wsovod_f16mx_encode(const float* src, long long ld_src, int rows, int cols, int nseg, void* dst, long long ld_dst,
                         unsigned char* scales, wsovod_stream_t stream);
+/* The same with ONE scale for the whole tensor, given as an E8M0 byte in DEVICE memory (`tensor_scale`; chosen by the caller
+ * from the tensor's largest magnitude with headroom); scales[rows] is filled with that byte, so the tensor is an ordinary
+ * row-scaled operand of wsovod_gemm_f16mx.  A trained weight keeps its byte from step to step: the optimizer kernels re-encode
+ * it element-wise inside the update pass (wsovod_sgd_tensor.mx_scale) instead of a separate two-pass encode per step. */
+int wsovod_f16mx_encode_with(const float* src, long long ld_src, int rows, int cols, void* dst, long long ld_dst,
+                             unsigned char* scales, const unsigned char* tensor_scale, wsovod_stream_t stream);
 /* n values (whole groups of 32) of an interleaved bf16x2 tensor -> unit-scale f16mx (the map that crosses from the bf16x2
  * layers, res3, to the f16mx ones, res4). */
 int wsovod_f16mx_from_bf16x2(const void* src, void* dst, long long n, wsovod_stream_t stream);

@@ -225,3 +225,40 @@ def test_last_round_of_tiles_as_split_k_slices(gpu, form, monkeypatch):
     assert not torch.equal(got[: got.shape[0] // 2], torch.zeros_like(got[: got.shape[0] // 2]))
     assert float((got - want).abs().max()) <= tol * float(want.abs().max())
     assert torch.equal(got == 0, want == 0) or form != "gemm"  # the same ReLU / dropout pattern
+
+
+def test_optimizer_kernels_refresh_the_f16mx_weight_operand(gpu):
+    """A trained weight's f16mx operand has ONE scale for the tensor (chosen at its first encode, kept as a byte in device
+    memory): the multi-tensor SGD kernel and the fused weight-gradient + update kernel re-encode it element-wise in their pass
+    -- the bytes a fresh encode of the updated parameter with that scale writes -- and the cache is re-stamped (no encode pass
+    in steady state)."""
+    from wsovod_amd.engine.trainer import _mx_shadow, _restamp_shadow
+    from wsovod_amd.layers import hip_ops as H
+
+    torch.manual_seed(8)
+    NI, NJ, M = 512, 1024, 256
+    w = (torch.randn(NI, NJ, device=gpu) * 0.01).requires_grad_(True)
+    car, sc = H.mx_cached(w, tensor_scale=True)
+    byte = w._mx_scale
+    assert int(byte) == int(torch.floor(torch.log2(w.detach().abs().max()))) - 7 + H.MX_WEIGHT_HEADROOM + 127
+    assert torch.equal(sc, byte.expand(NI, 1)) and torch.equal(car.view(torch.int32), H.mx_encode(w.detach(), tensor_byte=byte)[0].view(torch.int32))
+    hi, q, ql = H.mx_decode(car, sc)
+    assert float((hi + ql - w.detach()).abs().max() / w.detach().abs().max()) < 2.0 ** -14
+    g, buf = torch.randn(NI, NJ, device=gpu) * 1e-3, torch.zeros(NI, NJ, device=gpu)
+    sh = _mx_shadow(w)
+    assert sh is not None and sh[0] is car
+    with torch.no_grad():
+        H.sgd_momentum_multi([(w.data, g, buf, sh, 0.5, 1e-4)], 0.9)
+        torch.autograd.graph.increment_version(w)
+        _restamp_shadow(w, sh)
+    assert torch.equal(car.view(torch.int32), H.mx_encode(w.detach(), tensor_byte=byte)[0].view(torch.int32))
+    assert H.mx_cached(w, tensor_scale=True)[0] is car  # the cache is current: no encode
+    dA = (torch.randn(M, NI, device=gpu) * 0.1).to(torch.bfloat16)
+    x = torch.randn(M, NJ, device=gpu).to(torch.bfloat16)
+    with torch.no_grad():
+        H.gemm_tn_sgd(dA, x, w.data, buf, _mx_shadow(w), 0.01, 1e-4, 0.9)
+    assert torch.equal(car.view(torch.int32), H.mx_encode(w.detach(), tensor_byte=byte)[0].view(torch.int32))
+    with torch.no_grad():  # a change behind the optimizer's back (a loaded checkpoint): full encode, scale re-derived IN PLACE
+        w.mul_(8.0)
+    car2, _ = H.mx_cached(w, tensor_scale=True)
+    assert car2 is car and w._mx_scale is byte and int(byte) == int(torch.floor(torch.log2(w.detach().abs().max()))) - 7 + H.MX_WEIGHT_HEADROOM + 127

@@ -113,6 +113,7 @@ SIGNATURES = {
     "wsovod_gemm_tn_ex": [_P, _L, _P, _L, _I, _I, _I, _I, _P, _L, _F, _I, _P],
     "wsovod_gemm_tn_sgd": [_P, _L, _P, _L, _I, _I, _I, _I, _F, _P, _P],
     "wsovod_f16mx_encode": [_P, _L, _I, _I, _I, _P, _L, _P, _P],
+    "wsovod_f16mx_encode_with": [_P, _L, _I, _I, _P, _L, _P, _P, _P],
     "wsovod_f16mx_from_bf16x2": [_P, _P, _L, _P],
     "wsovod_gemm_f16mx": [_P, _P, _I, _P, _I, _P, _L, _P],
     "wsovod_mask_transpose_ex": [_P, _L, _I, _P, _L, _I, _I, _I, _F, _P, _L, _P, _L, _I, _P, _P],
@@ -130,14 +131,14 @@ class SgdTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("momentum_buf", C.c_void_p), ("bf16_shadow", C.c_void_p),
                 ("numel", C.c_longlong), ("lr", C.c_float), ("weight_decay", C.c_float), ("grad_is_bf16", C.c_int),
                 ("shadow_is_bf16x2", C.c_int), ("used_flag", C.c_void_p), ("grad_coef", C.c_void_p),
-                ("clip_value", C.c_float), ("lr_dev", C.c_void_p)]
+                ("clip_value", C.c_float), ("lr_dev", C.c_void_p), ("mx_scale", C.c_void_p)]
 
 
 class TnSgd(C.Structure):
     """wsovod_tn_sgd (include/wsovod_hip.h)."""
     _fields_ = [("param", C.c_void_p), ("momentum_buf", C.c_void_p), ("shadow", C.c_void_p), ("shadow_is_bf16x2", C.c_int),
                 ("lr", C.c_float), ("weight_decay", C.c_float), ("momentum", C.c_float), ("grad_scale", C.c_float),
-                ("lr_dev", C.c_void_p)]
+                ("lr_dev", C.c_void_p), ("mx_scale", C.c_void_p)]
 
 
 class PackTensor(C.Structure):

@@ -3,6 +3,7 @@
 // segmented column sums (bias / data-aware grads), device-scalar scaling, fused SGD-momentum.
 // All are coalesced 16-B-per-lane streaming kernels; none is reshaped into a GEMM.
 #include "common.h"
+#include "f16mx.h"
 
 namespace {
 
@@ -529,6 +530,8 @@ struct SgdTable {
   int count;
   unsigned g_bf16;  // bit k: g[k] points at bf16 values (gradients that travelled in the bf16 wire format)
   unsigned x2_shadow;  // bit k: shadow[k] is a bf16x2 copy of the parameter (include/wsovod_hip.h), n[k] a multiple of 32
+  unsigned mx_shadow;  // bit k: shadow[k] is an f16mx copy with the per-tensor E8M0 byte *mx_scale[k] (round 6)
+  const unsigned char* mx_scale[kSgdMax];
   const float* used[kSgdMax];  // optional device flag: 0 = no rank produced a gradient for the tensor -> left untouched
   const float* coef[kSgdMax];  // optional device scalar multiplied into the gradient scale (norm clipping coefficient)
   const float* lr_dev[kSgdMax];  // optional device scalar that replaces lr[k] (a captured step graph under an LR schedule)
@@ -547,6 +550,9 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
   const float lr = t.lr_dev[k] ? *t.lr_dev[k] : t.lr[k], wd = t.wd[k];
   const bool gb = (t.g_bf16 >> k) & 1u;
   const bool sx2 = (t.x2_shadow >> k) & 1u;
+  const bool smx = (t.mx_shadow >> k) & 1u;
+  const int mx_exp = smx ? (int)*t.mx_scale[k] - 127 : 0;
+  const float mx_iq = __builtin_ldexpf(1.0f, -mx_exp), mx_il = __builtin_ldexpf(1.0f, -(mx_exp - 11));
   const bf16_t* __restrict__ g16 = (const bf16_t*)t.g[k];
   if (t.used[k] && *t.used[k] == 0.f) return;  // torch.optim.SGD skips parameters whose grad is None
   const float gscale = t.coef[k] ? gscale0 * *t.coef[k] : gscale0;
@@ -575,7 +581,16 @@ __global__ __launch_bounds__(256) void sgd_momentum_multi_kernel(const SgdTable 
       pv -= lr * bv;
       __builtin_nontemporal_store(bv, (f32x4*)(buf + i));
       __builtin_nontemporal_store(pv, (f32x4*)(p + i));
-      if (shadow) {
+      if (shadow && smx) {  // f16mx: 8 B of fp16 hi, 4 B of e4m3 q, 4 B of e4m3 ql in the value's 128-byte group
+        wsovod_mx::f16x4 h4;
+        int q4, l4;
+        wsovod_mx::mx_enc4(pv, mx_iq, mx_il, h4, q4, l4);
+        char* grp = (char*)shadow + ((i >> 5) << 7);
+        const int w = (int)(i & 31);
+        *(wsovod_mx::f16x4*)(grp + 2 * w) = h4;
+        *(int*)(grp + 64 + w) = q4;
+        *(int*)(grp + 96 + w) = l4;
+      } else if (shadow) {
         const bf16x4 hi = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
         if (sx2) {  // hi at slot 64 (i / 32) + i % 32, lo 32 slots further (4 consecutive values never straddle a group)
           bf16_t* q = shadow + ((i >> 5) << 6) + (i & 31);
@@ -1220,8 +1235,14 @@ int wsovod_sgd_momentum_multi(const wsovod_sgd_tensor* tensors, int count, float
       if (d.grad_is_bf16) t.g_bf16 |= 1u << k;
       if (d.shadow_is_bf16x2 && d.bf16_shadow) {
         WS_CHECK_ARG(d.numel % 32 == 0 && ((uintptr_t)d.bf16_shadow & 15) == 0,
-                     "wsovod_sgd_momentum_multi: a bf16x2 shadow needs numel a multiple of 32 and 16-byte alignment");
-        t.x2_shadow |= 1u << k;
+                     "wsovod_sgd_momentum_multi: a bf16x2 / f16mx shadow needs numel a multiple of 32 and 16-byte alignment");
+        if (d.shadow_is_bf16x2 == 2) {
+          WS_CHECK_ARG(d.mx_scale, "wsovod_sgd_momentum_multi: an f16mx shadow needs its per-tensor scale byte (entry %d)", start + k);
+          t.mx_shadow |= 1u << k;
+          t.mx_scale[k] = d.mx_scale;
+        } else {
+          t.x2_shadow |= 1u << k;
+        }
       }
       t.used[k] = d.used_flag;
       t.coef[k] = d.grad_coef;

@@ -729,14 +729,18 @@ __global__ __launch_bounds__(256) void mx_from_x2_kernel(const bf16_t* __restric
 // pass 1 the segment's largest |fp16(x)| (exponent field), pass 2 the planes.  scales == NULL: the unit-scale form
 __global__ __launch_bounds__(256) void mx_encode_kernel(const float* __restrict__ src, long long ld_src, int rows, int cols,
                                                         int nseg, unsigned char* __restrict__ dst, long long ld_dst_bytes,
-                                                        unsigned char* __restrict__ scales) {
+                                                        unsigned char* __restrict__ scales,
+                                                        const unsigned char* __restrict__ tscale = nullptr) {
 #if defined(__HIP_DEVICE_COMPILE__)
   __shared__ unsigned red[4];
   const int r = blockIdx.x / nseg, sg = blockIdx.x - r * nseg;
   const int seg_cols = cols / nseg, c0 = sg * seg_cols;
   const float* s = src + (long long)r * ld_src + c0;
   int sexp = 0;  // q scale 2^sexp; ql scale 2^(sexp - 11)
-  if (scales) {
+  if (tscale) {  // one scale for the whole tensor, chosen by the caller
+    sexp = (int)*tscale - 127;
+    if (threadIdx.x == 0) scales[(long long)r * nseg + sg] = *tscale;
+  } else if (scales) {
     unsigned mx = 0;
     for (int e = threadIdx.x * 4; e < seg_cols; e += 256 * 4) {
       const f32x4 t = *(const f32x4*)(s + e);
@@ -787,8 +791,24 @@ extern "C" int wsovod_f16mx_encode(const float* src, long long ld_src, int rows,
   hipStream_t s = (hipStream_t)stream;
   wsovod::ProfScope prof(slot, s, 0.0, (double)rows * cols * 8.0);
   hipLaunchKernelGGL(mx_encode_kernel, dim3((unsigned)((long long)rows * nseg)), dim3(256), 0, s, src, ld_src, rows, cols, nseg,
-                     (unsigned char*)dst, ld_dst * 4, scales);
+                     (unsigned char*)dst, ld_dst * 4, scales, (const unsigned char*)nullptr);
   WS_CHECK_LAUNCH("wsovod_f16mx_encode");
+  return WSOVOD_OK;
+}
+
+extern "C" int wsovod_f16mx_encode_with(const float* src, long long ld_src, int rows, int cols, void* dst, long long ld_dst,
+                                        unsigned char* scales, const unsigned char* tensor_scale, wsovod_stream_t stream) {
+  WS_CHECK_ARG(rows >= 0 && cols >= 0 && cols % 32 == 0, "wsovod_f16mx_encode_with: cols=%d must be a multiple of 32", cols);
+  if (rows == 0 || cols == 0) return WSOVOD_OK;
+  WS_CHECK_ARG(src && dst && scales && tensor_scale && ld_src >= cols && ld_src % 4 == 0 && ld_dst >= cols && ld_dst % 4 == 0 &&
+                   (((uintptr_t)dst | (uintptr_t)src) & 15) == 0,
+               "wsovod_f16mx_encode_with: bad pointer / leading dimension");
+  static int slot = wsovod::prof_slot("f16mx_encode");
+  hipStream_t s = (hipStream_t)stream;
+  wsovod::ProfScope prof(slot, s, 0.0, (double)rows * cols * 8.0);
+  hipLaunchKernelGGL(mx_encode_kernel, dim3((unsigned)rows), dim3(256), 0, s, src, ld_src, rows, cols, 1, (unsigned char*)dst,
+                     ld_dst * 4, scales, tensor_scale);
+  WS_CHECK_LAUNCH("wsovod_f16mx_encode_with");
   return WSOVOD_OK;
 }
 

@@ -17,6 +17,7 @@
 // K-step (4 instructions: P/Q x two 128-column sub-images) and waits vmcnt(4), i.e. for the half issued one phase
 // earlier, which is read one phase later.  A row half is overwritten two phases after its last read.
 #include "gemm_common.h"
+#include "f16mx.h"
 #include <vector>
 
 namespace wsovod_gemm {
@@ -47,7 +48,8 @@ struct TnArgs {
   // SGD form (wsovod_gemm_tn_sgd): C is the PARAMETER itself; the tile's gradient never goes to memory
   float* mom;            // momentum buffer, the parameter's shape
   bf16_t* shadow;        // optional bf16 / bf16x2 operand copy of the parameter, refreshed in the same pass
-  int shadow_x2;
+  int shadow_x2;         // 1: bf16x2; 2: f16mx with the per-tensor E8M0 byte *mx_scale (round 6)
+  const unsigned char* mx_scale;
   float lr, wd, mu, gscale;
   const float* lr_dev;   // optional device scalar read instead of lr
   // SGD form with a split tile-round tail: the K slices of the tail tiles meet by atomics in a COMPACT scratch
@@ -447,6 +449,8 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
     float* stg = (float*)smem + wave * (64 * SROW);
     const float lr = p.lr_dev ? *p.lr_dev : p.lr;
     const float ag = p.alpha, gs = p.gscale, mu = p.mu, wd = p.wd;
+    const int mx_exp = p.shadow_x2 == 2 ? (int)*p.mx_scale - 127 : 0;
+    const float mx_iq = __builtin_ldexpf(1.0f, -mx_exp), mx_il = __builtin_ldexpf(1.0f, -(mx_exp - 11));
     const int cbase = j0 + wc * 64;
     const int rsub = lane >> 4, c4 = (lane & 15) << 2;  // lane -> (row it * 4 + rsub, 4 consecutive columns c4 ..)
 #pragma unroll
@@ -474,7 +478,16 @@ __global__ __launch_bounds__(512) void gemm_tn8_kernel(const TnArgs p) {
           pv -= lr * bv;
           __builtin_nontemporal_store(bv, (f32x4*)(p.mom + e));
           __builtin_nontemporal_store(pv, (f32x4*)(p.C + e));
-          if (p.shadow) {
+          if (p.shadow && p.shadow_x2 == 2) {
+            wsovod_mx::f16x4 h4;
+            int q4, l4;
+            wsovod_mx::mx_enc4(pv, mx_iq, mx_il, h4, q4, l4);
+            char* grp = (char*)p.shadow + ((e >> 5) << 7);
+            const int w = (int)(e & 31);
+            *(wsovod_mx::f16x4*)(grp + 2 * w) = h4;
+            *(int*)(grp + 64 + w) = q4;
+            *(int*)(grp + 96 + w) = l4;
+          } else if (p.shadow) {
             const bf16x4 hi = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
             if (p.shadow_x2) {
               bf16_t* q = p.shadow + ((e >> 5) << 6) + (e & 31);
@@ -570,7 +583,17 @@ __global__ __launch_bounds__(256) void tn_sgd_tail_kernel(const TnArgs p) {
     pv -= lr * bv;
     *(f32x4*)(p.mom + q) = bv;
     *(f32x4*)(p.C + q) = pv;
-    if (p.shadow) {
+    if (p.shadow && p.shadow_x2 == 2) {
+      const int mx_exp = (int)*p.mx_scale - 127;
+      wsovod_mx::f16x4 h4;
+      int q4, l4;
+      wsovod_mx::mx_enc4(pv, __builtin_ldexpf(1.0f, -mx_exp), __builtin_ldexpf(1.0f, -(mx_exp - 11)), h4, q4, l4);
+      char* grp = (char*)p.shadow + ((q >> 5) << 7);
+      const int w = (int)(q & 31);
+      *(wsovod_mx::f16x4*)(grp + 2 * w) = h4;
+      *(int*)(grp + 64 + w) = q4;
+      *(int*)(grp + 96 + w) = l4;
+    } else if (p.shadow) {
       const bf16x4 hi = bf16x4{(bf16_t)pv[0], (bf16_t)pv[1], (bf16_t)pv[2], (bf16_t)pv[3]};
       if (p.shadow_x2) {
         bf16_t* d = p.shadow + ((q >> 5) << 6) + (q & 31);
@@ -601,7 +624,9 @@ extern "C" int wsovod_gemm_tn_sgd(const void* P, long long ldp, const void* Q, l
   WS_CHECK_ARG((((uintptr_t)upd->param | (uintptr_t)upd->momentum_buf) & 15) == 0 && ((uintptr_t)upd->shadow & 7) == 0,
                "wsovod_gemm_tn_sgd: parameter / momentum buffer must be 16-byte aligned (shadow: 8)");
   WS_CHECK_ARG(!upd->shadow || !upd->shadow_is_bf16x2 || NJ % 32 == 0,
-               "wsovod_gemm_tn_sgd: a bf16x2 shadow needs rows of whole 32-value groups");
+               "wsovod_gemm_tn_sgd: a bf16x2 / f16mx shadow needs rows of whole 32-value groups");
+  WS_CHECK_ARG(!upd->shadow || upd->shadow_is_bf16x2 != 2 || (upd->mx_scale && ((uintptr_t)upd->shadow & 15) == 0),
+               "wsovod_gemm_tn_sgd: an f16mx shadow needs its per-tensor scale byte and 16-byte alignment");
   return tn_launch(P, ldp, Q, ldq, q_dtype, Mred, NI, NJ, upd->param, NJ, alpha, 2, upd, stream);
 }
 
@@ -641,6 +666,7 @@ static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq,
   a.mom = nullptr;
   a.shadow = nullptr;
   a.shadow_x2 = 0;
+  a.mx_scale = nullptr;
   a.lr = a.wd = a.mu = 0.f;
   a.gscale = 1.f;
   a.lr_dev = nullptr;
@@ -650,6 +676,7 @@ static int tn_launch(const void* P, long long ldp, const void* Q, long long ldq,
     a.mom = upd->momentum_buf;
     a.shadow = (bf16_t*)upd->shadow;
     a.shadow_x2 = upd->shadow_is_bf16x2;
+    a.mx_scale = upd->mx_scale;
     a.lr = upd->lr;
     a.wd = upd->weight_decay;
     a.mu = upd->momentum;

@@ -51,6 +51,7 @@ class HipSGD(torch.optim.Optimizer):
                 xe = getattr(p, "_x2_enc", None)  # "parity" precision: the bf16x2 operand (hip_ops.x2_cached) instead
                 if xe is not None and xe[0] == (p._version, p.data_ptr(), None) and p.numel() % 32 == 0:
                     shadow = xe[1]
+                shadow = _mx_shadow(p) or shadow  # "parity_mx": the f16mx operand (hip_ops.mx_cached, one scale per tensor)
                 lr = group["lr"] if self.lr_device is None else self.lr_device[p]
                 by_momentum.setdefault(group["momentum"], []).append(
                     (p.data, g, state["momentum_buffer"], shadow, lr, group["weight_decay"],
@@ -65,10 +66,29 @@ class HipSGD(torch.optim.Optimizer):
                 # conv weights, class matrices) are rebuilt, and re-stamp the bf16 shadow the kernel refreshed itself
                 p, shadow = e[7], e[3]
                 torch.autograd.graph.increment_version(p)
-                if shadow is not None and shadow.dtype == torch.float32:
-                    p._x2_enc = ((p._version, p.data_ptr(), None), shadow)
-                elif shadow is not None:
-                    p._hip_shadow = (shadow, p._version)
+                _restamp_shadow(p, shadow)
+
+
+def _mx_shadow(p):
+    """(f16mx carrier, per-tensor E8M0 byte) of a parameter whose CURRENT f16mx operand was encoded with one scale for the
+    tensor (hip_ops.mx_cached(tensor_scale=True): the FC weights under "parity_mx"), else None: the update kernels re-encode
+    it element-wise in their pass."""
+    me = getattr(p, "_mx_enc", None)
+    if me is None or len(me) < 3 or not me[2] or me[0] != (p._version, p.data_ptr(), None) or p.numel() % 32:
+        return None
+    byte = getattr(p, "_mx_scale", None)
+    return (me[1][0], byte) if byte is not None else None
+
+
+def _restamp_shadow(p, shadow):
+    """After an update kernel refreshed `shadow` through raw pointers: the operand cache of the parameter carries its new
+    version (a stale second format, if the parameter has one, stays behind and is re-encoded at its next use)."""
+    if isinstance(shadow, tuple):
+        p._mx_enc = ((p._version, p.data_ptr(), None), p._mx_enc[1], True)
+    elif shadow is not None and shadow.dtype == torch.float32:
+        p._x2_enc = ((p._version, p.data_ptr(), None), shadow)
+    elif shadow is not None:
+        p._hip_shadow = (shadow, p._version)
 
 
 class _FusedUpdate:
@@ -105,14 +125,12 @@ class _FusedUpdate:
         xe = getattr(p, "_x2_enc", None)
         if xe is not None and xe[0] == (p._version, p.data_ptr(), None) and p.numel() % 32 == 0:
             shadow = xe[1]
+        shadow = _mx_shadow(p) or shadow
         lr = g["lr"] if opt.lr_device is None else opt.lr_device[p]
         H.gemm_tn_sgd(dA, x, p.data, state["momentum_buffer"], shadow, lr, g["weight_decay"], g["momentum"],
                       grad_scale=opt.grad_scale, q_x2=q_x2)
         torch.autograd.graph.increment_version(p)  # (as HipSGD.step: caches keyed on the version are rebuilt ...
-        if shadow is not None and shadow.dtype == torch.float32:  # ... and the refreshed operand copy is re-stamped)
-            p._x2_enc = ((p._version, p.data_ptr(), None), shadow)
-        elif shadow is not None:
-            p._hip_shadow = (shadow, p._version)
+        _restamp_shadow(p, shadow)                 # ... and the refreshed operand copy is re-stamped)
         self.calls += 1
         return True
 

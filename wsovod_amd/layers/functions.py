@@ -111,7 +111,7 @@ class _Linear(Function):
             # fp16 hi*hi + block-scaled e4m3 cross terms on the f16mx weight (one re-encode per optimizer step).  An f16mx
             # output comes with its plain bf16 rounding: the mask source of this layer's backward and the operand of the
             # NEXT layer's weight gradient
-            wq, wscale = H.mx_cached(weight)
+            wq, wscale = H.mx_cached(weight, tensor_scale=weight.is_leaf and weight.requires_grad)
             y_bf16 = None
             # (grad_on: the caller's grad mode -- it is off inside Function.forward, and needs_input_grad ignores no_grad)
             if out_dtype == H.MX and grad_on and any(ctx.needs_input_grad):

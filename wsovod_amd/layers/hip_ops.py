@@ -435,14 +435,19 @@ def x2_decode(src):
     return out
 
 
-def mx_encode(src, nseg=1, unit=False):
+def mx_encode(src, nseg=1, unit=False, tensor_byte=None):
     """fp32 (rows, cols), cols % (32 nseg) == 0 -> (f16mx carrier (rows, cols) float32-typed, scales (rows, nseg) uint8: one
     tied E8M0 scale per row segment): include/wsovod_hip.h, wsovod_f16mx_encode.  unit: the activations' form, no scales
-    (-> (carrier, None))."""
-    require_gpu(src)
+    (-> (carrier, None)).  tensor_byte: a 1-element uint8 DEVICE tensor = ONE scale for the tensor (wsovod_f16mx_encode_with)."""
+    require_gpu(src, tensor_byte)
     src = src.contiguous()
     rows, cols = src.shape
     out = torch.empty((rows, cols), dtype=torch.float32, device=src.device)
+    if tensor_byte is not None:
+        scales = torch.empty((rows, 1), dtype=torch.uint8, device=src.device)
+        check(lib().wsovod_f16mx_encode_with(ptr(src), src.stride(0), rows, cols, ptr(out), out.stride(0), ptr(scales),
+                                             ptr(tensor_byte), stream()), "f16mx_encode_with")
+        return out, scales
     scales = None if unit else torch.empty((rows, nseg), dtype=torch.uint8, device=src.device)
     check(lib().wsovod_f16mx_encode(ptr(src), src.stride(0), rows, cols, int(nseg), ptr(out), out.stride(0), ptr(scales),
                                     stream()), "f16mx_encode")
@@ -531,17 +536,58 @@ def gemm_mx(A, a_scale, B, b_scale, *, bias=None, relu=False, dropout_p=0.0, dro
     return out
 
 
-def mx_cached(t, view_rows_cols=None):
-    """f16mx encoding (carrier, per-row scales) of a weight, cached on the tensor object and keyed by its version counter (one
-    re-encode per optimizer step at most; frozen backbone weights once)."""
+MX_WEIGHT_HEADROOM = 1  # binades between a trained weight's largest magnitude at its first encode and the q plane's 256
+
+
+def mx_tensor_scale(t):
+    """The per-tensor E8M0 byte (1-element uint8 DEVICE tensor) of a TRAINED weight's f16mx operand, derived from the tensor's
+    largest magnitude (+ MX_WEIGHT_HEADROOM binades) without a host read at every FULL encode of the weight (the first use, a
+    loaded checkpoint) and written IN PLACE into the tensor kept on the parameter (`_mx_scale`: captured step graphs and the
+    optimizer's table keep its address).  Between full encodes the scale is fixed and the optimizer kernels re-encode the
+    operand element-wise inside their update pass; e4m3's own exponent carries the rows and the growth of the weights
+    (beyond 448 / 256 x 2^headroom of that maximum the cross terms saturate: their accuracy goes, not the product's)."""
+    amax = t.detach().abs().amax().float().clamp_(min=2.0 ** -14)
+    byte = (torch.floor(torch.log2(amax)) - 7 + MX_WEIGHT_HEADROOM + 127).clamp_(1, 254).to(torch.uint8).reshape(1)
+    s = getattr(t, "_mx_scale", None)
+    if s is None:
+        s = byte
+        try:
+            t._mx_scale = s
+        except AttributeError:
+            pass
+    else:
+        s.copy_(byte)
+    return s
+
+
+def mx_cached(t, view_rows_cols=None, tensor_scale=False):
+    """f16mx encoding (carrier, per-row scales) of a weight, cached on the tensor object and keyed by its version counter (frozen
+    backbone weights: once, with their own row scales).  tensor_scale (trained weights): ONE scale for the tensor
+    (mx_tensor_scale) -- the optimizer then refreshes the carrier in its update pass and re-stamps the cache, so that in steady
+    state no encode pass runs."""
     key = (t._version, t.data_ptr(), view_rows_cols)
     c = getattr(t, "_mx_enc", None)
     if c is not None and c[0] == key:
         return c[1]
     src = t.detach()
+    if tensor_scale and view_rows_cols is None and src.dim() == 2 and src.is_contiguous() and src.shape[1] % 32 == 0:
+        byte = mx_tensor_scale(t)
+        if c is not None and len(c) > 2 and c[2] and c[1][0].shape == src.shape:
+            car, scales = c[1]  # (re-encoded in place: a captured graph / the optimizer's table keep the addresses)
+        else:
+            car = torch.empty_like(src)
+            scales = torch.empty((src.shape[0], 1), dtype=torch.uint8, device=src.device)
+        check(lib().wsovod_f16mx_encode_with(ptr(src), src.stride(0), src.shape[0], src.shape[1], ptr(car), car.stride(0),
+                                             ptr(scales), ptr(byte), stream()), "f16mx_encode_with")
+        out = (car, scales)
+        try:
+            t._mx_enc = (key, out, True)  # (True: ONE scale for the tensor -- what the optimizer kernels can refresh)
+        except AttributeError:
+            pass
+        return out
     out = mx_encode(src.reshape(view_rows_cols) if view_rows_cols is not None else src)
     try:
-        t._mx_enc = (key, out)
+        t._mx_enc = (key, out, False)
     except AttributeError:
         pass
     return out
@@ -1313,7 +1359,10 @@ def gemm_tn_sgd(P, Q, param, momentum_buf, shadow, lr, weight_decay, momentum, g
     (float32-typed) copy of param, refreshed in the same pass; lr: a float or a 1-element fp32 DEVICE tensor."""
     from .._lib import TnSgd
 
-    require_gpu(P, Q, param, momentum_buf, shadow)
+    mx_byte = None
+    if isinstance(shadow, tuple):  # (f16mx carrier, per-tensor E8M0 byte): the "parity_mx" weight operand
+        shadow, mx_byte = shadow
+    require_gpu(P, Q, param, momentum_buf, shadow, mx_byte)
     _refuse_undeclared_planar("gemm_tn_sgd", P, Q)
     assert P.dtype == torch.bfloat16 and Q.dtype == (torch.float32 if q_x2 else torch.bfloat16) and P.shape[0] == Q.shape[0]
     Mred, NI, NJ = P.shape[0], P.shape[1], Q.shape[1]
@@ -1326,7 +1375,8 @@ def gemm_tn_sgd(P, Q, param, momentum_buf, shadow, lr, weight_decay, momentum, g
     u = TnSgd()
     u.param, u.momentum_buf = param.data_ptr(), momentum_buf.data_ptr()
     u.shadow = shadow.data_ptr() if shadow is not None else None
-    u.shadow_is_bf16x2 = int(shadow is not None and shadow.dtype == torch.float32)
+    u.shadow_is_bf16x2 = 2 if mx_byte is not None else int(shadow is not None and shadow.dtype == torch.float32)
+    u.mx_scale = mx_byte.data_ptr() if mx_byte is not None else None
     if shadow is not None and (shadow.numel() != param.numel() or not shadow.is_contiguous()):
         raise RuntimeError("wsovod_hip gemm_tn_sgd: the shadow must be a contiguous copy of the parameter")
     if torch.is_tensor(lr):
@@ -1355,7 +1405,10 @@ def sgd_momentum_multi(entries, momentum, grad_scale=1.0, clip=None):
     for d, e in zip(arr, entries):
         p, g, b, sh, lr, wd = e[:6]
         used = e[6] if len(e) > 6 else None
-        require_gpu(p, g, b, sh, used)
+        mx_byte = None
+        if isinstance(sh, tuple):  # (f16mx carrier, per-tensor E8M0 byte)
+            sh, mx_byte = sh
+        require_gpu(p, g, b, sh, used, mx_byte)
         if torch.is_tensor(lr):  # a 1-element fp32 DEVICE tensor: the rate is read from memory when the kernel runs
             require_gpu(lr)
             assert lr.dtype == torch.float32 and lr.numel() == 1
@@ -1365,7 +1418,8 @@ def sgd_momentum_multi(entries, momentum, grad_scale=1.0, clip=None):
             raise RuntimeError("sgd_momentum_multi: gradient must be fp32 or bf16 with the parameter's element count")
         d.param, d.grad, d.momentum_buf = p.data_ptr(), g.data_ptr(), b.data_ptr()
         d.bf16_shadow = sh.data_ptr() if sh is not None else None
-        d.shadow_is_bf16x2 = 1 if (sh is not None and sh.dtype == torch.float32) else 0
+        d.shadow_is_bf16x2 = 2 if mx_byte is not None else (1 if (sh is not None and sh.dtype == torch.float32) else 0)
+        d.mx_scale = mx_byte.data_ptr() if mx_byte is not None else None
         d.numel, d.lr, d.weight_decay = p.numel(), lr, wd
         d.grad_is_bf16 = 1 if g.dtype == torch.bfloat16 else 0
     if clip is not None:
