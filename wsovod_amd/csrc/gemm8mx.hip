@@ -420,6 +420,15 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
 #if !defined(MX_ABL_NODMA)
       dma_b(SB, 0, sob); dma_b(SB, 1, sob); dma_b(SB, 2, sob); dma_b(SB, 3, sob);
 #endif
+      if constexpr (CONV) {
+        // the tap after next and its per-lane offsets (branch-free, ~20 VALU + ~25 scalar instructions), HERE in the read
+        // section behind the DMA issue: interleaved with the products of this phase (gemm8.hip's place for them) they made
+        // the 512-cycle product block of this format ~100 cycles longer (tools/mx_conv_ab.py: 7.80 -> 7.59 ms for the eight
+        // convs); the empty asm keeps hipcc from sinking the selects to their use in front of the next K-step's DMA issue
+        t2 = tap_next(t2);
+        conv_va(t2);
+        asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]));
+      }
       MX_VMCNT(8);  // younger: the eight pieces of K-step kt + 2 -> K-step kt + 1 has landed
     } else {
       MX_VMCNT(0);
@@ -430,22 +439,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
     MX_PHASE(4, sa_c[2], sa_c[3]);
-    if constexpr (CONV) {
-      // the tap after next and its per-lane offsets, one instruction at a time behind the products: they issue in the
-      // matrix pipe's shadow (the empty asm pins the results HERE: hipcc otherwise sinks the selects to their use, in front
-      // of the next K-step's DMA instructions -- the section the other group's products have to cover)
-      t2 = tap_next(t2);
-      conv_va(t2);
-      asm volatile("" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]));
-    }
     asm volatile("" : "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]));
-    if constexpr (CONV) {
-#pragma unroll
-      for (int g_ = 0; g_ < 10; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-      }
-    }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
