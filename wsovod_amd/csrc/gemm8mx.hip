@@ -67,7 +67,11 @@ __device__ __forceinline__ i32x8 mx_cat(const u32x4 a, const u32x4 b) {
   return i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
 }
 
-template <bool CONV>
+// EPI: the epilogue's output / residual formats as compile-time facts (0 = read from the arguments: every combination, ~100 KB
+// of code behind runtime branches that each tile streamed through the instruction cache; the hot combinations are built
+// apart): 1 = f16mx out, no residual; 2 = f16mx out + f16mx residual; 3 = fp32 out + f16mx residual; 4 = bf16x2 out, no
+// residual -- each with N a multiple of 64 (the staged row-image stores).
+template <bool CONV, int EPI = 0>
 __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
   const GemmArgs& p = q.g;
   [[maybe_unused]] constexpr int BM = 256, BN = 256, BKE = 64, EPC = 8, esz = 2, LR = 64;
@@ -512,11 +516,16 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       const int nb = n0 + wc * 64 + 32 * u + 16 * hh + 4 * g;
       bv[u][g] = (p.bias && nb < p.N) ? *(const f32x4*)(p.bias + nb) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  const bool res_mx = p.residual && p.dtype_r == WSOVOD_F16MX;
+  // (the specialised conv forms: no dropout, no bf16 copy -- the launcher sends anything else to EPI = 0)
+  const bool drop = (CONV && EPI != 0) ? false : p.dropout_p > 0.f;
+  void* const c_bf16 = (CONV && EPI != 0) ? nullptr : q.c_bf16;
+  const int dtype_c = EPI == 1 || EPI == 2 ? (int)WSOVOD_F16MX : EPI == 3 ? (int)WSOVOD_F32 : EPI == 4 ? (int)WSOVOD_BF16X2 : p.dtype_c;
+  const bool has_res = EPI == 1 || EPI == 4 ? false : EPI == 2 || EPI == 3 ? true : p.residual != nullptr;
+  const bool res_mx = EPI == 2 || EPI == 3 ? true : EPI == 0 ? (p.residual && p.dtype_r == WSOVOD_F16MX) : false;
   // 4-byte-per-value outputs of whole 64-column wavefront blocks leave through a row image in LDS (free behind the K loop:
   // every fragment read was waited for in front of the last barrier each wavefront passed)
   constexpr int IMG_LD = 256 + 16;  // (+16: the 8 rows of a ds_write_b128 lane group fall on different banks)
-  const bool via_lds = p.N % 64 == 0 && (p.dtype_c == WSOVOD_F16MX || p.dtype_c == WSOVOD_BF16X2 || p.dtype_c == WSOVOD_F32);
+  const bool via_lds = EPI != 0 || (p.N % 64 == 0 && (dtype_c == WSOVOD_F16MX || dtype_c == WSOVOD_BF16X2 || dtype_c == WSOVOD_F32));
   char* img = smem + wave_u * (32 * IMG_LD);
   auto emit_tile = [&](const f32x16& a, auto T_c, const f16x8 rh0, const f16x8 rh1, const i32x4 rl) {
     constexpr int T = decltype(T_c)::value;  // (a compile-time tile index: a runtime one would index bv[] in scratch)
@@ -535,11 +544,11 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
           const f16x8 h = g < 2 ? rh0 : rh1;
           const int o = 4 * (g & 1);
           x += mx_dec4_unit(f16x4{h[o], h[o + 1], h[o + 2], h[o + 3]}, rl[g]);
-        } else if (p.residual) {
+        } else if (has_res) {
           x += load4_as_f32(p.residual, mc, p.ldr, nb, p.dtype_r);
         }
         x = f32x4{fmaxf(x[0], lo), fmaxf(x[1], lo), fmaxf(x[2], lo), fmaxf(x[3], lo)};
-        if (p.dropout_p > 0.f) {
+        if (drop) {
           const unsigned long long dz = dropout_quad(dseed, mc, p.N, nb);
 #pragma unroll
           for (int r = 0; r < 4; ++r) x[r] = dropout_keep(dz, r, dthr) ? x[r] * keep_scale : 0.f;
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
       // the lane's 16 values as the bytes of the output format, into the wavefront's row image [32 rows][256 B + 16]: the
       // stores then leave as whole 256-byte row segments (emit_pair) instead of 64 separate 16-byte pieces per instruction
       char* slot = img + r32 * IMG_LD + (T & 1) * 128;
-      if (p.dtype_c == WSOVOD_F16MX) {
+      if (dtype_c == WSOVOD_F16MX) {
         f16x4 h[4];
         int qv[4], lv[4];
 #pragma unroll
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
         *(f16x8*)(slot + 32 * hh + 16) = f16x8{h[2][0], h[2][1], h[2][2], h[2][3], h[3][0], h[3][1], h[3][2], h[3][3]};
         *(i32x4*)(slot + 64 + 16 * hh) = i32x4{qv[0], qv[1], qv[2], qv[3]};
         *(i32x4*)(slot + 96 + 16 * hh) = i32x4{lv[0], lv[1], lv[2], lv[3]};
-      } else if (p.dtype_c == WSOVOD_BF16X2) {
+      } else if (dtype_c == WSOVOD_BF16X2) {
         bf16x8 hi0, hi1, lo0, lo1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -574,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) *(f32x4*)(slot + 64 * hh + 16 * g) = y[g];
       }
-    } else if (p.dtype_c == WSOVOD_F16MX) {  // 16 values = half a group: 32 B of hi, 16 B of q, 16 B of ql
+    } else if (dtype_c == WSOVOD_F16MX) {  // 16 values = half a group: 32 B of hi, 16 B of q, 16 B of ql
       f16x4 h[4];
       int qv[4], lv[4];
 #pragma unroll
@@ -588,10 +597,10 @@ __global__ __launch_bounds__(512) void gemm256_mx_kernel(const MxArgs q) {
     } else {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        if (nb0 + 4 * g < p.N) store4_from_f32(p.C, m, p.ldc, nb0 + 4 * g, p.dtype_c, y[g]);
+        if (nb0 + 4 * g < p.N) store4_from_f32(p.C, m, p.ldc, nb0 + 4 * g, dtype_c, y[g]);
     }
-    if (q.c_bf16 && m < p.M && nb0 < p.N) {
-      bf16_t* cb = (bf16_t*)q.c_bf16 + (long long)m * q.ld_cb + nb0;
+    if (c_bf16 && m < p.M && nb0 < p.N) {
+      bf16_t* cb = (bf16_t*)c_bf16 + (long long)m * q.ld_cb + nb0;
       if (nb0 + 16 <= p.N) {
         *(bf16x8*)cb = bf16x8{(bf16_t)y[0][0], (bf16_t)y[0][1], (bf16_t)y[0][2], (bf16_t)y[0][3],
                               (bf16_t)y[1][0], (bf16_t)y[1][1], (bf16_t)y[1][2], (bf16_t)y[1][3]};
@@ -929,10 +938,12 @@ extern "C" int wsovod_gemm_f16mx(const wsovod_gemm_desc* d, const unsigned char*
   static bool attr_set = false;
   constexpr int lds_bytes = (3 * 256 + 2 * 256) * 128;  // 160 KiB: the whole CU
   if (!attr_set) {
-    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_mx_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
-                 "wsovod_gemm_f16mx: LDS opt-in");
-    WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_mx_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes),
-                 "wsovod_gemm_f16mx: LDS opt-in (conv)");
+#define MX_OPT_IN(C, E)                                                                                                  \
+  WS_CHECK_HIP(hipFuncSetAttribute((const void*)gemm256_mx_kernel<C, E>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes), \
+               "wsovod_gemm_f16mx: LDS opt-in")
+    MX_OPT_IN(false, 0); MX_OPT_IN(false, 1); MX_OPT_IN(false, 4);
+    MX_OPT_IN(true, 0); MX_OPT_IN(true, 1); MX_OPT_IN(true, 2); MX_OPT_IN(true, 3);
+#undef MX_OPT_IN
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
@@ -996,8 +1007,25 @@ extern "C" int wsovod_gemm_f16mx(const wsovod_gemm_desc* d, const unsigned char*
   }
   wsovod::ProfScope prof(d->conv ? slot_c : slot_g, s, 2.0 * d->M * (double)d->N * d->K, bytes);
   auto launch = [&](const MxArgs& qq, int grid) {
-    if (d->conv) hipLaunchKernelGGL(gemm256_mx_kernel<true>, dim3(grid), dim3(512), lds_bytes, s, qq);
-    else hipLaunchKernelGGL(gemm256_mx_kernel<false>, dim3(grid), dim3(512), lds_bytes, s, qq);
+    // the epilogue form (the kernel's EPI): the hot combinations have their own builds
+    const bool mxr = d->residual && d->dtype_r == WSOVOD_F16MX;
+    const int epi = (d->N % 64 != 0 || qq.g.ksplit > 1 || (d->conv && (d->dropout_p > 0.f || c_bf16))) ? 0
+                    : (d->dtype_c == WSOVOD_F16MX && !d->residual) ? 1
+                    : (d->dtype_c == WSOVOD_F16MX && mxr && d->conv) ? 2
+                    : (d->dtype_c == WSOVOD_F32 && mxr && d->conv) ? 3
+                    : (d->dtype_c == WSOVOD_BF16X2 && !d->residual && !d->conv) ? 4 : 0;
+#define MX_LAUNCH(C, E) hipLaunchKernelGGL((gemm256_mx_kernel<C, E>), dim3(grid), dim3(512), lds_bytes, s, qq)
+    if (d->conv) {
+      if (epi == 1) MX_LAUNCH(true, 1);
+      else if (epi == 2) MX_LAUNCH(true, 2);
+      else if (epi == 3) MX_LAUNCH(true, 3);
+      else MX_LAUNCH(true, 0);
+    } else {
+      if (epi == 1) MX_LAUNCH(false, 1);
+      else if (epi == 4) MX_LAUNCH(false, 4);
+      else MX_LAUNCH(false, 0);
+    }
+#undef MX_LAUNCH
   };
   if (tail_mt == 0) {
     launch(q, ntiles);
