@@ -124,8 +124,8 @@ def pmc_traffic(kernel_name, args):
     if not m:
         return None, None
     conv, x3 = m.group(1) == "conv_igemm", m.group(2) == "bf16x2"
-    if m.group(2) == "f16mx":  # csrc/gemm8mx.hip: gemm256_mx_kernel<CONV>
-        tags = ("gemm256_mx_kernel<%s>" % ("true" if conv else "false"),)
+    if m.group(2) == "f16mx":  # csrc/gemm8mx.hip: gemm256_mx_kernel<CONV, EPI> -- one instantiation per epilogue form
+        tags = ("gemm256_mx_kernel<%s," % ("true" if conv else "false"), "gemm256_mx_kernel<%s>" % ("true" if conv else "false"))
     elif m.group(5) == "_8ph":  # rocprofv3 prints this one demangled: gemm256_8ph_kernel<CONV, X3, PH, LEAN>
         c, x = ("true" if conv else "false"), ("true" if x3 else "false")
         tags = (f"gemm256_8ph_kernel<{c}, {x},", f"gemm256_8ph_kernel<{c}>") if not x3 else (f"gemm256_8ph_kernel<{c}, {x},",)
@@ -137,10 +137,14 @@ def pmc_traffic(kernel_name, args):
     with open(path) as f:
         table = json.load(f)["kernels"]
     hits = [v for k, v in table.items() if any(t in k for t in tags)]
-    if len(hits) != 1:
+    if not hits or (len(hits) != 1 and m.group(2) != "f16mx"):
         return None, None
-    return hits[0]["traffic_bytes_per_launch"], (f"profiles/{os.path.basename(path)}: builder-run rocprofv3 --pmc FETCH_SIZE / "
-                                                 f"WRITE_SIZE passes of this command, NOT measured in this run")
+    # (f16mx: the kernel's instantiations -- epilogue forms, the split-K last rounds -- as one family: launch-weighted mean)
+    n = sum(max(1, int(v.get("launches_sampled", 1))) for v in hits)
+    traffic = sum(v["traffic_bytes_per_launch"] * max(1, int(v.get("launches_sampled", 1))) for v in hits) / n
+    return traffic, (f"profiles/{os.path.basename(path)}: builder-run rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                     f"command, NOT measured in this run" + ("; launch-weighted mean over the kernel's instantiations"
+                                                              if len(hits) > 1 else ""))
 
 
 def to_device_batch(batch, dev):
