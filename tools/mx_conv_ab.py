@@ -54,6 +54,12 @@ for name, Cin, Cout, Cin2, cnt in (("res4.0.conv1", 128, 256, 0, 1), ("res4.0.co
     os.environ["WSOVOD_MX_TAIL"] = "1"
     t_mx = t(lambda: H.gemm_mx(xm, None, wm, sw, conv=geom, A2=a2m, bias=bias, relu=True, out=o2, out_dtype=H.MX))
     tot_one = globals().get("tot_one", 0.0) + cnt * t_mx1
+    if cnt == 2:  # the second conv of the identity blocks adds the block's input (residual) in its epilogue
+        rx, rm = H.x2_encode(torch.randn(n * Hi * Wi, Cout, device="cuda")), H.mx_encode(torch.randn(n * Hi * Wi, Cout, device="cuda"), unit=True)[0]
+        t_x2r = t(lambda: H.gemm_nt(xx, wx, conv=geom, x2=True, bias=bias, relu=True, out=o1, out_dtype=H.X2, residual=rx, residual_x2=True))
+        t_mxr = t(lambda: H.gemm_mx(xm, None, wm, sw, conv=geom, bias=bias, relu=True, out=o2, out_dtype=H.MX, residual=rm, residual_fmt=H.MX))
+        print(f"   with the residual: bf16x2 {t_x2r:.3f} ms   f16mx {t_mxr:.3f} ms", flush=True)
+        del rx, rm
     fl = 2.0 * n * Hi * Wi * Cout * (9 * Cin + Cin2)
     d1, d2 = H.x2_decode(o1), H.mx_to_f32(o2)
     err = float((d1 - d2).abs().max() / d1.abs().max())
