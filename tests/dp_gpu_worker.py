@@ -1,8 +1,9 @@
 """Worker of tests/test_gpu_data_parallel.py: one data-parallel rank of the REAL HIP model.  Two of these share
 cuda:0 on the 1-GPU box (gloo backend; the collective code path of HotPathTrainer is the same one RCCL runs).
 
-    python -m tests.dp_gpu_worker <rank> <world> <port> <out.pt> <mode>      mode: single | mixed | direct
-(direct = single with exchange="direct": all-to-all + fp32 shard sum + all-gather instead of the all-reduce)
+    python -m tests.dp_gpu_worker <rank> <world> <port> <out.pt> <mode>      mode: single | mixed | direct | mx
+(direct = single with exchange="direct": all-to-all + fp32 shard sum + all-gather instead of the all-reduce;
+ mx = single in the "parity_mx" precision -- the launcher lowers the f16mx thresholds through the environment)
 """
 import os
 import sys
@@ -60,7 +61,7 @@ def build(mode):
         model.load_state_dict(gen.mixed_seeded_state(shapes, seed=17), strict=True)
         model.train()
     else:
-        cfg, model, _ = build_seeded_hip_model("bf16")
+        cfg, model, _ = build_seeded_hip_model("parity_mx" if mode == "mx" else "bf16")
     for m in model.modules():
         if isinstance(m, torch.nn.Dropout):
             m.eval()
@@ -69,6 +70,9 @@ def build(mode):
 
 
 def main():
+    import faulthandler
+
+    faulthandler.dump_traceback_later(240, exit=True)  # a hung rank says where (the launcher prints the log on a timeout)
     rank, world, port, out, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     torch.cuda.set_device(0)
