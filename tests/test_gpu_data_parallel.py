@@ -40,7 +40,7 @@ dist.destroy_process_group()
 
 
 @pytest.fixture(scope="module")
-def shared_gpu(gpu):
+def shared_gpu(gpu, second_gpu_process):
     """These tests put TWO processes on the box's one GPU and exchange device tensors over gloo.  Some boxes of the pool do not
     let a second process onto the device (round 6: every gloo broadcast of a device tensor hung there, before any of this
     package's code ran -- the first `dist.broadcast` of `broadcast_parameters`): a 90-second probe of exactly that decides, and

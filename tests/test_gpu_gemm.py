@@ -558,7 +558,7 @@ print("WS_OK")
 """
 
 
-def test_split_k_workspace_outlives_a_captured_graph(gpu):
+def test_split_k_workspace_outlives_a_captured_graph(gpu, second_gpu_process):
     """the split-K workspace grows with the shape.  A HIP graph captured on a SMALL split-K launch
     keeps the workspace pointer it was captured with; a later, larger split-K launch must retire that block (keep it
     allocated), never free it, and growing UNDER capture must be refused instead of calling hipMalloc inside the capture.
