@@ -17,6 +17,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ long long mx_group(long long k) { return (k >> 5) << 7; }
 
 // (the builtins exist in the device pass only; the host pass sees the same declarations with inert bodies)
+// mx_sat: v_cvt_pk_fp8_f32 does NOT saturate on gfx950 -- probed: 449 -> 0x7e, 480 and everything above -> 0x7f (NaN) -- so the
+// value is clamped to the format's +-448 first
 __device__ __forceinline__ float mx_sat(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_fmed3f(v, -448.0f, 448.0f);
